@@ -1,0 +1,95 @@
+"""Build and load libbn254hip.so (the HIP kernels + C ABI of include/bn254_hip.h).
+
+There is no CPU fallback: if the shared library is missing or no HIP device is present, the
+calls raise.  The library is built in-tree (bn254_amd/libbn254hip.so) with hipcc for gfx950.
+"""
+import ctypes
+import os
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_PKG, "csrc")
+LIB_PATH = os.path.join(_PKG, "libbn254hip.so")
+_SOURCES = ["bn254_hip.hip", "bn254_field.h", "bn254_curve.h", "bn254_pairing.h", "bn254_hash.h", "bn254_io.h", "gen_constants.py"]
+
+HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC"]
+
+
+def _stale():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    paths = [os.path.join(_CSRC, s) for s in _SOURCES] + [os.path.join(os.path.dirname(_PKG), "include", "bn254_hip.h")]
+    return any(os.path.exists(p) and os.path.getmtime(p) > t for p in paths)
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP extension for gfx950 (hipcc cross-compiles without a GPU)."""
+    const_h = os.path.join(_CSRC, "bn254_constants.h")
+    gen = os.path.join(_CSRC, "gen_constants.py")
+    if not os.path.exists(const_h) or os.path.getmtime(const_h) < os.path.getmtime(gen):
+        subprocess.check_call(["python3", gen], stdout=None if verbose else subprocess.DEVNULL)
+    if force or _stale():
+        hipcc = os.environ.get("HIPCC", "hipcc")
+        cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB_PATH, os.path.join(_CSRC, "bn254_hip.hip")]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library and declare the C ABI.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libbn254hip.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
+                           "bn254_amd has no CPU fallback")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, sz, u32, i32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_int
+    L.bn254_version.restype = ctypes.c_char_p
+    L.bn254_ctx_create.argtypes = [i32, ctypes.POINTER(vp)]
+    L.bn254_ctx_destroy.argtypes = [vp]
+    L.bn254_ctx_destroy.restype = None
+    L.bn254_ctx_reserve.argtypes = [vp, sz]
+    L.bn254_ctx_synchronize.argtypes = [vp]
+    L.bn254_ctx_set_profiling.argtypes = [vp, i32]
+    L.bn254_ctx_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+    L.bn254_batch_verify.argtypes = [vp, vp, vp, vp, vp, sz, u32, vp]
+    L.bn254_batch_verify_device.argtypes = [vp, vp, vp, vp, vp, sz, u32, vp, vp]
+    L.bn254_batch_hash_to_g1.argtypes = [vp, vp, vp, sz, vp, vp, vp]
+    L.bn254_batch_hash_to_g1_device.argtypes = [vp, vp, vp, sz, vp, vp, vp, vp]
+    L.bn254_batch_pairing_check.argtypes = [vp, vp, vp, sz, sz, u32, vp]
+    L.bn254_batch_pairing.argtypes = [vp, vp, vp, sz, sz, u32, vp, vp]
+    L.bn254_batch_pairing_device.argtypes = [vp, vp, vp, sz, sz, u32, vp, vp, vp]
+    L.bn254_batch_check_public_keys.argtypes = [vp, vp, vp, sz, u32, vp]
+    L.bn254_batch_g1_add.argtypes = [vp, vp, vp, sz, vp, vp]
+    L.bn254_batch_g2_add.argtypes = [vp, vp, vp, sz, vp, vp]
+    L.bn254_batch_g1_mul.argtypes = [vp, vp, vp, sz, i32, vp, vp]
+    L.bn254_batch_g2_mul.argtypes = [vp, vp, vp, sz, i32, vp, vp]
+    L.bn254_batch_g1_mul_device.argtypes = [vp, vp, vp, sz, i32, vp, vp, vp]
+    L.bn254_batch_g2_mul_device.argtypes = [vp, vp, vp, sz, i32, vp, vp, vp]
+    L.bn254_batch_sign.argtypes = [vp, vp, vp, vp, sz, vp, vp]
+    L.bn254_batch_sign_device.argtypes = [vp, vp, vp, vp, sz, vp, vp, vp]
+    L.bn254_batch_g1_sum.argtypes = [vp, vp, vp, sz, vp, vp]
+    L.bn254_batch_g2_sum.argtypes = [vp, vp, vp, sz, vp, vp]
+    L.bn254_debug_fp_op.argtypes = [vp, i32, vp, vp, sz, vp, vp]
+    L.bn254_debug_fp12_op.argtypes = [vp, i32, vp, vp, sz, vp]
+    L.bn254_debug_miller_loop.argtypes = [vp, vp, vp, sz, vp]
+    _lib = L
+    return L
+
+
+# every symbol include/bn254_hip.h declares (checked by tests/test_abi.py without a GPU)
+EXPORTED_SYMBOLS = [
+    "bn254_version", "bn254_ctx_create", "bn254_ctx_destroy", "bn254_ctx_reserve", "bn254_ctx_synchronize",
+    "bn254_batch_verify", "bn254_batch_verify_device", "bn254_batch_hash_to_g1", "bn254_batch_hash_to_g1_device",
+    "bn254_batch_pairing_check", "bn254_batch_pairing", "bn254_batch_pairing_device", "bn254_batch_check_public_keys",
+    "bn254_batch_g1_add", "bn254_batch_g2_add", "bn254_batch_g1_mul", "bn254_batch_g2_mul", "bn254_batch_g1_mul_device",
+    "bn254_batch_g2_mul_device", "bn254_batch_sign", "bn254_batch_sign_device", "bn254_batch_g1_sum", "bn254_batch_g2_sum",
+    "bn254_debug_fp_op", "bn254_debug_fp12_op", "bn254_debug_miller_loop", "bn254_ctx_set_profiling", "bn254_ctx_last_kernel_ms",
+]

@@ -1,0 +1,134 @@
+// G1 / G2 group arithmetic (Jacobian coordinates), generic over the coordinate field.
+//
+// Replaces, for the hot path, `bn::{G1,G2}` point addition / doubling / scalar multiplication
+// as used by aggregation (/root/reference/src/types.rs:126-132, :264-270), signing and key
+// derivation (/root/reference/src/ecdsa.rs:31, /root/reference/src/types.rs:86, :156) and the
+// curve / subgroup checks of the decoders (/root/reference/src/utils.rs:113, :125).
+#pragma once
+#include "bn254_field.h"
+
+namespace bn254 {
+
+// field traits so one template serves G1 (Fq) and G2 (Fq2)
+BN_DEV Fp f_add(const Fp& a, const Fp& b) { return fp_add(a, b); }
+BN_DEV Fp f_sub(const Fp& a, const Fp& b) { return fp_sub(a, b); }
+BN_DEV Fp f_dbl(const Fp& a) { return fp_dbl(a); }
+BN_DEV Fp f_mul(const Fp& a, const Fp& b) { return fp_mul(a, b); }
+BN_DEV Fp f_sqr(const Fp& a) { return fp_sqr(a); }
+BN_DEV Fp f_neg(const Fp& a) { return fp_neg(a); }
+BN_DEV bool f_is_zero(const Fp& a) { return fp_is_zero(a); }
+BN_DEV bool f_eq(const Fp& a, const Fp& b) { return fp_eq(a, b); }
+BN_DEV Fp f_select(bool c, const Fp& a, const Fp& b) { return fp_select(c, a, b); }
+BN_DEV Fp f_inv(const Fp& a) { return fp_inv(a); }
+BN_DEV void f_set_one(Fp& a) { a = fp_one(); }
+BN_DEV void f_set_zero(Fp& a) { a = fp_zero(); }
+
+BN_DEV Fp2 f_add(const Fp2& a, const Fp2& b) { return fp2_add(a, b); }
+BN_DEV Fp2 f_sub(const Fp2& a, const Fp2& b) { return fp2_sub(a, b); }
+BN_DEV Fp2 f_dbl(const Fp2& a) { return fp2_dbl(a); }
+BN_DEV Fp2 f_mul(const Fp2& a, const Fp2& b) { return fp2_mul(a, b); }
+BN_DEV Fp2 f_sqr(const Fp2& a) { return fp2_sqr(a); }
+BN_DEV Fp2 f_neg(const Fp2& a) { return fp2_neg(a); }
+BN_DEV bool f_is_zero(const Fp2& a) { return fp2_is_zero(a); }
+BN_DEV bool f_eq(const Fp2& a, const Fp2& b) { return fp2_eq(a, b); }
+BN_DEV Fp2 f_select(bool c, const Fp2& a, const Fp2& b) { return fp2_select(c, a, b); }
+BN_DEV Fp2 f_inv(const Fp2& a) { return fp2_inv(a); }
+BN_DEV void f_set_one(Fp2& a) { a = fp2_one(); }
+BN_DEV void f_set_zero(Fp2& a) { a = fp2_zero(); }
+
+template <class F> struct Affine { F x, y; bool inf; };
+template <class F> struct Jac { F x, y, z; };   // z == 0 <=> identity
+typedef Affine<Fp> G1Affine;
+typedef Affine<Fp2> G2Affine;
+typedef Jac<Fp> G1Jac;
+typedef Jac<Fp2> G2Jac;
+
+template <class F> BN_DEV void jac_set_identity(Jac<F>& r) { f_set_one(r.x); f_set_one(r.y); f_set_zero(r.z); }
+template <class F> BN_DEV bool jac_is_identity(const Jac<F>& p) { return f_is_zero(p.z); }
+template <class F> BN_DEV void jac_from_affine(Jac<F>& r, const Affine<F>& p) {
+  if (p.inf) { jac_set_identity(r); return; }
+  r.x = p.x; r.y = p.y; f_set_one(r.z);
+}
+template <class F> BN_DEV void jac_select(Jac<F>& r, bool c, const Jac<F>& a, const Jac<F>& b) {
+  r.x = f_select(c, a.x, b.x); r.y = f_select(c, a.y, b.y); r.z = f_select(c, a.z, b.z);
+}
+
+// dbl-2009-l (a = 0); the identity (z = 0) maps to z = 0 without a branch
+template <class F> BN_DEVN void jac_dbl(Jac<F>& r, const Jac<F>& p) {
+  F a = f_sqr(p.x), b = f_sqr(p.y), c = f_sqr(b);
+  F d = f_dbl(f_sub(f_sub(f_sqr(f_add(p.x, b)), a), c));
+  F e = f_add(f_dbl(a), a), f = f_sqr(e);
+  F x3 = f_sub(f, f_dbl(d));
+  F z3 = f_dbl(f_mul(p.y, p.z));
+  F c8 = f_dbl(f_dbl(f_dbl(c)));
+  F y3 = f_sub(f_mul(e, f_sub(d, x3)), c8);
+  r.x = x3; r.y = y3; r.z = z3;
+}
+
+// add-2007-bl with every exceptional case resolved by selects (lanes never diverge):
+// P = O -> Q, Q = O -> P, P = Q -> 2P, P = -Q -> O
+template <class F> BN_DEVN void jac_add(Jac<F>& r, const Jac<F>& p, const Jac<F>& q) {
+  F z1z1 = f_sqr(p.z), z2z2 = f_sqr(q.z);
+  F u1 = f_mul(p.x, z2z2), u2 = f_mul(q.x, z1z1);
+  F s1 = f_mul(f_mul(p.y, q.z), z2z2), s2 = f_mul(f_mul(q.y, p.z), z1z1);
+  F h = f_sub(u2, u1), i = f_sqr(f_dbl(h)), j = f_mul(h, i);
+  F rr = f_dbl(f_sub(s2, s1)), v = f_mul(u1, i);
+  Jac<F> o;
+  o.x = f_sub(f_sub(f_sqr(rr), j), f_dbl(v));
+  o.y = f_sub(f_mul(rr, f_sub(v, o.x)), f_dbl(f_mul(s1, j)));
+  o.z = f_mul(f_sub(f_sub(f_sqr(f_add(p.z, q.z)), z1z1), z2z2), h);
+  bool p_inf = f_is_zero(p.z), q_inf = f_is_zero(q.z);
+  bool same_x = f_is_zero(h), same_y = f_is_zero(rr);
+  Jac<F> d;
+  jac_dbl(d, p);
+  Jac<F> id;
+  jac_set_identity(id);
+  // generic result, then overrides in increasing priority
+  jac_select(o, same_x && same_y, d, o);
+  jac_select(o, same_x && !same_y, id, o);
+  jac_select(o, q_inf, p, o);
+  jac_select(o, p_inf, q, o);
+  r = o;
+}
+
+// k * P for a per-lane 256-bit scalar (plain little-endian limbs, used as-is, not reduced —
+// /root/reference/src/bn256.json:54-159 has scalars up to 2^256-1).  Fixed 256-step ladder of
+// double + add-with-select: identical control flow in every lane.
+template <class F> BN_DEVN void jac_mul(Jac<F>& r, const Jac<F>& p, const uint32_t* k) {
+  Jac<F> acc, t;
+  jac_set_identity(acc);
+  for (int i = 255; i >= 0; --i) {
+    jac_dbl(acc, acc);
+    jac_add(t, acc, p);
+    bool bit = (k[i >> 5] >> (i & 31)) & 1;
+    jac_select(acc, bit, t, acc);
+  }
+  r = acc;
+}
+
+template <class F> BN_DEVN void jac_to_affine(Affine<F>& r, const Jac<F>& p) {
+  bool inf = f_is_zero(p.z);
+  F zi = f_inv(p.z), zi2 = f_sqr(zi);
+  r.x = f_mul(p.x, zi2);
+  r.y = f_mul(p.y, f_mul(zi2, zi));
+  r.inf = inf;
+  if (inf) { f_set_zero(r.x); f_set_zero(r.y); }
+}
+
+BN_DEV bool g1_on_curve(const G1Affine& p) {   // y^2 = x^3 + 3
+  return p.inf || fp_eq(fp_sqr(p.y), fp_add(fp_mul(fp_sqr(p.x), p.x), fp_load_const(C_THREE)));
+}
+BN_DEV bool g2_on_curve(const G2Affine& p) {   // y^2 = x^3 + 3/xi
+  return p.inf || fp2_eq(fp2_sqr(p.y), fp2_add(fp2_mul(fp2_sqr(p.x), p.x), fp2_load_const(C_TWIST_B)));
+}
+// order-r subgroup membership of a twist point: [r]P == O  (what AffineG2::new enforces)
+BN_DEVN bool g2_in_subgroup(const G2Affine& p) {
+  G2Jac j, o;
+  jac_from_affine(j, p);
+  uint32_t k[8];
+  for (int i = 0; i < 8; ++i) k[i] = C_ORDER_R[i];
+  jac_mul(o, j, k);
+  return p.inf || jac_is_identity(o);
+}
+
+}  // namespace bn254

@@ -1,0 +1,120 @@
+// SHA-256 and the try-and-increment hash-to-G1 of the reference, one message per lane.
+//
+// Follows /root/reference/src/hash.rs:29-63 step by step (see hash_to_g1 below); the SHA-256
+// is the `sha2::Sha256::digest` call at /root/reference/src/hash.rs:42, restated from FIPS 180-4.
+// Byte/status formats: include/bn254_hip.h.
+#pragma once
+#include "bn254_curve.h"
+
+namespace bn254 {
+
+BN_CONST uint32_t C_SHA_K[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be,
+    0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa,
+    0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85,
+    0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3,
+    0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f,
+    0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+
+BN_DEV uint32_t rotr32(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+
+BN_DEVN void sha256_compress(uint32_t* h, const uint32_t* blk) {
+  uint32_t w[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) w[i] = blk[i];
+  uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+#pragma unroll
+  for (int i = 0; i < 64; ++i) {
+    uint32_t wi;
+    if (i < 16) {
+      wi = w[i];
+    } else {
+      uint32_t w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15];
+      uint32_t s0 = rotr32(w15, 7) ^ rotr32(w15, 18) ^ (w15 >> 3);
+      uint32_t s1 = rotr32(w2, 17) ^ rotr32(w2, 19) ^ (w2 >> 10);
+      wi = w[i & 15] + s0 + w[(i - 7) & 15] + s1;
+      w[i & 15] = wi;
+    }
+    uint32_t t1 = hh + (rotr32(e, 6) ^ rotr32(e, 11) ^ rotr32(e, 25)) + ((e & f) ^ (~e & g)) + C_SHA_K[i] + wi;
+    uint32_t t2 = (rotr32(a, 2) ^ rotr32(a, 13) ^ rotr32(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+    hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+  }
+  h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+}
+
+// byte `pos` of the padded stream  msg || ctr || 0x80 || 0.. || be64(8*(len+1))
+BN_DEV uint32_t padded_byte(const uint8_t* msg, uint64_t len, uint32_t ctr, uint64_t pos, uint64_t padded_len) {
+  if (pos < len) return msg[pos];
+  if (pos == len) return ctr;
+  if (pos == len + 1) return 0x80;
+  if (pos >= padded_len - 8) {
+    uint64_t bits = (len + 1) * 8;
+    return (uint32_t)(bits >> (8 * (padded_len - 1 - pos))) & 0xFF;
+  }
+  return 0;
+}
+BN_DEV void load_block(uint32_t* blk, const uint8_t* msg, uint64_t len, uint32_t ctr, uint64_t b, uint64_t padded_len) {
+  for (int i = 0; i < 16; ++i) {
+    uint64_t p = b * 64 + 4 * (uint64_t)i;
+    blk[i] = (padded_byte(msg, len, ctr, p, padded_len) << 24) | (padded_byte(msg, len, ctr, p + 1, padded_len) << 16) |
+             (padded_byte(msg, len, ctr, p + 2, padded_len) << 8) | padded_byte(msg, len, ctr, p + 3, padded_len);
+  }
+}
+
+struct HashState {
+  uint32_t mid[8];       // SHA-256 state after the blocks that do not contain the counter byte
+  uint64_t first_block;  // index of the block holding the counter byte
+  uint64_t n_blocks;     // total blocks of the padded stream
+  uint64_t padded_len;
+};
+BN_DEV void hash_state_init(HashState& s, const uint8_t* msg, uint64_t len) {
+  const uint32_t iv[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+  for (int i = 0; i < 8; ++i) s.mid[i] = iv[i];
+  s.n_blocks = (len + 1 + 1 + 8 + 63) / 64;
+  s.padded_len = s.n_blocks * 64;
+  s.first_block = len / 64;
+  uint32_t blk[16];
+  for (uint64_t b = 0; b < s.first_block; ++b) {
+    load_block(blk, msg, len, 0, b, s.padded_len);
+    sha256_compress(s.mid, blk);
+  }
+}
+
+// One try of /root/reference/src/hash.rs:40-59 for counter `ctr`; true iff it yields a point.
+BN_DEV bool hash_try(G1Affine& out, const HashState& s, const uint8_t* msg, uint64_t len, uint32_t ctr) {
+  uint32_t h[8], blk[16];
+  for (int i = 0; i < 8; ++i) h[i] = s.mid[i];
+  for (uint64_t b = s.first_block; b < s.n_blocks; ++b) {        // hash.rs:41-42  SHA256(msg || ctr)
+    load_block(blk, msg, len, ctr, b, s.padded_len);
+    sha256_compress(h, blk);
+  }
+  Fp x;                                                          // hash.rs:44: digest read big-endian
+#pragma unroll
+  for (int i = 0; i < 8; ++i) x.v[i] = h[7 - i];
+  if (u256_geq(x.v, C_QMULT[4])) return false;                   // hash.rs:49-51: h >= 5q -> next ctr
+  // utils.rs:27-37 mod_u256: while x > q { x -= q } (strict), i.e. x mod q except exact multiples
+  // k*q (k >= 1), which stop at q and are then rejected by Fq::from_slice
+  bool was_reduced = false;
+  for (int k = 3; k >= 0; --k) {
+    if (!was_reduced && u256_geq(x.v, C_QMULT[k])) {
+      uint32_t bw = 0;
+      for (int i = 0; i < 8; ++i) {
+        uint64_t d = (uint64_t)x.v[i] - C_QMULT[k][i] - bw;
+        x.v[i] = (uint32_t)d; bw = (uint32_t)(d >> 63);
+      }
+      was_reduced = true;
+    }
+  }
+  if (was_reduced && fp_is_zero(x)) return false;
+  // utils.rs:56-63 arbitrary_string_to_g1 -> G1::from_compressed(0x02 || x): even root of x^3 + 3
+  Fp xm = fp_to_mont(x);
+  Fp rhs = fp_add(fp_mul(fp_sqr(xm), xm), fp_load_const(C_THREE));
+  Fp y;
+  if (!fp_sqrt(y, rhs)) return false;
+  Fp yp = fp_from_mont(y);
+  if (yp.v[0] & 1) y = fp_neg(y);
+  out.x = xm; out.y = y; out.inf = false;
+  return true;
+}
+
+}  // namespace bn254

@@ -1,0 +1,778 @@
+// libbn254hip.so — HIP kernels for gfx950 (MI355X) + the C ABI declared in include/bn254_hip.h.
+//
+// Execution model: one item (verify / pairing / point operation) per wavefront lane, one
+// 64-lane wave per workgroup so the dispatcher can spread waves over all 1024 SIMDs.  A batch
+// is processed by a short chain of kernels that hand per-item state to each other through an
+// HBM workspace laid out limb-major ("planes"): word k of field element e of item i lives at
+//   ws[(e*8 + k) * stride + i]
+// so the 64 lanes of a wave read/write 256 contiguous bytes per limb (fully coalesced), and the
+// caller-facing byte formats (AoS, big-endian) are touched exactly once on the way in/out.
+//
+//   batch_verify:  k_verify_decode -> k_hash_to_g1 -> k_miller_verify -> k_final_exp
+//
+// HBM traffic per verify is 225 B of input/output + 2 x ~1 KB of workspace hand-off against
+// ~24 k Montgomery products: the path is bound by VALU integer-multiply issue, not by HBM.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "../../include/bn254_hip.h"
+#include "bn254_hash.h"
+#include "bn254_io.h"
+#include "bn254_pairing.h"
+
+using namespace bn254;
+
+#define BN_WAVE 64
+#define KERNEL __global__ __launch_bounds__(BN_WAVE)
+
+// ------------------------------------------------------------------------------------------
+// workspace planes
+// ------------------------------------------------------------------------------------------
+struct Ws {
+  uint32_t* planes;   // [N_PLANES * 8][stride] u32
+  uint8_t* bytes;     // [N_BYTE_PLANES][stride]
+  size_t stride;
+};
+enum { PL_P1X = 0, PL_P1Y, PL_QX0, PL_QX1, PL_QY0, PL_QY1, PL_P2X, PL_P2Y, PL_F0, N_PLANES = PL_F0 + 12 };
+enum { BY_ST_DECODE = 0, BY_ST_HASH, BY_P1_INF, BY_Q_INF, BY_P2_INF, N_BYTE_PLANES };
+
+__device__ __forceinline__ Fp ws_load_fp(const Ws& ws, int plane, size_t i) {
+  Fp r;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) r.v[k] = ws.planes[((size_t)plane * 8 + k) * ws.stride + i];
+  return r;
+}
+__device__ __forceinline__ void ws_store_fp(const Ws& ws, int plane, size_t i, const Fp& a) {
+#pragma unroll
+  for (int k = 0; k < 8; ++k) ws.planes[((size_t)plane * 8 + k) * ws.stride + i] = a.v[k];
+}
+__device__ __forceinline__ uint8_t& ws_byte(const Ws& ws, int plane, size_t i) { return ws.bytes[(size_t)plane * ws.stride + i]; }
+
+__device__ __forceinline__ void ws_store_f12(const Ws& ws, size_t i, const Fp12& f) {
+  const Fp2* c[6] = {&f.c0.c0, &f.c0.c1, &f.c0.c2, &f.c1.c0, &f.c1.c1, &f.c1.c2};
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { ws_store_fp(ws, PL_F0 + 2 * k, i, c[k]->c0); ws_store_fp(ws, PL_F0 + 2 * k + 1, i, c[k]->c1); }
+}
+__device__ __forceinline__ void ws_load_f12(const Ws& ws, size_t i, Fp12& f) {
+  Fp2* c[6] = {&f.c0.c0, &f.c0.c1, &f.c0.c2, &f.c1.c0, &f.c1.c1, &f.c1.c2};
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { c[k]->c0 = ws_load_fp(ws, PL_F0 + 2 * k, i); c[k]->c1 = ws_load_fp(ws, PL_F0 + 2 * k + 1, i); }
+}
+__device__ __forceinline__ void ws_store_g1(const Ws& ws, int px, int inf_plane, size_t i, const G1Affine& p) {
+  ws_store_fp(ws, px, i, p.x); ws_store_fp(ws, px + 1, i, p.y); ws_byte(ws, inf_plane, i) = p.inf;
+}
+__device__ __forceinline__ void ws_load_g1(const Ws& ws, int px, int inf_plane, size_t i, G1Affine& p) {
+  p.x = ws_load_fp(ws, px, i); p.y = ws_load_fp(ws, px + 1, i); p.inf = ws_byte(ws, inf_plane, i) != 0;
+}
+__device__ __forceinline__ void ws_store_g2(const Ws& ws, size_t i, const G2Affine& q) {
+  ws_store_fp(ws, PL_QX0, i, q.x.c0); ws_store_fp(ws, PL_QX1, i, q.x.c1);
+  ws_store_fp(ws, PL_QY0, i, q.y.c0); ws_store_fp(ws, PL_QY1, i, q.y.c1);
+  ws_byte(ws, BY_Q_INF, i) = q.inf;
+}
+__device__ __forceinline__ void ws_load_g2(const Ws& ws, size_t i, G2Affine& q) {
+  q.x.c0 = ws_load_fp(ws, PL_QX0, i); q.x.c1 = ws_load_fp(ws, PL_QX1, i);
+  q.y.c0 = ws_load_fp(ws, PL_QY0, i); q.y.c1 = ws_load_fp(ws, PL_QY1, i);
+  q.inf = ws_byte(ws, BY_Q_INF, i) != 0;
+}
+// a lane whose input failed to decode walks the rest of the pipeline on the generators so that
+// every wave stays convergent; its status byte keeps the decode error.
+__device__ __forceinline__ void g1_set_generator(G1Affine& p) { p.x = fp_load_const(C_G1_GEN[0]); p.y = fp_load_const(C_G1_GEN[1]); p.inf = false; }
+__device__ __forceinline__ void g2_set_generator(G2Affine& q) { q.x = fp2_load_const(C_G2_GEN[0]); q.y = fp2_load_const(C_G2_GEN[1]); q.inf = false; }
+
+// ------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------
+// decode n G1 points (64 B each) into planes (px, px+1) + inf byte plane; status into st_plane
+// (first error wins if `accumulate`)
+KERNEL void k_decode_g1(const uint8_t* pts, size_t n, uint32_t flags, Ws ws, int px, int inf_plane, int accumulate) {
+  size_t i = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
+  if (i >= n) return;
+  G1Affine p;
+  uint8_t st = decode_g1(p, pts + 64 * i, flags);
+  if (st != ST_OK) g1_set_generator(p);
+  ws_store_g1(ws, px, inf_plane, i, p);
+  uint8_t prev = accumulate ? ws_byte(ws, BY_ST_DECODE, i) : (uint8_t)ST_OK;
+  ws_byte(ws, BY_ST_DECODE, i) = prev != ST_OK ? prev : st;
+}
+KERNEL void k_decode_g2(const uint8_t* pts, size_t n, uint32_t flags, Ws ws, int accumulate) {
+  size_t i = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
+  if (i >= n) return;
+  G2Affine q;
+  uint8_t st = decode_g2(q, pts + 128 * i, flags);
+  if (st != ST_OK) g2_set_generator(q);
+  if (flags & FLAG_G2_SUBGROUP_CHECK) {   // wave-uniform branch; every lane runs the ladder
+    bool in = g2_in_subgroup(q);
+    if (st == ST_OK && !in) { st = ST_INVALID_GROUP_POINT; g2_set_generator(q); }
+  }
+  ws_store_g2(ws, i, q);
+  uint8_t prev = accumulate ? ws_byte(ws, BY_ST_DECODE, i) : (uint8_t)ST_OK;
+  ws_byte(ws, BY_ST_DECODE, i) = prev != ST_OK ? prev : st;
+}
+
+// hash_to_try_and_increment of message i -> G1 planes (px, px+1); naive per-lane retry loop:
+// a wave iterates until its slowest lane has found a point.
+KERNEL void k_hash_to_g1(const uint8_t* msgs, const uint64_t* off, size_t n, Ws ws, int px, int inf_plane, uint8_t* tries_out) {
+  size_t i = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t* msg = msgs + off[i];
+  uint64_t len = off[i + 1] - off[i];
+  HashState hs;
+  hash_state_init(hs, msg, len);
+  G1Affine p;
+  g1_set_generator(p);
+  bool done = false;
+  uint32_t tries = 0;
+  for (uint32_t ctr = 0; ctr < 255; ++ctr) {          // hash.rs:40  (0..255)
+    if (!done) {
+      done = hash_try(p, hs, msg, len, ctr);
+      tries = ctr + 1;
+    }
+    if (!__any(!done)) break;
+  }
+  if (!done) g1_set_generator(p);
+  ws_store_g1(ws, px, inf_plane, i, p);
+  ws_byte(ws, BY_ST_HASH, i) = done ? ST_OK : ST_HASH_TO_POINT;   // hash.rs:62
+  if (tries_out) tries_out[i] = (uint8_t)tries;
+}
+
+// ECDSA::verify Miller loop: f = miller(H(m), pk) * miller(sig, -G2)   (ecdsa.rs:53-57)
+// P1 planes hold sig, P2 planes hold H(m), Q planes hold pk.
+KERNEL void k_miller_verify(size_t n, Ws ws) {
+  size_t i = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
+  if (i >= n) return;
+  G1Affine sig, h;
+  G2Affine pk;
+  ws_load_g1(ws, PL_P1X, BY_P1_INF, i, sig);
+  ws_load_g1(ws, PL_P2X, BY_P2_INF, i, h);
+  ws_load_g2(ws, i, pk);
+  Fp12 f;
+  miller_loop<true, true>(f, h, pk, sig);
+  ws_store_f12(ws, i, f);
+}
+// generic single pair per lane: f = miller(P1, Q)
+KERNEL void k_miller_var(size_t n, Ws ws) {
+  size_t i = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
+  if (i >= n) return;
+  G1Affine p;
+  G2Affine q;
+  ws_load_g1(ws, PL_P1X, BY_P1_INF, i, p);
+  ws_load_g2(ws, i, q);
+  Fp12 f;
+  miller_loop<true, false>(f, p, q, p);
+  ws_store_f12(ws, i, f);
+}
+// check_public_keys Miller loop: miller(G1::one(), pk_g2) * miller(pk_g1, -G2)   (ecdsa.rs:80-86)
+KERNEL void k_miller_cpk(size_t n, Ws ws) {
+  size_t i = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
+  if (i >= n) return;
+  G1Affine pk1, g;
+  G2Affine pk2;
+  ws_load_g1(ws, PL_P1X, BY_P1_INF, i, pk1);
+  ws_load_g2(ws, i, pk2);
+  g1_set_generator(g);
+  Fp12 f;
+  miller_loop<true, true>(f, g, pk2, pk1);
+  ws_store_f12(ws, i, f);
+}
+
+// item i: product of the k Miller values f[i*k .. i*k+k), final exponentiation, compare with one.
+// status = first decode error among its pairs, else hash error (if use_hash), else 0 / 9.
+KERNEL void k_final_exp(size_t n, size_t k, Ws ws, int use_hash, uint8_t* gt_out, uint8_t* status_out, int raw_only) {
+  size_t i = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
+  if (i >= n) return;
+  Fp12 f, g;
+  ws_load_f12(ws, i * k, f);
+  uint8_t st = ws_byte(ws, BY_ST_DECODE, i * k);
+  for (size_t j = 1; j < k; ++j) {
+    ws_load_f12(ws, i * k + j, g);
+    fp12_mul(f, f, g);
+    uint8_t sj = ws_byte(ws, BY_ST_DECODE, i * k + j);
+    if (st == ST_OK) st = sj;
+  }
+  if (st == ST_OK && use_hash) st = ws_byte(ws, BY_ST_HASH, i);
+  if (!raw_only) final_exponentiation(f, f);
+  if (gt_out) encode_fp12(gt_out + 384 * i, f);
+  if (status_out) status_out[i] = st != ST_OK ? st : (fp12_is_one(f) ? (uint8_t)ST_OK : (uint8_t)ST_VERIFICATION_FAILED);
+}
+
+// out[i] = a[i] + b[i]
+KERNEL void k_g1_add(const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out, uint8_t* status) {
+  size_t i = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
+  if (i >= n) return;
+  G1Affine pa, pb, r;
+  uint8_t st = decode_g1(pa, a + 64 * i, 0);
+  uint8_t sb = decode_g1(pb, b + 64 * i, 0);
+  if (st == ST_OK) st = sb;
+  if (st != ST_OK) { g1_set_generator(pa); g1_set_generator(pb); }
+  G1Jac ja, jb, jo;
+  jac_from_affine(ja, pa); jac_from_affine(jb, pb);
+  jac_add(jo, ja, jb);
+  jac_to_affine(r, jo);
+  if (st != ST_OK) r.inf = true;
+  encode_g1(out + 64 * i, r);
+  status[i] = st;
+}
+KERNEL void k_g2_add(const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out, uint8_t* status) {
+  size_t i = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
+  if (i >= n) return;
+  G2Affine pa, pb, r;
+  uint8_t st = decode_g2(pa, a + 128 * i, 0);
+  uint8_t sb = decode_g2(pb, b + 128 * i, 0);
+  if (st == ST_OK) st = sb;
+  if (st != ST_OK) { g2_set_generator(pa); g2_set_generator(pb); }
+  G2Jac ja, jb, jo;
+  jac_from_affine(ja, pa); jac_from_affine(jb, pb);
+  jac_add(jo, ja, jb);
+  jac_to_affine(r, jo);
+  if (st != ST_OK) r.inf = true;
+  encode_g2(out + 128 * i, r);
+  status[i] = st;
+}
+// out[i] = scalar[i] * p[i]; p == nullptr: the point comes from the P1 planes (ECDSA::sign: H(m))
+KERNEL void k_g1_mul(const uint8_t* p, const uint8_t* scalars, size_t n, int reduce, Ws ws, uint8_t* out, uint8_t* status) {
+  size_t i = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
+  if (i >= n) return;
+  G1Affine pa, r;
+  uint8_t st;
+  if (p) {
+    st = decode_g1(pa, p + 64 * i, 0);
+  } else {
+    ws_load_g1(ws, PL_P1X, BY_P1_INF, i, pa);
+    st = ws_byte(ws, BY_ST_HASH, i);
+  }
+  if (st != ST_OK) g1_set_generator(pa);
+  uint32_t k[8];
+  scalar_from_be(k, scalars + 32 * i, reduce != 0);
+  G1Jac ja, jo;
+  jac_from_affine(ja, pa);
+  jac_mul(jo, ja, k);
+  jac_to_affine(r, jo);
+  if (st != ST_OK) r.inf = true;
+  encode_g1(out + 64 * i, r);
+  status[i] = st;
+}
+// p == nullptr: multiply the G2 generator (PublicKey::from_private_key)
+KERNEL void k_g2_mul(const uint8_t* p, const uint8_t* scalars, size_t n, int reduce, uint8_t* out, uint8_t* status) {
+  size_t i = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
+  if (i >= n) return;
+  G2Affine pa, r;
+  uint8_t st = ST_OK;
+  if (p) st = decode_g2(pa, p + 128 * i, 0); else g2_set_generator(pa);
+  if (st != ST_OK) g2_set_generator(pa);
+  uint32_t k[8];
+  scalar_from_be(k, scalars + 32 * i, reduce != 0);
+  G2Jac ja, jo;
+  jac_from_affine(ja, pa);
+  jac_mul(jo, ja, k);
+  jac_to_affine(r, jo);
+  if (st != ST_OK) r.inf = true;
+  encode_g2(out + 128 * i, r);
+  status[i] = st;
+}
+// segmented sums (aggregation): out[i] = sum points[seg[i] .. seg[i+1])
+KERNEL void k_g1_sum(const uint8_t* pts, const uint64_t* seg, size_t n, uint8_t* out, uint8_t* status) {
+  size_t i = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
+  if (i >= n) return;
+  G1Jac acc, t;
+  jac_set_identity(acc);
+  uint8_t st = ST_OK;
+  for (uint64_t j = seg[i]; j < seg[i + 1]; ++j) {
+    G1Affine p;
+    uint8_t s = decode_g1(p, pts + 64 * j, 0);
+    if (s != ST_OK) { if (st == ST_OK) st = s; continue; }
+    jac_from_affine(t, p);
+    jac_add(acc, acc, t);
+  }
+  G1Affine r;
+  jac_to_affine(r, acc);
+  if (st != ST_OK) r.inf = true;
+  encode_g1(out + 64 * i, r);
+  status[i] = st;
+}
+KERNEL void k_g2_sum(const uint8_t* pts, const uint64_t* seg, size_t n, uint8_t* out, uint8_t* status) {
+  size_t i = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
+  if (i >= n) return;
+  G2Jac acc, t;
+  jac_set_identity(acc);
+  uint8_t st = ST_OK;
+  for (uint64_t j = seg[i]; j < seg[i + 1]; ++j) {
+    G2Affine p;
+    uint8_t s = decode_g2(p, pts + 128 * j, 0);
+    if (s != ST_OK) { if (st == ST_OK) st = s; continue; }
+    jac_from_affine(t, p);
+    jac_add(acc, acc, t);
+  }
+  G2Affine r;
+  jac_to_affine(r, acc);
+  if (st != ST_OK) r.inf = true;
+  encode_g2(out + 128 * i, r);
+  status[i] = st;
+}
+// encode the G1 planes (px, px+1) as uncompressed bytes
+KERNEL void k_encode_g1(size_t n, Ws ws, int px, int inf_plane, uint8_t* out, uint8_t* status_out) {
+  size_t i = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
+  if (i >= n) return;
+  G1Affine p;
+  ws_load_g1(ws, px, inf_plane, i, p);
+  uint8_t st = ws_byte(ws, BY_ST_HASH, i);
+  if (st != ST_OK) p.inf = true;
+  encode_g1(out + 64 * i, p);
+  if (status_out) status_out[i] = st;
+}
+
+// --- test hooks ---------------------------------------------------------------------------
+KERNEL void k_debug_fp_op(int op, const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out, uint8_t* status) {
+  size_t i = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
+  if (i >= n) return;
+  uint32_t any = 0;
+  Fp x, y, r;
+  bool ok = fp_from_be(x, a + 32 * i, any);
+  if (b) ok = fp_from_be(y, b + 32 * i, any) && ok; else y = fp_zero();
+  uint8_t st = ok ? ST_OK : ST_NOT_MEMBER;
+  switch (op) {
+    case 0: r = fp_mul(x, y); break;
+    case 1: r = fp_add(x, y); break;
+    case 2: r = fp_sub(x, y); break;
+    case 3: r = fp_inv(x); break;
+    case 4: r = fp_sqr(x); break;
+    default: if (!fp_sqrt(r, x) && st == ST_OK) st = ST_NOT_MEMBER; break;
+  }
+  fp_to_be(out + 32 * i, r);
+  status[i] = st;
+}
+__device__ __forceinline__ void decode_fp12(Fp12& f, const uint8_t* b) {
+  uint32_t any = 0;
+  Fp2* c[6] = {&f.c0.c0, &f.c0.c1, &f.c0.c2, &f.c1.c0, &f.c1.c1, &f.c1.c2};
+  for (int k = 0; k < 6; ++k) { fp_from_be(c[k]->c0, b + 64 * k, any); fp_from_be(c[k]->c1, b + 64 * k + 32, any); }
+}
+KERNEL void k_debug_fp12_op(int op, const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out) {
+  size_t i = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
+  if (i >= n) return;
+  Fp12 x, y, r;
+  decode_fp12(x, a + 384 * i);
+  if (b) decode_fp12(y, b + 384 * i); else fp12_set_one(y);
+  switch (op) {
+    case 0: fp12_mul(r, x, y); break;
+    case 1: fp12_sqr(r, x); break;
+    case 2: fp12_inv(r, x); break;
+    case 3: fp12_conj(r, x); break;
+    case 4: fp12_frob(r, x, 1); break;
+    case 5: fp12_frob(r, x, 2); break;
+    case 6: fp12_frob(r, x, 3); break;
+    case 7: fp12_cyclotomic_sqr(r, x); break;
+    default: final_exponentiation(r, x); break;
+  }
+  encode_fp12(out + 384 * i, r);
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+struct bn254_ctx {
+  int device;
+  hipStream_t stream;
+  Ws ws;
+  // staging buffers for the host-pointer entry points (device memory, grown on demand)
+  uint8_t* stage[8];
+  size_t stage_cap[8];
+  int profiling;
+  hipEvent_t ev[5];
+  int ev_valid;
+};
+
+#define HIP_TRY(expr)                                      \
+  do {                                                     \
+    hipError_t e_ = (expr);                                \
+    if (e_ != hipSuccess) return -(int)e_;                 \
+  } while (0)
+
+static inline unsigned grid_for(size_t n) { return (unsigned)((n + BN_WAVE - 1) / BN_WAVE); }
+
+static int ws_reserve(bn254_ctx* c, size_t n) {
+  if (n <= c->ws.stride) return 0;
+  size_t cap = (n + 255) & ~(size_t)255;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (c->ws.planes) { HIP_TRY(hipFree(c->ws.planes)); c->ws.planes = nullptr; }
+  if (c->ws.bytes) { HIP_TRY(hipFree(c->ws.bytes)); c->ws.bytes = nullptr; }
+  c->ws.stride = 0;
+  HIP_TRY(hipMalloc((void**)&c->ws.planes, (size_t)N_PLANES * 8 * sizeof(uint32_t) * cap));
+  HIP_TRY(hipMalloc((void**)&c->ws.bytes, (size_t)N_BYTE_PLANES * cap));
+  c->ws.stride = cap;
+  return 0;
+}
+static int stage_reserve(bn254_ctx* c, int slot, size_t bytes) {
+  if (bytes <= c->stage_cap[slot]) return 0;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (c->stage[slot]) { HIP_TRY(hipFree(c->stage[slot])); c->stage[slot] = nullptr; c->stage_cap[slot] = 0; }
+  size_t cap = (bytes + 4095) & ~(size_t)4095;
+  HIP_TRY(hipMalloc((void**)&c->stage[slot], cap));
+  c->stage_cap[slot] = cap;
+  return 0;
+}
+static int stage_in(bn254_ctx* c, int slot, const void* host, size_t bytes) {
+  int rc = stage_reserve(c, slot, bytes ? bytes : 1);
+  if (rc) return rc;
+  if (bytes) HIP_TRY(hipMemcpyAsync(c->stage[slot], host, bytes, hipMemcpyHostToDevice, c->stream));
+  return 0;
+}
+static int stage_out(bn254_ctx* c, int slot, void* host, size_t bytes) {
+  if (bytes) HIP_TRY(hipMemcpyAsync(host, c->stage[slot], bytes, hipMemcpyDeviceToHost, c->stream));
+  return 0;
+}
+static bool misaligned(const void* p) { return ((uintptr_t)p & 3u) != 0; }
+
+extern "C" {
+
+const char* bn254_version(void) { return "bn254-mi355x 0.1 (gfx950; 8x32-bit Montgomery limbs, one item per lane)"; }
+
+int bn254_ctx_create(int hip_device, bn254_ctx** out) {
+  if (!out) return BN254_E_BAD_ARGUMENT;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) return BN254_E_NO_DEVICE;   // no CPU fallback, by design
+  if (hip_device < 0 || hip_device >= count) return BN254_E_BAD_ARGUMENT;
+  HIP_TRY(hipSetDevice(hip_device));
+  bn254_ctx* c = new (std::nothrow) bn254_ctx();
+  if (!c) return BN254_E_BAD_ARGUMENT;
+  memset(c, 0, sizeof *c);
+  c->device = hip_device;
+  HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  for (int i = 0; i < 5; ++i) HIP_TRY(hipEventCreate(&c->ev[i]));
+  *out = c;
+  return 0;
+}
+void bn254_ctx_destroy(bn254_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  if (c->ws.planes) (void)hipFree(c->ws.planes);
+  if (c->ws.bytes) (void)hipFree(c->ws.bytes);
+  for (int i = 0; i < 8; ++i) if (c->stage[i]) (void)hipFree(c->stage[i]);
+  for (int i = 0; i < 5; ++i) (void)hipEventDestroy(c->ev[i]);
+  (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+int bn254_ctx_reserve(bn254_ctx* c, size_t n) { return c ? ws_reserve(c, n) : BN254_E_BAD_ARGUMENT; }
+int bn254_ctx_synchronize(bn254_ctx* c) {
+  if (!c) return BN254_E_BAD_ARGUMENT;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+int bn254_ctx_set_profiling(bn254_ctx* c, int enabled) {
+  if (!c) return BN254_E_BAD_ARGUMENT;
+  c->profiling = enabled;
+  c->ev_valid = 0;
+  return 0;
+}
+int bn254_ctx_last_kernel_ms(bn254_ctx* c, float ms[4]) {
+  if (!c || !ms || !c->ev_valid) return BN254_E_BAD_ARGUMENT;
+  HIP_TRY(hipEventSynchronize(c->ev[4]));
+  for (int i = 0; i < 4; ++i) HIP_TRY(hipEventElapsedTime(&ms[i], c->ev[i], c->ev[i + 1]));
+  return 0;
+}
+
+#define PROF_MARK(idx) do { if (c->profiling && s == c->stream) HIP_TRY(hipEventRecord(c->ev[idx], s)); } while (0)
+
+int bn254_batch_verify_device(bn254_ctx* c, const uint8_t* d_msgs, const uint64_t* d_off, const uint8_t* d_sigs, const uint8_t* d_pks,
+                              size_t n, uint32_t flags, uint8_t* d_status, void* stream) {
+  if (!c || (n && (!d_msgs || !d_off || !d_sigs || !d_pks || !d_status))) return BN254_E_BAD_ARGUMENT;
+  if (n == 0) return 0;
+  if (misaligned(d_sigs) || misaligned(d_pks) || ((uintptr_t)d_off & 7u)) return BN254_E_MISALIGNED;
+  HIP_TRY(hipSetDevice(c->device));
+  int rc = ws_reserve(c, n);
+  if (rc) return rc;
+  hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  unsigned g = grid_for(n);
+  PROF_MARK(0);
+  k_decode_g1<<<g, BN_WAVE, 0, s>>>(d_sigs, n, flags, c->ws, PL_P1X, BY_P1_INF, 0);
+  k_decode_g2<<<g, BN_WAVE, 0, s>>>(d_pks, n, flags, c->ws, 1);
+  PROF_MARK(1);
+  k_hash_to_g1<<<g, BN_WAVE, 0, s>>>(d_msgs, d_off, n, c->ws, PL_P2X, BY_P2_INF, nullptr);
+  PROF_MARK(2);
+  k_miller_verify<<<g, BN_WAVE, 0, s>>>(n, c->ws);
+  PROF_MARK(3);
+  k_final_exp<<<g, BN_WAVE, 0, s>>>(n, 1, c->ws, 1, nullptr, d_status, 0);
+  PROF_MARK(4);
+  if (c->profiling && s == c->stream) c->ev_valid = 1;
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int bn254_batch_verify(bn254_ctx* c, const uint8_t* msgs, const uint64_t* off, const uint8_t* sigs, const uint8_t* pks, size_t n,
+                       uint32_t flags, uint8_t* status) {
+  if (!c || (n && (!off || !sigs || !pks || !status))) return BN254_E_BAD_ARGUMENT;
+  if (n == 0) return 0;
+  HIP_TRY(hipSetDevice(c->device));
+  size_t msg_bytes = (size_t)off[n];
+  int rc;
+  if ((rc = stage_in(c, 0, msgs, msg_bytes))) return rc;
+  if ((rc = stage_in(c, 1, off, (n + 1) * sizeof(uint64_t)))) return rc;
+  if ((rc = stage_in(c, 2, sigs, n * 64))) return rc;
+  if ((rc = stage_in(c, 3, pks, n * 128))) return rc;
+  if ((rc = stage_reserve(c, 4, n))) return rc;
+  if ((rc = bn254_batch_verify_device(c, c->stage[0], (const uint64_t*)c->stage[1], c->stage[2], c->stage[3], n, flags, c->stage[4], nullptr))) return rc;
+  if ((rc = stage_out(c, 4, status, n))) return rc;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int bn254_batch_hash_to_g1_device(bn254_ctx* c, const uint8_t* d_msgs, const uint64_t* d_off, size_t n, uint8_t* d_points, uint8_t* d_status,
+                                  uint8_t* d_tries, void* stream) {
+  if (!c || (n && (!d_msgs || !d_off || !d_points || !d_status))) return BN254_E_BAD_ARGUMENT;
+  if (n == 0) return 0;
+  if (misaligned(d_points) || ((uintptr_t)d_off & 7u)) return BN254_E_MISALIGNED;
+  HIP_TRY(hipSetDevice(c->device));
+  int rc = ws_reserve(c, n);
+  if (rc) return rc;
+  hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  unsigned g = grid_for(n);
+  k_hash_to_g1<<<g, BN_WAVE, 0, s>>>(d_msgs, d_off, n, c->ws, PL_P1X, BY_P1_INF, d_tries);
+  k_encode_g1<<<g, BN_WAVE, 0, s>>>(n, c->ws, PL_P1X, BY_P1_INF, d_points, d_status);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+int bn254_batch_hash_to_g1(bn254_ctx* c, const uint8_t* msgs, const uint64_t* off, size_t n, uint8_t* points, uint8_t* status, uint8_t* tries) {
+  if (!c || (n && (!off || !points || !status))) return BN254_E_BAD_ARGUMENT;
+  if (n == 0) return 0;
+  HIP_TRY(hipSetDevice(c->device));
+  int rc;
+  if ((rc = stage_in(c, 0, msgs, (size_t)off[n]))) return rc;
+  if ((rc = stage_in(c, 1, off, (n + 1) * sizeof(uint64_t)))) return rc;
+  if ((rc = stage_reserve(c, 2, n * 64))) return rc;
+  if ((rc = stage_reserve(c, 3, n))) return rc;
+  if ((rc = stage_reserve(c, 4, n))) return rc;
+  if ((rc = bn254_batch_hash_to_g1_device(c, c->stage[0], (const uint64_t*)c->stage[1], n, c->stage[2], c->stage[3], c->stage[4], nullptr))) return rc;
+  if ((rc = stage_out(c, 2, points, n * 64))) return rc;
+  if ((rc = stage_out(c, 3, status, n))) return rc;
+  if (tries && (rc = stage_out(c, 4, tries, n))) return rc;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// shared by pairing / pairing_check: mode 0 = reduced Gt + status, 1 = raw Miller value (debug)
+static int pairing_device(bn254_ctx* c, const uint8_t* d_g1, const uint8_t* d_g2, size_t n, size_t k, uint32_t flags, uint8_t* d_gt,
+                          uint8_t* d_status, void* stream, int raw_only) {
+  if (!c || k == 0 || (n && (!d_g1 || !d_g2))) return BN254_E_BAD_ARGUMENT;
+  if (n == 0) return 0;
+  if (misaligned(d_g1) || misaligned(d_g2) || (d_gt && misaligned(d_gt))) return BN254_E_MISALIGNED;
+  HIP_TRY(hipSetDevice(c->device));
+  size_t lanes = n * k;
+  int rc = ws_reserve(c, lanes);
+  if (rc) return rc;
+  hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  k_decode_g1<<<grid_for(lanes), BN_WAVE, 0, s>>>(d_g1, lanes, flags, c->ws, PL_P1X, BY_P1_INF, 0);
+  k_decode_g2<<<grid_for(lanes), BN_WAVE, 0, s>>>(d_g2, lanes, flags, c->ws, 1);
+  k_miller_var<<<grid_for(lanes), BN_WAVE, 0, s>>>(lanes, c->ws);
+  k_final_exp<<<grid_for(n), BN_WAVE, 0, s>>>(n, k, c->ws, 0, d_gt, d_status, raw_only);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+int bn254_batch_pairing_device(bn254_ctx* c, const uint8_t* d_g1, const uint8_t* d_g2, size_t n, size_t k, uint32_t flags, uint8_t* d_gt,
+                               uint8_t* d_status, void* stream) {
+  return pairing_device(c, d_g1, d_g2, n, k, flags, d_gt, d_status, stream, 0);
+}
+static int pairing_host(bn254_ctx* c, const uint8_t* g1, const uint8_t* g2, size_t n, size_t k, uint32_t flags, uint8_t* gt, uint8_t* status,
+                        int raw_only) {
+  if (!c || k == 0 || (n && (!g1 || !g2))) return BN254_E_BAD_ARGUMENT;
+  if (n == 0) return 0;
+  HIP_TRY(hipSetDevice(c->device));
+  int rc;
+  if ((rc = stage_in(c, 0, g1, n * k * 64))) return rc;
+  if ((rc = stage_in(c, 1, g2, n * k * 128))) return rc;
+  if ((rc = stage_reserve(c, 2, n * 384))) return rc;
+  if ((rc = stage_reserve(c, 3, n))) return rc;
+  if ((rc = pairing_device(c, c->stage[0], c->stage[1], n, k, flags, gt ? c->stage[2] : nullptr, c->stage[3], nullptr, raw_only))) return rc;
+  if (gt && (rc = stage_out(c, 2, gt, n * 384))) return rc;
+  if (status && (rc = stage_out(c, 3, status, n))) return rc;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+int bn254_batch_pairing_check(bn254_ctx* c, const uint8_t* g1, const uint8_t* g2, size_t n, size_t k, uint32_t flags, uint8_t* status) {
+  if (!status && n) return BN254_E_BAD_ARGUMENT;
+  return pairing_host(c, g1, g2, n, k, flags, nullptr, status, 0);
+}
+int bn254_batch_pairing(bn254_ctx* c, const uint8_t* g1, const uint8_t* g2, size_t n, size_t k, uint32_t flags, uint8_t* gt, uint8_t* status) {
+  if (!gt && n) return BN254_E_BAD_ARGUMENT;
+  return pairing_host(c, g1, g2, n, k, flags, gt, status, 0);
+}
+int bn254_debug_miller_loop(bn254_ctx* c, const uint8_t* g1, const uint8_t* g2, size_t n, uint8_t* f) {
+  if (!f && n) return BN254_E_BAD_ARGUMENT;
+  return pairing_host(c, g1, g2, n, 1, 0, f, nullptr, 1);
+}
+
+int bn254_batch_check_public_keys(bn254_ctx* c, const uint8_t* pk_g2, const uint8_t* pk_g1, size_t n, uint32_t flags, uint8_t* status) {
+  if (!c || (n && (!pk_g2 || !pk_g1 || !status))) return BN254_E_BAD_ARGUMENT;
+  if (n == 0) return 0;
+  HIP_TRY(hipSetDevice(c->device));
+  int rc;
+  if ((rc = ws_reserve(c, n))) return rc;
+  if ((rc = stage_in(c, 0, pk_g2, n * 128))) return rc;
+  if ((rc = stage_in(c, 1, pk_g1, n * 64))) return rc;
+  if ((rc = stage_reserve(c, 2, n))) return rc;
+  hipStream_t s = c->stream;
+  unsigned g = grid_for(n);
+  k_decode_g2<<<g, BN_WAVE, 0, s>>>(c->stage[0], n, flags, c->ws, 0);       // ecdsa.rs:82: pk_g2 first
+  k_decode_g1<<<g, BN_WAVE, 0, s>>>(c->stage[1], n, flags, c->ws, PL_P1X, BY_P1_INF, 1);
+  k_miller_cpk<<<g, BN_WAVE, 0, s>>>(n, c->ws);
+  k_final_exp<<<g, BN_WAVE, 0, s>>>(n, 1, c->ws, 0, nullptr, c->stage[2], 0);
+  HIP_TRY(hipGetLastError());
+  if ((rc = stage_out(c, 2, status, n))) return rc;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// ---- group operations --------------------------------------------------------------------
+static int binop_host(bn254_ctx* c, int g2, const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out, uint8_t* status) {
+  if (!c || (n && (!a || !b || !out || !status))) return BN254_E_BAD_ARGUMENT;
+  if (n == 0) return 0;
+  HIP_TRY(hipSetDevice(c->device));
+  size_t sz = g2 ? 128 : 64;
+  int rc;
+  if ((rc = stage_in(c, 0, a, n * sz))) return rc;
+  if ((rc = stage_in(c, 1, b, n * sz))) return rc;
+  if ((rc = stage_reserve(c, 2, n * sz))) return rc;
+  if ((rc = stage_reserve(c, 3, n))) return rc;
+  if (g2) k_g2_add<<<grid_for(n), BN_WAVE, 0, c->stream>>>(c->stage[0], c->stage[1], n, c->stage[2], c->stage[3]);
+  else k_g1_add<<<grid_for(n), BN_WAVE, 0, c->stream>>>(c->stage[0], c->stage[1], n, c->stage[2], c->stage[3]);
+  HIP_TRY(hipGetLastError());
+  if ((rc = stage_out(c, 2, out, n * sz))) return rc;
+  if ((rc = stage_out(c, 3, status, n))) return rc;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+int bn254_batch_g1_add(bn254_ctx* c, const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out, uint8_t* status) { return binop_host(c, 0, a, b, n, out, status); }
+int bn254_batch_g2_add(bn254_ctx* c, const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out, uint8_t* status) { return binop_host(c, 1, a, b, n, out, status); }
+
+int bn254_batch_g1_mul_device(bn254_ctx* c, const uint8_t* d_p, const uint8_t* d_k, size_t n, int reduce, uint8_t* d_out, uint8_t* d_status, void* stream) {
+  if (!c || (n && (!d_p || !d_k || !d_out || !d_status))) return BN254_E_BAD_ARGUMENT;
+  if (n == 0) return 0;
+  if (misaligned(d_p) || misaligned(d_k) || misaligned(d_out)) return BN254_E_MISALIGNED;
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  k_g1_mul<<<grid_for(n), BN_WAVE, 0, s>>>(d_p, d_k, n, reduce, c->ws, d_out, d_status);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+int bn254_batch_g2_mul_device(bn254_ctx* c, const uint8_t* d_p, const uint8_t* d_k, size_t n, int reduce, uint8_t* d_out, uint8_t* d_status, void* stream) {
+  if (!c || (n && (!d_k || !d_out || !d_status))) return BN254_E_BAD_ARGUMENT;   // d_p == NULL: generator
+  if (n == 0) return 0;
+  if ((d_p && misaligned(d_p)) || misaligned(d_k) || misaligned(d_out)) return BN254_E_MISALIGNED;
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  k_g2_mul<<<grid_for(n), BN_WAVE, 0, s>>>(d_p, d_k, n, reduce, d_out, d_status);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+static int mul_host(bn254_ctx* c, int g2, const uint8_t* p, const uint8_t* k, size_t n, int reduce, uint8_t* out, uint8_t* status) {
+  if (!c || (n && (!k || !out || !status)) || (!g2 && n && !p)) return BN254_E_BAD_ARGUMENT;
+  if (n == 0) return 0;
+  HIP_TRY(hipSetDevice(c->device));
+  size_t sz = g2 ? 128 : 64;
+  int rc;
+  if (p && (rc = stage_in(c, 0, p, n * sz))) return rc;
+  if ((rc = stage_in(c, 1, k, n * 32))) return rc;
+  if ((rc = stage_reserve(c, 2, n * sz))) return rc;
+  if ((rc = stage_reserve(c, 3, n))) return rc;
+  rc = g2 ? bn254_batch_g2_mul_device(c, p ? c->stage[0] : nullptr, c->stage[1], n, reduce, c->stage[2], c->stage[3], nullptr)
+          : bn254_batch_g1_mul_device(c, c->stage[0], c->stage[1], n, reduce, c->stage[2], c->stage[3], nullptr);
+  if (rc) return rc;
+  if ((rc = stage_out(c, 2, out, n * sz))) return rc;
+  if ((rc = stage_out(c, 3, status, n))) return rc;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+int bn254_batch_g1_mul(bn254_ctx* c, const uint8_t* p, const uint8_t* k, size_t n, int reduce, uint8_t* out, uint8_t* status) { return mul_host(c, 0, p, k, n, reduce, out, status); }
+int bn254_batch_g2_mul(bn254_ctx* c, const uint8_t* p, const uint8_t* k, size_t n, int reduce, uint8_t* out, uint8_t* status) { return mul_host(c, 1, p, k, n, reduce, out, status); }
+
+int bn254_batch_sign_device(bn254_ctx* c, const uint8_t* d_msgs, const uint64_t* d_off, const uint8_t* d_sks, size_t n, uint8_t* d_sigs,
+                            uint8_t* d_status, void* stream) {
+  if (!c || (n && (!d_msgs || !d_off || !d_sks || !d_sigs || !d_status))) return BN254_E_BAD_ARGUMENT;
+  if (n == 0) return 0;
+  if (misaligned(d_sks) || misaligned(d_sigs) || ((uintptr_t)d_off & 7u)) return BN254_E_MISALIGNED;
+  HIP_TRY(hipSetDevice(c->device));
+  int rc = ws_reserve(c, n);
+  if (rc) return rc;
+  hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  k_hash_to_g1<<<grid_for(n), BN_WAVE, 0, s>>>(d_msgs, d_off, n, c->ws, PL_P1X, BY_P1_INF, nullptr);   // ecdsa.rs:28
+  k_g1_mul<<<grid_for(n), BN_WAVE, 0, s>>>(nullptr, d_sks, n, 1, c->ws, d_sigs, d_status);              // ecdsa.rs:31
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+int bn254_batch_sign(bn254_ctx* c, const uint8_t* msgs, const uint64_t* off, const uint8_t* sks, size_t n, uint8_t* sigs, uint8_t* status) {
+  if (!c || (n && (!off || !sks || !sigs || !status))) return BN254_E_BAD_ARGUMENT;
+  if (n == 0) return 0;
+  HIP_TRY(hipSetDevice(c->device));
+  int rc;
+  if ((rc = stage_in(c, 0, msgs, (size_t)off[n]))) return rc;
+  if ((rc = stage_in(c, 1, off, (n + 1) * sizeof(uint64_t)))) return rc;
+  if ((rc = stage_in(c, 2, sks, n * 32))) return rc;
+  if ((rc = stage_reserve(c, 3, n * 64))) return rc;
+  if ((rc = stage_reserve(c, 4, n))) return rc;
+  if ((rc = bn254_batch_sign_device(c, c->stage[0], (const uint64_t*)c->stage[1], c->stage[2], n, c->stage[3], c->stage[4], nullptr))) return rc;
+  if ((rc = stage_out(c, 3, sigs, n * 64))) return rc;
+  if ((rc = stage_out(c, 4, status, n))) return rc;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+static int sum_host(bn254_ctx* c, int g2, const uint8_t* pts, const uint64_t* seg, size_t n, uint8_t* out, uint8_t* status) {
+  if (!c || (n && (!seg || !out || !status))) return BN254_E_BAD_ARGUMENT;
+  if (n == 0) return 0;
+  HIP_TRY(hipSetDevice(c->device));
+  size_t sz = g2 ? 128 : 64;
+  size_t total = (size_t)seg[n];
+  int rc;
+  if ((rc = stage_in(c, 0, pts, total * sz))) return rc;
+  if ((rc = stage_in(c, 1, seg, (n + 1) * sizeof(uint64_t)))) return rc;
+  if ((rc = stage_reserve(c, 2, n * sz))) return rc;
+  if ((rc = stage_reserve(c, 3, n))) return rc;
+  if (g2) k_g2_sum<<<grid_for(n), BN_WAVE, 0, c->stream>>>(c->stage[0], (const uint64_t*)c->stage[1], n, c->stage[2], c->stage[3]);
+  else k_g1_sum<<<grid_for(n), BN_WAVE, 0, c->stream>>>(c->stage[0], (const uint64_t*)c->stage[1], n, c->stage[2], c->stage[3]);
+  HIP_TRY(hipGetLastError());
+  if ((rc = stage_out(c, 2, out, n * sz))) return rc;
+  if ((rc = stage_out(c, 3, status, n))) return rc;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+int bn254_batch_g1_sum(bn254_ctx* c, const uint8_t* pts, const uint64_t* seg, size_t n, uint8_t* out, uint8_t* status) { return sum_host(c, 0, pts, seg, n, out, status); }
+int bn254_batch_g2_sum(bn254_ctx* c, const uint8_t* pts, const uint64_t* seg, size_t n, uint8_t* out, uint8_t* status) { return sum_host(c, 1, pts, seg, n, out, status); }
+
+// ---- test hooks --------------------------------------------------------------------------
+int bn254_debug_fp_op(bn254_ctx* c, int op, const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out, uint8_t* status) {
+  if (!c || (n && (!a || !out || !status))) return BN254_E_BAD_ARGUMENT;
+  if (n == 0) return 0;
+  HIP_TRY(hipSetDevice(c->device));
+  int rc;
+  if ((rc = stage_in(c, 0, a, n * 32))) return rc;
+  if (b && (rc = stage_in(c, 1, b, n * 32))) return rc;
+  if ((rc = stage_reserve(c, 2, n * 32))) return rc;
+  if ((rc = stage_reserve(c, 3, n))) return rc;
+  k_debug_fp_op<<<grid_for(n), BN_WAVE, 0, c->stream>>>(op, c->stage[0], b ? c->stage[1] : nullptr, n, c->stage[2], c->stage[3]);
+  HIP_TRY(hipGetLastError());
+  if ((rc = stage_out(c, 2, out, n * 32))) return rc;
+  if ((rc = stage_out(c, 3, status, n))) return rc;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+int bn254_debug_fp12_op(bn254_ctx* c, int op, const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out) {
+  if (!c || (n && (!a || !out))) return BN254_E_BAD_ARGUMENT;
+  if (n == 0) return 0;
+  HIP_TRY(hipSetDevice(c->device));
+  int rc;
+  if ((rc = stage_in(c, 0, a, n * 384))) return rc;
+  if (b && (rc = stage_in(c, 1, b, n * 384))) return rc;
+  if ((rc = stage_reserve(c, 2, n * 384))) return rc;
+  k_debug_fp12_op<<<grid_for(n), BN_WAVE, 0, c->stream>>>(op, c->stage[0], b ? c->stage[1] : nullptr, n, c->stage[2]);
+  HIP_TRY(hipGetLastError());
+  if ((rc = stage_out(c, 2, out, n * 384))) return rc;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+}  // extern "C"

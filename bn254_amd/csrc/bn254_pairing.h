@@ -1,0 +1,152 @@
+// Optimal-ate pairing on BN254: Miller loop (variable Q, and the table-driven constant
+// Q = -G2::one() of every verify) and the final exponentiation.
+//
+// This is the device-side replacement for `bn::pairing_batch` at its two call sites
+// /root/reference/src/ecdsa.rs:57 (ECDSA::verify) and :86 (check_public_keys): a product of
+// Miller functions sharing one accumulator f (one squaring per loop step for all pairs), pairs
+// with an identity member skipped, then f^((q^12-1)/r) and a comparison with one.
+//
+// Line shape (D-type twist, untwist (x',y') -> (x' w^2, y' w^3)):
+//   l(P) = l0 + l1 w + l2 w^3,  l0 = c0 * yP, l1 = c1 * xP, l2 = c2   with (c0,c1,c2) in Fq2
+// Lines are scaled by Fq2 factors (killed by the final exponentiation).
+#pragma once
+#include "bn254_curve.h"
+
+namespace bn254 {
+
+struct G2Proj { Fp2 x, y, z; };            // homogeneous projective twist point
+struct LineCoef { Fp2 c0, c1, c2; };
+
+// T <- 2T;  c0 = 2YZ, c1 = -3X^2, c2 = Y^2 - 3b'Z^2
+BN_DEVN void dbl_step(G2Proj& t, LineCoef& l) {
+  Fp2 xy = fp2_mul(t.x, t.y), b = fp2_sqr(t.y), c = fp2_sqr(t.z);
+  Fp2 e = fp2_mul(c, fp2_load_const(C_TWIST_3B));
+  Fp2 f = fp2_add(fp2_dbl(e), e);
+  Fp2 h = fp2_sub(fp2_sub(fp2_sqr(fp2_add(t.y, t.z)), b), c);
+  Fp2 x2 = fp2_sqr(t.x);
+  Fp2 e2 = fp2_sqr(e);
+  Fp2 e2x4 = fp2_dbl(fp2_dbl(e2));
+  Fp2 e2x12 = fp2_add(fp2_dbl(e2x4), e2x4);
+  G2Proj o;
+  o.x = fp2_dbl(fp2_mul(xy, fp2_sub(b, f)));
+  o.y = fp2_sub(fp2_sqr(fp2_add(b, f)), e2x12);
+  o.z = fp2_dbl(fp2_dbl(fp2_mul(b, h)));
+  l.c0 = h;
+  l.c1 = fp2_neg(fp2_add(fp2_dbl(x2), x2));
+  l.c2 = fp2_sub(b, e);
+  t = o;
+}
+// T <- T + Q (Q affine);  c0 = mu, c1 = -theta, c2 = theta*x2 - mu*y2
+BN_DEVN void add_step(G2Proj& t, LineCoef& l, const Fp2& qx, const Fp2& qy) {
+  Fp2 theta = fp2_sub(t.y, fp2_mul(qy, t.z));
+  Fp2 mu = fp2_sub(t.x, fp2_mul(qx, t.z));
+  Fp2 c = fp2_sqr(theta), d = fp2_sqr(mu), e = fp2_mul(mu, d);
+  Fp2 f = fp2_mul(t.z, c), g = fp2_mul(t.x, d);
+  Fp2 h = fp2_sub(fp2_sub(fp2_add(e, f), g), g);
+  G2Proj o;
+  o.x = fp2_mul(mu, h);
+  o.y = fp2_sub(fp2_mul(theta, fp2_sub(g, h)), fp2_mul(e, t.y));
+  o.z = fp2_mul(t.z, e);
+  l.c0 = mu;
+  l.c1 = fp2_neg(theta);
+  l.c2 = fp2_sub(fp2_mul(theta, qx), fp2_mul(mu, qy));
+  t = o;
+}
+// f <- f * line(P); a skipped pair multiplies by one
+BN_DEV void mul_by_line(Fp12& f, const LineCoef& l, const Fp& px, const Fp& py, bool skip) {
+  Fp2 l0 = fp2_mul_fp(l.c0, py), l1 = fp2_mul_fp(l.c1, px), l2 = l.c2;
+  l0 = fp2_select(skip, fp2_one(), l0);
+  l1 = fp2_select(skip, fp2_zero(), l1);
+  l2 = fp2_select(skip, fp2_zero(), l2);
+  fp12_mul_line(f, f, l0, l1, l2);
+}
+BN_DEV void fixed_line(LineCoef& l, int idx) {
+  l.c0 = fp2_load_const(C_NEG_G2_LINES[idx][0]);
+  l.c1 = fp2_load_const(C_NEG_G2_LINES[idx][1]);
+  l.c2 = fp2_load_const(C_NEG_G2_LINES[idx][2]);
+}
+
+// Miller loop over up to two pairs sharing f:
+//   pair A: (pa, qa) with a variable twist point qa   (enabled by has_a; skipped if skip_a)
+//   pair B: (pb, -G2::one()) through the constant line table (enabled by HAS_B; skipped if skip_b)
+// "skipped" = the pair has an identity member and contributes 1; the
+// lane still walks the loop with dummy coordinates so the wave stays convergent.
+template <bool HAS_A, bool HAS_B>
+BN_DEVN void miller_loop(Fp12& f, const G1Affine& pa, const G2Affine& qa, const G1Affine& pb) {
+  fp12_set_one(f);
+  G2Proj t;
+  LineCoef l;
+  Fp2 qa_yneg;
+  bool skip_a = !HAS_A || pa.inf || qa.inf;
+  bool skip_b = !HAS_B || pb.inf;
+  if (HAS_A) { t.x = qa.x; t.y = qa.y; t.z = fp2_one(); qa_yneg = fp2_neg(qa.y); }
+  int idx = 0;
+  for (int d = 0; d < 64; ++d) {
+    fp12_sqr(f, f);
+    if (HAS_A) { dbl_step(t, l); mul_by_line(f, l, pa.x, pa.y, skip_a); }
+    if (HAS_B) { fixed_line(l, idx++); mul_by_line(f, l, pb.x, pb.y, skip_b); }
+    int digit = C_ATE_NAF[d];
+    if (digit != 0) {   // wave-uniform
+      if (HAS_A) { add_step(t, l, qa.x, digit > 0 ? qa.y : qa_yneg); mul_by_line(f, l, pa.x, pa.y, skip_a); }
+      if (HAS_B) { fixed_line(l, idx++); mul_by_line(f, l, pb.x, pb.y, skip_b); }
+    }
+  }
+  // + pi(Q), - pi^2(Q)
+  if (HAS_A) {
+    Fp2 q1x = fp2_mul(fp2_conj(qa.x), fp2_load_const(C_TW_FROB_X1));
+    Fp2 q1y = fp2_mul(fp2_conj(qa.y), fp2_load_const(C_TW_FROB_Y1));
+    add_step(t, l, q1x, q1y);
+    mul_by_line(f, l, pa.x, pa.y, skip_a);
+  }
+  if (HAS_B) { fixed_line(l, idx++); mul_by_line(f, l, pb.x, pb.y, skip_b); }
+  if (HAS_A) {
+    Fp2 q2x = fp2_mul(qa.x, fp2_load_const(C_TW_FROB_X2));
+    add_step(t, l, q2x, qa.y);
+    mul_by_line(f, l, pa.x, pa.y, skip_a);
+  }
+  if (HAS_B) { fixed_line(l, idx++); mul_by_line(f, l, pb.x, pb.y, skip_b); }
+}
+
+// a^u for a in the cyclotomic subgroup (u = 4965661367192848881, 63 bits)
+BN_DEVN void fp12_pow_u(Fp12& r, const Fp12& a) {
+  const uint64_t u = ((uint64_t)BN_U_HI << 32) | BN_U_LO;
+  Fp12 acc = a;
+  for (int i = 61; i >= 0; --i) {
+    fp12_cyclotomic_sqr(acc, acc);
+    if ((u >> i) & 1) fp12_mul(acc, acc, a);
+  }
+  r = acc;
+}
+
+// f^((q^12-1)/r): easy part (q^6-1)(q^2+1), then the exact hard part (q^4-q^2+1)/r =
+// q^3 + (6u^2+1) q^2 + (-36u^3-18u^2-12u+1) q + (-36u^3-30u^2-18u-2) by the vectorial
+// addition chain y0 * y1^2 * y2^6 * y3^12 * y4^18 * y5^30 * y6^36.
+BN_DEVN void final_exponentiation(Fp12& r, const Fp12& fin) {
+  Fp12 f, t, a, b;
+  fp12_inv(t, fin);
+  fp12_conj(a, fin);
+  fp12_mul(f, a, t);
+  fp12_frob(t, f, 2);
+  fp12_mul(f, t, f);
+  Fp12 fu, fu2, fu3, y0, y1, y2, y3, y4, y5, y6;
+  fp12_pow_u(fu, f);
+  fp12_pow_u(fu2, fu);
+  fp12_pow_u(fu3, fu2);
+  fp12_frob(a, f, 1); fp12_frob(b, f, 2); fp12_mul(y0, a, b); fp12_frob(a, f, 3); fp12_mul(y0, y0, a);
+  fp12_conj(y1, f);
+  fp12_frob(y2, fu2, 2);
+  fp12_frob(a, fu, 1); fp12_conj(y3, a);
+  fp12_frob(a, fu2, 1); fp12_mul(a, a, fu); fp12_conj(y4, a);
+  fp12_conj(y5, fu2);
+  fp12_frob(a, fu3, 1); fp12_mul(a, a, fu3); fp12_conj(y6, a);
+  Fp12 t0, t1;
+  fp12_cyclotomic_sqr(t0, y6); fp12_mul(t0, t0, y4); fp12_mul(t0, t0, y5);
+  fp12_mul(t1, y3, y5); fp12_mul(t1, t1, t0);
+  fp12_mul(t0, t0, y2);
+  fp12_cyclotomic_sqr(t1, t1); fp12_mul(t1, t1, t0); fp12_cyclotomic_sqr(t1, t1);
+  fp12_mul(t0, t1, y1); fp12_mul(t1, t1, y0);
+  fp12_cyclotomic_sqr(t0, t0);
+  fp12_mul(r, t0, t1);
+}
+
+}  // namespace bn254

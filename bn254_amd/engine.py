@@ -1,0 +1,209 @@
+"""Thin Python binding of the C ABI (include/bn254_hip.h): one `Engine` per GPU.
+
+Host-pointer methods take/return `bytes`; `*_device` methods take raw device pointers (e.g.
+`tensor.data_ptr()` of torch uint8 tensors resident in HBM) and only enqueue work.
+"""
+import ctypes
+
+from . import _native
+
+G1_BYTES, G2_BYTES, GT_BYTES, SCALAR_BYTES = 64, 128, 384, 32
+FLAG_G2_SUBGROUP_CHECK = 1
+FLAG_REJECT_IDENTITY = 2
+
+
+class NativeError(RuntimeError):
+    """A call into libbn254hip.so failed (HIP runtime error or bad argument) — not a per-item status."""
+
+    def __init__(self, fn, rc):
+        what = "HIP error %d" % (-rc) if -10000 < rc < 0 else {-10001: "bad argument", -10002: "misaligned device pointer",
+                                                                -10003: "no HIP device (bn254_amd has no CPU fallback)"}.get(rc, "error")
+        super().__init__("%s failed: %s (rc=%d)" % (fn, what, rc))
+        self.rc = rc
+
+
+def _check(fn, rc):
+    if rc != 0:
+        raise NativeError(fn, rc)
+
+
+def pack_messages(messages):
+    """list of bytes -> (concatenated bytes, ctypes uint64 offsets[n+1])"""
+    n = len(messages)
+    off = (ctypes.c_uint64 * (n + 1))()
+    pos = 0
+    for i, m in enumerate(messages):
+        off[i] = pos
+        pos += len(m)
+    off[n] = pos
+    return b"".join(bytes(m) for m in messages), off
+
+
+class Engine:
+    def __init__(self, device=0):
+        self._lib = _native.load()
+        h = ctypes.c_void_p()
+        _check("bn254_ctx_create", self._lib.bn254_ctx_create(device, ctypes.byref(h)))
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.bn254_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def version(self):
+        return self._lib.bn254_version().decode()
+
+    def reserve(self, n):
+        _check("bn254_ctx_reserve", self._lib.bn254_ctx_reserve(self._h, n))
+
+    def synchronize(self):
+        _check("bn254_ctx_synchronize", self._lib.bn254_ctx_synchronize(self._h))
+
+    def set_profiling(self, on):
+        _check("bn254_ctx_set_profiling", self._lib.bn254_ctx_set_profiling(self._h, 1 if on else 0))
+
+    def last_kernel_ms(self):
+        ms = (ctypes.c_float * 4)()
+        _check("bn254_ctx_last_kernel_ms", self._lib.bn254_ctx_last_kernel_ms(self._h, ms))
+        return {"decode": ms[0], "hash_to_g1": ms[1], "miller_loop": ms[2], "final_exp": ms[3]}
+
+    # ---- host-pointer entry points ------------------------------------------------------
+    def batch_verify(self, messages, sigs, pks, flags=0):
+        n = len(messages)
+        assert len(sigs) == n * G1_BYTES and len(pks) == n * G2_BYTES
+        msgs, off = pack_messages(messages)
+        status = ctypes.create_string_buffer(max(n, 1))
+        _check("bn254_batch_verify", self._lib.bn254_batch_verify(self._h, msgs, off, bytes(sigs), bytes(pks), n, flags, status))
+        return status.raw[:n]
+
+    def batch_hash_to_g1(self, messages):
+        n = len(messages)
+        msgs, off = pack_messages(messages)
+        pts = ctypes.create_string_buffer(max(n, 1) * G1_BYTES)
+        status = ctypes.create_string_buffer(max(n, 1))
+        tries = ctypes.create_string_buffer(max(n, 1))
+        _check("bn254_batch_hash_to_g1", self._lib.bn254_batch_hash_to_g1(self._h, msgs, off, n, pts, status, tries))
+        return pts.raw[:n * G1_BYTES], status.raw[:n], tries.raw[:n]
+
+    def batch_pairing_check(self, g1s, g2s, n, k, flags=0):
+        assert len(g1s) == n * k * G1_BYTES and len(g2s) == n * k * G2_BYTES
+        status = ctypes.create_string_buffer(max(n, 1))
+        _check("bn254_batch_pairing_check", self._lib.bn254_batch_pairing_check(self._h, bytes(g1s), bytes(g2s), n, k, flags, status))
+        return status.raw[:n]
+
+    def batch_pairing(self, g1s, g2s, n, k=1, flags=0):
+        assert len(g1s) == n * k * G1_BYTES and len(g2s) == n * k * G2_BYTES
+        gt = ctypes.create_string_buffer(max(n, 1) * GT_BYTES)
+        status = ctypes.create_string_buffer(max(n, 1))
+        _check("bn254_batch_pairing", self._lib.bn254_batch_pairing(self._h, bytes(g1s), bytes(g2s), n, k, flags, gt, status))
+        return gt.raw[:n * GT_BYTES], status.raw[:n]
+
+    def batch_check_public_keys(self, pk_g2, pk_g1, n, flags=0):
+        status = ctypes.create_string_buffer(max(n, 1))
+        _check("bn254_batch_check_public_keys", self._lib.bn254_batch_check_public_keys(self._h, bytes(pk_g2), bytes(pk_g1), n, flags, status))
+        return status.raw[:n]
+
+    def _binop(self, name, a, b, n, size):
+        out = ctypes.create_string_buffer(max(n, 1) * size)
+        status = ctypes.create_string_buffer(max(n, 1))
+        _check(name, getattr(self._lib, name)(self._h, bytes(a), bytes(b), n, out, status))
+        return out.raw[:n * size], status.raw[:n]
+
+    def batch_g1_add(self, a, b, n):
+        return self._binop("bn254_batch_g1_add", a, b, n, G1_BYTES)
+
+    def batch_g2_add(self, a, b, n):
+        return self._binop("bn254_batch_g2_add", a, b, n, G2_BYTES)
+
+    def batch_g1_mul(self, points, scalars, n, reduce_scalar=False):
+        out = ctypes.create_string_buffer(max(n, 1) * G1_BYTES)
+        status = ctypes.create_string_buffer(max(n, 1))
+        _check("bn254_batch_g1_mul", self._lib.bn254_batch_g1_mul(self._h, bytes(points), bytes(scalars), n, int(reduce_scalar), out, status))
+        return out.raw[:n * G1_BYTES], status.raw[:n]
+
+    def batch_g2_mul(self, points, scalars, n, reduce_scalar=False):
+        """points=None multiplies the G2 generator (PublicKey::from_private_key)."""
+        out = ctypes.create_string_buffer(max(n, 1) * G2_BYTES)
+        status = ctypes.create_string_buffer(max(n, 1))
+        _check("bn254_batch_g2_mul", self._lib.bn254_batch_g2_mul(self._h, None if points is None else bytes(points), bytes(scalars), n,
+                                                               int(reduce_scalar), out, status))
+        return out.raw[:n * G2_BYTES], status.raw[:n]
+
+    def batch_sign(self, messages, sks):
+        n = len(messages)
+        msgs, off = pack_messages(messages)
+        sigs = ctypes.create_string_buffer(max(n, 1) * G1_BYTES)
+        status = ctypes.create_string_buffer(max(n, 1))
+        _check("bn254_batch_sign", self._lib.bn254_batch_sign(self._h, msgs, off, bytes(sks), n, sigs, status))
+        return sigs.raw[:n * G1_BYTES], status.raw[:n]
+
+    def _sum(self, name, points, seg_off, size):
+        n = len(seg_off) - 1
+        off = (ctypes.c_uint64 * (n + 1))(*seg_off)
+        out = ctypes.create_string_buffer(max(n, 1) * size)
+        status = ctypes.create_string_buffer(max(n, 1))
+        _check(name, getattr(self._lib, name)(self._h, bytes(points), off, n, out, status))
+        return out.raw[:n * size], status.raw[:n]
+
+    def batch_g1_sum(self, points, seg_off):
+        return self._sum("bn254_batch_g1_sum", points, seg_off, G1_BYTES)
+
+    def batch_g2_sum(self, points, seg_off):
+        return self._sum("bn254_batch_g2_sum", points, seg_off, G2_BYTES)
+
+    # ---- test hooks -----------------------------------------------------------------------
+    def debug_fp_op(self, op, a, b, n):
+        out = ctypes.create_string_buffer(max(n, 1) * 32)
+        status = ctypes.create_string_buffer(max(n, 1))
+        _check("bn254_debug_fp_op", self._lib.bn254_debug_fp_op(self._h, op, bytes(a), None if b is None else bytes(b), n, out, status))
+        return out.raw[:n * 32], status.raw[:n]
+
+    def debug_fp12_op(self, op, a, b, n):
+        out = ctypes.create_string_buffer(max(n, 1) * GT_BYTES)
+        _check("bn254_debug_fp12_op", self._lib.bn254_debug_fp12_op(self._h, op, bytes(a), None if b is None else bytes(b), n, out))
+        return out.raw[:n * GT_BYTES]
+
+    def debug_miller_loop(self, g1s, g2s, n):
+        out = ctypes.create_string_buffer(max(n, 1) * GT_BYTES)
+        _check("bn254_debug_miller_loop", self._lib.bn254_debug_miller_loop(self._h, bytes(g1s), bytes(g2s), n, out))
+        return out.raw[:n * GT_BYTES]
+
+    # ---- device-pointer entry points (inputs resident in HBM; enqueue only) ---------------
+    def batch_verify_device(self, d_msgs, d_off, d_sigs, d_pks, n, d_status, flags=0, stream=None):
+        _check("bn254_batch_verify_device",
+               self._lib.bn254_batch_verify_device(self._h, d_msgs, d_off, d_sigs, d_pks, n, flags, d_status, stream))
+
+    def batch_hash_to_g1_device(self, d_msgs, d_off, n, d_points, d_status, d_tries=None, stream=None):
+        _check("bn254_batch_hash_to_g1_device",
+               self._lib.bn254_batch_hash_to_g1_device(self._h, d_msgs, d_off, n, d_points, d_status, d_tries, stream))
+
+    def batch_pairing_device(self, d_g1, d_g2, n, k, d_gt, d_status, flags=0, stream=None):
+        _check("bn254_batch_pairing_device", self._lib.bn254_batch_pairing_device(self._h, d_g1, d_g2, n, k, flags, d_gt, d_status, stream))
+
+    def batch_sign_device(self, d_msgs, d_off, d_sks, n, d_sigs, d_status, stream=None):
+        _check("bn254_batch_sign_device", self._lib.bn254_batch_sign_device(self._h, d_msgs, d_off, d_sks, n, d_sigs, d_status, stream))
+
+    def batch_g2_mul_device(self, d_points, d_scalars, n, d_out, d_status, reduce_scalar=False, stream=None):
+        _check("bn254_batch_g2_mul_device",
+               self._lib.bn254_batch_g2_mul_device(self._h, d_points, d_scalars, n, int(reduce_scalar), d_out, d_status, stream))
+
+    def batch_g1_mul_device(self, d_points, d_scalars, n, d_out, d_status, reduce_scalar=False, stream=None):
+        _check("bn254_batch_g1_mul_device",
+               self._lib.bn254_batch_g1_mul_device(self._h, d_points, d_scalars, n, int(reduce_scalar), d_out, d_status, stream))
+
+
+_default = {}
+
+
+def default_engine(device=0):
+    if device not in _default:
+        _default[device] = Engine(device)
+    return _default[device]

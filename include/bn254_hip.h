@@ -1,0 +1,147 @@
+/*
+ * bn254_hip.h — C ABI of libbn254hip.so, the MI355X (gfx950) batch BN254 aggregate-signature
+ * verifier.  This is the drop-in boundary: plain pointers and sizes, no HIP/torch types.
+ *
+ * The reference (sedaprotocol/bn254, a pure-Rust crate) has no FFI; its only boundary is the
+ * Rust API re-exported at /root/reference/src/lib.rs:60-63.  Each entry point below states the
+ * reference function whose per-item semantics it reproduces; INTEGRATION.md shows the Rust
+ * `extern "C"` block + `ECDSA::batch_verify` shim a maintainer would add.
+ *
+ * Byte formats (the reference's *uncompressed* encodings):
+ *   G1 point  : 64 bytes  x || y                       big-endian   (src/utils.rs:182-194)
+ *   G2 point  : 128 bytes x.re || x.im || y.re || y.im big-endian   (src/utils.rs:161-179)
+ *   scalar    : 32 bytes big-endian
+ *   Gt        : 384 bytes, 12 x BE32 in tower order (Fq12 = Fq6[w]/(w^2-v), Fq6 = Fq2[v]/(v^3-xi)):
+ *               a0.re a0.im a1.re a1.im a2.re a2.im b0.re ... b2.im  (build-defined: the reference
+ *               never serialises Gt, src/lib.rs:60-63)
+ *   identity  : all-zero bytes (the reference's typed API can hold it but to_uncompressed cannot
+ *               encode it — PointInJacobian, src/utils.rs:163,184)
+ *   messages  : one concatenated byte buffer + n+1 offsets (msg i = msgs[off[i] .. off[i+1]))
+ *
+ * Per-item status byte: 0 = Ok, otherwise 1 + the index of the reference's Error variant
+ * (src/error.rs:6-29):  1 HashToPointError, 2 IndexOutOfBounds, 3 InvalidEncoding,
+ * 4 InvalidGroupPoint, 5 InvalidLength, 6 NotMemberError, 7 ToAffineConversion, 8 PointInJacobian,
+ * 9 VerificationFailed, 10 SerializationError, 11 HexDecodeFailed.
+ *
+ * Return value of every call: 0 on success (bad *items* only set their status byte),
+ * -(hipError_t) for a HIP runtime failure, BN254_E_* for bad arguments.
+ *
+ * Ownership/threading: the caller owns every buffer; the library keeps no pointer after a
+ * host-pointer call returns.  A bn254_ctx is used by one thread at a time; distinct contexts
+ * (distinct devices) are fully concurrent.  There is NO CPU fallback: every entry point runs
+ * HIP kernels on the context's device and fails if that is impossible.
+ *
+ * *_device variants take DEVICE pointers (4-byte aligned, resident in HBM), enqueue on `stream`
+ * (a hipStream_t passed as void*; NULL = the context's own stream) and do not synchronise.
+ */
+#ifndef BN254_HIP_H
+#define BN254_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bn254_ctx bn254_ctx;
+
+#define BN254_FLAG_G2_SUBGROUP_CHECK 1u /* decode G2 inputs with the order-r check AffineG2::new performs */
+#define BN254_FLAG_REJECT_IDENTITY 2u   /* treat all-zero encodings as InvalidGroupPoint (from_uncompressed behaviour) */
+
+#define BN254_E_BAD_ARGUMENT (-10001)
+#define BN254_E_MISALIGNED (-10002)
+#define BN254_E_NO_DEVICE (-10003)
+
+/* status codes */
+#define BN254_OK 0
+#define BN254_ERR_HASH_TO_POINT 1
+#define BN254_ERR_INVALID_ENCODING 3
+#define BN254_ERR_INVALID_GROUP_POINT 4
+#define BN254_ERR_INVALID_LENGTH 5
+#define BN254_ERR_NOT_MEMBER 6
+#define BN254_ERR_POINT_IN_JACOBIAN 8
+#define BN254_ERR_VERIFICATION_FAILED 9
+
+const char *bn254_version(void);
+
+/* opaque context: device id, stream, workspace in HBM (grown on demand, reused across calls) */
+int bn254_ctx_create(int hip_device, bn254_ctx **out);
+void bn254_ctx_destroy(bn254_ctx *ctx);
+/* pre-size the HBM workspace for batches of up to n items / n*k pairs (optional; avoids a
+ * hipMalloc inside a later *_device call) */
+int bn254_ctx_reserve(bn254_ctx *ctx, size_t n_items);
+int bn254_ctx_synchronize(bn254_ctx *ctx);
+
+/* status[i] = what ECDSA::verify(msg_i, sig_i, pk_i) returns (src/ecdsa.rs:49-64):
+ * e(H(m), pk) * e(sig, -G2::one()) == 1.  Decoding errors of sig (first) or pk are reported with
+ * the code from_uncompressed would give (src/utils.rs:107-127). */
+int bn254_batch_verify(bn254_ctx *ctx, const uint8_t *msgs, const uint64_t *msg_off /* n+1 */, const uint8_t *sigs /* n*64 */,
+                       const uint8_t *pks /* n*128 */, size_t n, uint32_t flags, uint8_t *status /* n */);
+int bn254_batch_verify_device(bn254_ctx *ctx, const uint8_t *d_msgs, const uint64_t *d_msg_off, const uint8_t *d_sigs,
+                              const uint8_t *d_pks, size_t n, uint32_t flags, uint8_t *d_status, void *stream);
+
+/* points[i] = hash_to_try_and_increment(msg_i) (src/hash.rs:29-63), uncompressed; status 1 =
+ * HashToPointError; tries[i] (optional, may be NULL) = number of counters consumed (1..255). */
+int bn254_batch_hash_to_g1(bn254_ctx *ctx, const uint8_t *msgs, const uint64_t *msg_off, size_t n, uint8_t *points /* n*64 */,
+                           uint8_t *status /* n */, uint8_t *tries /* n or NULL */);
+int bn254_batch_hash_to_g1_device(bn254_ctx *ctx, const uint8_t *d_msgs, const uint64_t *d_msg_off, size_t n, uint8_t *d_points,
+                                  uint8_t *d_status, uint8_t *d_tries, void *stream);
+
+/* status[i] = (bn::pairing_batch(&[(g1[i*k+j], g2[i*k+j]); k]) == Gt::one()) ? 0 : 9 — the kernel
+ * shared by ECDSA::verify and check_public_keys (src/ecdsa.rs:57-63, :86-92). */
+int bn254_batch_pairing_check(bn254_ctx *ctx, const uint8_t *g1 /* n*k*64 */, const uint8_t *g2 /* n*k*128 */, size_t n, size_t k,
+                              uint32_t flags, uint8_t *status /* n */);
+/* gt[i] = prod_j e(g1[i*k+j], g2[i*k+j]) = Miller product ^ ((q^12-1)/r), 384 bytes each */
+int bn254_batch_pairing(bn254_ctx *ctx, const uint8_t *g1, const uint8_t *g2, size_t n, size_t k, uint32_t flags,
+                        uint8_t *gt /* n*384 */, uint8_t *status /* n */);
+int bn254_batch_pairing_device(bn254_ctx *ctx, const uint8_t *d_g1, const uint8_t *d_g2, size_t n, size_t k, uint32_t flags,
+                               uint8_t *d_gt /* n*384 or NULL */, uint8_t *d_status, void *stream);
+
+/* status[i] = check_public_keys(pk_g2[i], pk_g1[i]) (src/ecdsa.rs:78-93) */
+int bn254_batch_check_public_keys(bn254_ctx *ctx, const uint8_t *pk_g2 /* n*128 */, const uint8_t *pk_g1 /* n*64 */, size_t n,
+                                  uint32_t flags, uint8_t *status);
+
+/* group operations: aggregation = `Add for Signature/PublicKey` (src/types.rs:126-132, :264-270),
+ * sign / key derivation = G1*Fr, G2*Fr (src/ecdsa.rs:31, src/types.rs:86, :156).
+ * reduce_scalar != 0: scalars are first reduced mod r like Fr::from_slice; 0: used as 256-bit integers. */
+int bn254_batch_g1_add(bn254_ctx *ctx, const uint8_t *a /* n*64 */, const uint8_t *b /* n*64 */, size_t n, uint8_t *out, uint8_t *status);
+int bn254_batch_g2_add(bn254_ctx *ctx, const uint8_t *a /* n*128 */, const uint8_t *b /* n*128 */, size_t n, uint8_t *out, uint8_t *status);
+int bn254_batch_g1_mul(bn254_ctx *ctx, const uint8_t *p /* n*64 */, const uint8_t *scalars /* n*32 */, size_t n, int reduce_scalar,
+                       uint8_t *out, uint8_t *status);
+int bn254_batch_g2_mul(bn254_ctx *ctx, const uint8_t *p /* n*128 */, const uint8_t *scalars /* n*32 */, size_t n, int reduce_scalar,
+                       uint8_t *out, uint8_t *status);
+int bn254_batch_g1_mul_device(bn254_ctx *ctx, const uint8_t *d_p, const uint8_t *d_scalars, size_t n, int reduce_scalar,
+                              uint8_t *d_out, uint8_t *d_status, void *stream);
+int bn254_batch_g2_mul_device(bn254_ctx *ctx, const uint8_t *d_p, const uint8_t *d_scalars, size_t n, int reduce_scalar,
+                              uint8_t *d_out, uint8_t *d_status, void *stream);
+/* sigs[i] = ECDSA::sign(msg_i, sk_i) = H(msg_i) * sk_i (src/ecdsa.rs:26-35), uncompressed */
+int bn254_batch_sign(bn254_ctx *ctx, const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *sks /* n*32 */, size_t n,
+                     uint8_t *sigs /* n*64 */, uint8_t *status);
+int bn254_batch_sign_device(bn254_ctx *ctx, const uint8_t *d_msgs, const uint64_t *d_msg_off, const uint8_t *d_sks, size_t n,
+                            uint8_t *d_sigs, uint8_t *d_status, void *stream);
+/* segmented aggregation: out[i] = sum of `counts[i]` consecutive points starting at points[first[i]]
+ * (unit-scalar "MSM" of config 3: aggregate public key / aggregate signature) */
+int bn254_batch_g1_sum(bn254_ctx *ctx, const uint8_t *points, const uint64_t *seg_off /* n+1 */, size_t n, uint8_t *out /* n*64 */, uint8_t *status);
+int bn254_batch_g2_sum(bn254_ctx *ctx, const uint8_t *points, const uint64_t *seg_off /* n+1 */, size_t n, uint8_t *out /* n*128 */, uint8_t *status);
+
+/* test hooks: element-wise field/tower operations on byte-encoded operands, used by the parity
+ * tests to compare each layer of the HIP arithmetic with the oracle.
+ *   op: 0 mul, 1 add, 2 sub, 3 inverse(a), 4 square(a), 5 sqrt(a) (status 6 if none)   [Fq, 32 B]
+ *   fp12 op: 0 mul, 1 square, 2 inverse, 3 conj, 4 frobenius^1, 5 ^2, 6 ^3, 7 cyclotomic square,
+ *            8 final exponentiation                                                    [384 B] */
+int bn254_debug_fp_op(bn254_ctx *ctx, int op, const uint8_t *a, const uint8_t *b, size_t n, uint8_t *out, uint8_t *status);
+int bn254_debug_fp12_op(bn254_ctx *ctx, int op, const uint8_t *a, const uint8_t *b, size_t n, uint8_t *out);
+/* un-exponentiated Miller-loop value of each single pair (debugging aid) */
+int bn254_debug_miller_loop(bn254_ctx *ctx, const uint8_t *g1, const uint8_t *g2, size_t n, uint8_t *f /* n*384 */);
+
+/* timing of the most recent batch_verify*(…) on this context, from HIP events recorded on the
+ * launch stream around each kernel: ms[0] decode, ms[1] hash-to-G1, ms[2] Miller loop,
+ * ms[3] final exponentiation.  Synchronises the stream.  Requires bn254_ctx_set_profiling(ctx, 1). */
+int bn254_ctx_set_profiling(bn254_ctx *ctx, int enabled);
+int bn254_ctx_last_kernel_ms(bn254_ctx *ctx, float ms[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BN254_HIP_H */

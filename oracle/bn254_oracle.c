@@ -420,6 +420,9 @@ static void oracle_init(void) {
     else digs[nd++] = 0;
     s >>= 1;
   }
+  /* canonical NAF of 6u+2 starts 1,0,-1: rewrite the top as 1,1 (same value, one doubling fewer;
+   * the 64-digit form of SURVEY.md Appendix A.1) */
+  if (nd >= 3 && digs[nd - 1] == 1 && digs[nd - 2] == 0 && digs[nd - 3] == -1) { digs[nd - 3] = 1; digs[nd - 2] = 1; --nd; }
   /* digs[nd-1] is the leading 1; store the rest most-significant first */
   ATE_NAF_LEN = 0;
   for (int i = nd - 2; i >= 0; --i) ATE_NAF[ATE_NAF_LEN++] = digs[i];

@@ -1,0 +1,214 @@
+// hostsim — TEST INFRASTRUCTURE ONLY.
+//
+// Compiles the *device* arithmetic headers of the product (bn254_amd/csrc/bn254_{field,curve,
+// pairing,hash,io}.h — plain C++ by design) for the host CPU, one item at a time, composed the
+// same way the HIP kernels in bn254_amd/csrc/bn254_hip.hip compose them.  The CPU test-suite
+// (-m "not gpu", no GPU in the build container) uses it to check the kernels' algorithm source
+// against the oracle before any GPU time is spent.  It is NOT a fallback: nothing in bn254_amd/
+// loads it, and the product fails loudly without a HIP device (bn254_ctx_create -> -10003).
+#include <cstdint>
+#include <cstring>
+
+#include "../../bn254_amd/csrc/bn254_hash.h"
+#include "../../bn254_amd/csrc/bn254_io.h"
+#include "../../bn254_amd/csrc/bn254_pairing.h"
+
+using namespace bn254;
+
+static void set_g1_gen(G1Affine& p) { p.x = fp_load_const(C_G1_GEN[0]); p.y = fp_load_const(C_G1_GEN[1]); p.inf = false; }
+static void set_g2_gen(G2Affine& q) { q.x = fp2_load_const(C_G2_GEN[0]); q.y = fp2_load_const(C_G2_GEN[1]); q.inf = false; }
+
+static uint8_t dec_g1(G1Affine& p, const uint8_t* b, uint32_t flags) {
+  alignas(4) uint8_t tmp[64];
+  memcpy(tmp, b, 64);
+  uint8_t st = decode_g1(p, tmp, flags);
+  if (st != ST_OK) set_g1_gen(p);
+  return st;
+}
+static uint8_t dec_g2(G2Affine& q, const uint8_t* b, uint32_t flags) {
+  alignas(4) uint8_t tmp[128];
+  memcpy(tmp, b, 128);
+  uint8_t st = decode_g2(q, tmp, flags);
+  if (st != ST_OK) set_g2_gen(q);
+  if (flags & FLAG_G2_SUBGROUP_CHECK) {
+    bool in = g2_in_subgroup(q);
+    if (st == ST_OK && !in) { st = ST_INVALID_GROUP_POINT; set_g2_gen(q); }
+  }
+  return st;
+}
+static uint8_t hash_item(G1Affine& p, const uint8_t* msg, uint64_t len, int* tries) {
+  HashState hs;
+  hash_state_init(hs, msg, len);
+  set_g1_gen(p);
+  for (uint32_t ctr = 0; ctr < 255; ++ctr) {
+    if (hash_try(p, hs, msg, len, ctr)) { if (tries) *tries = (int)ctr + 1; return ST_OK; }
+  }
+  if (tries) *tries = 255;
+  set_g1_gen(p);
+  return ST_HASH_TO_POINT;
+}
+
+extern "C" {
+
+int hs_hash_to_g1(const uint8_t* msg, uint64_t len, uint8_t* out64, int* tries) {
+  G1Affine p;
+  uint8_t st = hash_item(p, msg, len, tries);
+  if (st != ST_OK) p.inf = true;
+  alignas(4) uint8_t tmp[64];
+  encode_g1(tmp, p);
+  memcpy(out64, tmp, 64);
+  return st;
+}
+
+// mirrors k_decode_g1 + k_decode_g2 + k_hash_to_g1 + k_miller_verify + k_final_exp
+int hs_verify(const uint8_t* msg, uint64_t len, const uint8_t* sig64, const uint8_t* pk128, uint32_t flags) {
+  G1Affine sig, h;
+  G2Affine pk;
+  uint8_t st = dec_g1(sig, sig64, flags);
+  uint8_t s2 = dec_g2(pk, pk128, flags);
+  if (st == ST_OK) st = s2;
+  uint8_t sh = hash_item(h, msg, len, nullptr);
+  Fp12 f;
+  miller_loop<true, true>(f, h, pk, sig);
+  if (st == ST_OK) st = sh;
+  final_exponentiation(f, f);
+  return st != ST_OK ? st : (fp12_is_one(f) ? ST_OK : ST_VERIFICATION_FAILED);
+}
+
+// mirrors pairing_device: k pairs, one Miller loop each, product, final exponentiation
+int hs_pairing(const uint8_t* g1s, const uint8_t* g2s, uint64_t k, uint32_t flags, uint8_t* gt384, int raw_only) {
+  Fp12 f, g;
+  uint8_t st = ST_OK;
+  for (uint64_t j = 0; j < k; ++j) {
+    G1Affine p;
+    G2Affine q;
+    uint8_t s1 = dec_g1(p, g1s + 64 * j, flags);
+    uint8_t s2 = dec_g2(q, g2s + 128 * j, flags);
+    if (s1 == ST_OK) s1 = s2;
+    if (st == ST_OK) st = s1;
+    miller_loop<true, false>(g, p, q, p);
+    if (j == 0) f = g; else fp12_mul(f, f, g);
+  }
+  if (!raw_only) final_exponentiation(f, f);
+  alignas(4) uint8_t tmp[384];
+  encode_fp12(tmp, f);
+  if (gt384) memcpy(gt384, tmp, 384);
+  return st != ST_OK ? st : (fp12_is_one(f) ? ST_OK : ST_VERIFICATION_FAILED);
+}
+
+int hs_check_public_keys(const uint8_t* pk_g2, const uint8_t* pk_g1, uint32_t flags) {
+  G1Affine pk1, g;
+  G2Affine pk2;
+  uint8_t st = dec_g2(pk2, pk_g2, flags);
+  uint8_t s1 = dec_g1(pk1, pk_g1, flags);
+  if (st == ST_OK) st = s1;
+  set_g1_gen(g);
+  Fp12 f;
+  miller_loop<true, true>(f, g, pk2, pk1);
+  final_exponentiation(f, f);
+  return st != ST_OK ? st : (fp12_is_one(f) ? ST_OK : ST_VERIFICATION_FAILED);
+}
+
+int hs_g1_add(const uint8_t* a, const uint8_t* b, uint8_t* out) {
+  G1Affine pa, pb, r;
+  uint8_t st = dec_g1(pa, a, 0), sb = dec_g1(pb, b, 0);
+  if (st == ST_OK) st = sb;
+  G1Jac ja, jb, jo;
+  jac_from_affine(ja, pa); jac_from_affine(jb, pb);
+  jac_add(jo, ja, jb);
+  jac_to_affine(r, jo);
+  if (st != ST_OK) r.inf = true;
+  alignas(4) uint8_t tmp[64];
+  encode_g1(tmp, r);
+  memcpy(out, tmp, 64);
+  return st;
+}
+int hs_g2_add(const uint8_t* a, const uint8_t* b, uint8_t* out) {
+  G2Affine pa, pb, r;
+  uint8_t st = dec_g2(pa, a, 0), sb = dec_g2(pb, b, 0);
+  if (st == ST_OK) st = sb;
+  G2Jac ja, jb, jo;
+  jac_from_affine(ja, pa); jac_from_affine(jb, pb);
+  jac_add(jo, ja, jb);
+  jac_to_affine(r, jo);
+  if (st != ST_OK) r.inf = true;
+  alignas(4) uint8_t tmp[128];
+  encode_g2(tmp, r);
+  memcpy(out, tmp, 128);
+  return st;
+}
+int hs_g1_mul(const uint8_t* p, const uint8_t* scalar32, int reduce, uint8_t* out) {
+  G1Affine pa, r;
+  uint8_t st = dec_g1(pa, p, 0);
+  alignas(4) uint8_t sc[32];
+  memcpy(sc, scalar32, 32);
+  uint32_t k[8];
+  scalar_from_be(k, sc, reduce != 0);
+  G1Jac ja, jo;
+  jac_from_affine(ja, pa);
+  jac_mul(jo, ja, k);
+  jac_to_affine(r, jo);
+  if (st != ST_OK) r.inf = true;
+  alignas(4) uint8_t tmp[64];
+  encode_g1(tmp, r);
+  memcpy(out, tmp, 64);
+  return st;
+}
+int hs_g2_mul(const uint8_t* p, const uint8_t* scalar32, int reduce, uint8_t* out) {
+  G2Affine pa, r;
+  uint8_t st = ST_OK;
+  if (p) st = dec_g2(pa, p, 0); else set_g2_gen(pa);
+  alignas(4) uint8_t sc[32];
+  memcpy(sc, scalar32, 32);
+  uint32_t k[8];
+  scalar_from_be(k, sc, reduce != 0);
+  G2Jac ja, jo;
+  jac_from_affine(ja, pa);
+  jac_mul(jo, ja, k);
+  jac_to_affine(r, jo);
+  if (st != ST_OK) r.inf = true;
+  alignas(4) uint8_t tmp[128];
+  encode_g2(tmp, r);
+  memcpy(out, tmp, 128);
+  return st;
+}
+int hs_sign(const uint8_t* msg, uint64_t len, const uint8_t* sk32, uint8_t* sig64) {
+  G1Affine h, r;
+  uint8_t st = hash_item(h, msg, len, nullptr);
+  alignas(4) uint8_t sc[32];
+  memcpy(sc, sk32, 32);
+  uint32_t k[8];
+  scalar_from_be(k, sc, true);
+  G1Jac ja, jo;
+  jac_from_affine(ja, h);
+  jac_mul(jo, ja, k);
+  jac_to_affine(r, jo);
+  if (st != ST_OK) r.inf = true;
+  alignas(4) uint8_t tmp[64];
+  encode_g1(tmp, r);
+  memcpy(sig64, tmp, 64);
+  return st;
+}
+// op codes as bn254_debug_fp_op
+int hs_fp_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+  alignas(4) uint8_t ta[32], tb[32], to[32];
+  memcpy(ta, a, 32);
+  if (b) memcpy(tb, b, 32); else memset(tb, 0, 32);
+  uint32_t any = 0;
+  Fp x, y, r;
+  bool ok = fp_from_be(x, ta, any);
+  ok = fp_from_be(y, tb, any) && ok;
+  uint8_t st = ok ? ST_OK : ST_NOT_MEMBER;
+  switch (op) {
+    case 0: r = fp_mul(x, y); break;
+    case 1: r = fp_add(x, y); break;
+    case 2: r = fp_sub(x, y); break;
+    case 3: r = fp_inv(x); break;
+    case 4: r = fp_sqr(x); break;
+    default: if (!fp_sqrt(r, x) && st == ST_OK) st = ST_NOT_MEMBER; break;
+  }
+  fp_to_be(to, r);
+  memcpy(out, to, 32);
+  return st;
+}
+}  // extern "C"

@@ -1,0 +1,75 @@
+"""ctypes binding of tests/hostsim/libhostsim.so (device headers compiled for the host; test-only)."""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostsim")
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        subprocess.check_call(["make", "-C", _HERE], stdout=subprocess.DEVNULL)
+        L = ctypes.CDLL(os.path.join(_HERE, "libhostsim.so"))
+        cp = ctypes.c_char_p
+        L.hs_hash_to_g1.argtypes = [cp, ctypes.c_uint64, cp, ctypes.POINTER(ctypes.c_int)]
+        L.hs_verify.argtypes = [cp, ctypes.c_uint64, cp, cp, ctypes.c_uint32]
+        L.hs_pairing.argtypes = [cp, cp, ctypes.c_uint64, ctypes.c_uint32, cp, ctypes.c_int]
+        L.hs_check_public_keys.argtypes = [cp, cp, ctypes.c_uint32]
+        for f in ("hs_g1_add", "hs_g2_add"):
+            getattr(L, f).argtypes = [cp, cp, cp]
+        for f in ("hs_g1_mul", "hs_g2_mul"):
+            getattr(L, f).argtypes = [cp, cp, ctypes.c_int, cp]
+        L.hs_sign.argtypes = [cp, ctypes.c_uint64, cp, cp]
+        L.hs_fp_op.argtypes = [ctypes.c_int, cp, cp, cp]
+        _lib = L
+    return _lib
+
+
+def _b(n):
+    return ctypes.create_string_buffer(n)
+
+
+def hash_to_g1(msg):
+    o, t = _b(64), ctypes.c_int(0)
+    st = lib().hs_hash_to_g1(bytes(msg), len(msg), o, ctypes.byref(t))
+    return st, o.raw, t.value
+
+
+def verify(msg, sig, pk, flags=1):
+    return lib().hs_verify(bytes(msg), len(msg), bytes(sig), bytes(pk), flags)
+
+
+def pairing(g1s, g2s, k=1, flags=0, raw=False):
+    o = _b(384)
+    st = lib().hs_pairing(bytes(g1s), bytes(g2s), k, flags, o, 1 if raw else 0)
+    return st, o.raw
+
+
+def check_public_keys(pk2, pk1, flags=1):
+    return lib().hs_check_public_keys(bytes(pk2), bytes(pk1), flags)
+
+
+def g1_add(a, b):
+    o = _b(64); st = lib().hs_g1_add(bytes(a), bytes(b), o); return st, o.raw
+
+
+def g2_add(a, b):
+    o = _b(128); st = lib().hs_g2_add(bytes(a), bytes(b), o); return st, o.raw
+
+
+def g1_mul(p, k, reduce=False):
+    o = _b(64); st = lib().hs_g1_mul(bytes(p), bytes(k), int(reduce), o); return st, o.raw
+
+
+def g2_mul(p, k, reduce=False):
+    o = _b(128); st = lib().hs_g2_mul(None if p is None else bytes(p), bytes(k), int(reduce), o); return st, o.raw
+
+
+def sign(msg, sk):
+    o = _b(64); st = lib().hs_sign(bytes(msg), len(msg), bytes(sk), o); return st, o.raw
+
+
+def fp_op(op, a, b=None):
+    o = _b(32); st = lib().hs_fp_op(op, bytes(a), None if b is None else bytes(b), o); return st, o.raw

@@ -1,0 +1,50 @@
+"""The C-ABI library loads and exports every symbol include/bn254_hip.h declares; without a GPU it
+refuses to create a context (no CPU fallback).  CPU only — no compute calls."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from bn254_amd import _native
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    _native.build()
+    return _native.load()
+
+
+def test_header_symbols_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "bn254_hip.h")).read()
+    declared = set(re.findall(r"\b(bn254_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_native.EXPORTED_SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_version(lib):
+    assert b"gfx950" in lib.bn254_version()
+
+
+def test_no_cpu_fallback(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    h = ctypes.c_void_p()
+    assert lib.bn254_ctx_create(0, ctypes.byref(h)) == -10003     # BN254_E_NO_DEVICE
+    with pytest.raises(Exception):
+        import bn254_amd
+        bn254_amd.Engine(0)
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "bn254_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".hpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
+                assert "libbn254_oracle" not in src and "hostsim" not in src.replace("tests/hostsim", ""), f

@@ -1,0 +1,276 @@
+"""GPU parity tests: the HIP path, through the C ABI (libbn254hip.so), against the oracle on the
+same inputs — bit-exact (integer/byte work, no tolerance).  Run on the MI355X box: -m gpu."""
+import hashlib
+import random
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+H = bytes.fromhex
+Q = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47
+R = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import bn254_amd
+    return bn254_amd.Engine(0)
+
+
+@pytest.fixture(scope="module")
+def c():
+    from oracle import c_oracle
+    return c_oracle
+
+
+def test_native_library_loaded(eng):
+    assert "gfx950" in eng.version()
+    with open("/proc/self/maps") as f:
+        assert "libbn254hip.so" in f.read()
+
+
+# ---- layer by layer ------------------------------------------------------------------------
+def test_fp_ops(eng):
+    rnd = random.Random(11)
+    edge = [0, 1, 2, Q - 1, Q - 2, (1 << 256) % Q, 0xFFFFFFFF, 1 << 32, (1 << 224) - 1]
+    n = 4096
+    a = [edge[i % len(edge)] if i < 81 else rnd.randrange(Q) for i in range(n)]
+    b = [edge[(i // len(edge)) % len(edge)] if i < 81 else rnd.randrange(Q) for i in range(n)]
+    ab = b"".join(x.to_bytes(32, "big") for x in a)
+    bb = b"".join(x.to_bytes(32, "big") for x in b)
+    for op, fn in ((0, lambda x, y: x * y % Q), (1, lambda x, y: (x + y) % Q), (2, lambda x, y: (x - y) % Q), (4, lambda x, y: x * x % Q)):
+        out, st = eng.debug_fp_op(op, ab, bb, n)
+        assert st == bytes(n)
+        got = [int.from_bytes(out[32 * i:32 * i + 32], "big") for i in range(n)]
+        assert got == [fn(x, y) for x, y in zip(a, b)], "fp op %d" % op
+    out, _ = eng.debug_fp_op(3, ab, None, n)
+    for i in range(n):
+        assert int.from_bytes(out[32 * i:32 * i + 32], "big") == (pow(a[i], -1, Q) if a[i] else 0)
+    sq = b"".join((x * x % Q).to_bytes(32, "big") for x in a)
+    out, st = eng.debug_fp_op(5, sq, None, n)
+    assert st == bytes(n)
+    for i in range(n):
+        assert pow(int.from_bytes(out[32 * i:32 * i + 32], "big"), 2, Q) == a[i] * a[i] % Q
+    # x >= q is NotMemberError(6)
+    _, st = eng.debug_fp_op(0, Q.to_bytes(32, "big"), (1).to_bytes(32, "big"), 1)
+    assert st[0] == 6
+
+
+def _rand_points(c, n, seed):
+    g1, g2 = c.g1_generator(), c.g2_generator()
+    ps, qs = [], []
+    for i in range(n):
+        a = int.from_bytes(hashlib.sha256(b"%s-a%d" % (seed, i)).digest(), "big") % R
+        b = int.from_bytes(hashlib.sha256(b"%s-b%d" % (seed, i)).digest(), "big") % R
+        ps.append(c.g1_mul(g1, a.to_bytes(32, "big")))
+        qs.append(c.g2_mul(g2, b.to_bytes(32, "big")))
+    return ps, qs
+
+
+def test_miller_loop_raw(eng, c):
+    ps, qs = _rand_points(c, 70, b"ml")
+    got = eng.debug_miller_loop(b"".join(ps), b"".join(qs), 70)
+    for i in range(70):
+        assert got[384 * i:384 * i + 384] == c.miller_loop(ps[i], qs[i]), i
+
+
+def test_fp12_ops(eng, c):
+    ps, qs = _rand_points(c, 66, b"f12")
+    fs = [c.miller_loop(ps[i], qs[i]) for i in range(66)]       # generic Fq12 elements
+    gts = [c.pairing(ps[i], qs[i]) for i in range(66)]          # cyclotomic-subgroup elements
+    a = b"".join(fs)
+    # final exponentiation of raw Miller values == oracle Gt
+    out = eng.debug_fp12_op(8, a, None, 66)
+    assert out == b"".join(gts)
+    # algebraic identities checked on the device results themselves
+    sq = eng.debug_fp12_op(1, a, None, 66)
+    assert sq == eng.debug_fp12_op(0, a, a, 66)
+    inv = eng.debug_fp12_op(2, a, None, 66)
+    one = eng.debug_fp12_op(0, a, inv, 66)
+    from tests.conftest import GOLDEN  # noqa: F401
+    gt_one = (1).to_bytes(32, "big") + bytes(352)
+    assert one == gt_one * 66
+    g = b"".join(gts)
+    assert eng.debug_fp12_op(7, g, None, 66) == eng.debug_fp12_op(1, g, None, 66)     # cyclotomic sqr == sqr on Gt
+    assert eng.debug_fp12_op(0, g, eng.debug_fp12_op(3, g, None, 66), 66) == gt_one * 66   # conj = inverse on Gt
+    f1 = eng.debug_fp12_op(4, a, None, 66)
+    f2 = eng.debug_fp12_op(5, a, None, 66)
+    f3 = eng.debug_fp12_op(6, a, None, 66)
+    assert eng.debug_fp12_op(4, f1, None, 66) == f2 and eng.debug_fp12_op(4, f2, None, 66) == f3
+
+
+# ---- golden vectors --------------------------------------------------------------------------
+def test_hash_to_g1_golden(eng, kats, derived):
+    vs = [(H(v["message_hex"]), v["uncompressed"], v["tries"]) for v in derived["hash_to_g1"]]
+    pts, st, tries = eng.batch_hash_to_g1([m for m, _, _ in vs])
+    assert st == bytes(len(vs))
+    for i, (_, want, t) in enumerate(vs):
+        assert pts[64 * i:64 * i + 64].hex() == want and tries[i] == t
+    for v in kats["hash_to_g1"]:
+        pts, st, _ = eng.batch_hash_to_g1([H(v["message_hex"])])
+        assert st == b"\x00" and pts[:32].hex() == v["compressed"][2:] and (pts[63] & 1) == 0
+
+
+def test_hash_to_g1_vs_oracle_ragged(eng, c):
+    msgs = [hashlib.sha256(b"rag%d" % i).digest()[: i % 33] * (1 + i % 7) for i in range(1000)] + [b"", b"\x00" * 200]
+    pts, st, tries = eng.batch_hash_to_g1(msgs)
+    for i, m in enumerate(msgs):
+        wst, wpt, wtries = c.hash_to_g1(m)
+        assert (st[i], pts[64 * i:64 * i + 64], tries[i]) == (wst, wpt, wtries), i
+
+
+def test_pairing_gt_golden(eng, derived):
+    vs = derived["pairing_gt"]
+    gt, st = eng.batch_pairing(b"".join(H(v["g1"]) for v in vs), b"".join(H(v["g2"]) for v in vs), len(vs))
+    assert st == bytes([9]) * len(vs)           # e(P,Q) != 1
+    for i, v in enumerate(vs):
+        assert gt[384 * i:384 * i + 384].hex() == v["gt"]
+    gt, st = eng.batch_pairing(bytes(64), H(derived["g2_generator"]), 1)
+    assert gt.hex() == derived["gt_one"] and st == b"\x00"
+
+
+def test_verify_cases_golden(eng, derived):
+    cs = derived["verify_cases"]
+    st = eng.batch_verify([H(v["message_hex"]) for v in cs], b"".join(H(v["sig"]) for v in cs), b"".join(H(v["pk"]) for v in cs), flags=1)
+    assert list(st) == [v["status"] for v in cs], [v["name"] for v, s in zip(cs, st) if s != v["status"]]
+    v = [x for x in cs if "not-in-subgroup" in x["name"]][0]
+    assert eng.batch_verify([H(v["message_hex"])], H(v["sig"]), H(v["pk"]), flags=0) == b"\x09"
+    assert eng.batch_verify([b"x"], bytes(64), bytes(128), flags=2) == b"\x04"
+    assert eng.batch_verify([], b"", b"") == b""
+
+
+def test_reference_kats_through_api(eng, c, kats):
+    import bn254_amd as bn
+    # src/ecdsa_test.rs:5-17 (sign KAT) and :20-38 (verify)
+    for v in kats["sign"]:
+        sk = bn.PrivateKey.try_from(v["private_key"])
+        sig = bn.ECDSA.sign(H(v["message_hex"]), sk)
+        assert sig.to_compressed().hex() == v["signature_compressed"]
+        bn.ECDSA.verify(H(v["message_hex"]), sig, bn.PublicKey.from_private_key(sk))
+        again = bn.Signature.from_uncompressed(sig.to_uncompressed())      # :131-153
+        bn.ECDSA.verify(H(v["message_hex"]), again, bn.PublicKey.from_private_key(sk))
+    # src/ecdsa_test.rs:41-78 aggregate
+    a = kats["aggregate"]
+    sks = [bn.PrivateKey.try_from(k) for k in a["private_keys"]]
+    msg = H(a["message_hex"])
+    sigs = [bn.ECDSA.sign(msg, k) for k in sks]
+    pks = [bn.PublicKey.from_private_key(k) for k in sks]
+    for s, p in zip(sigs, pks):
+        bn.ECDSA.verify(msg, s, p)
+    bn.ECDSA.verify(msg, sigs[0] + sigs[1], pks[0] + pks[1])
+    with pytest.raises(bn.Error) as e:
+        bn.ECDSA.verify(msg, sigs[0], pks[1])
+    assert e.value.kind == bn.ErrorKind.VerificationFailed
+    # src/ecdsa_test.rs:81-112 check_public_keys
+    for v in kats["check_public_keys"]:
+        pk2 = bn.PublicKey.from_private_key(bn.PrivateKey.try_from(v["sk_g2"]))
+        pk1 = bn.PublicKeyG1.from_private_key(bn.PrivateKey.try_from(v["sk_g1"]))
+        pk1 = bn.PublicKeyG1.from_uncompressed(pk1.to_uncompressed())      # :114-128
+        if v["status"] == 0:
+            bn.check_public_keys(pk2, pk1)
+        else:
+            with pytest.raises(bn.Error) as e:
+                bn.check_public_keys(pk2, pk1)
+            assert e.value.kind == bn.ErrorKind.VerificationFailed
+    # src/types_test.rs
+    for v in kats["public_key_from_private_key"]:
+        pk = bn.PublicKey.from_private_key(bn.PrivateKey.try_from(v["private_key"]))
+        assert pk.to_uncompressed().hex() == v["uncompressed"]
+        assert bn.PublicKey.from_uncompressed(H(v["uncompressed"])) == pk
+    g2 = bn.PublicKey(c.g2_generator())
+    assert (g2 + g2).to_compressed().hex() == kats["g2_double_generator_compressed"]["hex"]
+    g1 = bn.Signature(c.g1_generator())
+    assert (g1 + g1).to_compressed().hex() == kats["g1_double_generator_compressed"]["hex"]
+    hx = kats["private_key_roundtrip"]["hex"]
+    assert bn.PrivateKey.try_from(hx).to_hex() == hx
+    for bad in kats["private_key_invalid_length"]["hex"]:
+        with pytest.raises(bn.Error) as e:
+            bn.PrivateKey.try_from(H(bad))
+        assert e.value.kind == bn.ErrorKind.InvalidLength
+    # examples/bn254.rs
+    ex = kats["example"]
+    ks = [bn.PrivateKey.try_from(k) for k in ex["private_keys"]]
+    m = ex["message"].encode()
+    agg_sig = bn.ECDSA.sign(m, ks[0]) + bn.ECDSA.sign(m, ks[1])
+    agg_pk = bn.PublicKey.from_private_key(ks[0]) + bn.PublicKey.from_private_key(ks[1])
+    bn.ECDSA.verify(m, agg_sig, agg_pk)
+    assert bn.ECDSA.batch_verify([m, m], [agg_sig, agg_sig], [agg_pk, pks[0]]) == [None, bn.Error(9)]
+
+
+def test_bn256_vectors(eng, kats):
+    adds = kats["g1_add"]
+    out, st = eng.batch_g1_add(b"".join(H(v["x1"] + v["y1"]) for v in adds), b"".join(H(v["x2"] + v["y2"]) for v in adds), len(adds))
+    assert st == bytes(len(adds)) and out.hex() == "".join(v["result"] for v in adds)
+    muls = kats["g1_mul"]
+    out, st = eng.batch_g1_mul(b"".join(H(v["x"] + v["y"]) for v in muls), b"".join(H(v["scalar"]) for v in muls), len(muls))
+    assert st == bytes(len(muls)) and out.hex() == "".join(v["result"] for v in muls)
+
+
+# ---- batches vs the oracle -----------------------------------------------------------------
+def test_batch_verify_vs_oracle_4k(eng, c):
+    from tests.datagen import make_verify_batch
+    n = 4096 + 37                      # ragged tail wave
+    msgs, sigs, pks, expected = make_verify_batch(eng, n)
+    got = eng.batch_verify(msgs, sigs, pks, flags=0)
+    assert got == expected
+    want, _ = c.batch_verify(msgs[:512], sigs[:512 * 64], pks[:512 * 128], flags=0, nthreads=8)
+    assert got[:512] == want
+    # signatures produced on the GPU equal the oracle's
+    for i in range(0, 64, 7):
+        from tests.datagen import sk_bytes
+        assert sigs[64 * i:64 * i + 64] == c.sign(msgs[i], sk_bytes(i % 256)) or expected[i] == 9
+
+
+def test_pairing_check_k_pairs(eng, c):
+    ps, qs = _rand_points(c, 6, b"kp")
+    # e(aP, Q) * e(-aP, Q) == 1  and a 3-pair product that is not one
+    neg = lambda p: p[:32] + ((Q - int.from_bytes(p[32:], "big")) % Q).to_bytes(32, "big")   # noqa: E731
+    g1 = ps[0] + neg(ps[0]) + ps[1] + ps[2] + ps[3] + ps[4]
+    g2 = qs[0] + qs[0] + qs[1] + qs[2] + qs[3] + qs[4]
+    st = eng.batch_pairing_check(g1[:128] + g1[128:256], g2[:256] + g2[256:512], 2, 2)
+    assert st == bytes([0, 9])
+    assert st[0] == c.pairing_check(g1[:128], g2[:256], 2) and st[1] == c.pairing_check(g1[128:256], g2[256:512], 2)
+    gt, _ = eng.batch_pairing(g1[128:320], g2[256:640], 1, 3)
+    assert gt == c.pairing(g1[128:320], g2[256:640], k=3)
+
+
+def test_group_ops_vs_oracle(eng, c):
+    ps, qs = _rand_points(c, 40, b"grp")
+    n = 40
+    out, st = eng.batch_g2_add(b"".join(qs), b"".join(qs[::-1]), n)
+    assert st == bytes(n)
+    for i in range(n):
+        assert out[128 * i:128 * i + 128] == c.g2_add(qs[i], qs[n - 1 - i])
+    ks = [hashlib.sha256(b"k%d" % i).digest() for i in range(n)]
+    out, st = eng.batch_g2_mul(b"".join(qs), b"".join(ks), n)
+    for i in range(0, n, 5):
+        assert out[128 * i:128 * i + 128] == c.g2_mul(qs[i], ks[i])
+    # segmented sums (aggregation)
+    seg = [0, 1, 1, 8, 40]
+    out, st = eng.batch_g1_sum(b"".join(ps), seg)
+    acc = bytes(64)
+    for p in ps[8:40]:
+        acc = c.g1_add(acc, p)
+    assert out[192:256] == acc and out[64:128] == bytes(64) and out[:64] == ps[0]
+    out2, _ = eng.batch_g2_sum(b"".join(qs), seg)
+    acc = bytes(128)
+    for q in qs[1:8]:
+        acc = c.g2_add(acc, q)
+    assert out2[256:384] == acc
+
+
+def test_full_size_batch_properties(eng):
+    """config-2 size (65 536): expected-status pattern (valid except every 64th), and
+    permutation-equivariance of the result — size-independent properties, no oracle needed."""
+    from tests.datagen import make_verify_batch
+    n = 65536
+    msgs, sigs, pks, expected = make_verify_batch(eng, n)
+    got = eng.batch_verify(msgs, sigs, pks, flags=0)
+    assert got == expected
+    assert hashlib.sha256(got).hexdigest() == hashlib.sha256(expected).hexdigest()
+    # reversing the batch reverses the statuses
+    rm = msgs[::-1]
+    rs = b"".join(sigs[64 * i:64 * i + 64] for i in range(n - 1, -1, -1))
+    rp = b"".join(pks[128 * i:128 * i + 128] for i in range(n - 1, -1, -1))
+    assert eng.batch_verify(rm, rs, rp, flags=0) == expected[::-1]

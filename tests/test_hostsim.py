@@ -1,0 +1,79 @@
+"""The product's device arithmetic source (bn254_amd/csrc/*.h), compiled for the host, against the
+oracle, the reference KATs and the derived golden vectors.  CPU only: this is the pre-flight check
+of the kernels' algorithm; the GPU parity tests proper are tests/test_gpu_parity.py."""
+import hashlib
+import random
+
+from oracle import c_oracle as c
+from tests import hostsim_binding as hs
+
+H = bytes.fromhex
+Q = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47
+
+
+def test_fp_ops_vs_python_ints():
+    rnd = random.Random(7)
+    edge = [0, 1, 2, Q - 1, Q - 2, (1 << 256) % Q, (1 << 255) % Q, 0xFFFFFFFF, 1 << 32, (1 << 224) - 1]
+    vals = edge + [rnd.randrange(Q) for _ in range(40)]
+    for a in vals:
+        for b in vals[:14]:
+            ab, bb = a.to_bytes(32, "big"), b.to_bytes(32, "big")
+            assert int.from_bytes(hs.fp_op(0, ab, bb)[1], "big") == a * b % Q
+            assert int.from_bytes(hs.fp_op(1, ab, bb)[1], "big") == (a + b) % Q
+            assert int.from_bytes(hs.fp_op(2, ab, bb)[1], "big") == (a - b) % Q
+        ab = a.to_bytes(32, "big")
+        assert int.from_bytes(hs.fp_op(4, ab)[1], "big") == a * a % Q
+        if a:
+            assert int.from_bytes(hs.fp_op(3, ab)[1], "big") * a % Q == 1
+        st, r = hs.fp_op(5, (a * a % Q).to_bytes(32, "big"))
+        assert st == 0 and pow(int.from_bytes(r, "big"), 2, Q) == a * a % Q
+    assert hs.fp_op(0, Q.to_bytes(32, "big"), (1).to_bytes(32, "big"))[0] == 6   # >= q -> NotMember
+
+
+def test_hash_vectors(kats, derived):
+    for v in kats["hash_to_g1"]:
+        st, pt, _ = hs.hash_to_g1(H(v["message_hex"]))
+        assert st == 0 and c.g1_compress(pt).hex() == v["compressed"]
+    for v in derived["hash_to_g1"]:
+        st, pt, tries = hs.hash_to_g1(H(v["message_hex"]))
+        assert (st, pt.hex(), tries) == (0, v["uncompressed"], v["tries"])
+
+
+def test_hash_random_vs_oracle():
+    for i in range(200):
+        msg = hashlib.sha256(b"hs%d" % i).digest()[: (i % 40)] * (1 + i % 5)
+        assert hs.hash_to_g1(msg) == c.hash_to_g1(msg)
+
+
+def test_pairing_gt_and_raw_miller(derived):
+    for v in derived["pairing_gt"]:
+        assert hs.pairing(H(v["g1"]), H(v["g2"]))[1].hex() == v["gt"]
+        assert hs.pairing(H(v["g1"]), H(v["g2"]), raw=True)[1] == c.miller_loop(H(v["g1"]), H(v["g2"]))
+    # 2-pair product through the generic path == oracle
+    a, b = derived["pairing_gt"][1], derived["pairing_gt"][2]
+    g1s, g2s = H(a["g1"]) + H(b["g1"]), H(a["g2"]) + H(b["g2"])
+    assert hs.pairing(g1s, g2s, k=2)[1] == c.pairing(g1s, g2s, k=2)
+    assert hs.pairing(bytes(64), H(a["g2"]))[1].hex() == derived["gt_one"]
+
+
+def test_verify_cases(derived):
+    for v in derived["verify_cases"]:
+        assert hs.verify(H(v["message_hex"]), H(v["sig"]), H(v["pk"])) == v["status"], v["name"]
+    assert hs.verify(b"x", bytes(64), bytes(128), flags=2) == 4
+
+
+def test_reference_kats(kats):
+    for v in kats["g1_add"]:
+        assert hs.g1_add(H(v["x1"] + v["y1"]), H(v["x2"] + v["y2"]))[1].hex() == v["result"]
+    for v in kats["g1_mul"]:
+        assert hs.g1_mul(H(v["x"] + v["y"]), H(v["scalar"]))[1].hex() == v["result"]
+    for v in kats["public_key_from_private_key"]:
+        assert hs.g2_mul(None, H(v["private_key"]), reduce=True)[1].hex() == v["uncompressed"]
+    for v in kats["sign"]:
+        assert c.g1_compress(hs.sign(H(v["message_hex"]), H(v["private_key"]))[1]).hex() == v["signature_compressed"]
+    for v in kats["check_public_keys"]:
+        assert hs.check_public_keys(c.public_key_g2(H(v["sk_g2"])), c.public_key_g1(H(v["sk_g1"]))) == v["status"]
+    ex = kats["example"]
+    sigs = [hs.sign(ex["message"].encode(), H(k))[1] for k in ex["private_keys"]]
+    pks = [hs.g2_mul(None, H(k), reduce=True)[1] for k in ex["private_keys"]]
+    assert hs.verify(ex["message"].encode(), hs.g1_add(*sigs)[1], hs.g2_add(*pks)[1]) == 0
