@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py — BN254 pairings/s of the batch-verify hot path on N MI355X (driver contract).
+
+A "step" = one pass of ECDSA::verify over one batch of 65 536 (message, signature, public key)
+tuples per GPU (BASELINE.json configs[1]), inputs already resident in HBM, through the C ABI
+(bn254_batch_verify_device): decode -> SHA-256 try-and-increment hash-to-G1 -> 2-pair Miller loop
+-> final exponentiation -> status byte.  One verify = 2 pairings (two Miller loops, one final
+exponentiation), so pairings/s = 2 x verifies/s.
+
+Multi-GPU: one process per GPU (torchrun), each rank verifies its own 65 536-tuple shard
+(weak scaling, no data-path collective) and the per-item status bytes are all-gathered over
+RCCL/xGMI inside every timed step (the "final boolean gather" of the north star).
+
+Prints ONE JSON line on rank 0 (see README/DESIGN.md for the roofline + cpu_baseline objects).
+"""
+import argparse
+import hashlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+BATCH = 65536                      # tuples per GPU per step (configs[1])
+CORRUPT_EVERY = 64                 # every 64th signature is wrong -> expected status 9 there
+# Algorithmic work per verify, counted by instrumenting the device arithmetic source compiled for
+# the host (tests/test_workcount.py keeps these in sync): Montgomery products per kernel stage.
+FP_MUL_DECODE = 16
+FP_MUL_HASH_PER_TRY = 369.2        # 370 first try incl. conversion; measured mean tries 2.12
+FP_MUL_MILLER = 12182
+FP_MUL_FINAL_EXP = 9223
+MAC32_PER_FP_MUL = 136             # 8-limb Montgomery product: 2*8*8 + 8 32x32->64 multiply-accumulates
+# VALU roofline: v_mad_u64_u32 issues once per 4 cycles per SIMD (half the 2-cycle full rate):
+# 256 CU x 4 SIMD x 64 lanes x 2.4 GHz / 4 = 39.3 T MAC32/s.  The committed microbenchmark
+# (profiles/r01_valu_rates_microbench.jsonl) sustains 29.9 T/s of that.
+PEAK_MAC32_THEORETICAL = 256 * 4 * 64 * 2.4e9 / 4
+PEAK_MAC32_MEASURED = 2.99e13
+HBM_PEAK_GBPS = 8000.0
+BYTES_PER_VERIFY_IO = 32 + 8 + 64 + 128 + 1   # message + offset + sig + pk + status
+
+
+def D(tag, i):
+    return hashlib.sha256(tag.encode() + i.to_bytes(8, "little")).digest()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=BATCH, help="tuples per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (bn254_amd has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import bn254_amd
+    from tests.datagen import KEY_POOL, sk_bytes
+
+    eng = bn254_amd.Engine(local_rank)
+    n = args.batch
+    eng.reserve(n)
+
+    # ---- synthetic inputs, generated on the GPU by the product's own sign / keygen kernels -------
+    base = rank * n                                          # each rank owns a distinct shard
+    msgs = [D("bn254/msg2", base + i) for i in range(n)]
+    pool = min(KEY_POOL, n)
+    sks = [sk_bytes(j) for j in range(pool)]
+    pk_pool, st = eng.batch_g2_mul(None, b"".join(sks), pool, reduce_scalar=True)
+    assert st == bytes(pool)
+    sigs, st = eng.batch_sign(msgs, b"".join(sks[(base + i) % pool] for i in range(n)))
+    assert st == bytes(n)
+    sigs = bytearray(sigs)
+    expected = bytearray(n)
+    good = bytes(sigs)
+    for i in range(CORRUPT_EVERY - 1, n, CORRUPT_EVERY):
+        sigs[64 * i:64 * i + 64] = good[64 * (i - 1):64 * i]
+        expected[i] = 9
+    pks = b"".join(pk_pool[128 * ((base + i) % pool):128 * ((base + i) % pool) + 128] for i in range(n))
+
+    def to_dev(b, dtype=torch.uint8):
+        return torch.frombuffer(bytearray(b), dtype=dtype).to(dev)
+
+    d_msgs = to_dev(b"".join(msgs))
+    d_off = torch.arange(0, 32 * (n + 1), 32, dtype=torch.int64, device=dev)
+    d_sigs = to_dev(bytes(sigs))
+    d_pks = to_dev(pks)
+    d_status = torch.zeros(n, dtype=torch.uint8, device=dev)
+    d_all = torch.zeros(n * world, dtype=torch.uint8, device=dev) if world > 1 else None
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        eng.batch_verify_device(d_msgs.data_ptr(), d_off.data_ptr(), d_sigs.data_ptr(), d_pks.data_ptr(), n, d_status.data_ptr(),
+                                flags=0, stream=stream)
+        if world > 1:
+            dist.all_gather_into_tensor(d_all, d_status)     # RCCL over xGMI: the only collective
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    # parity gate before any timing is accepted: device statuses == expected pattern
+    got = bytes(d_status.cpu().numpy())
+    assert got == bytes(expected), "GPU status bytes differ from the expected pattern"
+
+    eng.set_profiling(True)
+    kernel_ms = {"decode": 0.0, "hash_to_g1": 0.0, "miller_loop": 0.0, "final_exp": 0.0}
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        ms = eng.last_kernel_ms()                            # HIP events on the launch stream
+        for k in kernel_ms:
+            kernel_ms[k] += ms[k]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        assert bytes(d_all[rank * n:(rank + 1) * n].cpu().numpy()) == bytes(expected)
+
+    verifies = n * world * args.steps
+    verifies_per_s = verifies / elapsed
+    result = {
+        "metric": "BN254 pairings/sec (batch verify)",
+        "value": 2.0 * verifies_per_s,
+        "unit": "pairings/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u32",
+        "data": "synthetic",
+        "config": {"workload": "configs[1]: batch of 65536 independent e(H(m),pk)*e(sig,-G2)==1 verifies per GPU "
+                               "(32-byte messages, 1/64 corrupted), 2 pairings per verify",
+                   "batch_per_gpu": n, "verifies_per_s": verifies_per_s, "bit_exact_vs_expected": True},
+    }
+
+    if rank == 0:
+        k_avg = {k: v / args.steps for k, v in kernel_ms.items()}
+        dom = max(("miller_loop", "final_exp"), key=lambda k: k_avg[k])
+        fp_mul = FP_MUL_MILLER if dom == "miller_loop" else FP_MUL_FINAL_EXP
+        mac_per_launch = fp_mul * MAC32_PER_FP_MUL * n
+        achieved = mac_per_launch / (k_avg[dom] * 1e-3) / 1e12
+        io_bytes = BYTES_PER_VERIFY_IO * n
+        result["roofline"] = {
+            "bound": "valu",                       # integer multiply issue (v_mad_u64_u32); not HBM, not MFMA
+            "kernel": "k_miller_verify" if dom == "miller_loop" else "k_final_exp",
+            "achieved": achieved, "peak": PEAK_MAC32_THEORETICAL / 1e12, "unit": "TMAC32/s",
+            "frac": achieved / (PEAK_MAC32_THEORETICAL / 1e12),
+            "peak_measured_microbench": PEAK_MAC32_MEASURED / 1e12,
+            "frac_of_measured_peak": achieved / (PEAK_MAC32_MEASURED / 1e12),
+            "traffic": None,
+            "kernel_ms": k_avg,
+            "mac32_per_verify": {"miller_loop": FP_MUL_MILLER * MAC32_PER_FP_MUL, "final_exp": FP_MUL_FINAL_EXP * MAC32_PER_FP_MUL,
+                                 "hash_to_g1_mean": FP_MUL_HASH_PER_TRY * 2.12 * MAC32_PER_FP_MUL, "decode": FP_MUL_DECODE * MAC32_PER_FP_MUL},
+            "hbm": {"algorithmic_bytes_per_step": io_bytes, "achieved_GBps": io_bytes / (1e-3 * 1e3 * elapsed / args.steps) / 1e9,
+                    "peak_GBps": HBM_PEAK_GBPS, "note": "evidence that the path is not memory-bound"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import c_oracle
+            cores = os.cpu_count() or 1
+            sample = min(n, max(256, 32 * cores))            # ~10-20 CPU-seconds of work in total
+            t1 = time.perf_counter()
+            st_cpu, _ = c_oracle.batch_verify(msgs[:sample], bytes(sigs[:64 * sample]), pks[:128 * sample], flags=0, nthreads=cores)
+            dt_all = time.perf_counter() - t1
+            assert st_cpu == bytes(expected[:sample]), "oracle disagrees with the expected pattern"
+            one = min(sample, 256)
+            t1 = time.perf_counter()
+            c_oracle.batch_verify(msgs[:one], bytes(sigs[:64 * one]), pks[:128 * one], flags=0, nthreads=1)
+            dt_one = time.perf_counter() - t1
+            result["cpu_baseline"] = {
+                "value": 2.0 * sample / dt_all, "unit": "pairings/s", "cores": cores, "kind": "port",
+                "sample": "first %d tuples of the same batch, oracle/bn254_oracle.c (C restatement of the reference path, "
+                          "4x64-bit Montgomery limbs, pthreads, gcc -O2)" % sample,
+                "single_thread_value": 2.0 * one / dt_one,
+            }
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -31,6 +31,15 @@
 
 #include "bn254_constants.h"
 
+// host-only instrumentation (tests/hostsim): exact count of Montgomery products per kernel stage,
+// the algorithmic-work figure behind bench.py's roofline (1 product = 136 MAC32)
+#if defined(BN_COUNT_FP_MUL) && !defined(__HIPCC__)
+extern "C" unsigned long long bn_fp_mul_counter;
+#define BN_COUNT_MUL() (++bn_fp_mul_counter)
+#else
+#define BN_COUNT_MUL()
+#endif
+
 namespace bn254 {
 
 #define BN_Q_ARRAY {BN_Q0, BN_Q1, BN_Q2, BN_Q3, BN_Q4, BN_Q5, BN_Q6, BN_Q7}
@@ -129,6 +138,7 @@ BN_DEV Fp fp_dbl(const Fp& a) { return fp_add(a, a); }
 
 // Montgomery product a*b*R^-1 mod q, CIOS over 8 x 32-bit limbs.
 BN_DEVN Fp fp_mul(Fp a, Fp b) {
+  BN_COUNT_MUL();
   const uint32_t q[8] = BN_Q_ARRAY;
   uint32_t t[10];
 #pragma unroll

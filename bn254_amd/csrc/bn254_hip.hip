@@ -477,7 +477,7 @@ int bn254_ctx_last_kernel_ms(bn254_ctx* c, float ms[4]) {
   return 0;
 }
 
-#define PROF_MARK(idx) do { if (c->profiling && s == c->stream) HIP_TRY(hipEventRecord(c->ev[idx], s)); } while (0)
+#define PROF_MARK(idx) do { if (c->profiling) HIP_TRY(hipEventRecord(c->ev[idx], s)); } while (0)
 
 int bn254_batch_verify_device(bn254_ctx* c, const uint8_t* d_msgs, const uint64_t* d_off, const uint8_t* d_sigs, const uint8_t* d_pks,
                               size_t n, uint32_t flags, uint8_t* d_status, void* stream) {
@@ -499,7 +499,7 @@ int bn254_batch_verify_device(bn254_ctx* c, const uint8_t* d_msgs, const uint64_
   PROF_MARK(3);
   k_final_exp<<<g, BN_WAVE, 0, s>>>(n, 1, c->ws, 1, nullptr, d_status, 0);
   PROF_MARK(4);
-  if (c->profiling && s == c->stream) c->ev_valid = 1;
+  if (c->profiling) c->ev_valid = 1;
   HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -9,6 +9,9 @@
 #include <cstdint>
 #include <cstring>
 
+#define BN_COUNT_FP_MUL 1
+extern "C" { unsigned long long bn_fp_mul_counter = 0; }
+
 #include "../../bn254_amd/csrc/bn254_hash.h"
 #include "../../bn254_amd/csrc/bn254_io.h"
 #include "../../bn254_amd/csrc/bn254_pairing.h"
@@ -49,6 +52,28 @@ static uint8_t hash_item(G1Affine& p, const uint8_t* msg, uint64_t len, int* tri
 }
 
 extern "C" {
+
+unsigned long long hs_fp_mul_count(void) { return bn_fp_mul_counter; }
+void hs_fp_mul_count_reset(void) { bn_fp_mul_counter = 0; }
+
+// Montgomery products per stage of one verify, in kernel order: decode(sig)+decode(pk) [no subgroup
+// check], hash-to-G1 (this message), Miller loop (2 pairs), final exponentiation + compare
+void hs_verify_stage_counts(const uint8_t* msg, uint64_t len, const uint8_t* sig64, const uint8_t* pk128, unsigned long long* out4) {
+  G1Affine sig, h;
+  G2Affine pk;
+  unsigned long long c0 = bn_fp_mul_counter;
+  dec_g1(sig, sig64, 0); dec_g2(pk, pk128, 0);
+  unsigned long long c1 = bn_fp_mul_counter;
+  hash_item(h, msg, len, nullptr);
+  unsigned long long c2 = bn_fp_mul_counter;
+  Fp12 f;
+  miller_loop<true, true>(f, h, pk, sig);
+  unsigned long long c3 = bn_fp_mul_counter;
+  final_exponentiation(f, f);
+  (void)fp12_is_one(f);
+  unsigned long long c4 = bn_fp_mul_counter;
+  out4[0] = c1 - c0; out4[1] = c2 - c1; out4[2] = c3 - c2; out4[3] = c4 - c3;
+}
 
 int hs_hash_to_g1(const uint8_t* msg, uint64_t len, uint8_t* out64, int* tries) {
   G1Affine p;
