@@ -71,6 +71,7 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     import bn254_amd
+    from bn254_amd.sharding import gather_status
     from tests.datagen import KEY_POOL, sk_bytes
 
     eng = bn254_amd.Engine(local_rank)
@@ -109,7 +110,7 @@ def main():
         eng.batch_verify_device(d_msgs.data_ptr(), d_off.data_ptr(), d_sigs.data_ptr(), d_pks.data_ptr(), n, d_status.data_ptr(),
                                 flags=0, stream=stream)
         if world > 1:
-            dist.all_gather_into_tensor(d_all, d_status)     # RCCL over xGMI: the only collective
+            gather_status(d_status, out=d_all)               # RCCL all-gather over xGMI: the only collective
 
     for _ in range(args.warmup):
         step()

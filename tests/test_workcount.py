@@ -1,0 +1,43 @@
+"""bench.py's algorithmic-work constants (Montgomery products per kernel stage) are the exact counts
+of the device arithmetic source (instrumented host compilation).  CPU only."""
+import ctypes
+import importlib.util
+import os
+
+from tests import hostsim_binding as hs
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_stage_counts_match_bench_constants(derived):
+    b = _bench()
+    L = hs.lib()
+    L.hs_verify_stage_counts.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_ulonglong)]
+    per_try = []
+    for v in derived["verify_cases"][:6]:
+        out = (ctypes.c_ulonglong * 4)()
+        msg = bytes.fromhex(v["message_hex"])
+        L.hs_verify_stage_counts(msg, len(msg), bytes.fromhex(v["sig"]), bytes.fromhex(v["pk"]), out)
+        assert out[0] == b.FP_MUL_DECODE
+        assert out[2] == b.FP_MUL_MILLER
+        assert out[3] == b.FP_MUL_FINAL_EXP
+        tries = hs.hash_to_g1(msg)[2]
+        per_try.append(out[1] / tries)
+    assert all(abs(x - b.FP_MUL_HASH_PER_TRY) < 2.0 for x in per_try), per_try
+
+
+def test_host_example_compiles():
+    """the C++ host mirror (bn254_amd/host/bn254.hpp) compiles and links against the C ABI"""
+    import subprocess
+    from bn254_amd import _native
+    _native.build()
+    host = os.path.join(ROOT, "bn254_amd", "host")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", os.path.join(host, "example.cpp"), "-L" + os.path.join(ROOT, "bn254_amd"),
+                           "-lbn254hip", "-Wl,-rpath," + os.path.join(ROOT, "bn254_amd"), "-o", os.path.join(host, "example")])
