@@ -28,11 +28,12 @@ BATCH = 65536                      # tuples per GPU per step (configs[1])
 CORRUPT_EVERY = 64                 # every 64th signature is wrong -> expected status 9 there
 # Algorithmic work per verify, counted by instrumenting the device arithmetic source compiled for
 # the host (tests/test_workcount.py keeps these in sync): Montgomery products per kernel stage.
-FP_MUL_DECODE = 16
-FP_MUL_HASH_PER_TRY = 369.2        # 370 first try incl. conversion; measured mean tries 2.12
+FP_MUL_DECODE = 19
+FP_MUL_HASH_PER_TRY = 370.3        # 371 on the first try (incl. conversions), 370 after; measured mean tries 2.12
 FP_MUL_MILLER = 12182
-FP_MUL_FINAL_EXP = 9223
-MAC32_PER_FP_MUL = 136             # 8-limb Montgomery product: 2*8*8 + 8 32x32->64 multiply-accumulates
+FP_MUL_FINAL_EXP = 9235           # incl. 12 canonicalisations for the == 1 test
+MAC32_PER_FP_MUL = 136             # ALGORITHMIC unit: an 8x32-bit Montgomery product = 2*8*8 + 8 MAC32.
+MUL_INSTR_PER_FP_MUL = 210         # what the kernels actually issue per product with 10x27-bit limbs: 200 v_mad_*64 + 10 v_mul_lo
 # VALU roofline: v_mad_u64_u32 issues once per 4 cycles per SIMD (half the 2-cycle full rate):
 # 256 CU x 4 SIMD x 64 lanes x 2.4 GHz / 4 = 39.3 T MAC32/s.  The committed microbenchmark
 # (profiles/r01_valu_rates_microbench.jsonl) sustains 29.9 T/s of that.
@@ -175,6 +176,7 @@ def main():
             "peak_measured_microbench": PEAK_MAC32_MEASURED / 1e12,
             "frac_of_measured_peak": achieved / (PEAK_MAC32_MEASURED / 1e12),
             "traffic": None,
+            "multiplier_issue_frac": (fp_mul * MUL_INSTR_PER_FP_MUL * n / (k_avg[dom] * 1e-3)) / PEAK_MAC32_THEORETICAL,
             "kernel_ms": k_avg,
             "mac32_per_verify": {"miller_loop": FP_MUL_MILLER * MAC32_PER_FP_MUL, "final_exp": FP_MUL_FINAL_EXP * MAC32_PER_FP_MUL,
                                  "hash_to_g1_mean": FP_MUL_HASH_PER_TRY * 2.12 * MAC32_PER_FP_MUL, "decode": FP_MUL_DECODE * MAC32_PER_FP_MUL},

@@ -22,6 +22,7 @@ BN_DEV Fp f_select(bool c, const Fp& a, const Fp& b) { return fp_select(c, a, b)
 BN_DEV Fp f_inv(const Fp& a) { return fp_inv(a); }
 BN_DEV void f_set_one(Fp& a) { a = fp_one(); }
 BN_DEV void f_set_zero(Fp& a) { a = fp_zero(); }
+BN_DEV Fp f_norm(const Fp& a) { return fp_norm(a); }
 
 BN_DEV Fp2 f_add(const Fp2& a, const Fp2& b) { return fp2_add(a, b); }
 BN_DEV Fp2 f_sub(const Fp2& a, const Fp2& b) { return fp2_sub(a, b); }
@@ -35,6 +36,7 @@ BN_DEV Fp2 f_select(bool c, const Fp2& a, const Fp2& b) { return fp2_select(c, a
 BN_DEV Fp2 f_inv(const Fp2& a) { return fp2_inv(a); }
 BN_DEV void f_set_one(Fp2& a) { a = fp2_one(); }
 BN_DEV void f_set_zero(Fp2& a) { a = fp2_zero(); }
+BN_DEV Fp2 f_norm(const Fp2& a) { return fp2_norm(a); }
 
 template <class F> struct Affine { F x, y; bool inf; };
 template <class F> struct Jac { F x, y, z; };   // z == 0 <=> identity
@@ -53,30 +55,31 @@ template <class F> BN_DEV void jac_select(Jac<F>& r, bool c, const Jac<F>& a, co
   r.x = f_select(c, a.x, b.x); r.y = f_select(c, a.y, b.y); r.z = f_select(c, a.z, b.z);
 }
 
-// dbl-2009-l (a = 0); the identity (z = 0) maps to z = 0 without a branch
+// dbl-2009-l (a = 0); the identity (z = 0) maps to z = 0 without a branch.
+// Coordinates in and out are tight (normalised limbs); f_norm marks where lazy sums are carried.
 template <class F> BN_DEVN void jac_dbl(Jac<F>& r, const Jac<F>& p) {
-  F a = f_sqr(p.x), b = f_sqr(p.y), c = f_sqr(b);
-  F d = f_dbl(f_sub(f_sub(f_sqr(f_add(p.x, b)), a), c));
-  F e = f_add(f_dbl(a), a), f = f_sqr(e);
-  F x3 = f_sub(f, f_dbl(d));
-  F z3 = f_dbl(f_mul(p.y, p.z));
+  F a = f_norm(f_sqr(p.x)), b = f_norm(f_sqr(p.y)), c = f_norm(f_sqr(b));
+  F d = f_norm(f_dbl(f_sub(f_sub(f_sqr(f_add(p.x, b)), a), c)));
+  F e = f_norm(f_add(f_dbl(a), a)), f = f_sqr(e);
+  F x3 = f_norm(f_sub(f, f_dbl(d)));
+  F z3 = f_norm(f_dbl(f_mul(p.y, p.z)));
   F c8 = f_dbl(f_dbl(f_dbl(c)));
-  F y3 = f_sub(f_mul(e, f_sub(d, x3)), c8);
+  F y3 = f_norm(f_sub(f_mul(e, f_norm(f_sub(d, x3))), c8));
   r.x = x3; r.y = y3; r.z = z3;
 }
 
 // add-2007-bl with every exceptional case resolved by selects (lanes never diverge):
 // P = O -> Q, Q = O -> P, P = Q -> 2P, P = -Q -> O
 template <class F> BN_DEVN void jac_add(Jac<F>& r, const Jac<F>& p, const Jac<F>& q) {
-  F z1z1 = f_sqr(p.z), z2z2 = f_sqr(q.z);
-  F u1 = f_mul(p.x, z2z2), u2 = f_mul(q.x, z1z1);
-  F s1 = f_mul(f_mul(p.y, q.z), z2z2), s2 = f_mul(f_mul(q.y, p.z), z1z1);
-  F h = f_sub(u2, u1), i = f_sqr(f_dbl(h)), j = f_mul(h, i);
-  F rr = f_dbl(f_sub(s2, s1)), v = f_mul(u1, i);
+  F z1z1 = f_norm(f_sqr(p.z)), z2z2 = f_norm(f_sqr(q.z));
+  F u1 = f_norm(f_mul(p.x, z2z2)), u2 = f_norm(f_mul(q.x, z1z1));
+  F s1 = f_norm(f_mul(f_norm(f_mul(p.y, q.z)), z2z2)), s2 = f_norm(f_mul(f_norm(f_mul(q.y, p.z)), z1z1));
+  F h = f_norm(f_sub(u2, u1)), i = f_norm(f_sqr(f_dbl(h))), j = f_norm(f_mul(h, i));
+  F rr = f_norm(f_dbl(f_sub(s2, s1))), v = f_norm(f_mul(u1, i));
   Jac<F> o;
-  o.x = f_sub(f_sub(f_sqr(rr), j), f_dbl(v));
-  o.y = f_sub(f_mul(rr, f_sub(v, o.x)), f_dbl(f_mul(s1, j)));
-  o.z = f_mul(f_sub(f_sub(f_sqr(f_add(p.z, q.z)), z1z1), z2z2), h);
+  o.x = f_norm(f_sub(f_sub(f_sqr(rr), j), f_dbl(v)));
+  o.y = f_norm(f_sub(f_mul(rr, f_norm(f_sub(v, o.x))), f_dbl(f_mul(s1, j))));
+  o.z = f_norm(f_mul(f_norm(f_sub(f_sub(f_sqr(f_add(p.z, q.z)), z1z1), z2z2)), h));
   bool p_inf = f_is_zero(p.z), q_inf = f_is_zero(q.z);
   bool same_x = f_is_zero(h), same_y = f_is_zero(rr);
   Jac<F> d;
@@ -108,9 +111,9 @@ template <class F> BN_DEVN void jac_mul(Jac<F>& r, const Jac<F>& p, const uint32
 
 template <class F> BN_DEVN void jac_to_affine(Affine<F>& r, const Jac<F>& p) {
   bool inf = f_is_zero(p.z);
-  F zi = f_inv(p.z), zi2 = f_sqr(zi);
-  r.x = f_mul(p.x, zi2);
-  r.y = f_mul(p.y, f_mul(zi2, zi));
+  F zi = f_norm(f_inv(p.z)), zi2 = f_norm(f_sqr(zi));
+  r.x = f_norm(f_mul(p.x, zi2));
+  r.y = f_norm(f_mul(p.y, f_norm(f_mul(zi2, zi))));
   r.inf = inf;
   if (inf) { f_set_zero(r.x); f_set_zero(r.y); }
 }

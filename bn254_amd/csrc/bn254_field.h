@@ -1,10 +1,10 @@
 // BN254 base field Fq and the tower Fq2 / Fq6 / Fq12 for gfx950 lanes.
 //
-// One field element per lane: 8 x 32-bit limbs in VGPRs, Montgomery form (R = 2^256), always
-// fully reduced to [0, q).  The hot primitive is the 8x8 CIOS Montgomery product built from
-// v_mad_u64_u32 (measured on MI355X: ~5 cycles per wave64 instruction per SIMD — the same
-// issue cost as v_mul_lo/hi_u32 or v_fma_f64, so one instruction per 32x32->64 MAC is the
-// best this ISA offers; no MFMA — this is carry-chain integer work).
+// One field element per lane: 10 signed limbs of 27 bits in VGPRs, Montgomery form (R = 2^270).
+// The hot primitive is a product-scanning Montgomery product built from v_mad_i64_i32 /
+// v_mad_u64_u32 (measured on MI355X: ~5 cycles per wave64 instruction per SIMD — the same issue
+// cost as v_mul_lo/hi_u32, v_add_co/v_addc or v_fma_f64, so what matters is the instruction COUNT:
+// unsaturated limbs let a 64-bit column accumulator absorb every carry; no MFMA — integer work).
 //
 // Tower: Fq2 = Fq[i]/(i^2+1), Fq6 = Fq2[v]/(v^3 - xi), Fq12 = Fq6[w]/(w^2 - v), xi = 9+i
 // (SURVEY.md Appendix A.1).  This replaces, for the hot path only, the arithmetic the
@@ -42,49 +42,93 @@ extern "C" unsigned long long bn_fp_mul_counter;
 
 namespace bn254 {
 
-#define BN_Q_ARRAY {BN_Q0, BN_Q1, BN_Q2, BN_Q3, BN_Q4, BN_Q5, BN_Q6, BN_Q7}
+// ------------------------------------------------------------------------------------------
+// Fq: unsaturated signed limbs.
+//
+// An element is 10 int32 limbs of nominally 27 bits, value = sum v[i] * 2^(27 i), Montgomery form
+// with R = 2^270.  Limbs are SIGNED and may temporarily exceed 27 bits:
+//   * add / sub / neg / dbl are 10 plain v_add/v_sub (no carry chain, no modular correction);
+//   * mul is a product-scanning Montgomery product: each of the 19 columns accumulates its
+//     a_i*b_j and m_i*q_j terms in one 64-bit register with v_mad_i64_i32 / v_mad_u64_u32 — no
+//     carry handling at all — followed by one shift per column (~280 instructions instead of
+//     ~575 for saturated 8x32-bit CIOS);
+//   * norm() propagates carries so that limbs 0..8 are back in [0, 2^27) (the top limb absorbs);
+//   * canon() produces the unique representative in [0, q) (only for comparisons and output).
+// Safety conditions (machine-checked by the bound-tracking host build, tests/test_bounds.py):
+//   mul(a,b): 10 * max|a_i| * max|b_j| + 10 * 2^54 + 2^37 < 2^63   and   |a||b| < q*R/2^6
+//   every limb always fits int32.
+// mul outputs are "tight": limbs 0..8 in [0, 2^27), |value| < q * (1 + |a||b|/(qR)).
+// ------------------------------------------------------------------------------------------
+#define BN_QL_ARRAY {BN_QL0, BN_QL1, BN_QL2, BN_QL3, BN_QL4, BN_QL5, BN_QL6, BN_QL7, BN_QL8, BN_QL9}
 
-struct Fp { uint32_t v[8]; };
+#if defined(BN_TRACK_BOUNDS) && !defined(__HIPCC__)
+// Host-only interval bookkeeping: [lo,hi] bounds every limb, [vlo,vhi] bounds value/q.  The
+// bounds depend only on the sequence of operations, not on the data, so one pass of the test
+// vectors through this build proves the safety conditions for every formula on the path.
+}  // namespace bn254
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <execinfo.h>
+namespace bn254 {
+struct FpBounds { double lo, hi, top, vlo, vhi; };   // limbs 0..8 in [lo,hi], |limb 9| <= top, value/q in [vlo,vhi]
+#define BN_BOUNDS_MEMBER FpBounds bd;
+#define BN_T 134217728.0 /* 2^27 */
+static inline void bn_bound_fail(const char* what, double x) {
+  fprintf(stderr, "BOUND VIOLATION: %s (%g)\n", what, x);
+  void* bt[24];
+  int n = backtrace(bt, 24);
+  backtrace_symbols_fd(bt, n, 2);
+  abort();
+}
+#else
+#define BN_BOUNDS_MEMBER
+#endif
+
+struct Fp { int32_t v[BN_LIMBS]; BN_BOUNDS_MEMBER };
 struct Fp2 { Fp c0, c1; };
 struct Fp6 { Fp2 c0, c1, c2; };
 struct Fp12 { Fp6 c0, c1; };
+struct U256 { uint32_t w[8]; };   // plain 256-bit integer
 
-// ------------------------------------------------------------------------------------------
-// Fq
-// ------------------------------------------------------------------------------------------
-BN_DEV Fp fp_load_const(const uint32_t* c) {
+#if defined(BN_TRACK_BOUNDS) && !defined(__HIPCC__)
+static inline double bn_absmax(const Fp& a) { return std::fmax(std::fmax(std::fabs(a.bd.lo), std::fabs(a.bd.hi)), a.bd.top); }
+static inline double bn_vabs(const Fp& a) { return std::fmax(std::fabs(a.bd.vlo), std::fabs(a.bd.vhi)); }
+// "tight": limbs 0..8 in [0, 2^27); the top limb is then exactly floor(value / 2^243), |top| <= |value/q| * 1549 + 1
+static inline void bn_set_tight(Fp& r, double vlo, double vhi) {
+  r.bd.lo = 0; r.bd.hi = BN_T; r.bd.vlo = vlo; r.bd.vhi = vhi;
+  r.bd.top = std::fmax(std::fabs(vlo), std::fabs(vhi)) * 1549.0 + 2.0;
+}
+static inline void bn_chk_i32(const Fp& r) { if (bn_absmax(r) >= 2147483648.0) bn_bound_fail("limb exceeds int32", bn_absmax(r)); }
+#define BN_TRK(stmt) do { stmt; } while (0)
+#else
+#define BN_TRK(stmt) do { } while (0)
+#endif
+
+BN_DEV Fp fp_load_const(const int32_t* c) {
   Fp r;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) r.v[i] = c[i];
+  for (int i = 0; i < BN_LIMBS; ++i) r.v[i] = c[i];
+  BN_TRK(bn_set_tight(r, 0, 1));
   return r;
 }
 BN_DEV Fp fp_zero() {
   Fp r;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) r.v[i] = 0;
+  for (int i = 0; i < BN_LIMBS; ++i) r.v[i] = 0;
+  BN_TRK(r.bd = FpBounds({0, 0, 0, 0, 0}));
   return r;
 }
 BN_DEV Fp fp_one() { return fp_load_const(C_ONE); }
-BN_DEV bool fp_is_zero(const Fp& a) {
-  uint32_t o = 0;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) o |= a.v[i];
-  return o == 0;
-}
-BN_DEV bool fp_eq(const Fp& a, const Fp& b) {
-  uint32_t o = 0;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) o |= a.v[i] ^ b.v[i];
-  return o == 0;
-}
 // r = c ? a : b
 BN_DEV Fp fp_select(bool c, const Fp& a, const Fp& b) {
   Fp r;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) r.v[i] = c ? a.v[i] : b.v[i];
+  for (int i = 0; i < BN_LIMBS; ++i) r.v[i] = c ? a.v[i] : b.v[i];
+  BN_TRK(r.bd = FpBounds({std::fmin(a.bd.lo, b.bd.lo), std::fmax(a.bd.hi, b.bd.hi), std::fmax(a.bd.top, b.bd.top), std::fmin(a.bd.vlo, b.bd.vlo), std::fmax(a.bd.vhi, b.bd.vhi)}));
   return r;
 }
-// a >= b as 256-bit integers (plain limbs)
+// a >= b as 256-bit integers
 BN_DEV bool u256_geq(const uint32_t* a, const uint32_t* b) {
   uint32_t bw = 0;
 #pragma unroll
@@ -95,97 +139,252 @@ BN_DEV bool u256_geq(const uint32_t* a, const uint32_t* b) {
   return bw == 0;
 }
 BN_DEV Fp fp_add(const Fp& a, const Fp& b) {
-  const uint32_t q[8] = BN_Q_ARRAY;
-  uint32_t s[8], d[8];
-  uint32_t c = 0;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    uint64_t x = (uint64_t)a.v[i] + b.v[i] + c;
-    s[i] = (uint32_t)x; c = (uint32_t)(x >> 32);
-  }
-  uint32_t bw = 0;   // a + b < 2q < 2^255: no carry out of the top limb
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    uint64_t x = (uint64_t)s[i] - q[i] - bw;
-    d[i] = (uint32_t)x; bw = (uint32_t)(x >> 63);
-  }
   Fp r;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) r.v[i] = bw ? s[i] : d[i];
+  for (int i = 0; i < BN_LIMBS; ++i) r.v[i] = a.v[i] + b.v[i];
+  BN_TRK(r.bd = FpBounds({a.bd.lo + b.bd.lo, a.bd.hi + b.bd.hi, a.bd.top + b.bd.top, a.bd.vlo + b.bd.vlo, a.bd.vhi + b.bd.vhi}); bn_chk_i32(r));
   return r;
 }
 BN_DEV Fp fp_sub(const Fp& a, const Fp& b) {
-  const uint32_t q[8] = BN_Q_ARRAY;
-  uint32_t d[8];
-  uint32_t bw = 0;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    uint64_t x = (uint64_t)a.v[i] - b.v[i] - bw;
-    d[i] = (uint32_t)x; bw = (uint32_t)(x >> 63);
-  }
-  uint32_t mask = 0u - bw;   // borrow -> add q back
-  uint32_t c = 0;
   Fp r;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    uint64_t x = (uint64_t)d[i] + (q[i] & mask) + c;
-    r.v[i] = (uint32_t)x; c = (uint32_t)(x >> 32);
-  }
+  for (int i = 0; i < BN_LIMBS; ++i) r.v[i] = a.v[i] - b.v[i];
+  BN_TRK(r.bd = FpBounds({a.bd.lo - b.bd.hi, a.bd.hi - b.bd.lo, a.bd.top + b.bd.top, a.bd.vlo - b.bd.vhi, a.bd.vhi - b.bd.vlo}); bn_chk_i32(r));
   return r;
 }
-BN_DEV Fp fp_neg(const Fp& a) { return fp_sub(fp_zero(), a); }
+BN_DEV Fp fp_neg(const Fp& a) {
+  Fp r;
+#pragma unroll
+  for (int i = 0; i < BN_LIMBS; ++i) r.v[i] = -a.v[i];
+  BN_TRK(r.bd = FpBounds({-a.bd.hi, -a.bd.lo, a.bd.top, -a.bd.vhi, -a.bd.vlo}));
+  return r;
+}
 BN_DEV Fp fp_dbl(const Fp& a) { return fp_add(a, a); }
-
-// Montgomery product a*b*R^-1 mod q, CIOS over 8 x 32-bit limbs.
-BN_DEVN Fp fp_mul(Fp a, Fp b) {
-  BN_COUNT_MUL();
-  const uint32_t q[8] = BN_Q_ARRAY;
-  uint32_t t[10];
-#pragma unroll
-  for (int i = 0; i < 10; ++i) t[i] = 0;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    uint32_t c = 0;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      uint64_t uv = (uint64_t)a.v[j] * b.v[i] + t[j] + c;
-      t[j] = (uint32_t)uv; c = (uint32_t)(uv >> 32);
-    }
-    uint64_t s = (uint64_t)t[8] + c;
-    t[8] = (uint32_t)s; t[9] = (uint32_t)(s >> 32);
-    uint32_t m = t[0] * BN_N0;
-    uint64_t uv = (uint64_t)m * q[0] + t[0];
-    c = (uint32_t)(uv >> 32);
-#pragma unroll
-    for (int j = 1; j < 8; ++j) {
-      uv = (uint64_t)m * q[j] + t[j] + c;
-      t[j - 1] = (uint32_t)uv; c = (uint32_t)(uv >> 32);
-    }
-    s = (uint64_t)t[8] + c;
-    t[7] = (uint32_t)s; t[8] = t[9] + (uint32_t)(s >> 32);
-  }
-  // result < 2q < 2^255 (t[8] == 0): one conditional subtraction
-  uint32_t d[8];
-  uint32_t bw = 0;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    uint64_t x = (uint64_t)t[i] - q[i] - bw;
-    d[i] = (uint32_t)x; bw = (uint32_t)(x >> 63);
-  }
+// carry propagation: limbs 0..8 -> [0, 2^27), the top limb absorbs; the value is unchanged
+BN_DEV Fp fp_norm(const Fp& a) {
   Fp r;
+  int32_t c = 0;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) r.v[i] = bw ? t[i] : d[i];
+  for (int i = 0; i < BN_LIMBS - 1; ++i) {
+    int32_t x = a.v[i] + c;
+    r.v[i] = (int32_t)((uint32_t)x & BN_MASK);
+    c = x >> BN_W;
+  }
+  r.v[BN_LIMBS - 1] = a.v[BN_LIMBS - 1] + c;
+  BN_TRK(if (bn_absmax(a) + 64 >= 2147483648.0) bn_bound_fail("norm input", bn_absmax(a)); bn_set_tight(r, a.bd.vlo, a.bd.vhi));
   return r;
 }
-BN_DEV Fp fp_sqr(const Fp& a) { return fp_mul(a, a); }
 
-BN_DEV Fp fp_to_mont(const Fp& plain) { return fp_mul(plain, fp_load_const(C_R2)); }
-BN_DEV Fp fp_from_mont(const Fp& a) {
+// Weak modular reduction of a tight element: subtract k*q with k ~ value/q estimated from the top
+// limb (k = floor(top * 21 / 2^15), 21/2^15 = 0.9924 * 2^243/q).  The residue is unchanged and the
+// value drops to within [-0.0076|V| - 0.01, 0.0076|V| + 1.02] * q.  Used where an output is LINEAR in
+// an input (cyclotomic squaring) so that values cannot build up across iterations.
+BN_DEV Fp fp_reduce_weak(const Fp& a) {
+  const int32_t q[BN_LIMBS] = BN_QL_ARRAY;
+  int32_t k = (a.v[BN_LIMBS - 1] * 21) >> 15;
+  int32_t carry = 0;
+  Fp r;
+#pragma unroll
+  for (int i = 0; i < BN_LIMBS; ++i) {
+    int64_t acc = (int64_t)(a.v[i] + carry) - (int64_t)k * q[i];
+    if (i < BN_LIMBS - 1) {
+      r.v[i] = (int32_t)((uint32_t)acc & BN_MASK);
+      carry = (int32_t)(acc >> BN_W);
+    } else {
+      r.v[i] = (int32_t)acc;
+    }
+  }
+  BN_TRK(if (a.bd.lo < 0 || a.bd.hi > BN_T || a.bd.top * 21.0 >= 2147483648.0) bn_bound_fail("reduce_weak needs a tight input", a.bd.hi);
+         double va_ = bn_vabs(a); bn_set_tight(r, -0.0076 * va_ - 0.01, 0.0076 * va_ + 1.02));
+  return r;
+}
+
+// Montgomery product a*b*R^-1 (mod q), product scanning.  Columns are accumulated in a signed
+// 64-bit register; m_k = (column * -q^-1) mod 2^27 makes each column divisible by 2^27.
+#if defined(__HIPCC__)
+typedef int32_t bn_i32x16 __attribute__((vector_size(64)));   // 10 limbs travel in VGPRs across the call
+#define BN_LIMB_VEC bn_i32x16
+#else
+struct bn_limbvec { int32_t e[16]; int32_t& operator[](int i) { return e[i]; } const int32_t& operator[](int i) const { return e[i]; } };
+#define BN_LIMB_VEC bn_limbvec
+#endif
+
+#define BN_COLUMN_SHIFT(acc)                                         \
+  do {                                                               \
+    uint32_t lo_ = (uint32_t)(acc);                                  \
+    int32_t hi_ = (int32_t)((acc) >> 32);                            \
+    uint32_t nlo_ = (lo_ >> BN_W) | ((uint32_t)hi_ << (32 - BN_W));  \
+    int32_t nhi_ = hi_ >> BN_W;                                      \
+    (acc) = (int64_t)(((uint64_t)(uint32_t)nhi_ << 32) | nlo_);      \
+  } while (0)
+
+BN_DEVN BN_LIMB_VEC fp_mul_impl(BN_LIMB_VEC a, BN_LIMB_VEC b) {
+  BN_COUNT_MUL();
+  const int32_t q[BN_LIMBS] = BN_QL_ARRAY;
+  int64_t acc = 0;
+  int32_t m[BN_LIMBS];
+  BN_LIMB_VEC r;
+#pragma unroll
+  for (int k = 0; k < 2 * BN_LIMBS - 1; ++k) {
+#pragma unroll
+    for (int i = 0; i < BN_LIMBS; ++i) {
+      int j = k - i;
+      if (j < 0 || j >= BN_LIMBS) continue;
+      acc += (int64_t)a[i] * b[j];
+    }
+#pragma unroll
+    for (int i = 0; i < BN_LIMBS; ++i) {
+      int j = k - i;
+      if (j < 0 || j >= BN_LIMBS) continue;
+      if (k < BN_LIMBS && i >= k) continue;     // m_k itself is added below, once it is known
+      acc += (int64_t)m[i] * q[j];
+    }
+    if (k < BN_LIMBS) {
+      m[k] = (int32_t)(((uint32_t)acc * BN_N0) & BN_MASK);
+      acc += (int64_t)m[k] * q[0];
+    } else {
+      r[k - BN_LIMBS] = (int32_t)((uint32_t)acc & BN_MASK);
+    }
+    BN_COLUMN_SHIFT(acc);
+  }
+  r[BN_LIMBS - 1] = (int32_t)acc;
+  return r;
+}
+// a^2: 55 limb products instead of 100 (cross terms through the doubled operand)
+BN_DEVN BN_LIMB_VEC fp_sqr_impl(BN_LIMB_VEC a) {
+  BN_COUNT_MUL();
+  const int32_t q[BN_LIMBS] = BN_QL_ARRAY;
+  int32_t a2[BN_LIMBS];
+#pragma unroll
+  for (int i = 0; i < BN_LIMBS; ++i) a2[i] = a[i] + a[i];
+  int64_t acc = 0;
+  int32_t m[BN_LIMBS];
+  BN_LIMB_VEC r;
+#pragma unroll
+  for (int k = 0; k < 2 * BN_LIMBS - 1; ++k) {
+#pragma unroll
+    for (int i = 0; i < BN_LIMBS; ++i) {
+      int j = k - i;
+      if (j < 0 || j >= BN_LIMBS || i > j) continue;
+      if (i == j) acc += (int64_t)a[i] * a[i]; else acc += (int64_t)a2[i] * a[j];
+    }
+#pragma unroll
+    for (int i = 0; i < BN_LIMBS; ++i) {
+      int j = k - i;
+      if (j < 0 || j >= BN_LIMBS) continue;
+      if (k < BN_LIMBS && i >= k) continue;
+      acc += (int64_t)m[i] * q[j];
+    }
+    if (k < BN_LIMBS) {
+      m[k] = (int32_t)(((uint32_t)acc * BN_N0) & BN_MASK);
+      acc += (int64_t)m[k] * q[0];
+    } else {
+      r[k - BN_LIMBS] = (int32_t)((uint32_t)acc & BN_MASK);
+    }
+    BN_COLUMN_SHIFT(acc);
+  }
+  r[BN_LIMBS - 1] = (int32_t)acc;
+  return r;
+}
+
+#if defined(BN_TRACK_BOUNDS) && !defined(__HIPCC__)
+static inline void bn_trk_mul(Fp& r, const Fp& a, const Fp& b) {
+  double A = bn_absmax(a), B = bn_absmax(b);
+  double col = 10.0 * A * B + 10.0 * 18014398509481984.0 /* 2^54 */ + 137438953472.0 /* 2^37 */;
+  if (col >= 9223372036854775808.0) bn_bound_fail("mul column overflow: 10*A*B", col);
+  double vv = bn_vabs(a) * bn_vabs(b) / 86000.0;   // |a||b| / (q R) in units of q  (q/R = 2^-16.4 < 1/86000)
+  if (vv > 64.0) { fprintf(stderr, "  |a| < %g q, |b| < %g q, limbs %g %g\n", bn_vabs(a), bn_vabs(b), A / BN_T, B / BN_T); bn_bound_fail("mul value bound |a||b|/(qR)", vv); }
+  // value = (ab + mq)/R with 0 <= m < R
+  double plo = std::fmin(std::fmin(a.bd.vlo * b.bd.vlo, a.bd.vlo * b.bd.vhi), std::fmin(a.bd.vhi * b.bd.vlo, a.bd.vhi * b.bd.vhi)) / 86000.0;
+  double phi = std::fmax(std::fmax(a.bd.vlo * b.bd.vlo, a.bd.vlo * b.bd.vhi), std::fmax(a.bd.vhi * b.bd.vlo, a.bd.vhi * b.bd.vhi)) / 86000.0;
+  bn_set_tight(r, std::fmin(plo, 0.0), 1.0 + std::fmax(phi, 0.0));
+}
+#endif
+
+BN_DEV Fp fp_mul(const Fp& a, const Fp& b) {
+  BN_LIMB_VEC x, y;
+#pragma unroll
+  for (int i = 0; i < BN_LIMBS; ++i) { x[i] = a.v[i]; y[i] = b.v[i]; }
+  BN_LIMB_VEC z = fp_mul_impl(x, y);
+  Fp r;
+#pragma unroll
+  for (int i = 0; i < BN_LIMBS; ++i) r.v[i] = z[i];
+  BN_TRK(bn_trk_mul(r, a, b));
+  return r;
+}
+BN_DEV Fp fp_sqr(const Fp& a) {
+  BN_LIMB_VEC x;
+#pragma unroll
+  for (int i = 0; i < BN_LIMBS; ++i) x[i] = a.v[i];
+  BN_LIMB_VEC z = fp_sqr_impl(x);
+  Fp r;
+#pragma unroll
+  for (int i = 0; i < BN_LIMBS; ++i) r.v[i] = z[i];
+  BN_TRK(bn_trk_mul(r, a, a));
+  return r;
+}
+
+// the unique representative in [0, q) with canonical limbs (same Montgomery residue).
+// One product by the Montgomery one brings |value| into (-eps q, (1+eps) q); then at most one
+// correction by q either way.
+BN_DEVN Fp fp_canon(Fp a) {
+  Fp t = fp_norm(fp_mul(a, fp_one()));
+  Fp ql = fp_load_const(C_QL);
+  Fp up = fp_norm(fp_add(t, ql));
+  t = fp_select(t.v[BN_LIMBS - 1] < 0, up, t);
+  Fp dn = fp_norm(fp_sub(t, ql));
+  t = fp_select(dn.v[BN_LIMBS - 1] >= 0, dn, t);
+  BN_TRK(bn_set_tight(t, 0, 1));
+  return t;
+}
+BN_DEV bool fp_limbs_all_zero(const Fp& a) {
+  int32_t o = 0;
+#pragma unroll
+  for (int i = 0; i < BN_LIMBS; ++i) o |= a.v[i];
+  return o == 0;
+}
+BN_DEV bool fp_is_zero(const Fp& a) { return fp_limbs_all_zero(fp_canon(a)); }
+BN_DEV bool fp_eq(const Fp& a, const Fp& b) { return fp_is_zero(fp_sub(a, b)); }
+
+// plain U256 (< 2^256) -> limbs (not yet Montgomery)
+BN_DEV Fp fp_from_u256_plain(const U256& x) {
+  Fp r;
+#pragma unroll
+  for (int i = 0; i < BN_LIMBS; ++i) {
+    int bit = BN_W * i, w = bit >> 5, s = bit & 31;
+    uint32_t v = x.w[w] >> s;
+    if (s + BN_W > 32 && w + 1 < 8) v |= x.w[w + 1] << (32 - s);
+    r.v[i] = (int32_t)(v & BN_MASK);
+  }
+  BN_TRK(bn_set_tight(r, 0, 5.3));   // any 256-bit integer is < 5.3 q
+  return r;
+}
+// integer x (any U256) -> Montgomery form of x mod q
+BN_DEV Fp fp_from_u256(const U256& x) { return fp_mul(fp_from_u256_plain(x), fp_load_const(C_R2)); }
+// Montgomery element -> canonical integer in [0, q)
+BN_DEVN U256 fp_to_u256(Fp a) {
   Fp one = fp_zero();
   one.v[0] = 1;
-  return fp_mul(a, one);
+  BN_TRK(bn_set_tight(one, 0, 1));
+  // a * 1 / R is the plain residue; canonicalise it with the same +-q correction as fp_canon
+  Fp t = fp_norm(fp_mul(a, one));
+  Fp ql = fp_load_const(C_QL);
+  Fp up = fp_norm(fp_add(t, ql));
+  t = fp_select(t.v[BN_LIMBS - 1] < 0, up, t);
+  Fp dn = fp_norm(fp_sub(t, ql));
+  t = fp_select(dn.v[BN_LIMBS - 1] >= 0, dn, t);
+  U256 r;
+#pragma unroll
+  for (int w = 0; w < 8; ++w) r.w[w] = 0;
+#pragma unroll
+  for (int i = 0; i < BN_LIMBS; ++i) {
+    int bit = BN_W * i, w = bit >> 5, s = bit & 31;
+    r.w[w] |= (uint32_t)t.v[i] << s;
+    if (s + BN_W > 32 && w + 1 < 8) r.w[w + 1] |= (uint32_t)t.v[i] >> (32 - s);
+  }
+  return r;
 }
-// a^e for a fixed public exponent (plain limbs in constant memory); wave-uniform control flow
+// a^e for a fixed public exponent (plain U256 words in constant memory); wave-uniform control flow
 BN_DEVN Fp fp_pow_const(Fp a, const uint32_t* e) {
   Fp acc = fp_one();
   for (int i = 255; i >= 0; --i) {
@@ -194,24 +393,27 @@ BN_DEVN Fp fp_pow_const(Fp a, const uint32_t* e) {
   }
   return acc;
 }
-BN_DEV Fp fp_inv(const Fp& a) { return fp_pow_const(a, C_EXP_QM2); }   // Fermat; inv(0) = 0
+BN_DEV Fp fp_inv(const Fp& a) { return fp_pow_const(fp_norm(a), C_EXP_QM2); }   // Fermat; inv(0) = 0
 // y = a^((q+1)/4) (q = 3 mod 4); returns true iff y^2 == a
 BN_DEV bool fp_sqrt(Fp& y, const Fp& a) {
-  y = fp_pow_const(a, C_EXP_QP1D4);
+  y = fp_pow_const(fp_norm(a), C_EXP_QP1D4);
   return fp_eq(fp_sqr(y), a);
 }
 
 // ------------------------------------------------------------------------------------------
-// Fq2
+// Fq2.  Inline helpers are LAZY: results of add/sub/mul_xi/mul carry whatever limb bounds their
+// inputs imply; callers place fp2_norm where the next product needs it (tests/test_bounds.py).
 // ------------------------------------------------------------------------------------------
 BN_DEV Fp2 fp2_zero() { Fp2 r; r.c0 = fp_zero(); r.c1 = fp_zero(); return r; }
 BN_DEV Fp2 fp2_one() { Fp2 r; r.c0 = fp_one(); r.c1 = fp_zero(); return r; }
-BN_DEV Fp2 fp2_load_const(const uint32_t (*c)[8]) { Fp2 r; r.c0 = fp_load_const(c[0]); r.c1 = fp_load_const(c[1]); return r; }
+BN_DEV Fp2 fp2_load_const(const int32_t (*c)[BN_LIMBS]) { Fp2 r; r.c0 = fp_load_const(c[0]); r.c1 = fp_load_const(c[1]); return r; }
 BN_DEV Fp2 fp2_add(const Fp2& a, const Fp2& b) { Fp2 r; r.c0 = fp_add(a.c0, b.c0); r.c1 = fp_add(a.c1, b.c1); return r; }
 BN_DEV Fp2 fp2_sub(const Fp2& a, const Fp2& b) { Fp2 r; r.c0 = fp_sub(a.c0, b.c0); r.c1 = fp_sub(a.c1, b.c1); return r; }
 BN_DEV Fp2 fp2_neg(const Fp2& a) { Fp2 r; r.c0 = fp_neg(a.c0); r.c1 = fp_neg(a.c1); return r; }
 BN_DEV Fp2 fp2_dbl(const Fp2& a) { return fp2_add(a, a); }
 BN_DEV Fp2 fp2_conj(const Fp2& a) { Fp2 r; r.c0 = a.c0; r.c1 = fp_neg(a.c1); return r; }
+BN_DEV Fp2 fp2_norm(const Fp2& a) { Fp2 r; r.c0 = fp_norm(a.c0); r.c1 = fp_norm(a.c1); return r; }
+BN_DEV Fp2 fp2_reduce_weak(const Fp2& a) { Fp2 r; r.c0 = fp_reduce_weak(a.c0); r.c1 = fp_reduce_weak(a.c1); return r; }
 BN_DEV bool fp2_is_zero(const Fp2& a) { return fp_is_zero(a.c0) && fp_is_zero(a.c1); }
 BN_DEV bool fp2_eq(const Fp2& a, const Fp2& b) { return fp_eq(a.c0, b.c0) && fp_eq(a.c1, b.c1); }
 BN_DEV Fp2 fp2_select(bool c, const Fp2& a, const Fp2& b) { Fp2 r; r.c0 = fp_select(c, a.c0, b.c0); r.c1 = fp_select(c, a.c1, b.c1); return r; }
@@ -231,7 +433,7 @@ BN_DEV Fp2 fp2_sqr(const Fp2& a) {                 // 2 Fq products
   return r;
 }
 BN_DEV Fp2 fp2_mul_fp(const Fp2& a, const Fp& k) { Fp2 r; r.c0 = fp_mul(a.c0, k); r.c1 = fp_mul(a.c1, k); return r; }
-BN_DEV Fp2 fp2_mul_xi(const Fp2& a) {              // (9 + i) * a
+BN_DEV Fp2 fp2_mul_xi(const Fp2& a) {              // (9 + i) * a; limb bounds grow 10x: input must be (near) tight
   Fp a2 = fp_dbl(a.c0), a4 = fp_dbl(a2), a8 = fp_dbl(a4);
   Fp b2 = fp_dbl(a.c1), b4 = fp_dbl(b2), b8 = fp_dbl(b4);
   Fp2 r;
@@ -239,6 +441,7 @@ BN_DEV Fp2 fp2_mul_xi(const Fp2& a) {              // (9 + i) * a
   r.c1 = fp_add(fp_add(b8, a.c1), a.c0);
   return r;
 }
+BN_DEV Fp2 fp2_mul_xi_n(const Fp2& a) { return fp2_mul_xi(fp2_norm(a)); }
 BN_DEV Fp2 fp2_inv(const Fp2& a) {
   Fp n = fp_inv(fp_add(fp_sqr(a.c0), fp_sqr(a.c1)));
   Fp2 r;
@@ -248,39 +451,41 @@ BN_DEV Fp2 fp2_inv(const Fp2& a) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Fq6, Fq12 — operate on memory (the per-lane private segment): real functions
+// Fq6, Fq12 — operate on memory (the per-lane private segment): real functions.
+// Contract: inputs with |limb| <= 2^27 ("tight"), outputs tight again (norm at the end).
 // ------------------------------------------------------------------------------------------
 BN_DEV void fp6_add(Fp6& r, const Fp6& a, const Fp6& b) { r.c0 = fp2_add(a.c0, b.c0); r.c1 = fp2_add(a.c1, b.c1); r.c2 = fp2_add(a.c2, b.c2); }
 BN_DEV void fp6_sub(Fp6& r, const Fp6& a, const Fp6& b) { r.c0 = fp2_sub(a.c0, b.c0); r.c1 = fp2_sub(a.c1, b.c1); r.c2 = fp2_sub(a.c2, b.c2); }
 BN_DEV void fp6_neg(Fp6& r, const Fp6& a) { r.c0 = fp2_neg(a.c0); r.c1 = fp2_neg(a.c1); r.c2 = fp2_neg(a.c2); }
-BN_DEV void fp6_mul_v(Fp6& r, const Fp6& a) { Fp2 t = fp2_mul_xi(a.c2); r.c2 = a.c1; r.c1 = a.c0; r.c0 = t; }
+BN_DEV void fp6_norm(Fp6& r, const Fp6& a) { r.c0 = fp2_norm(a.c0); r.c1 = fp2_norm(a.c1); r.c2 = fp2_norm(a.c2); }
+BN_DEV void fp6_mul_v(Fp6& r, const Fp6& a) { Fp2 t = fp2_mul_xi(a.c2); r.c2 = a.c1; r.c1 = a.c0; r.c0 = t; }   // a.c2 tight
 
 BN_DEVN void fp6_mul(Fp6& r, const Fp6& a, const Fp6& b) {
   Fp2 v0 = fp2_mul(a.c0, b.c0), v1 = fp2_mul(a.c1, b.c1), v2 = fp2_mul(a.c2, b.c2);
-  Fp2 c0 = fp2_add(fp2_mul_xi(fp2_sub(fp2_sub(fp2_mul(fp2_add(a.c1, a.c2), fp2_add(b.c1, b.c2)), v1), v2)), v0);
-  Fp2 c1 = fp2_add(fp2_sub(fp2_sub(fp2_mul(fp2_add(a.c0, a.c1), fp2_add(b.c0, b.c1)), v0), v1), fp2_mul_xi(v2));
+  Fp2 c0 = fp2_add(fp2_mul_xi_n(fp2_sub(fp2_sub(fp2_mul(fp2_add(a.c1, a.c2), fp2_add(b.c1, b.c2)), v1), v2)), v0);
+  Fp2 c1 = fp2_add(fp2_sub(fp2_sub(fp2_mul(fp2_add(a.c0, a.c1), fp2_add(b.c0, b.c1)), v0), v1), fp2_mul_xi_n(v2));
   Fp2 c2 = fp2_add(fp2_sub(fp2_sub(fp2_mul(fp2_add(a.c0, a.c2), fp2_add(b.c0, b.c2)), v0), v2), v1);
-  r.c0 = c0; r.c1 = c1; r.c2 = c2;
+  r.c0 = fp2_norm(c0); r.c1 = fp2_norm(c1); r.c2 = fp2_norm(c2);
 }
 BN_DEVN void fp6_mul_fp2(Fp6& r, const Fp6& a, const Fp2& k) {
   Fp2 c0 = fp2_mul(a.c0, k), c1 = fp2_mul(a.c1, k), c2 = fp2_mul(a.c2, k);
-  r.c0 = c0; r.c1 = c1; r.c2 = c2;
+  r.c0 = fp2_norm(c0); r.c1 = fp2_norm(c1); r.c2 = fp2_norm(c2);
 }
 // a * (b0 + b1 v)
 BN_DEVN void fp6_mul_01(Fp6& r, const Fp6& a, const Fp2& b0, const Fp2& b1) {
   Fp2 v0 = fp2_mul(a.c0, b0), v1 = fp2_mul(a.c1, b1);
-  Fp2 c0 = fp2_add(fp2_mul_xi(fp2_mul(a.c2, b1)), v0);
+  Fp2 c0 = fp2_add(fp2_mul_xi_n(fp2_mul(a.c2, b1)), v0);
   Fp2 c1 = fp2_sub(fp2_sub(fp2_mul(fp2_add(a.c0, a.c1), fp2_add(b0, b1)), v0), v1);
   Fp2 c2 = fp2_add(fp2_mul(a.c2, b0), v1);
-  r.c0 = c0; r.c1 = c1; r.c2 = c2;
+  r.c0 = fp2_norm(c0); r.c1 = fp2_norm(c1); r.c2 = fp2_norm(c2);
 }
 BN_DEVN void fp6_inv(Fp6& r, const Fp6& a) {
-  Fp2 t0 = fp2_sub(fp2_sqr(a.c0), fp2_mul_xi(fp2_mul(a.c1, a.c2)));
-  Fp2 t1 = fp2_sub(fp2_mul_xi(fp2_sqr(a.c2)), fp2_mul(a.c0, a.c1));
-  Fp2 t2 = fp2_sub(fp2_sqr(a.c1), fp2_mul(a.c0, a.c2));
-  Fp2 d = fp2_add(fp2_mul_xi(fp2_add(fp2_mul(a.c2, t1), fp2_mul(a.c1, t2))), fp2_mul(a.c0, t0));
-  d = fp2_inv(d);
-  r.c0 = fp2_mul(t0, d); r.c1 = fp2_mul(t1, d); r.c2 = fp2_mul(t2, d);
+  Fp2 t0 = fp2_norm(fp2_sub(fp2_sqr(a.c0), fp2_mul_xi_n(fp2_mul(a.c1, a.c2))));
+  Fp2 t1 = fp2_norm(fp2_sub(fp2_mul_xi_n(fp2_sqr(a.c2)), fp2_mul(a.c0, a.c1)));
+  Fp2 t2 = fp2_norm(fp2_sub(fp2_sqr(a.c1), fp2_mul(a.c0, a.c2)));
+  Fp2 d = fp2_add(fp2_mul_xi_n(fp2_add(fp2_mul(a.c2, t1), fp2_mul(a.c1, t2))), fp2_mul(a.c0, t0));
+  d = fp2_norm(fp2_inv(fp2_norm(d)));
+  r.c0 = fp2_norm(fp2_mul(t0, d)); r.c1 = fp2_norm(fp2_mul(t1, d)); r.c2 = fp2_norm(fp2_mul(t2, d));
 }
 
 BN_DEV void fp12_set_one(Fp12& r) {
@@ -295,51 +500,55 @@ BN_DEVN void fp12_mul(Fp12& r, const Fp12& a, const Fp12& b) {
   Fp6 t0, t1, s, t, u;
   fp6_mul(t0, a.c0, b.c0);
   fp6_mul(t1, a.c1, b.c1);
-  fp6_add(s, a.c0, a.c1);
-  fp6_add(t, b.c0, b.c1);
+  fp6_add(s, a.c0, a.c1); fp6_norm(s, s);
+  fp6_add(t, b.c0, b.c1); fp6_norm(t, t);
   fp6_mul(u, s, t);
   fp6_sub(u, u, t0);
   fp6_sub(u, u, t1);
   fp6_mul_v(s, t1);
-  fp6_add(r.c0, t0, s);
-  r.c1 = u;
+  fp6_add(s, t0, s);
+  fp6_norm(r.c0, s);
+  fp6_norm(r.c1, u);
 }
 BN_DEVN void fp12_sqr(Fp12& r, const Fp12& a) {
   Fp6 ab, s, t, u;
   fp6_mul(ab, a.c0, a.c1);
-  fp6_add(s, a.c0, a.c1);
+  fp6_add(s, a.c0, a.c1); fp6_norm(s, s);
   fp6_mul_v(t, a.c1);
-  fp6_add(t, t, a.c0);
+  fp6_add(t, t, a.c0); fp6_norm(t, t);
   fp6_mul(u, s, t);
   fp6_sub(u, u, ab);
   fp6_mul_v(s, ab);
-  fp6_sub(r.c0, u, s);
-  fp6_add(r.c1, ab, ab);
+  fp6_sub(u, u, s);
+  fp6_norm(r.c0, u);
+  fp6_add(s, ab, ab);
+  fp6_norm(r.c1, s);
 }
-BN_DEV void fp12_conj(Fp12& r, const Fp12& a) { r.c0 = a.c0; fp6_neg(r.c1, a.c1); }
+BN_DEV void fp12_conj(Fp12& r, const Fp12& a) { r.c0 = a.c0; fp6_neg(r.c1, a.c1); fp6_norm(r.c1, r.c1); }
 BN_DEVN void fp12_inv(Fp12& r, const Fp12& a) {
   Fp6 t0, t1, d;
   fp6_mul(t0, a.c0, a.c0);
   fp6_mul(t1, a.c1, a.c1);
   fp6_mul_v(t1, t1);
-  fp6_sub(d, t0, t1);
+  fp6_sub(d, t0, t1); fp6_norm(d, d);
   fp6_inv(d, d);
   fp6_mul(t0, a.c1, d);
   fp6_mul(r.c0, a.c0, d);
-  fp6_neg(r.c1, t0);
+  fp6_neg(t0, t0); fp6_norm(r.c1, t0);
 }
 // f * (l0 + (l1 + l2 v) w): the sparse shape of a D-twist line (l0 at w^0, l1 at w^1, l2 at w^3)
 BN_DEVN void fp12_mul_line(Fp12& r, const Fp12& f, const Fp2& l0, const Fp2& l1, const Fp2& l2) {
   Fp6 t0, t1, s, u;
   fp6_mul_fp2(t0, f.c0, l0);
   fp6_mul_01(t1, f.c1, l1, l2);
-  fp6_add(s, f.c0, f.c1);
+  fp6_add(s, f.c0, f.c1); fp6_norm(s, s);
   fp6_mul_01(u, s, fp2_add(l0, l1), l2);
   fp6_sub(u, u, t0);
   fp6_sub(u, u, t1);
   fp6_mul_v(s, t1);
-  fp6_add(r.c0, t0, s);
-  r.c1 = u;
+  fp6_add(s, t0, s);
+  fp6_norm(r.c0, s);
+  fp6_norm(r.c1, u);
 }
 // coefficient k of w^k in the polynomial basis: c[2i] = c0.c_i, c[2i+1] = c1.c_i
 BN_DEV Fp2& fp12_coef(Fp12& a, int k) {
@@ -352,16 +561,16 @@ BN_DEVN void fp12_frob(Fp12& r, const Fp12& a, int power) {
   for (int k = 0; k < 6; ++k) {
     Fp2& c = fp12_coef(t, k);
     Fp2 x = (power & 1) ? fp2_conj(c) : c;
-    const uint32_t (*g)[8] = power == 1 ? C_FROB1[k] : power == 2 ? C_FROB2[k] : C_FROB3[k];
-    c = fp2_mul(x, fp2_load_const(g));
+    const int32_t (*g)[BN_LIMBS] = power == 1 ? C_FROB1[k] : power == 2 ? C_FROB2[k] : C_FROB3[k];
+    c = fp2_norm(fp2_mul(x, fp2_load_const(g)));
   }
   r = t;
 }
 // (a + b s)^2 in Fq4 = Fq2[s]/(s^2 - xi): r0 = a^2 + xi b^2, r1 = 2ab
 BN_DEV void fp4_sqr(Fp2& r0, Fp2& r1, const Fp2& a, const Fp2& b) {
   Fp2 a2 = fp2_sqr(a), b2 = fp2_sqr(b);
-  r1 = fp2_sub(fp2_sub(fp2_sqr(fp2_add(a, b)), a2), b2);
-  r0 = fp2_add(a2, fp2_mul_xi(b2));
+  r1 = fp2_norm(fp2_sub(fp2_sub(fp2_sqr(fp2_add(a, b)), a2), b2));
+  r0 = fp2_norm(fp2_add(a2, fp2_mul_xi_n(b2)));
 }
 // Granger-Scott squaring for the cyclotomic subgroup (after the easy part of the final exp.)
 BN_DEVN void fp12_cyclotomic_sqr(Fp12& r, const Fp12& a) {
@@ -369,14 +578,15 @@ BN_DEVN void fp12_cyclotomic_sqr(Fp12& r, const Fp12& a) {
   fp4_sqr(t0, t1, a.c0.c0, a.c1.c1);
   fp4_sqr(t2, t3, a.c1.c0, a.c0.c2);
   fp4_sqr(t4, t5, a.c0.c1, a.c1.c2);
+  // outputs 3t -+ 2a are linear in a: use a weakly reduced copy of a for that term (see fp_reduce_weak)
   Fp12 o;
-  o.c0.c0 = fp2_add(fp2_dbl(fp2_sub(t0, a.c0.c0)), t0);
-  o.c1.c1 = fp2_add(fp2_dbl(fp2_add(t1, a.c1.c1)), t1);
-  t5 = fp2_mul_xi(t5);
-  o.c1.c0 = fp2_add(fp2_dbl(fp2_add(t5, a.c1.c0)), t5);
-  o.c0.c2 = fp2_add(fp2_dbl(fp2_sub(t4, a.c0.c2)), t4);
-  o.c0.c1 = fp2_add(fp2_dbl(fp2_sub(t2, a.c0.c1)), t2);
-  o.c1.c2 = fp2_add(fp2_dbl(fp2_add(t3, a.c1.c2)), t3);
+  o.c0.c0 = fp2_norm(fp2_add(fp2_dbl(fp2_sub(t0, fp2_reduce_weak(a.c0.c0))), t0));
+  o.c1.c1 = fp2_norm(fp2_add(fp2_dbl(fp2_add(t1, fp2_reduce_weak(a.c1.c1))), t1));
+  t5 = fp2_norm(fp2_mul_xi(t5));
+  o.c1.c0 = fp2_norm(fp2_add(fp2_dbl(fp2_add(t5, fp2_reduce_weak(a.c1.c0))), t5));
+  o.c0.c2 = fp2_norm(fp2_add(fp2_dbl(fp2_sub(t4, fp2_reduce_weak(a.c0.c2))), t4));
+  o.c0.c1 = fp2_norm(fp2_add(fp2_dbl(fp2_sub(t2, fp2_reduce_weak(a.c0.c1))), t2));
+  o.c1.c2 = fp2_norm(fp2_add(fp2_dbl(fp2_add(t3, fp2_reduce_weak(a.c1.c2))), t3));
   r = o;
 }
 

@@ -88,31 +88,33 @@ BN_DEV bool hash_try(G1Affine& out, const HashState& s, const uint8_t* msg, uint
     load_block(blk, msg, len, ctr, b, s.padded_len);
     sha256_compress(h, blk);
   }
-  Fp x;                                                          // hash.rs:44: digest read big-endian
+  U256 x;                                                        // hash.rs:44: digest read big-endian
 #pragma unroll
-  for (int i = 0; i < 8; ++i) x.v[i] = h[7 - i];
-  if (u256_geq(x.v, C_QMULT[4])) return false;                   // hash.rs:49-51: h >= 5q -> next ctr
+  for (int i = 0; i < 8; ++i) x.w[i] = h[7 - i];
+  if (u256_geq(x.w, C_QMULT[4])) return false;                   // hash.rs:49-51: h >= 5q -> next ctr
   // utils.rs:27-37 mod_u256: while x > q { x -= q } (strict), i.e. x mod q except exact multiples
   // k*q (k >= 1), which stop at q and are then rejected by Fq::from_slice
   bool was_reduced = false;
   for (int k = 3; k >= 0; --k) {
-    if (!was_reduced && u256_geq(x.v, C_QMULT[k])) {
+    if (!was_reduced && u256_geq(x.w, C_QMULT[k])) {
       uint32_t bw = 0;
       for (int i = 0; i < 8; ++i) {
-        uint64_t d = (uint64_t)x.v[i] - C_QMULT[k][i] - bw;
-        x.v[i] = (uint32_t)d; bw = (uint32_t)(d >> 63);
+        uint64_t d = (uint64_t)x.w[i] - C_QMULT[k][i] - bw;
+        x.w[i] = (uint32_t)d; bw = (uint32_t)(d >> 63);
       }
       was_reduced = true;
     }
   }
-  if (was_reduced && fp_is_zero(x)) return false;
+  uint32_t any = 0;
+  for (int i = 0; i < 8; ++i) any |= x.w[i];
+  if (was_reduced && any == 0) return false;
   // utils.rs:56-63 arbitrary_string_to_g1 -> G1::from_compressed(0x02 || x): even root of x^3 + 3
-  Fp xm = fp_to_mont(x);
+  Fp xm = fp_from_u256(x);
   Fp rhs = fp_add(fp_mul(fp_sqr(xm), xm), fp_load_const(C_THREE));
   Fp y;
   if (!fp_sqrt(y, rhs)) return false;
-  Fp yp = fp_from_mont(y);
-  if (yp.v[0] & 1) y = fp_neg(y);
+  U256 yp = fp_to_u256(y);
+  if (yp.w[0] & 1) y = fp_norm(fp_neg(y));
   out.x = xm; out.y = y; out.inf = false;
   return true;
 }

@@ -4,7 +4,7 @@
 // 64-lane wave per workgroup so the dispatcher can spread waves over all 1024 SIMDs.  A batch
 // is processed by a short chain of kernels that hand per-item state to each other through an
 // HBM workspace laid out limb-major ("planes"): word k of field element e of item i lives at
-//   ws[(e*8 + k) * stride + i]
+//   ws[(e*10 + k) * stride + i]      (10 x 27-bit limbs per field element)
 // so the 64 lanes of a wave read/write 256 contiguous bytes per limb (fully coalesced), and the
 // caller-facing byte formats (AoS, big-endian) are touched exactly once on the way in/out.
 //
@@ -33,7 +33,7 @@ using namespace bn254;
 // workspace planes
 // ------------------------------------------------------------------------------------------
 struct Ws {
-  uint32_t* planes;   // [N_PLANES * 8][stride] u32
+  int32_t* planes;    // [N_PLANES * BN_LIMBS][stride] i32
   uint8_t* bytes;     // [N_BYTE_PLANES][stride]
   size_t stride;
 };
@@ -43,12 +43,12 @@ enum { BY_ST_DECODE = 0, BY_ST_HASH, BY_P1_INF, BY_Q_INF, BY_P2_INF, N_BYTE_PLAN
 __device__ __forceinline__ Fp ws_load_fp(const Ws& ws, int plane, size_t i) {
   Fp r;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) r.v[k] = ws.planes[((size_t)plane * 8 + k) * ws.stride + i];
+  for (int k = 0; k < BN_LIMBS; ++k) r.v[k] = ws.planes[((size_t)plane * BN_LIMBS + k) * ws.stride + i];
   return r;
 }
 __device__ __forceinline__ void ws_store_fp(const Ws& ws, int plane, size_t i, const Fp& a) {
 #pragma unroll
-  for (int k = 0; k < 8; ++k) ws.planes[((size_t)plane * 8 + k) * ws.stride + i] = a.v[k];
+  for (int k = 0; k < BN_LIMBS; ++k) ws.planes[((size_t)plane * BN_LIMBS + k) * ws.stride + i] = a.v[k];
 }
 __device__ __forceinline__ uint8_t& ws_byte(const Ws& ws, int plane, size_t i) { return ws.bytes[(size_t)plane * ws.stride + i]; }
 
@@ -400,7 +400,7 @@ static int ws_reserve(bn254_ctx* c, size_t n) {
   if (c->ws.planes) { HIP_TRY(hipFree(c->ws.planes)); c->ws.planes = nullptr; }
   if (c->ws.bytes) { HIP_TRY(hipFree(c->ws.bytes)); c->ws.bytes = nullptr; }
   c->ws.stride = 0;
-  HIP_TRY(hipMalloc((void**)&c->ws.planes, (size_t)N_PLANES * 8 * sizeof(uint32_t) * cap));
+  HIP_TRY(hipMalloc((void**)&c->ws.planes, (size_t)N_PLANES * BN_LIMBS * sizeof(int32_t) * cap));
   HIP_TRY(hipMalloc((void**)&c->ws.bytes, (size_t)N_BYTE_PLANES * cap));
   c->ws.stride = cap;
   return 0;
@@ -429,7 +429,7 @@ static bool misaligned(const void* p) { return ((uintptr_t)p & 3u) != 0; }
 
 extern "C" {
 
-const char* bn254_version(void) { return "bn254-mi355x 0.1 (gfx950; 8x32-bit Montgomery limbs, one item per lane)"; }
+const char* bn254_version(void) { return "bn254-mi355x 0.2 (gfx950; 10x27-bit signed Montgomery limbs, one item per lane)"; }
 
 int bn254_ctx_create(int hip_device, bn254_ctx** out) {
   if (!out) return BN254_E_BAD_ARGUMENT;

@@ -33,17 +33,17 @@ BN_DEV void u256_to_be(uint8_t* p, const uint32_t* v) {
 }
 // Fq::from_slice: value must be < q.  Returns false otherwise.  `any` ORs in the raw bits.
 BN_DEV bool fp_from_be(Fp& r, const uint8_t* p, uint32_t& any) {
-  Fp t;
-  u256_from_be(t.v, p);
+  U256 t;
+  u256_from_be(t.w, p);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) any |= t.v[i];
-  bool ok = !u256_geq(t.v, C_Q);
-  r = fp_to_mont(t);
+  for (int i = 0; i < 8; ++i) any |= t.w[i];
+  bool ok = !u256_geq(t.w, C_Q);
+  r = fp_from_u256(t);
   return ok;
 }
 BN_DEV void fp_to_be(uint8_t* p, const Fp& a) {
-  Fp t = fp_from_mont(a);
-  u256_to_be(p, t.v);
+  U256 t = fp_to_u256(a);
+  u256_to_be(p, t.w);
 }
 
 BN_DEV uint8_t decode_g1(G1Affine& pt, const uint8_t* b, uint32_t flags) {

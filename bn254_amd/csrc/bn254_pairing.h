@@ -17,44 +17,44 @@ namespace bn254 {
 struct G2Proj { Fp2 x, y, z; };            // homogeneous projective twist point
 struct LineCoef { Fp2 c0, c1, c2; };
 
-// T <- 2T;  c0 = 2YZ, c1 = -3X^2, c2 = Y^2 - 3b'Z^2
+// T <- 2T;  c0 = 2YZ, c1 = -3X^2, c2 = Y^2 - 3b'Z^2.   T and the line coefficients are tight.
 BN_DEVN void dbl_step(G2Proj& t, LineCoef& l) {
-  Fp2 xy = fp2_mul(t.x, t.y), b = fp2_sqr(t.y), c = fp2_sqr(t.z);
-  Fp2 e = fp2_mul(c, fp2_load_const(C_TWIST_3B));
+  Fp2 xy = fp2_norm(fp2_mul(t.x, t.y)), b = fp2_norm(fp2_sqr(t.y)), c = fp2_norm(fp2_sqr(t.z));
+  Fp2 e = fp2_norm(fp2_mul(c, fp2_load_const(C_TWIST_3B)));
   Fp2 f = fp2_add(fp2_dbl(e), e);
-  Fp2 h = fp2_sub(fp2_sub(fp2_sqr(fp2_add(t.y, t.z)), b), c);
+  Fp2 h = fp2_norm(fp2_sub(fp2_sub(fp2_sqr(fp2_add(t.y, t.z)), b), c));
   Fp2 x2 = fp2_sqr(t.x);
-  Fp2 e2 = fp2_sqr(e);
+  Fp2 e2 = fp2_norm(fp2_sqr(e));
   Fp2 e2x4 = fp2_dbl(fp2_dbl(e2));
   Fp2 e2x12 = fp2_add(fp2_dbl(e2x4), e2x4);
   G2Proj o;
-  o.x = fp2_dbl(fp2_mul(xy, fp2_sub(b, f)));
-  o.y = fp2_sub(fp2_sqr(fp2_add(b, f)), e2x12);
-  o.z = fp2_dbl(fp2_dbl(fp2_mul(b, h)));
+  o.x = fp2_norm(fp2_dbl(fp2_mul(xy, fp2_norm(fp2_sub(b, f)))));
+  o.y = fp2_norm(fp2_sub(fp2_sqr(fp2_norm(fp2_add(b, f))), e2x12));
+  o.z = fp2_norm(fp2_dbl(fp2_dbl(fp2_mul(b, h))));
   l.c0 = h;
-  l.c1 = fp2_neg(fp2_add(fp2_dbl(x2), x2));
-  l.c2 = fp2_sub(b, e);
+  l.c1 = fp2_norm(fp2_neg(fp2_add(fp2_dbl(x2), x2)));
+  l.c2 = fp2_norm(fp2_sub(b, e));
   t = o;
 }
 // T <- T + Q (Q affine);  c0 = mu, c1 = -theta, c2 = theta*x2 - mu*y2
 BN_DEVN void add_step(G2Proj& t, LineCoef& l, const Fp2& qx, const Fp2& qy) {
-  Fp2 theta = fp2_sub(t.y, fp2_mul(qy, t.z));
-  Fp2 mu = fp2_sub(t.x, fp2_mul(qx, t.z));
-  Fp2 c = fp2_sqr(theta), d = fp2_sqr(mu), e = fp2_mul(mu, d);
-  Fp2 f = fp2_mul(t.z, c), g = fp2_mul(t.x, d);
-  Fp2 h = fp2_sub(fp2_sub(fp2_add(e, f), g), g);
+  Fp2 theta = fp2_norm(fp2_sub(t.y, fp2_mul(qy, t.z)));
+  Fp2 mu = fp2_norm(fp2_sub(t.x, fp2_mul(qx, t.z)));
+  Fp2 c = fp2_norm(fp2_sqr(theta)), d = fp2_norm(fp2_sqr(mu)), e = fp2_norm(fp2_mul(mu, d));
+  Fp2 f = fp2_mul(t.z, c), g = fp2_norm(fp2_mul(t.x, d));
+  Fp2 h = fp2_norm(fp2_sub(fp2_sub(fp2_add(e, f), g), g));
   G2Proj o;
-  o.x = fp2_mul(mu, h);
-  o.y = fp2_sub(fp2_mul(theta, fp2_sub(g, h)), fp2_mul(e, t.y));
-  o.z = fp2_mul(t.z, e);
+  o.x = fp2_norm(fp2_mul(mu, h));
+  o.y = fp2_norm(fp2_sub(fp2_mul(theta, fp2_norm(fp2_sub(g, h))), fp2_mul(e, t.y)));
+  o.z = fp2_norm(fp2_mul(t.z, e));
   l.c0 = mu;
-  l.c1 = fp2_neg(theta);
-  l.c2 = fp2_sub(fp2_mul(theta, qx), fp2_mul(mu, qy));
+  l.c1 = fp2_norm(fp2_neg(theta));
+  l.c2 = fp2_norm(fp2_sub(fp2_mul(theta, qx), fp2_mul(mu, qy)));
   t = o;
 }
 // f <- f * line(P); a skipped pair multiplies by one
 BN_DEV void mul_by_line(Fp12& f, const LineCoef& l, const Fp& px, const Fp& py, bool skip) {
-  Fp2 l0 = fp2_mul_fp(l.c0, py), l1 = fp2_mul_fp(l.c1, px), l2 = l.c2;
+  Fp2 l0 = fp2_norm(fp2_mul_fp(l.c0, py)), l1 = fp2_norm(fp2_mul_fp(l.c1, px)), l2 = l.c2;
   l0 = fp2_select(skip, fp2_one(), l0);
   l1 = fp2_select(skip, fp2_zero(), l1);
   l2 = fp2_select(skip, fp2_zero(), l2);
@@ -79,7 +79,7 @@ BN_DEVN void miller_loop(Fp12& f, const G1Affine& pa, const G2Affine& qa, const 
   Fp2 qa_yneg;
   bool skip_a = !HAS_A || pa.inf || qa.inf;
   bool skip_b = !HAS_B || pb.inf;
-  if (HAS_A) { t.x = qa.x; t.y = qa.y; t.z = fp2_one(); qa_yneg = fp2_neg(qa.y); }
+  if (HAS_A) { t.x = qa.x; t.y = qa.y; t.z = fp2_one(); qa_yneg = fp2_norm(fp2_neg(qa.y)); }
   int idx = 0;
   for (int d = 0; d < 64; ++d) {
     fp12_sqr(f, f);
@@ -93,14 +93,14 @@ BN_DEVN void miller_loop(Fp12& f, const G1Affine& pa, const G2Affine& qa, const 
   }
   // + pi(Q), - pi^2(Q)
   if (HAS_A) {
-    Fp2 q1x = fp2_mul(fp2_conj(qa.x), fp2_load_const(C_TW_FROB_X1));
-    Fp2 q1y = fp2_mul(fp2_conj(qa.y), fp2_load_const(C_TW_FROB_Y1));
+    Fp2 q1x = fp2_norm(fp2_mul(fp2_conj(qa.x), fp2_load_const(C_TW_FROB_X1)));
+    Fp2 q1y = fp2_norm(fp2_mul(fp2_conj(qa.y), fp2_load_const(C_TW_FROB_Y1)));
     add_step(t, l, q1x, q1y);
     mul_by_line(f, l, pa.x, pa.y, skip_a);
   }
   if (HAS_B) { fixed_line(l, idx++); mul_by_line(f, l, pb.x, pb.y, skip_b); }
   if (HAS_A) {
-    Fp2 q2x = fp2_mul(qa.x, fp2_load_const(C_TW_FROB_X2));
+    Fp2 q2x = fp2_norm(fp2_mul(qa.x, fp2_load_const(C_TW_FROB_X2)));
     add_step(t, l, q2x, qa.y);
     mul_by_line(f, l, pa.x, pa.y, skip_a);
   }

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Generate bn254_constants.h: every numeric table the HIP kernels need, as 8 x 32-bit
-little-endian limbs in Montgomery form (R = 2^256).
+"""Generate bn254_constants.h: every numeric table the HIP kernels need.  Field elements are
+10 little-endian limbs of 27 bits (stored in int32) in Montgomery form with R = 2^270; plain
+256-bit integers (moduli multiples, exponents, group order) stay 8 x 32-bit words.
 
 Self-contained (plain Python integers; imports nothing from oracle/): derived from the curve
 definition in SURVEY.md Appendix A.1 only — u, the polynomials q(u), r(u), xi = 9+i, the
@@ -18,7 +19,9 @@ import os
 U = 4965661367192848881
 Q = 36 * U**4 + 36 * U**3 + 24 * U**2 + 6 * U + 1
 R_ORDER = 36 * U**4 + 36 * U**3 + 18 * U**2 + 6 * U + 1
-MONT_R = 1 << 256
+LIMB_BITS = 27
+N_LIMBS = 10
+MONT_R = 1 << (LIMB_BITS * N_LIMBS)
 XI = (9, 1)
 G2X = (10857046999023057135944570762232829481370756359578518086990519993285655852781,
        11559732032986387107991004021392285783925812861821192530917403151452391805634)
@@ -100,16 +103,26 @@ def add_step(T, Qa):
     return (X3, Y3, Z3), (mu, neg(theta), sub(mul(theta, x2), mul(mu, y2)))
 
 
-def limbs(x):
+def words32(x):
     return [(x >> (32 * i)) & 0xFFFFFFFF for i in range(8)]
+
+
+def limbs27(x):
+    return [(x >> (LIMB_BITS * i)) & ((1 << LIMB_BITS) - 1) for i in range(N_LIMBS)]
 
 
 def mont(x):
     return (x * MONT_R) % Q
 
 
+def c_u256(x):
+    """plain 256-bit integer as 8 x u32"""
+    return "{" + ", ".join("0x%08xu" % w for w in words32(x)) + "}"
+
+
 def c_fp(x, m=True):
-    return "{" + ", ".join("0x%08xu" % w for w in limbs(mont(x) if m else x)) + "}"
+    """field element as 10 x 27-bit limbs (Montgomery form unless m=False)"""
+    return "{" + ", ".join("0x%07x" % w for w in limbs27(mont(x) if m else x)) + "}"
 
 
 def c_fp2(a):
@@ -146,37 +159,42 @@ def main():
 
     o = []
     o.append("// GENERATED by bn254_amd/csrc/gen_constants.py — do not edit.")
-    o.append("// BN254 constants as 8 x 32-bit little-endian limbs, Montgomery form (R = 2^256) unless noted.")
+    o.append("// BN254 constants.  Field elements: 10 x 27-bit limbs (int32), Montgomery form, R = 2^270.")
+    o.append("// Plain integers (U256): 8 x 32-bit words, little-endian.")
     o.append("#pragma once")
     o.append("")
-    for i, w in enumerate(limbs(Q)):
-        o.append("#define BN_Q%d 0x%08xu" % (i, w))
-    o.append("#define BN_N0 0x%08xu   /* -q^-1 mod 2^32 */" % ((-pow(Q, -1, 1 << 32)) % (1 << 32)))
+    o.append("#define BN_LIMBS %d" % N_LIMBS)
+    o.append("#define BN_W %d" % LIMB_BITS)
+    o.append("#define BN_MASK 0x%xu" % ((1 << LIMB_BITS) - 1))
+    for i, w in enumerate(limbs27(Q)):
+        o.append("#define BN_QL%d 0x%07x" % (i, w))
+    o.append("#define BN_N0 0x%07xu   /* -q^-1 mod 2^27 */" % ((-pow(Q, -1, 1 << LIMB_BITS)) % (1 << LIMB_BITS)))
     o.append("#define BN_U_LO 0x%08xu" % (U & 0xFFFFFFFF))
     o.append("#define BN_U_HI 0x%08xu" % (U >> 32))
     o.append("#define BN_N_FIXED_LINES %d" % len(lines))
     o.append("")
-    o.append("BN_CONST uint32_t C_Q[8] = %s;            /* plain integer */" % c_fp(Q, False))
-    o.append("BN_CONST uint32_t C_QMULT[5][8] = {%s};   /* k*q, k = 1..5, plain integers (5q = hash.rs:11-14) */" %
-             ", ".join(c_fp(k * Q, False) for k in range(1, 6)))
-    o.append("BN_CONST uint32_t C_R2[8] = %s;           /* R^2 mod q (plain limbs of that residue) */" % c_fp(MONT_R * MONT_R % Q, False))
-    o.append("BN_CONST uint32_t C_ONE[8] = %s;          /* 1 */" % c_fp(1))
-    o.append("BN_CONST uint32_t C_THREE[8] = %s;        /* curve b = 3 */" % c_fp(3))
-    o.append("BN_CONST uint32_t C_ORDER_R[8] = %s;      /* group order r, plain integer */" % c_fp(R_ORDER, False))
-    o.append("BN_CONST uint32_t C_EXP_QM2[8] = %s;      /* q-2, plain */" % c_fp(Q - 2, False))
-    o.append("BN_CONST uint32_t C_EXP_QP1D4[8] = %s;    /* (q+1)/4, plain */" % c_fp((Q + 1) // 4, False))
-    o.append("BN_CONST uint32_t C_TWIST_B[2][8] = %s;   /* 3/xi */" % c_fp2(TWIST_B))
-    o.append("BN_CONST uint32_t C_TWIST_3B[2][8] = %s;  /* 9/xi */" % c_fp2(TWIST_3B))
+    o.append("BN_CONST uint32_t C_Q[8] = %s;            /* q, plain U256 */" % c_u256(Q))
+    o.append("BN_CONST uint32_t C_QMULT[5][8] = {%s};   /* k*q, k = 1..5, plain U256 (5q = hash.rs:11-14) */" %
+             ", ".join(c_u256(k * Q) for k in range(1, 6)))
+    o.append("BN_CONST uint32_t C_ORDER_R[8] = %s;      /* group order r, plain U256 */" % c_u256(R_ORDER))
+    o.append("BN_CONST uint32_t C_EXP_QM2[8] = %s;      /* q-2, plain U256 */" % c_u256(Q - 2))
+    o.append("BN_CONST uint32_t C_EXP_QP1D4[8] = %s;    /* (q+1)/4, plain U256 */" % c_u256((Q + 1) // 4))
+    o.append("BN_CONST int32_t C_QL[10] = %s;           /* q as 27-bit limbs (plain) */" % c_fp(Q, False))
+    o.append("BN_CONST int32_t C_R2[10] = %s;           /* R^2 mod q, plain limbs: to_mont(x) = mul(x, R2) */" % c_fp(MONT_R * MONT_R % Q, False))
+    o.append("BN_CONST int32_t C_ONE[10] = %s;          /* 1 (Montgomery) */" % c_fp(1))
+    o.append("BN_CONST int32_t C_THREE[10] = %s;        /* curve b = 3 */" % c_fp(3))
+    o.append("BN_CONST int32_t C_TWIST_B[2][10] = %s;   /* 3/xi */" % c_fp2(TWIST_B))
+    o.append("BN_CONST int32_t C_TWIST_3B[2][10] = %s;  /* 9/xi */" % c_fp2(TWIST_3B))
     for j in (1, 2, 3):
-        o.append("BN_CONST uint32_t C_FROB%d[6][2][8] = {%s};  /* xi^(k(q^%d-1)/6), k=0..5 */" % (j, ", ".join(c_fp2(t) for t in frob[j]), j))
-    o.append("BN_CONST uint32_t C_TW_FROB_X1[2][8] = %s;" % c_fp2(g_x1))
-    o.append("BN_CONST uint32_t C_TW_FROB_Y1[2][8] = %s;" % c_fp2(g_y1))
-    o.append("BN_CONST uint32_t C_TW_FROB_X2[2][8] = %s;" % c_fp2(g_x2))
-    o.append("BN_CONST uint32_t C_G1_GEN[2][8] = {%s, %s};" % (c_fp(1), c_fp(2)))
-    o.append("BN_CONST uint32_t C_G2_GEN[2][2][8] = {%s, %s};" % (c_fp2(G2X), c_fp2(G2Y)))
+        o.append("BN_CONST int32_t C_FROB%d[6][2][10] = {%s};  /* xi^(k(q^%d-1)/6), k=0..5 */" % (j, ", ".join(c_fp2(t) for t in frob[j]), j))
+    o.append("BN_CONST int32_t C_TW_FROB_X1[2][10] = %s;" % c_fp2(g_x1))
+    o.append("BN_CONST int32_t C_TW_FROB_Y1[2][10] = %s;" % c_fp2(g_y1))
+    o.append("BN_CONST int32_t C_TW_FROB_X2[2][10] = %s;" % c_fp2(g_x2))
+    o.append("BN_CONST int32_t C_G1_GEN[2][10] = {%s, %s};" % (c_fp(1), c_fp(2)))
+    o.append("BN_CONST int32_t C_G2_GEN[2][2][10] = {%s, %s};" % (c_fp2(G2X), c_fp2(G2Y)))
     o.append("BN_CONST signed char C_ATE_NAF[64] = {%s};  /* digits of 6u+2 after the leading 1, MSB first */" % ", ".join(str(d) for d in naf))
     o.append("/* line coefficients (c0 -> *yP, c1 -> *xP, c2) for Q = -G2::one(), in order of use */")
-    o.append("BN_CONST uint32_t C_NEG_G2_LINES[BN_N_FIXED_LINES][3][2][8] = {")
+    o.append("BN_CONST int32_t C_NEG_G2_LINES[BN_N_FIXED_LINES][3][2][10] = {")
     for ln in lines:
         o.append("  {%s, %s, %s}," % (c_fp2(ln[0]), c_fp2(ln[1]), c_fp2(ln[2])))
     o.append("};")

@@ -1,0 +1,61 @@
+"""Limb/value bounds of the unsaturated Fq arithmetic, proven by interval bookkeeping.
+
+The device headers compiled with -DBN_TRACK_BOUNDS carry, next to every field element, an interval
+for its limbs, its top limb and its value; every operation propagates worst-case bounds and aborts
+if a product's 64-bit column accumulator could overflow, a limb could leave int32, or a value could
+outgrow the Montgomery range.  The bounds depend only on the operation sequence (control flow of the
+pairing/hash/group code is data-independent), so one pass of each flow is a proof for that flow.
+CPU only."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DRIVER = r'''
+import ctypes, json, sys
+root = sys.argv[1]; which = sys.argv[2]
+hs = ctypes.CDLL(root + "/tests/hostsim/libhostsim_bounds.so")
+d = json.load(open(root + "/tests/golden/derived_vectors.json")); k = json.load(open(root + "/tests/golden/reference_kats.json"))
+H = bytes.fromhex
+buf = ctypes.create_string_buffer
+if which == "fp":
+    o = buf(32)
+    for op in range(6):
+        hs.hs_fp_op(op, (5).to_bytes(32, "big"), (7).to_bytes(32, "big"), o)
+elif which == "hash":
+    for v in d["hash_to_g1"][:4]:
+        o = buf(64); t = ctypes.c_int(0); m = H(v["message_hex"])
+        hs.hs_hash_to_g1(m, len(m), o, ctypes.byref(t)); assert o.raw.hex() == v["uncompressed"]
+elif which == "pairing":
+    v = d["pairing_gt"][1]; o = buf(384); hs.hs_pairing(H(v["g1"]), H(v["g2"]), 1, 0, o, 0); assert o.raw.hex() == v["gt"]
+    a, b = d["pairing_gt"][1], d["pairing_gt"][2]
+    hs.hs_pairing(H(a["g1"]) + H(b["g1"]), H(a["g2"]) + H(b["g2"]), 2, 0, o, 0)
+elif which == "verify":
+    for v in d["verify_cases"]:
+        m = H(v["message_hex"]); st = hs.hs_verify(m, len(m), H(v["sig"]), H(v["pk"]), 0)
+        assert st == v["status"] or "subgroup" in v["name"], v["name"]
+    v = k["check_public_keys"][1]
+elif which == "group":
+    v = k["g1_add"][0]; o = buf(64); hs.hs_g1_add(H(v["x1"] + v["y1"]), H(v["x2"] + v["y2"]), o); assert o.raw.hex() == v["result"]
+    for v in k["g1_mul"][:3]:
+        hs.hs_g1_mul(H(v["x"] + v["y"]), H(v["scalar"]), 0, o); assert o.raw.hex() == v["result"]
+    v = k["public_key_from_private_key"][0]; o = buf(128); hs.hs_g2_mul(None, H(v["private_key"]), 1, o); assert o.raw.hex() == v["uncompressed"]
+    o2 = buf(128); hs.hs_g2_add(o.raw, o.raw, o2)
+    v = k["sign"][0]; o = buf(64); m = H(v["message_hex"]); hs.hs_sign(m, len(m), H(v["private_key"]), o)
+elif which == "subgroup":
+    v = d["verify_cases"][0]; m = H(v["message_hex"]); assert hs.hs_verify(m, len(m), H(v["sig"]), H(v["pk"]), 1) == 0
+print("ok")
+'''
+
+
+@pytest.fixture(scope="module")
+def bounds_lib():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "hostsim"), "libhostsim_bounds.so"], stdout=subprocess.DEVNULL)
+
+
+@pytest.mark.parametrize("flow", ["fp", "hash", "pairing", "verify", "group", "subgroup"])
+def test_bounds_hold(bounds_lib, flow):
+    p = subprocess.run([sys.executable, "-c", DRIVER, ROOT, flow], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and p.stdout.strip() == "ok", (p.stdout[-500:], p.stderr[-2000:])
