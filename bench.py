@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=BATCH, help="tuples per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fused-miller", action="store_true", help="force the fused 2-pair Miller kernel (A/B comparison)")
     args = ap.parse_args()
 
     import torch
@@ -77,7 +78,9 @@ def main():
 
     eng = bn254_amd.Engine(local_rank)
     n = args.batch
-    eng.reserve(n)
+    eng.reserve(2 * n)
+    if args.fused_miller:
+        eng.set_option(1, 1)
 
     # ---- synthetic inputs, generated on the GPU by the product's own sign / keygen kernels -------
     base = rank * n                                          # each rank owns a distinct shard

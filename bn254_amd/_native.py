@@ -9,7 +9,7 @@ import subprocess
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_PKG, "csrc")
-LIB_PATH = os.path.join(_PKG, "libbn254hip.so")
+LIB_PATH = os.environ.get("BN254_LIB", os.path.join(_PKG, "libbn254hip.so"))   # BN254_LIB: A/B-test another build
 _SOURCES = ["bn254_hip.hip", "bn254_field.h", "bn254_curve.h", "bn254_pairing.h", "bn254_hash.h", "bn254_io.h", "gen_constants.py"]
 
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC"]
@@ -59,6 +59,7 @@ def load():
     L.bn254_ctx_synchronize.argtypes = [vp]
     L.bn254_ctx_set_profiling.argtypes = [vp, i32]
     L.bn254_ctx_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+    L.bn254_ctx_set_option.argtypes = [vp, i32, i32]
     L.bn254_batch_verify.argtypes = [vp, vp, vp, vp, vp, sz, u32, vp]
     L.bn254_batch_verify_device.argtypes = [vp, vp, vp, vp, vp, sz, u32, vp, vp]
     L.bn254_batch_hash_to_g1.argtypes = [vp, vp, vp, sz, vp, vp, vp]
@@ -91,5 +92,5 @@ EXPORTED_SYMBOLS = [
     "bn254_batch_pairing_check", "bn254_batch_pairing", "bn254_batch_pairing_device", "bn254_batch_check_public_keys",
     "bn254_batch_g1_add", "bn254_batch_g2_add", "bn254_batch_g1_mul", "bn254_batch_g2_mul", "bn254_batch_g1_mul_device",
     "bn254_batch_g2_mul_device", "bn254_batch_sign", "bn254_batch_sign_device", "bn254_batch_g1_sum", "bn254_batch_g2_sum",
-    "bn254_debug_fp_op", "bn254_debug_fp12_op", "bn254_debug_miller_loop", "bn254_ctx_set_profiling", "bn254_ctx_last_kernel_ms",
+    "bn254_debug_fp_op", "bn254_debug_fp12_op", "bn254_debug_miller_loop", "bn254_ctx_set_profiling", "bn254_ctx_last_kernel_ms", "bn254_ctx_set_option",
 ]

@@ -451,7 +451,10 @@ BN_DEV Fp2 fp2_inv(const Fp2& a) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Fq6, Fq12 — operate on memory (the per-lane private segment): real functions.
+// Fq6, Fq12.  Fq12-level operations are real (non-inlined) functions on the per-lane private segment;
+// the Fq6 layer is inlined into them so that all intermediates of one Fq12 operation live in VGPRs and
+// each operand crosses memory once (rocprofv3 showed the earlier call-per-Fq6-product structure moving
+// ~1.5 MB of private-segment traffic per verify: HBM-bound instead of VALU-bound).
 // Contract: inputs with |limb| <= 2^27 ("tight"), outputs tight again (norm at the end).
 // ------------------------------------------------------------------------------------------
 BN_DEV void fp6_add(Fp6& r, const Fp6& a, const Fp6& b) { r.c0 = fp2_add(a.c0, b.c0); r.c1 = fp2_add(a.c1, b.c1); r.c2 = fp2_add(a.c2, b.c2); }
@@ -460,19 +463,19 @@ BN_DEV void fp6_neg(Fp6& r, const Fp6& a) { r.c0 = fp2_neg(a.c0); r.c1 = fp2_neg
 BN_DEV void fp6_norm(Fp6& r, const Fp6& a) { r.c0 = fp2_norm(a.c0); r.c1 = fp2_norm(a.c1); r.c2 = fp2_norm(a.c2); }
 BN_DEV void fp6_mul_v(Fp6& r, const Fp6& a) { Fp2 t = fp2_mul_xi(a.c2); r.c2 = a.c1; r.c1 = a.c0; r.c0 = t; }   // a.c2 tight
 
-BN_DEVN void fp6_mul(Fp6& r, const Fp6& a, const Fp6& b) {
+BN_DEV void fp6_mul(Fp6& r, const Fp6& a, const Fp6& b) {
   Fp2 v0 = fp2_mul(a.c0, b.c0), v1 = fp2_mul(a.c1, b.c1), v2 = fp2_mul(a.c2, b.c2);
   Fp2 c0 = fp2_add(fp2_mul_xi_n(fp2_sub(fp2_sub(fp2_mul(fp2_add(a.c1, a.c2), fp2_add(b.c1, b.c2)), v1), v2)), v0);
   Fp2 c1 = fp2_add(fp2_sub(fp2_sub(fp2_mul(fp2_add(a.c0, a.c1), fp2_add(b.c0, b.c1)), v0), v1), fp2_mul_xi_n(v2));
   Fp2 c2 = fp2_add(fp2_sub(fp2_sub(fp2_mul(fp2_add(a.c0, a.c2), fp2_add(b.c0, b.c2)), v0), v2), v1);
   r.c0 = fp2_norm(c0); r.c1 = fp2_norm(c1); r.c2 = fp2_norm(c2);
 }
-BN_DEVN void fp6_mul_fp2(Fp6& r, const Fp6& a, const Fp2& k) {
+BN_DEV void fp6_mul_fp2(Fp6& r, const Fp6& a, const Fp2& k) {
   Fp2 c0 = fp2_mul(a.c0, k), c1 = fp2_mul(a.c1, k), c2 = fp2_mul(a.c2, k);
   r.c0 = fp2_norm(c0); r.c1 = fp2_norm(c1); r.c2 = fp2_norm(c2);
 }
 // a * (b0 + b1 v)
-BN_DEVN void fp6_mul_01(Fp6& r, const Fp6& a, const Fp2& b0, const Fp2& b1) {
+BN_DEV void fp6_mul_01(Fp6& r, const Fp6& a, const Fp2& b0, const Fp2& b1) {
   Fp2 v0 = fp2_mul(a.c0, b0), v1 = fp2_mul(a.c1, b1);
   Fp2 c0 = fp2_add(fp2_mul_xi_n(fp2_mul(a.c2, b1)), v0);
   Fp2 c1 = fp2_sub(fp2_sub(fp2_mul(fp2_add(a.c0, a.c1), fp2_add(b0, b1)), v0), v1);

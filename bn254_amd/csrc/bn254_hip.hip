@@ -27,7 +27,15 @@
 using namespace bn254;
 
 #define BN_WAVE 64
-#define KERNEL __global__ __launch_bounds__(BN_WAVE)
+#define BN_SPLIT_MAX_N ((size_t)98304)   // <= 1.5 waves per SIMD with one lane per verify
+// Register budget: amdgpu_waves_per_eu(W, W) on the kernels is propagated to every device function
+// they call (AMDGPU attributor), capping VGPR+AGPR at 512/W so that W waves fit on each SIMD.
+// Two co-resident waves each keep the full single-wave issue rate on gfx950
+// (profiles/r01_issue_mix_microbench.jsonl), so W = 2 doubles a SIMD's throughput.
+#ifndef BN_WAVES_PER_EU
+#define BN_WAVES_PER_EU 2
+#endif
+#define KERNEL __global__ __launch_bounds__(BN_WAVE) __attribute__((amdgpu_waves_per_eu(BN_WAVES_PER_EU, BN_WAVES_PER_EU)))
 
 // ------------------------------------------------------------------------------------------
 // workspace planes
@@ -82,6 +90,13 @@ __device__ __forceinline__ void ws_load_g2(const Ws& ws, size_t i, G2Affine& q) 
 // every wave stays convergent; its status byte keeps the decode error.
 __device__ __forceinline__ void g1_set_generator(G1Affine& p) { p.x = fp_load_const(C_G1_GEN[0]); p.y = fp_load_const(C_G1_GEN[1]); p.inf = false; }
 __device__ __forceinline__ void g2_set_generator(G2Affine& q) { q.x = fp2_load_const(C_G2_GEN[0]); q.y = fp2_load_const(C_G2_GEN[1]); q.inf = false; }
+
+// The Miller accumulator f (12 field elements = 480 B per lane) is the hottest per-lane state: every
+// Fq12 squaring / line multiplication reads and rewrites it.  It is staged in LDS, one padded slot per
+// lane (121 words: an odd word stride keeps the 64 lanes of a wave on distinct banks), so those
+// accesses never leave the CU.  31 KB per 64-lane workgroup -> 5 workgroups per 160 KB CU.
+struct Fp12Slot { Fp12 v; int32_t pad; };
+static_assert(sizeof(Fp12Slot) == 484, "LDS slot must be 121 words");
 
 // ------------------------------------------------------------------------------------------
 // kernels
@@ -149,9 +164,42 @@ KERNEL void k_miller_verify(size_t n, Ws ws) {
   ws_load_g1(ws, PL_P1X, BY_P1_INF, i, sig);
   ws_load_g1(ws, PL_P2X, BY_P2_INF, i, h);
   ws_load_g2(ws, i, pk);
-  Fp12 f;
+  __shared__ Fp12Slot lds_f[BN_WAVE];
+  Fp12& f = lds_f[threadIdx.x].v;
   miller_loop<true, true>(f, h, pk, sig);
   ws_store_f12(ws, i, f);
+}
+// The same, one PAIRING per lane: the two Miller loops of a verify run in different waves so that a
+// 65 536-verify batch puts two waves on every SIMD (two co-resident waves each keep the full
+// single-wave issue rate on gfx950).  Workgroups [0, nblk) take pair A = (H(m), pk) with a variable
+// twist point, workgroups [nblk, 2 nblk) take pair B = (sig, -G2::one()) through the line table;
+// f_A lands at workspace index i, f_B at index f_stride + i; k_final_exp multiplies them.
+__device__ __noinline__ void miller_role_a(size_t i, Ws ws) {
+  G1Affine h, unused_g1;
+  G2Affine pk;
+  ws_load_g1(ws, PL_P2X, BY_P2_INF, i, h);
+  ws_load_g2(ws, i, pk);
+  g1_set_generator(unused_g1);
+  Fp12 f;
+  miller_loop<true, false>(f, h, pk, unused_g1);
+  ws_store_f12(ws, i, f);
+}
+__device__ __noinline__ void miller_role_b(size_t i, size_t f_stride, Ws ws) {
+  G1Affine sig, unused_g1;
+  G2Affine unused_g2;
+  ws_load_g1(ws, PL_P1X, BY_P1_INF, i, sig);
+  g1_set_generator(unused_g1);
+  g2_set_generator(unused_g2);
+  Fp12 f;
+  miller_loop<false, true>(f, unused_g1, unused_g2, sig);
+  ws_store_f12(ws, f_stride + i, f);
+  ws_byte(ws, BY_ST_DECODE, f_stride + i) = ST_OK;
+}
+KERNEL void k_miller_verify_split(size_t n, size_t f_stride, unsigned nblk, Ws ws) {
+  bool role_b = blockIdx.x >= nblk;     // wave-uniform
+  size_t i = (size_t)(blockIdx.x - (role_b ? nblk : 0u)) * BN_WAVE + threadIdx.x;
+  if (i >= n) return;
+  if (!role_b) miller_role_a(i, ws); else miller_role_b(i, f_stride, ws);
 }
 // generic single pair per lane: f = miller(P1, Q)
 KERNEL void k_miller_var(size_t n, Ws ws) {
@@ -181,16 +229,22 @@ KERNEL void k_miller_cpk(size_t n, Ws ws) {
 
 // item i: product of the k Miller values f[i*k .. i*k+k), final exponentiation, compare with one.
 // status = first decode error among its pairs, else hash error (if use_hash), else 0 / 9.
-KERNEL void k_final_exp(size_t n, size_t k, Ws ws, int use_hash, uint8_t* gt_out, uint8_t* status_out, int raw_only) {
+KERNEL void k_final_exp(size_t n, size_t k, size_t item_stride, size_t pair_stride, Ws ws, int use_hash, uint8_t* gt_out, uint8_t* status_out,
+                        int raw_only) {
   size_t i = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
   if (i >= n) return;
+  // factor j of item i sits at workspace index i*item_stride + j*pair_stride:
+  //   pairing API  (k adjacent pairs per item): item_stride = k, pair_stride = 1
+  //   split verify (f_A at i, f_B at half + i):  item_stride = 1, pair_stride = half
+  // every factor slot carries its own decode status (slots of the B half hold 0)
   Fp12 f, g;
-  ws_load_f12(ws, i * k, f);
-  uint8_t st = ws_byte(ws, BY_ST_DECODE, i * k);
+  ws_load_f12(ws, i * item_stride, f);
+  uint8_t st = ws_byte(ws, BY_ST_DECODE, i * item_stride);
   for (size_t j = 1; j < k; ++j) {
-    ws_load_f12(ws, i * k + j, g);
+    size_t idx = i * item_stride + j * pair_stride;
+    ws_load_f12(ws, idx, g);
     fp12_mul(f, f, g);
-    uint8_t sj = ws_byte(ws, BY_ST_DECODE, i * k + j);
+    uint8_t sj = ws_byte(ws, BY_ST_DECODE, idx);
     if (st == ST_OK) st = sj;
   }
   if (st == ST_OK && use_hash) st = ws_byte(ws, BY_ST_HASH, i);
@@ -380,6 +434,7 @@ struct bn254_ctx {
   uint8_t* stage[8];
   size_t stage_cap[8];
   int profiling;
+  int force_fused;   // test/bench knob: always use the fused 2-pair Miller kernel
   hipEvent_t ev[5];
   int ev_valid;
 };
@@ -470,6 +525,11 @@ int bn254_ctx_set_profiling(bn254_ctx* c, int enabled) {
   c->ev_valid = 0;
   return 0;
 }
+int bn254_ctx_set_option(bn254_ctx* c, int option, int value) {
+  if (!c) return BN254_E_BAD_ARGUMENT;
+  if (option == BN254_OPT_FORCE_FUSED_MILLER) { c->force_fused = value; return 0; }
+  return BN254_E_BAD_ARGUMENT;
+}
 int bn254_ctx_last_kernel_ms(bn254_ctx* c, float ms[4]) {
   if (!c || !ms || !c->ev_valid) return BN254_E_BAD_ARGUMENT;
   HIP_TRY(hipEventSynchronize(c->ev[4]));
@@ -485,7 +545,10 @@ int bn254_batch_verify_device(bn254_ctx* c, const uint8_t* d_msgs, const uint64_
   if (n == 0) return 0;
   if (misaligned(d_sigs) || misaligned(d_pks) || ((uintptr_t)d_off & 7u)) return BN254_E_MISALIGNED;
   HIP_TRY(hipSetDevice(c->device));
-  int rc = ws_reserve(c, n);
+  // small batches: one pairing per lane (2 waves per SIMD up to 65 536 verifies); large batches already
+  // oversubscribe the SIMDs and keep the fused loop, which shares the f^2 of every step
+  bool split = n <= BN_SPLIT_MAX_N && !c->force_fused;
+  int rc = ws_reserve(c, split ? 2 * n : n);
   if (rc) return rc;
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
   unsigned g = grid_for(n);
@@ -495,9 +558,15 @@ int bn254_batch_verify_device(bn254_ctx* c, const uint8_t* d_msgs, const uint64_
   PROF_MARK(1);
   k_hash_to_g1<<<g, BN_WAVE, 0, s>>>(d_msgs, d_off, n, c->ws, PL_P2X, BY_P2_INF, nullptr);
   PROF_MARK(2);
-  k_miller_verify<<<g, BN_WAVE, 0, s>>>(n, c->ws);
-  PROF_MARK(3);
-  k_final_exp<<<g, BN_WAVE, 0, s>>>(n, 1, c->ws, 1, nullptr, d_status, 0);
+  if (split) {
+    k_miller_verify_split<<<2 * g, BN_WAVE, 0, s>>>(n, c->ws.stride / 2, g, c->ws);
+    PROF_MARK(3);
+    k_final_exp<<<g, BN_WAVE, 0, s>>>(n, 2, 1, c->ws.stride / 2, c->ws, 1, nullptr, d_status, 0);
+  } else {
+    k_miller_verify<<<g, BN_WAVE, 0, s>>>(n, c->ws);
+    PROF_MARK(3);
+    k_final_exp<<<g, BN_WAVE, 0, s>>>(n, 1, 1, 1, c->ws, 1, nullptr, d_status, 0);
+  }
   PROF_MARK(4);
   if (c->profiling) c->ev_valid = 1;
   HIP_TRY(hipGetLastError());
@@ -569,7 +638,7 @@ static int pairing_device(bn254_ctx* c, const uint8_t* d_g1, const uint8_t* d_g2
   k_decode_g1<<<grid_for(lanes), BN_WAVE, 0, s>>>(d_g1, lanes, flags, c->ws, PL_P1X, BY_P1_INF, 0);
   k_decode_g2<<<grid_for(lanes), BN_WAVE, 0, s>>>(d_g2, lanes, flags, c->ws, 1);
   k_miller_var<<<grid_for(lanes), BN_WAVE, 0, s>>>(lanes, c->ws);
-  k_final_exp<<<grid_for(n), BN_WAVE, 0, s>>>(n, k, c->ws, 0, d_gt, d_status, raw_only);
+  k_final_exp<<<grid_for(n), BN_WAVE, 0, s>>>(n, k, k, 1, c->ws, 0, d_gt, d_status, raw_only);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -620,7 +689,7 @@ int bn254_batch_check_public_keys(bn254_ctx* c, const uint8_t* pk_g2, const uint
   k_decode_g2<<<g, BN_WAVE, 0, s>>>(c->stage[0], n, flags, c->ws, 0);       // ecdsa.rs:82: pk_g2 first
   k_decode_g1<<<g, BN_WAVE, 0, s>>>(c->stage[1], n, flags, c->ws, PL_P1X, BY_P1_INF, 1);
   k_miller_cpk<<<g, BN_WAVE, 0, s>>>(n, c->ws);
-  k_final_exp<<<g, BN_WAVE, 0, s>>>(n, 1, c->ws, 0, nullptr, c->stage[2], 0);
+  k_final_exp<<<g, BN_WAVE, 0, s>>>(n, 1, 1, 1, c->ws, 0, nullptr, c->stage[2], 0);
   HIP_TRY(hipGetLastError());
   if ((rc = stage_out(c, 2, status, n))) return rc;
   HIP_TRY(hipStreamSynchronize(c->stream));

@@ -79,32 +79,32 @@ BN_DEVN void miller_loop(Fp12& f, const G1Affine& pa, const G2Affine& qa, const 
   Fp2 qa_yneg;
   bool skip_a = !HAS_A || pa.inf || qa.inf;
   bool skip_b = !HAS_B || pb.inf;
-  if (HAS_A) { t.x = qa.x; t.y = qa.y; t.z = fp2_one(); qa_yneg = fp2_norm(fp2_neg(qa.y)); }
+  if constexpr (HAS_A) { t.x = qa.x; t.y = qa.y; t.z = fp2_one(); qa_yneg = fp2_norm(fp2_neg(qa.y)); }
   int idx = 0;
   for (int d = 0; d < 64; ++d) {
     fp12_sqr(f, f);
-    if (HAS_A) { dbl_step(t, l); mul_by_line(f, l, pa.x, pa.y, skip_a); }
-    if (HAS_B) { fixed_line(l, idx++); mul_by_line(f, l, pb.x, pb.y, skip_b); }
+    if constexpr (HAS_A) { dbl_step(t, l); mul_by_line(f, l, pa.x, pa.y, skip_a); }
+    if constexpr (HAS_B) { fixed_line(l, idx++); mul_by_line(f, l, pb.x, pb.y, skip_b); }
     int digit = C_ATE_NAF[d];
     if (digit != 0) {   // wave-uniform
-      if (HAS_A) { add_step(t, l, qa.x, digit > 0 ? qa.y : qa_yneg); mul_by_line(f, l, pa.x, pa.y, skip_a); }
-      if (HAS_B) { fixed_line(l, idx++); mul_by_line(f, l, pb.x, pb.y, skip_b); }
+      if constexpr (HAS_A) { Fp2 qy = fp2_select(digit > 0, qa.y, qa_yneg); add_step(t, l, qa.x, qy); mul_by_line(f, l, pa.x, pa.y, skip_a); }
+      if constexpr (HAS_B) { fixed_line(l, idx++); mul_by_line(f, l, pb.x, pb.y, skip_b); }
     }
   }
   // + pi(Q), - pi^2(Q)
-  if (HAS_A) {
+  if constexpr (HAS_A) {
     Fp2 q1x = fp2_norm(fp2_mul(fp2_conj(qa.x), fp2_load_const(C_TW_FROB_X1)));
     Fp2 q1y = fp2_norm(fp2_mul(fp2_conj(qa.y), fp2_load_const(C_TW_FROB_Y1)));
     add_step(t, l, q1x, q1y);
     mul_by_line(f, l, pa.x, pa.y, skip_a);
   }
-  if (HAS_B) { fixed_line(l, idx++); mul_by_line(f, l, pb.x, pb.y, skip_b); }
-  if (HAS_A) {
+  if constexpr (HAS_B) { fixed_line(l, idx++); mul_by_line(f, l, pb.x, pb.y, skip_b); }
+  if constexpr (HAS_A) {
     Fp2 q2x = fp2_norm(fp2_mul(qa.x, fp2_load_const(C_TW_FROB_X2)));
     add_step(t, l, q2x, qa.y);
     mul_by_line(f, l, pa.x, pa.y, skip_a);
   }
-  if (HAS_B) { fixed_line(l, idx++); mul_by_line(f, l, pb.x, pb.y, skip_b); }
+  if constexpr (HAS_B) { fixed_line(l, idx++); mul_by_line(f, l, pb.x, pb.y, skip_b); }
 }
 
 // a^u for a in the cyclotomic subgroup (u = 4965661367192848881, 63 bits)

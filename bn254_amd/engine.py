@@ -10,6 +10,7 @@ from . import _native
 G1_BYTES, G2_BYTES, GT_BYTES, SCALAR_BYTES = 64, 128, 384, 32
 FLAG_G2_SUBGROUP_CHECK = 1
 FLAG_REJECT_IDENTITY = 2
+OPT_FORCE_FUSED_MILLER = 1
 
 
 class NativeError(RuntimeError):
@@ -69,6 +70,9 @@ class Engine:
 
     def set_profiling(self, on):
         _check("bn254_ctx_set_profiling", self._lib.bn254_ctx_set_profiling(self._h, 1 if on else 0))
+
+    def set_option(self, option, value):
+        _check("bn254_ctx_set_option", self._lib.bn254_ctx_set_option(self._h, option, value))
 
     def last_kernel_ms(self):
         ms = (ctypes.c_float * 4)()

@@ -222,6 +222,20 @@ def test_batch_verify_vs_oracle_4k(eng, c):
         assert sigs[64 * i:64 * i + 64] == c.sign(msgs[i], sk_bytes(i % 256)) or expected[i] == 9
 
 
+def test_fused_and_split_miller_agree(eng, derived):
+    """the one-pairing-per-lane path (default for small batches) and the fused 2-pair loop give the same statuses"""
+    from bn254_amd.engine import OPT_FORCE_FUSED_MILLER
+    cs = derived["verify_cases"]
+    args = ([H(v["message_hex"]) for v in cs], b"".join(H(v["sig"]) for v in cs), b"".join(H(v["pk"]) for v in cs))
+    want = [v["status"] for v in cs]
+    assert list(eng.batch_verify(*args, flags=1)) == want
+    eng.set_option(OPT_FORCE_FUSED_MILLER, 1)
+    try:
+        assert list(eng.batch_verify(*args, flags=1)) == want
+    finally:
+        eng.set_option(OPT_FORCE_FUSED_MILLER, 0)
+
+
 def test_pairing_check_k_pairs(eng, c):
     ps, qs = _rand_points(c, 6, b"kp")
     # e(aP, Q) * e(-aP, Q) == 1  and a 3-pair product that is not one
