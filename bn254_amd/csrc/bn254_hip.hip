@@ -44,8 +44,18 @@ struct Ws {
   int32_t* planes;    // [N_PLANES * BN_LIMBS][stride] i32
   uint8_t* bytes;     // [N_BYTE_PLANES][stride]
   size_t stride;
+  // hash-to-G1 round state (see k_hash_round)
+  uint32_t* h_best;   // [stride]  smallest successful counter of the current round, or HASH_NONE
+  uint8_t* h_next;    // [stride]  first counter not yet tried
+  uint32_t* h_list;   // [2][stride] compacted indices of the messages still without a point
+  uint32_t* h_cnt;    // [HASH_MAX_ROUNDS + 1] number of entries of the list feeding round r
+  int32_t* h_cand;    // [2 * BN_LIMBS][HASH_CAND_CAP] candidate points of speculative lanes
 };
-enum { PL_P1X = 0, PL_P1Y, PL_QX0, PL_QX1, PL_QY0, PL_QY1, PL_P2X, PL_P2Y, PL_F0, N_PLANES = PL_F0 + 12 };
+#define HASH_NONE 0xFFFFFFFFu
+#define HASH_MAX_ROUNDS 64
+#define HASH_CAND_CAP ((size_t)1 << 18)        // speculative lanes per round (262 144)
+#define HASH_TARGET_LANES ((size_t)1 << 17)    // ~2 waves per SIMD
+enum { PL_P1X = 0, PL_P1Y, PL_QX0, PL_QX1, PL_QY0, PL_QY1, PL_P2X, PL_P2Y, PL_HASHX, PL_HASHY, PL_F0, N_PLANES = PL_F0 + 12 };
 enum { BY_ST_DECODE = 0, BY_ST_HASH, BY_P1_INF, BY_Q_INF, BY_P2_INF, N_BYTE_PLANES };
 
 __device__ __forceinline__ Fp ws_load_fp(const Ws& ws, int plane, size_t i) {
@@ -128,30 +138,99 @@ KERNEL void k_decode_g2(const uint8_t* pts, size_t n, uint32_t flags, Ws ws, int
   ws_byte(ws, BY_ST_DECODE, i) = prev != ST_OK ? prev : st;
 }
 
-// hash_to_try_and_increment of message i -> G1 planes (px, px+1); naive per-lane retry loop:
-// a wave iterates until its slowest lane has found a point.
-KERNEL void k_hash_to_g1(const uint8_t* msgs, const uint64_t* off, size_t n, Ws ws, int px, int inf_plane, uint8_t* tries_out) {
+// hash_to_try_and_increment (hash.rs:29-63) in ROUNDS.  The reference tries counters 0,1,2,... per
+// message until one yields a point (p = 0.4726 per try, 2.12 tries on average, 20+ for the unluckiest
+// message of a 65 536 batch).  One-message-per-lane with a retry loop makes every wave wait for its
+// slowest lane and the kernel for the slowest message.  Instead:
+//   * a round handles only the messages that still have no point (compacted index list),
+//   * each of them tries `width` consecutive counters at once in `width` different lanes
+//     (speculation; width grows as the survivors thin out so every round fills the SIMDs),
+//   * atomicMin picks the SMALLEST successful counter, exactly the point the sequential loop returns.
+// Lane w of a round: slot = w % n_act (message), j = w / n_act (counter offset) — consecutive lanes
+// work on consecutive messages with the same offset.
+KERNEL void k_hash_init(size_t n, Ws ws) {
   size_t i = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
-  if (i >= n) return;
-  const uint8_t* msg = msgs + off[i];
-  uint64_t len = off[i + 1] - off[i];
-  HashState hs;
-  hash_state_init(hs, msg, len);
-  G1Affine p;
-  g1_set_generator(p);
-  bool done = false;
-  uint32_t tries = 0;
-  for (uint32_t ctr = 0; ctr < 255; ++ctr) {          // hash.rs:40  (0..255)
-    if (!done) {
-      done = hash_try(p, hs, msg, len, ctr);
-      tries = ctr + 1;
+  if (i < n) { ws.h_best[i] = HASH_NONE; ws.h_next[i] = 0; }
+  if (i <= HASH_MAX_ROUNDS) ws.h_cnt[i] = (i == 0) ? (uint32_t)n : 0u;
+}
+KERNEL void k_hash_round(const uint8_t* msgs, const uint64_t* off, Ws ws, int round, uint32_t width, uint32_t max_ctr) {
+  const uint32_t n_act = ws.h_cnt[round];
+  if (n_act == 0) return;
+  uint32_t width_eff = width;
+  if ((size_t)n_act * width_eff > HASH_CAND_CAP) width_eff = (uint32_t)(HASH_CAND_CAP / n_act);
+  if (width_eff == 0) width_eff = 1;   // more survivors than candidate slots: plain one-try round (direct path below)
+  const uint32_t* list = round == 0 ? nullptr : ws.h_list + (size_t)(round & 1) * ws.stride;
+  const size_t total = (size_t)n_act * width_eff;
+  for (size_t w = (size_t)blockIdx.x * BN_WAVE + threadIdx.x; w < total; w += (size_t)gridDim.x * BN_WAVE) {
+    uint32_t slot = (uint32_t)(w % n_act), j = (uint32_t)(w / n_act);
+    uint32_t i = list ? list[slot] : slot;
+    uint32_t ctr = (uint32_t)ws.h_next[i] + j;
+    if (ctr >= max_ctr) continue;                                  // hash.rs:40: counters 0..=254
+    const uint8_t* msg = msgs + off[i];
+    uint64_t len = off[i + 1] - off[i];
+    HashState hs;
+    hash_state_init(hs, msg, len);
+    G1Affine p;
+    if (hash_try(p, hs, msg, len, ctr)) {
+      atomicMin(&ws.h_best[i], ctr);
+      if (width_eff > 1) {
+#pragma unroll
+        for (int k = 0; k < BN_LIMBS; ++k) {
+          ws.h_cand[(size_t)k * HASH_CAND_CAP + w] = p.x.v[k];
+          ws.h_cand[(size_t)(BN_LIMBS + k) * HASH_CAND_CAP + w] = p.y.v[k];
+        }
+      } else {   // the only try of this message in this round: it IS the result (wave-uniform branch)
+        ws_store_fp(ws, PL_HASHX, i, p.x);
+        ws_store_fp(ws, PL_HASHX + 1, i, p.y);
+      }
     }
-    if (!__any(!done)) break;
   }
-  if (!done) g1_set_generator(p);
-  ws_store_g1(ws, px, inf_plane, i, p);
-  ws_byte(ws, BY_ST_HASH, i) = done ? ST_OK : ST_HASH_TO_POINT;   // hash.rs:62
-  if (tries_out) tries_out[i] = (uint8_t)tries;
+}
+// after a round: commit the winning candidate or queue the message for the next round
+KERNEL void k_hash_resolve(Ws ws, int round, uint32_t width, uint32_t max_ctr, int px, int inf_plane, uint8_t* tries_out) {
+  const uint32_t n_act = ws.h_cnt[round];
+  if (n_act == 0) return;
+  uint32_t width_eff = width;
+  if ((size_t)n_act * width_eff > HASH_CAND_CAP) width_eff = (uint32_t)(HASH_CAND_CAP / n_act);
+  if (width_eff == 0) width_eff = 1;
+  const uint32_t* list = round == 0 ? nullptr : ws.h_list + (size_t)(round & 1) * ws.stride;
+  uint32_t* list_out = ws.h_list + (size_t)((round + 1) & 1) * ws.stride;
+  for (size_t slot = (size_t)blockIdx.x * BN_WAVE + threadIdx.x; slot < n_act; slot += (size_t)gridDim.x * BN_WAVE) {
+    uint32_t i = list ? list[slot] : (uint32_t)slot;
+    uint32_t best = ws.h_best[i];
+    uint32_t next = ws.h_next[i];
+    if (best != HASH_NONE) {
+      G1Affine p;
+      if (width_eff > 1) {
+        size_t w = (size_t)(best - next) * n_act + slot;
+#pragma unroll
+        for (int k = 0; k < BN_LIMBS; ++k) {
+          p.x.v[k] = ws.h_cand[(size_t)k * HASH_CAND_CAP + w];
+          p.y.v[k] = ws.h_cand[(size_t)(BN_LIMBS + k) * HASH_CAND_CAP + w];
+        }
+      } else {
+        p.x = ws_load_fp(ws, PL_HASHX, i);
+        p.y = ws_load_fp(ws, PL_HASHX + 1, i);
+      }
+      p.inf = false;
+      ws_store_g1(ws, px, inf_plane, i, p);
+      ws_byte(ws, BY_ST_HASH, i) = ST_OK;
+      if (tries_out) tries_out[i] = (uint8_t)(best + 1);
+    } else {
+      next += width_eff;
+      if (next >= max_ctr) {                                       // hash.rs:62: HashToPointError
+        G1Affine p;
+        g1_set_generator(p);
+        ws_store_g1(ws, px, inf_plane, i, p);
+        ws_byte(ws, BY_ST_HASH, i) = ST_HASH_TO_POINT;
+        if (tries_out) tries_out[i] = (uint8_t)max_ctr;
+      } else {
+        ws.h_next[i] = (uint8_t)next;
+        uint32_t pos = atomicAdd(&ws.h_cnt[round + 1], 1u);
+        list_out[pos] = i;
+      }
+    }
+  }
 }
 
 // ECDSA::verify Miller loop: f = miller(H(m), pk) * miller(sig, -G2)   (ecdsa.rs:53-57)
@@ -435,6 +514,7 @@ struct bn254_ctx {
   size_t stage_cap[8];
   int profiling;
   int force_fused;   // test/bench knob: always use the fused 2-pair Miller kernel
+  int hash_max_tries; // test knob: counters tried before HashToPointError (0 = the reference's 255)
   hipEvent_t ev[5];
   int ev_valid;
 };
@@ -454,9 +534,17 @@ static int ws_reserve(bn254_ctx* c, size_t n) {
   HIP_TRY(hipStreamSynchronize(c->stream));
   if (c->ws.planes) { HIP_TRY(hipFree(c->ws.planes)); c->ws.planes = nullptr; }
   if (c->ws.bytes) { HIP_TRY(hipFree(c->ws.bytes)); c->ws.bytes = nullptr; }
+  if (c->ws.h_best) { HIP_TRY(hipFree(c->ws.h_best)); c->ws.h_best = nullptr; }
+  if (c->ws.h_next) { HIP_TRY(hipFree(c->ws.h_next)); c->ws.h_next = nullptr; }
+  if (c->ws.h_list) { HIP_TRY(hipFree(c->ws.h_list)); c->ws.h_list = nullptr; }
   c->ws.stride = 0;
   HIP_TRY(hipMalloc((void**)&c->ws.planes, (size_t)N_PLANES * BN_LIMBS * sizeof(int32_t) * cap));
   HIP_TRY(hipMalloc((void**)&c->ws.bytes, (size_t)N_BYTE_PLANES * cap));
+  HIP_TRY(hipMalloc((void**)&c->ws.h_best, sizeof(uint32_t) * cap));
+  HIP_TRY(hipMalloc((void**)&c->ws.h_next, cap));
+  HIP_TRY(hipMalloc((void**)&c->ws.h_list, 2 * sizeof(uint32_t) * cap));
+  if (!c->ws.h_cnt) HIP_TRY(hipMalloc((void**)&c->ws.h_cnt, sizeof(uint32_t) * (HASH_MAX_ROUNDS + 1)));
+  if (!c->ws.h_cand) HIP_TRY(hipMalloc((void**)&c->ws.h_cand, (size_t)2 * BN_LIMBS * sizeof(int32_t) * HASH_CAND_CAP));
   c->ws.stride = cap;
   return 0;
 }
@@ -481,6 +569,36 @@ static int stage_out(bn254_ctx* c, int slot, void* host, size_t bytes) {
   return 0;
 }
 static bool misaligned(const void* p) { return ((uintptr_t)p & 3u) != 0; }
+
+// Enqueue the hash-to-G1 rounds for n messages; points land in planes (px, px+1), statuses in BY_ST_HASH.
+// The schedule (widths, grid sizes) is fixed on the host from the EXPECTED survivor counts
+// (p_fail = 0.5274 per try); the kernels read the actual counts from device memory and use grid-stride
+// loops, so a wrong estimate costs time, never correctness.  No host synchronisation.
+static int launch_hash_rounds(bn254_ctx* c, hipStream_t s, const uint8_t* d_msgs, const uint64_t* d_off, size_t n, int px, int inf_plane,
+                              uint8_t* d_tries) {
+  const uint32_t max_ctr = c->hash_max_tries ? (uint32_t)c->hash_max_tries : 255u;
+  k_hash_init<<<grid_for(n > HASH_MAX_ROUNDS + 1 ? n : HASH_MAX_ROUNDS + 1), BN_WAVE, 0, s>>>(n, c->ws);
+  double expect = (double)n;
+  uint32_t consumed = 0;
+  for (int round = 0; round < HASH_MAX_ROUNDS && consumed < max_ctr; ++round) {
+    bool last = round == HASH_MAX_ROUNDS - 1;
+    double lanes_per_msg = (double)HASH_TARGET_LANES / (expect < 1.0 ? 1.0 : expect);
+    uint32_t width = lanes_per_msg < 2.0 ? 1u : (uint32_t)lanes_per_msg;
+    if (width > max_ctr - consumed || last) width = max_ctr - consumed;
+    double bound = expect * 1.25 + 256.0;                 // generous estimate of the survivors
+    if (bound > (double)n) bound = (double)n;
+    size_t lanes = (size_t)(bound * width);
+    if (lanes > HASH_CAND_CAP && width > 1) lanes = HASH_CAND_CAP;
+    k_hash_round<<<grid_for(lanes), BN_WAVE, 0, s>>>(d_msgs, d_off, c->ws, round, width, max_ctr);
+    k_hash_resolve<<<grid_for((size_t)bound), BN_WAVE, 0, s>>>(c->ws, round, width, max_ctr, px, inf_plane, d_tries);
+    consumed += width;
+    double pf = 1.0;
+    for (uint32_t t = 0; t < width && pf > 1e-12; ++t) pf *= 0.5274;
+    expect *= pf;
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
 
 extern "C" {
 
@@ -508,6 +626,11 @@ void bn254_ctx_destroy(bn254_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   if (c->ws.planes) (void)hipFree(c->ws.planes);
   if (c->ws.bytes) (void)hipFree(c->ws.bytes);
+  if (c->ws.h_best) (void)hipFree(c->ws.h_best);
+  if (c->ws.h_next) (void)hipFree(c->ws.h_next);
+  if (c->ws.h_list) (void)hipFree(c->ws.h_list);
+  if (c->ws.h_cnt) (void)hipFree(c->ws.h_cnt);
+  if (c->ws.h_cand) (void)hipFree(c->ws.h_cand);
   for (int i = 0; i < 8; ++i) if (c->stage[i]) (void)hipFree(c->stage[i]);
   for (int i = 0; i < 5; ++i) (void)hipEventDestroy(c->ev[i]);
   (void)hipStreamDestroy(c->stream);
@@ -528,6 +651,7 @@ int bn254_ctx_set_profiling(bn254_ctx* c, int enabled) {
 int bn254_ctx_set_option(bn254_ctx* c, int option, int value) {
   if (!c) return BN254_E_BAD_ARGUMENT;
   if (option == BN254_OPT_FORCE_FUSED_MILLER) { c->force_fused = value; return 0; }
+  if (option == BN254_OPT_HASH_MAX_TRIES) { if (value < 0 || value > 255) return BN254_E_BAD_ARGUMENT; c->hash_max_tries = value; return 0; }
   return BN254_E_BAD_ARGUMENT;
 }
 int bn254_ctx_last_kernel_ms(bn254_ctx* c, float ms[4]) {
@@ -556,7 +680,7 @@ int bn254_batch_verify_device(bn254_ctx* c, const uint8_t* d_msgs, const uint64_
   k_decode_g1<<<g, BN_WAVE, 0, s>>>(d_sigs, n, flags, c->ws, PL_P1X, BY_P1_INF, 0);
   k_decode_g2<<<g, BN_WAVE, 0, s>>>(d_pks, n, flags, c->ws, 1);
   PROF_MARK(1);
-  k_hash_to_g1<<<g, BN_WAVE, 0, s>>>(d_msgs, d_off, n, c->ws, PL_P2X, BY_P2_INF, nullptr);
+  if ((rc = launch_hash_rounds(c, s, d_msgs, d_off, n, PL_P2X, BY_P2_INF, nullptr))) return rc;
   PROF_MARK(2);
   if (split) {
     k_miller_verify_split<<<2 * g, BN_WAVE, 0, s>>>(n, c->ws.stride / 2, g, c->ws);
@@ -601,7 +725,7 @@ int bn254_batch_hash_to_g1_device(bn254_ctx* c, const uint8_t* d_msgs, const uin
   if (rc) return rc;
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
   unsigned g = grid_for(n);
-  k_hash_to_g1<<<g, BN_WAVE, 0, s>>>(d_msgs, d_off, n, c->ws, PL_P1X, BY_P1_INF, d_tries);
+  if ((rc = launch_hash_rounds(c, s, d_msgs, d_off, n, PL_P1X, BY_P1_INF, d_tries))) return rc;
   k_encode_g1<<<g, BN_WAVE, 0, s>>>(n, c->ws, PL_P1X, BY_P1_INF, d_points, d_status);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -768,7 +892,7 @@ int bn254_batch_sign_device(bn254_ctx* c, const uint8_t* d_msgs, const uint64_t*
   int rc = ws_reserve(c, n);
   if (rc) return rc;
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
-  k_hash_to_g1<<<grid_for(n), BN_WAVE, 0, s>>>(d_msgs, d_off, n, c->ws, PL_P1X, BY_P1_INF, nullptr);   // ecdsa.rs:28
+  if ((rc = launch_hash_rounds(c, s, d_msgs, d_off, n, PL_P1X, BY_P1_INF, nullptr))) return rc;             // ecdsa.rs:28
   k_g1_mul<<<grid_for(n), BN_WAVE, 0, s>>>(nullptr, d_sks, n, 1, c->ws, d_sigs, d_status);              // ecdsa.rs:31
   HIP_TRY(hipGetLastError());
   return 0;

@@ -143,6 +143,7 @@ int bn254_ctx_set_profiling(bn254_ctx *ctx, int enabled);
  * one lane (sharing f^2); 0 (default) = one pairing per lane for batches that would otherwise leave a
  * single wave per SIMD.  Results are identical either way. */
 #define BN254_OPT_FORCE_FUSED_MILLER 1
+#define BN254_OPT_HASH_MAX_TRIES 2 /* test knob: counters tried before HashToPointError; 0 = 255 as in src/hash.rs:40 */
 int bn254_ctx_set_option(bn254_ctx *ctx, int option, int value);
 int bn254_ctx_last_kernel_ms(bn254_ctx *ctx, float ms[4]);
 

@@ -120,6 +120,39 @@ def test_hash_to_g1_vs_oracle_ragged(eng, c):
         assert (st[i], pts[64 * i:64 * i + 64], tries[i]) == (wst, wpt, wtries), i
 
 
+def test_hash_to_point_error_path(eng, derived):
+    """src/hash.rs:62: HashToPointError once the counters are exhausted.  255 failures in a row cannot be
+    provoked with real data (p = 0.53^255), so the test knob shrinks the counter budget to 3."""
+    from bn254_amd.engine import OPT_HASH_MAX_TRIES
+    vs = derived["hash_to_g1"]
+    msgs = [H(v["message_hex"]) for v in vs]
+    eng.set_option(OPT_HASH_MAX_TRIES, 3)
+    try:
+        pts, st, tries = eng.batch_hash_to_g1(msgs)
+        sigs, st_sign = eng.batch_sign(msgs, b"".join((i + 1).to_bytes(32, "big") for i in range(len(msgs))))
+    finally:
+        eng.set_option(OPT_HASH_MAX_TRIES, 0)
+    for i, v in enumerate(vs):
+        if v["tries"] <= 3:
+            assert st[i] == 0 and pts[64 * i:64 * i + 64].hex() == v["uncompressed"] and tries[i] == v["tries"]
+            assert st_sign[i] == 0
+        else:
+            assert st[i] == 1 and pts[64 * i:64 * i + 64] == bytes(64) and tries[i] == 3
+            assert st_sign[i] == 1 and sigs[64 * i:64 * i + 64] == bytes(64)     # ecdsa.rs:28 propagates the error
+
+
+def test_hash_large_batch_statistics(eng, c):
+    """200 000 messages: every round shape (speculative and one-try rounds) is exercised; spot-check
+    against the oracle and check the try-count distribution (mean 2.116 = 1/0.4726)."""
+    n = 200000
+    msgs = [hashlib.sha256(b"big%d" % i).digest() for i in range(n)]
+    pts, st, tries = eng.batch_hash_to_g1(msgs)
+    assert st == bytes(n)
+    assert abs(sum(tries) / n - 2.116) < 0.02
+    for i in list(range(0, n, 997)) + [max(range(n), key=lambda k: tries[k])]:
+        assert (0, pts[64 * i:64 * i + 64], tries[i]) == c.hash_to_g1(msgs[i])
+
+
 def test_pairing_gt_golden(eng, derived):
     vs = derived["pairing_gt"]
     gt, st = eng.batch_pairing(b"".join(H(v["g1"]) for v in vs), b"".join(H(v["g2"]) for v in vs), len(vs))
