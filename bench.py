@@ -31,7 +31,7 @@ CORRUPT_EVERY = 64                 # every 64th signature is wrong -> expected s
 FP_MUL_DECODE = 19
 FP_MUL_HASH_PER_TRY = 370.3        # 371 on the first try (incl. conversions), 370 after; measured mean tries 2.12
 FP_MUL_MILLER = 12182
-FP_MUL_FINAL_EXP = 9235           # incl. 12 canonicalisations for the == 1 test
+FP_MUL_FINAL_EXP = 8587           # NAF exponentiations by u; incl. 12 canonicalisations for the == 1 test
 MAC32_PER_FP_MUL = 136             # ALGORITHMIC unit: an 8x32-bit Montgomery product = 2*8*8 + 8 MAC32.
 MUL_INSTR_PER_FP_MUL = 210         # what the kernels actually issue per product with 10x27-bit limbs: 200 v_mad_*64 + 10 v_mul_lo
 # VALU roofline: v_mad_u64_u32 issues once per 4 cycles per SIMD (half the 2-cycle full rate):
@@ -54,7 +54,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=BATCH, help="tuples per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--fused-miller", action="store_true", help="force the fused 2-pair Miller kernel (A/B comparison)")
+    ap.add_argument("--split-miller", action="store_true", help="one pairing per lane instead of the fused 2-pair Miller loop (A/B)")
     args = ap.parse_args()
 
     import torch
@@ -79,7 +79,7 @@ def main():
     eng = bn254_amd.Engine(local_rank)
     n = args.batch
     eng.reserve(2 * n)
-    if args.fused_miller:
+    if args.split_miller:
         eng.set_option(1, 1)
 
     # ---- synthetic inputs, generated on the GPU by the product's own sign / keygen kernels -------

@@ -30,10 +30,12 @@ using namespace bn254;
 #define BN_SPLIT_MAX_N ((size_t)98304)   // <= 1.5 waves per SIMD with one lane per verify
 // Register budget: amdgpu_waves_per_eu(W, W) on the kernels is propagated to every device function
 // they call (AMDGPU attributor), capping VGPR+AGPR at 512/W so that W waves fit on each SIMD.
-// Two co-resident waves each keep the full single-wave issue rate on gfx950
-// (profiles/r01_issue_mix_microbench.jsonl), so W = 2 doubles a SIMD's throughput.
+// In a pure-VALU microbenchmark two co-resident waves each keep the full single-wave issue rate
+// (profiles/r01_issue_mix_microbench.jsonl), but the Fq12 bodies need ~400 live registers: at W = 2
+// they spill to the private segment and every kernel got slower (profiles/r01_c_ab_occupancy.log).
+// W = 1 (512 registers per lane) is the measured optimum for this code shape.
 #ifndef BN_WAVES_PER_EU
-#define BN_WAVES_PER_EU 2
+#define BN_WAVES_PER_EU 1
 #endif
 #define KERNEL __global__ __launch_bounds__(BN_WAVE) __attribute__((amdgpu_waves_per_eu(BN_WAVES_PER_EU, BN_WAVES_PER_EU)))
 
@@ -327,7 +329,8 @@ KERNEL void k_final_exp(size_t n, size_t k, size_t item_stride, size_t pair_stri
     if (st == ST_OK) st = sj;
   }
   if (st == ST_OK && use_hash) st = ws_byte(ws, BY_ST_HASH, i);
-  if (!raw_only) final_exponentiation(f, f);
+  __shared__ Fp12Slot lds_acc[BN_WAVE];
+  if (!raw_only) final_exponentiation(f, f, lds_acc[threadIdx.x].v);
   if (gt_out) encode_fp12(gt_out + 384 * i, f);
   if (status_out) status_out[i] = st != ST_OK ? st : (fp12_is_one(f) ? (uint8_t)ST_OK : (uint8_t)ST_VERIFICATION_FAILED);
 }
@@ -497,7 +500,7 @@ KERNEL void k_debug_fp12_op(int op, const uint8_t* a, const uint8_t* b, size_t n
     case 5: fp12_frob(r, x, 2); break;
     case 6: fp12_frob(r, x, 3); break;
     case 7: fp12_cyclotomic_sqr(r, x); break;
-    default: final_exponentiation(r, x); break;
+    default: { Fp12 acc; final_exponentiation(r, x, acc); } break;
   }
   encode_fp12(out + 384 * i, r);
 }
@@ -513,7 +516,7 @@ struct bn254_ctx {
   uint8_t* stage[8];
   size_t stage_cap[8];
   int profiling;
-  int force_fused;   // test/bench knob: always use the fused 2-pair Miller kernel
+  int split_miller;  // A/B knob: one pairing per lane (k_miller_verify_split) instead of the fused 2-pair loop
   int hash_max_tries; // test knob: counters tried before HashToPointError (0 = the reference's 255)
   hipEvent_t ev[5];
   int ev_valid;
@@ -650,7 +653,7 @@ int bn254_ctx_set_profiling(bn254_ctx* c, int enabled) {
 }
 int bn254_ctx_set_option(bn254_ctx* c, int option, int value) {
   if (!c) return BN254_E_BAD_ARGUMENT;
-  if (option == BN254_OPT_FORCE_FUSED_MILLER) { c->force_fused = value; return 0; }
+  if (option == BN254_OPT_SPLIT_MILLER) { c->split_miller = value; return 0; }
   if (option == BN254_OPT_HASH_MAX_TRIES) { if (value < 0 || value > 255) return BN254_E_BAD_ARGUMENT; c->hash_max_tries = value; return 0; }
   return BN254_E_BAD_ARGUMENT;
 }
@@ -669,9 +672,10 @@ int bn254_batch_verify_device(bn254_ctx* c, const uint8_t* d_msgs, const uint64_
   if (n == 0) return 0;
   if (misaligned(d_sigs) || misaligned(d_pks) || ((uintptr_t)d_off & 7u)) return BN254_E_MISALIGNED;
   HIP_TRY(hipSetDevice(c->device));
-  // small batches: one pairing per lane (2 waves per SIMD up to 65 536 verifies); large batches already
-  // oversubscribe the SIMDs and keep the fused loop, which shares the f^2 of every step
-  bool split = n <= BN_SPLIT_MAX_N && !c->force_fused;
+  // default: fused 2-pair loop (shares the f^2 of every step).  Option BN254_OPT_SPLIT_MILLER runs one
+  // pairing per lane instead (two waves per verify); measured slower while the Fq12 bodies need the
+  // full 512-register budget (occupancy 1) — kept for A/B runs, see profiles/r01_c_ab_occupancy.log
+  bool split = c->split_miller && n <= BN_SPLIT_MAX_N;
   int rc = ws_reserve(c, split ? 2 * n : n);
   if (rc) return rc;
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;

@@ -107,13 +107,19 @@ BN_DEVN void miller_loop(Fp12& f, const G1Affine& pa, const G2Affine& qa, const 
   if constexpr (HAS_B) { fixed_line(l, idx++); mul_by_line(f, l, pb.x, pb.y, skip_b); }
 }
 
-// a^u for a in the cyclotomic subgroup (u = 4965661367192848881, 63 bits)
-BN_DEVN void fp12_pow_u(Fp12& r, const Fp12& a) {
-  const uint64_t u = ((uint64_t)BN_U_HI << 32) | BN_U_LO;
-  Fp12 acc = a;
-  for (int i = 61; i >= 0; --i) {
+// a^u for a in the cyclotomic subgroup (u = 4965661367192848881, 63 bits): signed-digit (NAF)
+// square-and-multiply, 24 multiplications instead of 28 — a^-1 is the conjugate there.
+// `acc` is caller-provided working storage (the kernels pass an LDS slot: the accumulator is read and
+// rewritten by every one of the 62 cyclotomic squarings).
+BN_DEVN void fp12_pow_u(Fp12& r, const Fp12& a, Fp12& acc) {
+  Fp12 a_inv;
+  fp12_conj(a_inv, a);
+  acc = a;
+  for (int i = 0; i < BN_U_NAF_LEN; ++i) {
     fp12_cyclotomic_sqr(acc, acc);
-    if ((u >> i) & 1) fp12_mul(acc, acc, a);
+    int d = C_U_NAF[i];
+    if (d > 0) fp12_mul(acc, acc, a);
+    else if (d < 0) fp12_mul(acc, acc, a_inv);
   }
   r = acc;
 }
@@ -121,7 +127,7 @@ BN_DEVN void fp12_pow_u(Fp12& r, const Fp12& a) {
 // f^((q^12-1)/r): easy part (q^6-1)(q^2+1), then the exact hard part (q^4-q^2+1)/r =
 // q^3 + (6u^2+1) q^2 + (-36u^3-18u^2-12u+1) q + (-36u^3-30u^2-18u-2) by the vectorial
 // addition chain y0 * y1^2 * y2^6 * y3^12 * y4^18 * y5^30 * y6^36.
-BN_DEVN void final_exponentiation(Fp12& r, const Fp12& fin) {
+BN_DEVN void final_exponentiation(Fp12& r, const Fp12& fin, Fp12& acc) {
   Fp12 f, t, a, b;
   fp12_inv(t, fin);
   fp12_conj(a, fin);
@@ -129,9 +135,9 @@ BN_DEVN void final_exponentiation(Fp12& r, const Fp12& fin) {
   fp12_frob(t, f, 2);
   fp12_mul(f, t, f);
   Fp12 fu, fu2, fu3, y0, y1, y2, y3, y4, y5, y6;
-  fp12_pow_u(fu, f);
-  fp12_pow_u(fu2, fu);
-  fp12_pow_u(fu3, fu2);
+  fp12_pow_u(fu, f, acc);
+  fp12_pow_u(fu2, fu, acc);
+  fp12_pow_u(fu3, fu2, acc);
   fp12_frob(a, f, 1); fp12_frob(b, f, 2); fp12_mul(y0, a, b); fp12_frob(a, f, 3); fp12_mul(y0, y0, a);
   fp12_conj(y1, f);
   fp12_frob(y2, fu2, 2);

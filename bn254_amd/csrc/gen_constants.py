@@ -74,6 +74,25 @@ def naf_digits(s):
     return d[-2::-1]
 
 
+def naf_plain(s):
+    """canonical NAF, most-significant first, without the leading 1"""
+    d = []
+    while s:
+        if s & 1:
+            k = 2 - (s & 3)
+            s -= k
+        else:
+            k = 0
+        d.append(k)
+        s >>= 1
+    assert d[-1] == 1
+    v = 1
+    for x in d[-2::-1]:
+        v = 2 * v + x
+    assert v == U
+    return d[-2::-1]
+
+
 def dbl_step(T):
     """homogeneous projective doubling on the twist + line coefficients (pairing.h: dbl_step).
     line = c0*yP + c1*xP*w + c2*w^3 with c0 = 2YZ, c1 = -3X^2, c2 = Y^2 - 3b'Z^2"""
@@ -193,6 +212,10 @@ def main():
     o.append("BN_CONST int32_t C_G1_GEN[2][10] = {%s, %s};" % (c_fp(1), c_fp(2)))
     o.append("BN_CONST int32_t C_G2_GEN[2][2][10] = {%s, %s};" % (c_fp2(G2X), c_fp2(G2Y)))
     o.append("BN_CONST signed char C_ATE_NAF[64] = {%s};  /* digits of 6u+2 after the leading 1, MSB first */" % ", ".join(str(d) for d in naf))
+    unaf = naf_plain(U)
+    o.append("#define BN_U_NAF_LEN %d" % len(unaf))
+    o.append("BN_CONST signed char C_U_NAF[BN_U_NAF_LEN] = {%s};  /* NAF digits of u after the leading 1, MSB first (weight %d) */" %
+             (", ".join(str(d) for d in unaf), sum(1 for d in unaf if d)))
     o.append("/* line coefficients (c0 -> *yP, c1 -> *xP, c2) for Q = -G2::one(), in order of use */")
     o.append("BN_CONST int32_t C_NEG_G2_LINES[BN_N_FIXED_LINES][3][2][10] = {")
     for ln in lines:

@@ -10,7 +10,7 @@ from . import _native
 G1_BYTES, G2_BYTES, GT_BYTES, SCALAR_BYTES = 64, 128, 384, 32
 FLAG_G2_SUBGROUP_CHECK = 1
 FLAG_REJECT_IDENTITY = 2
-OPT_FORCE_FUSED_MILLER = 1
+OPT_SPLIT_MILLER = 1
 OPT_HASH_MAX_TRIES = 2
 
 

@@ -139,10 +139,10 @@ int bn254_debug_miller_loop(bn254_ctx *ctx, const uint8_t *g1, const uint8_t *g2
  * launch stream around each kernel: ms[0] decode, ms[1] hash-to-G1, ms[2] Miller loop,
  * ms[3] final exponentiation.  Synchronises the stream.  Requires bn254_ctx_set_profiling(ctx, 1). */
 int bn254_ctx_set_profiling(bn254_ctx *ctx, int enabled);
-/* tuning/test knobs.  BN254_OPT_FORCE_FUSED_MILLER: 1 = always run the two Miller loops of a verify in
- * one lane (sharing f^2); 0 (default) = one pairing per lane for batches that would otherwise leave a
- * single wave per SIMD.  Results are identical either way. */
-#define BN254_OPT_FORCE_FUSED_MILLER 1
+/* tuning/test knobs.  BN254_OPT_SPLIT_MILLER: 1 = run the two Miller loops of a verify in two lanes of
+ * different waves (one pairing per lane) instead of one lane sharing f^2 (default 0).  Results are
+ * identical either way. */
+#define BN254_OPT_SPLIT_MILLER 1
 #define BN254_OPT_HASH_MAX_TRIES 2 /* test knob: counters tried before HashToPointError; 0 = 255 as in src/hash.rs:40 */
 int bn254_ctx_set_option(bn254_ctx *ctx, int option, int value);
 int bn254_ctx_last_kernel_ms(bn254_ctx *ctx, float ms[4]);

@@ -69,7 +69,7 @@ void hs_verify_stage_counts(const uint8_t* msg, uint64_t len, const uint8_t* sig
   Fp12 f;
   miller_loop<true, true>(f, h, pk, sig);
   unsigned long long c3 = bn_fp_mul_counter;
-  final_exponentiation(f, f);
+  { Fp12 acc_; final_exponentiation(f, f, acc_); }
   (void)fp12_is_one(f);
   unsigned long long c4 = bn_fp_mul_counter;
   out4[0] = c1 - c0; out4[1] = c2 - c1; out4[2] = c3 - c2; out4[3] = c4 - c3;
@@ -96,7 +96,7 @@ int hs_verify(const uint8_t* msg, uint64_t len, const uint8_t* sig64, const uint
   Fp12 f;
   miller_loop<true, true>(f, h, pk, sig);
   if (st == ST_OK) st = sh;
-  final_exponentiation(f, f);
+  { Fp12 acc_; final_exponentiation(f, f, acc_); }
   return st != ST_OK ? st : (fp12_is_one(f) ? ST_OK : ST_VERIFICATION_FAILED);
 }
 
@@ -114,7 +114,7 @@ int hs_pairing(const uint8_t* g1s, const uint8_t* g2s, uint64_t k, uint32_t flag
     miller_loop<true, false>(g, p, q, p);
     if (j == 0) f = g; else fp12_mul(f, f, g);
   }
-  if (!raw_only) final_exponentiation(f, f);
+  if (!raw_only) { Fp12 acc_; final_exponentiation(f, f, acc_); }
   alignas(4) uint8_t tmp[384];
   encode_fp12(tmp, f);
   if (gt384) memcpy(gt384, tmp, 384);
@@ -130,7 +130,7 @@ int hs_check_public_keys(const uint8_t* pk_g2, const uint8_t* pk_g1, uint32_t fl
   set_g1_gen(g);
   Fp12 f;
   miller_loop<true, true>(f, g, pk2, pk1);
-  final_exponentiation(f, f);
+  { Fp12 acc_; final_exponentiation(f, f, acc_); }
   return st != ST_OK ? st : (fp12_is_one(f) ? ST_OK : ST_VERIFICATION_FAILED);
 }
 

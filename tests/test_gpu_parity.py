@@ -256,17 +256,17 @@ def test_batch_verify_vs_oracle_4k(eng, c):
 
 
 def test_fused_and_split_miller_agree(eng, derived):
-    """the one-pairing-per-lane path (default for small batches) and the fused 2-pair loop give the same statuses"""
-    from bn254_amd.engine import OPT_FORCE_FUSED_MILLER
+    """the fused 2-pair Miller loop (default) and the one-pairing-per-lane path give the same statuses"""
+    from bn254_amd.engine import OPT_SPLIT_MILLER
     cs = derived["verify_cases"]
     args = ([H(v["message_hex"]) for v in cs], b"".join(H(v["sig"]) for v in cs), b"".join(H(v["pk"]) for v in cs))
     want = [v["status"] for v in cs]
     assert list(eng.batch_verify(*args, flags=1)) == want
-    eng.set_option(OPT_FORCE_FUSED_MILLER, 1)
+    eng.set_option(OPT_SPLIT_MILLER, 1)
     try:
         assert list(eng.batch_verify(*args, flags=1)) == want
     finally:
-        eng.set_option(OPT_FORCE_FUSED_MILLER, 0)
+        eng.set_option(OPT_SPLIT_MILLER, 0)
 
 
 def test_pairing_check_k_pairs(eng, c):
