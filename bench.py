@@ -47,6 +47,21 @@ def D(tag, i):
     return hashlib.sha256(tag.encode() + i.to_bytes(8, "little")).digest()
 
 
+def measured_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC summary of this same command
+    (profiles/pmc_latest.json, produced by tests/pmc_profile.sh + tests/pmc_to_json.py): FETCH_SIZE and
+    WRITE_SIZE are KiB counts collected in separate passes; on gfx950 FETCH_SIZE under-counts wide coalesced
+    reads by 2x (MI355X_MICROARCH.md §HBM), so reads are doubled.  None if no profile is committed."""
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    try:
+        with open(path) as f:
+            k = json.load(f)["kernels"][kernel]
+        return {"bytes_per_launch": 2.0 * 1024.0 * k["FETCH_SIZE"] + 1024.0 * k["WRITE_SIZE"], "fetch_kib_raw": k["FETCH_SIZE"],
+                "write_kib_raw": k["WRITE_SIZE"], "batch": k.get("batch"), "source": "profiles/pmc_latest.json"}
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -178,7 +193,7 @@ def main():
             "frac": achieved / (PEAK_MAC32_THEORETICAL / 1e12),
             "peak_measured_microbench": PEAK_MAC32_MEASURED / 1e12,
             "frac_of_measured_peak": achieved / (PEAK_MAC32_MEASURED / 1e12),
-            "traffic": None,
+            "traffic": measured_traffic("k_miller_verify" if dom == "miller_loop" else "k_final_exp"),
             "multiplier_issue_frac": (fp_mul * MUL_INSTR_PER_FP_MUL * n / (k_avg[dom] * 1e-3)) / PEAK_MAC32_THEORETICAL,
             "kernel_ms": k_avg,
             "mac32_per_verify": {"miller_loop": FP_MUL_MILLER * MAC32_PER_FP_MUL, "final_exp": FP_MUL_FINAL_EXP * MAC32_PER_FP_MUL,
