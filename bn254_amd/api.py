@@ -110,6 +110,16 @@ class _G1Point:
         _raise(st[0] if data != bytes(64) else ErrorKind.InvalidGroupPoint)
         return cls(data)
 
+    @classmethod
+    def from_compressed(cls, data):
+        """bn::G1::from_compressed (types.rs:233-237): 0x02/0x03 || x."""
+        data = bytes(data)
+        if len(data) != 33:
+            raise Error(ErrorKind.InvalidEncoding)
+        out, st = _eng().batch_g1_decompress(data, 1)
+        _raise(st[0])
+        return cls(out)
+
     def to_uncompressed(self):
         if self.raw == bytes(64):
             raise Error(ErrorKind.PointInJacobian)          # utils.rs:184
@@ -178,6 +188,16 @@ class PublicKey:
         if st[0] not in (0, ErrorKind.VerificationFailed):
             raise Error(st[0])
         return cls(data)
+
+    @classmethod
+    def from_compressed(cls, data):
+        """bn::G2::from_compressed (types.rs:91-93): 0x0a/0x0b || BE64(x.im*q + x.re); subgroup-checked."""
+        data = bytes(data)
+        if len(data) != 65:
+            raise Error(ErrorKind.InvalidEncoding)
+        out, st = _eng().batch_g2_decompress(data, 1)
+        _raise(st[0])
+        return cls(out)
 
     def to_uncompressed(self):
         if self.raw == bytes(128):

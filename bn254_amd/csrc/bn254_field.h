@@ -450,6 +450,35 @@ BN_DEV Fp2 fp2_inv(const Fp2& a) {
   return r;
 }
 
+// a^e in Fq2 for a fixed public exponent (plain U256 words); wave-uniform control flow
+BN_DEVN Fp2 fp2_pow_const(Fp2 a, const uint32_t* e) {
+  Fp2 acc = fp2_one();
+  a = fp2_norm(a);
+  for (int i = 255; i >= 0; --i) {
+    acc = fp2_norm(fp2_sqr(acc));
+    if ((e[i >> 5] >> (i & 31)) & 1) acc = fp2_norm(fp2_mul(acc, a));
+  }
+  return acc;
+}
+// square root in Fq2 for q = 3 mod 4 (complex method, Adj & Rodriguez-Henriquez alg. 9):
+// a1 = a^((q-3)/4), alpha = a1^2 a, a0 = alpha^(q+1); a0 == -1 -> no root; x0 = a1 a;
+// alpha == -1 -> x = i x0, else x = (1+alpha)^((q-1)/2) x0.  Returns true iff x^2 == a.
+BN_DEVN bool fp2_sqrt(Fp2& x, const Fp2& a_in) {
+  Fp2 a = fp2_norm(a_in);
+  Fp2 a1 = fp2_pow_const(a, C_EXP_QM3D4);
+  Fp2 alpha = fp2_norm(fp2_mul(fp2_norm(fp2_sqr(a1)), a));
+  Fp2 x0 = fp2_norm(fp2_mul(a1, a));
+  Fp2 minus_one = fp2_norm(fp2_neg(fp2_one()));
+  bool alpha_is_m1 = fp2_eq(alpha, minus_one);
+  Fp2 b = fp2_pow_const(fp2_add(fp2_one(), alpha), C_EXP_QM1D2);
+  Fp2 xb = fp2_norm(fp2_mul(b, x0));
+  Fp2 xi_;                       // i * x0 = (-x0.c1, x0.c0)
+  xi_.c0 = fp_norm(fp_neg(x0.c1));
+  xi_.c1 = x0.c0;
+  x = fp2_select(alpha_is_m1, xi_, xb);
+  return fp2_eq(fp2_sqr(x), a);
+}
+
 // ------------------------------------------------------------------------------------------
 // Fq6, Fq12.  Fq12-level operations are real (non-inlined) functions on the per-lane private segment;
 // the Fq6 layer is inlined into them so that all intermediates of one Fq12 operation live in VGPRs and

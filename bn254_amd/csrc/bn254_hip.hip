@@ -448,6 +448,28 @@ KERNEL void k_g2_sum(const uint8_t* pts, const uint64_t* seg, size_t n, uint8_t*
   encode_g2(out + 128 * i, r);
   status[i] = st;
 }
+// compressed -> uncompressed (Signature/PublicKeyG1::from_compressed, PublicKey::from_compressed)
+KERNEL void k_g1_decompress(const uint8_t* in, size_t n, uint8_t* out, uint8_t* status) {
+  size_t i = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
+  if (i >= n) return;
+  G1Affine p;
+  uint8_t st = decompress_g1(p, in + 33 * i);
+  if (st != ST_OK) p.inf = true;
+  encode_g1(out + 64 * i, p);
+  status[i] = st;
+}
+KERNEL void k_g2_decompress(const uint8_t* in, size_t n, uint8_t* out, uint8_t* status) {
+  size_t i = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
+  if (i >= n) return;
+  G2Affine p;
+  uint8_t st = decompress_g2(p, in + 65 * i);
+  if (st != ST_OK) g2_set_generator(p);
+  bool in_sub = g2_in_subgroup(p);                 // wave-uniform ladder; AffineG2::new inside from_compressed
+  if (st == ST_OK && !in_sub) st = ST_NOT_MEMBER;
+  if (st != ST_OK) p.inf = true;
+  encode_g2(out + 128 * i, p);
+  status[i] = st;
+}
 // encode the G1 planes (px, px+1) as uncompressed bytes
 KERNEL void k_encode_g1(size_t n, Ws ws, int px, int inf_plane, uint8_t* out, uint8_t* status_out) {
   size_t i = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
@@ -939,6 +961,26 @@ static int sum_host(bn254_ctx* c, int g2, const uint8_t* pts, const uint64_t* se
 }
 int bn254_batch_g1_sum(bn254_ctx* c, const uint8_t* pts, const uint64_t* seg, size_t n, uint8_t* out, uint8_t* status) { return sum_host(c, 0, pts, seg, n, out, status); }
 int bn254_batch_g2_sum(bn254_ctx* c, const uint8_t* pts, const uint64_t* seg, size_t n, uint8_t* out, uint8_t* status) { return sum_host(c, 1, pts, seg, n, out, status); }
+
+static int decompress_host(bn254_ctx* c, int g2, const uint8_t* in, size_t n, uint8_t* out, uint8_t* status) {
+  if (!c || (n && (!in || !out || !status))) return BN254_E_BAD_ARGUMENT;
+  if (n == 0) return 0;
+  HIP_TRY(hipSetDevice(c->device));
+  size_t isz = g2 ? 65 : 33, osz = g2 ? 128 : 64;
+  int rc;
+  if ((rc = stage_in(c, 0, in, n * isz))) return rc;
+  if ((rc = stage_reserve(c, 2, n * osz))) return rc;
+  if ((rc = stage_reserve(c, 3, n))) return rc;
+  if (g2) k_g2_decompress<<<grid_for(n), BN_WAVE, 0, c->stream>>>(c->stage[0], n, c->stage[2], c->stage[3]);
+  else k_g1_decompress<<<grid_for(n), BN_WAVE, 0, c->stream>>>(c->stage[0], n, c->stage[2], c->stage[3]);
+  HIP_TRY(hipGetLastError());
+  if ((rc = stage_out(c, 2, out, n * osz))) return rc;
+  if ((rc = stage_out(c, 3, status, n))) return rc;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+int bn254_batch_g1_decompress(bn254_ctx* c, const uint8_t* in, size_t n, uint8_t* out, uint8_t* status) { return decompress_host(c, 0, in, n, out, status); }
+int bn254_batch_g2_decompress(bn254_ctx* c, const uint8_t* in, size_t n, uint8_t* out, uint8_t* status) { return decompress_host(c, 1, in, n, out, status); }
 
 // ---- test hooks --------------------------------------------------------------------------
 int bn254_debug_fp_op(bn254_ctx* c, int op, const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out, uint8_t* status) {

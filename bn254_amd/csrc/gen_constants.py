@@ -198,6 +198,8 @@ def main():
     o.append("BN_CONST uint32_t C_ORDER_R[8] = %s;      /* group order r, plain U256 */" % c_u256(R_ORDER))
     o.append("BN_CONST uint32_t C_EXP_QM2[8] = %s;      /* q-2, plain U256 */" % c_u256(Q - 2))
     o.append("BN_CONST uint32_t C_EXP_QP1D4[8] = %s;    /* (q+1)/4, plain U256 */" % c_u256((Q + 1) // 4))
+    o.append("BN_CONST uint32_t C_EXP_QM3D4[8] = %s;    /* (q-3)/4, plain U256 */" % c_u256((Q - 3) // 4))
+    o.append("BN_CONST uint32_t C_EXP_QM1D2[8] = %s;    /* (q-1)/2, plain U256 */" % c_u256((Q - 1) // 2))
     o.append("BN_CONST int32_t C_QL[10] = %s;           /* q as 27-bit limbs (plain) */" % c_fp(Q, False))
     o.append("BN_CONST int32_t C_R2[10] = %s;           /* R^2 mod q, plain limbs: to_mont(x) = mul(x, R2) */" % c_fp(MONT_R * MONT_R % Q, False))
     o.append("BN_CONST int32_t C_ONE[10] = %s;          /* 1 (Montgomery) */" % c_fp(1))

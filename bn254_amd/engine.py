@@ -164,6 +164,18 @@ class Engine:
     def batch_g2_sum(self, points, seg_off):
         return self._sum("bn254_batch_g2_sum", points, seg_off, G2_BYTES)
 
+    def batch_g1_decompress(self, data, n):
+        out = ctypes.create_string_buffer(max(n, 1) * G1_BYTES)
+        status = ctypes.create_string_buffer(max(n, 1))
+        _check("bn254_batch_g1_decompress", self._lib.bn254_batch_g1_decompress(self._h, bytes(data), n, out, status))
+        return out.raw[:n * G1_BYTES], status.raw[:n]
+
+    def batch_g2_decompress(self, data, n):
+        out = ctypes.create_string_buffer(max(n, 1) * G2_BYTES)
+        status = ctypes.create_string_buffer(max(n, 1))
+        _check("bn254_batch_g2_decompress", self._lib.bn254_batch_g2_decompress(self._h, bytes(data), n, out, status))
+        return out.raw[:n * G2_BYTES], status.raw[:n]
+
     # ---- test hooks -----------------------------------------------------------------------
     def debug_fp_op(self, op, a, b, n):
         out = ctypes.create_string_buffer(max(n, 1) * 32)

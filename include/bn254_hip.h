@@ -125,6 +125,13 @@ int bn254_batch_sign_device(bn254_ctx *ctx, const uint8_t *d_msgs, const uint64_
 int bn254_batch_g1_sum(bn254_ctx *ctx, const uint8_t *points, const uint64_t *seg_off /* n+1 */, size_t n, uint8_t *out /* n*64 */, uint8_t *status);
 int bn254_batch_g2_sum(bn254_ctx *ctx, const uint8_t *points, const uint64_t *seg_off /* n+1 */, size_t n, uint8_t *out /* n*128 */, uint8_t *status);
 
+/* compressed wire formats (src/utils.rs:84-104, :130-158): out = uncompressed point, status as
+ * bn::G1::from_compressed / bn::G2::from_compressed report through src/types.rs:91-93, :233-237:
+ * bad prefix byte (G1: 0x02/0x03, G2: 0x0a/0x0b) or x.im >= q -> 3 InvalidEncoding; x >= q, no square
+ * root, or (G2) not in the order-r subgroup -> 6 NotMemberError. */
+int bn254_batch_g1_decompress(bn254_ctx *ctx, const uint8_t *in /* n*33 */, size_t n, uint8_t *out /* n*64 */, uint8_t *status);
+int bn254_batch_g2_decompress(bn254_ctx *ctx, const uint8_t *in /* n*65 */, size_t n, uint8_t *out /* n*128 */, uint8_t *status);
+
 /* test hooks: element-wise field/tower operations on byte-encoded operands, used by the parity
  * tests to compare each layer of the HIP arithmetic with the oracle.
  *   op: 0 mul, 1 add, 2 sub, 3 inverse(a), 4 square(a), 5 sqrt(a) (status 6 if none)   [Fq, 32 B]

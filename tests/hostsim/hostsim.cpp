@@ -214,6 +214,27 @@ int hs_sign(const uint8_t* msg, uint64_t len, const uint8_t* sk32, uint8_t* sig6
   memcpy(sig64, tmp, 64);
   return st;
 }
+int hs_g1_decompress(const uint8_t* in33, uint8_t* out64) {
+  G1Affine p;
+  uint8_t st = decompress_g1(p, in33);
+  if (st != ST_OK) p.inf = true;
+  alignas(4) uint8_t tmp[64];
+  encode_g1(tmp, p);
+  memcpy(out64, tmp, 64);
+  return st;
+}
+int hs_g2_decompress(const uint8_t* in65, uint8_t* out128) {
+  G2Affine p;
+  uint8_t st = decompress_g2(p, in65);
+  if (st != ST_OK) set_g2_gen(p);
+  bool in_sub = g2_in_subgroup(p);
+  if (st == ST_OK && !in_sub) st = ST_NOT_MEMBER;
+  if (st != ST_OK) p.inf = true;
+  alignas(4) uint8_t tmp[128];
+  encode_g2(tmp, p);
+  memcpy(out128, tmp, 128);
+  return st;
+}
 // op codes as bn254_debug_fp_op
 int hs_fp_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
   alignas(4) uint8_t ta[32], tb[32], to[32];

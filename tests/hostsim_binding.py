@@ -23,6 +23,8 @@ def lib():
             getattr(L, f).argtypes = [cp, cp, ctypes.c_int, cp]
         L.hs_sign.argtypes = [cp, ctypes.c_uint64, cp, cp]
         L.hs_fp_op.argtypes = [ctypes.c_int, cp, cp, cp]
+        L.hs_g1_decompress.argtypes = [cp, cp]
+        L.hs_g2_decompress.argtypes = [cp, cp]
         _lib = L
     return _lib
 
@@ -73,3 +75,11 @@ def sign(msg, sk):
 
 def fp_op(op, a, b=None):
     o = _b(32); st = lib().hs_fp_op(op, bytes(a), None if b is None else bytes(b), o); return st, o.raw
+
+
+def g1_decompress(c33):
+    o = _b(64); st = lib().hs_g1_decompress(bytes(c33), o); return st, o.raw
+
+
+def g2_decompress(c65):
+    o = _b(128); st = lib().hs_g2_decompress(bytes(c65), o); return st, o.raw

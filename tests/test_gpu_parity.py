@@ -231,6 +231,37 @@ def test_reference_kats_through_api(eng, c, kats):
     assert bn.ECDSA.batch_verify([m, m], [agg_sig, agg_sig], [agg_pk, pks[0]]) == [None, bn.Error(9)]
 
 
+def test_compressed_codecs(eng, kats, derived):
+    """from_compressed on the device (src/types.rs:91-93, :233-237) vs the big-integer model, incl. error codes,
+    and compressed round trips through the host API (src/types_test.rs:48-54, :131-159)."""
+    import bn254_amd as bn
+    from oracle import bn254_model as m
+    from tests.test_hostsim import _codec_cases
+    g1, g2, bad_g1, bad_g2 = _codec_cases(kats, derived)
+    datas = [d for hx in g1 for d in (H(hx), bytes([5 - H(hx)[0]]) + H(hx)[1:])] + [d for d, _ in bad_g1]
+    out, st = eng.batch_g1_decompress(b"".join(datas), len(datas))
+    for i, d in enumerate(datas):
+        if i < 2 * len(g1):
+            assert st[i] == 0 and out[64 * i:64 * i + 64] == m.g1_to_uncompressed(m.g1_from_compressed(d))
+        else:
+            assert st[i] == bad_g1[i - 2 * len(g1)][1] and out[64 * i:64 * i + 64] == bytes(64)
+    datas = [d for hx in g2 for d in (H(hx), bytes([0x15 - H(hx)[0]]) + H(hx)[1:])] + [d for d, _ in bad_g2]
+    out, st = eng.batch_g2_decompress(b"".join(datas), len(datas))
+    for i, d in enumerate(datas):
+        if i < 2 * len(g2):
+            assert st[i] == 0 and out[128 * i:128 * i + 128] == m.g2_to_uncompressed(m.g2_from_compressed(d))
+        else:
+            assert st[i] == bad_g2[i - 2 * len(g2)][1]
+    c2 = H(kats["g2_compressed_roundtrip"]["hex"])
+    assert bn.PublicKey.from_compressed(c2).to_compressed() == c2
+    sig = bn.Signature.from_compressed(H(kats["sign"][0]["signature_compressed"]))          # src/ecdsa_test.rs:26-28
+    sk = bn.PrivateKey.try_from(kats["sign"][0]["private_key"])
+    bn.ECDSA.verify(H(kats["sign"][0]["message_hex"]), sig, bn.PublicKey.from_private_key(sk))
+    with pytest.raises(bn.Error) as e:
+        bn.PublicKey.from_compressed(b"\x0c" + c2[1:])
+    assert e.value.kind == bn.ErrorKind.InvalidEncoding
+
+
 def test_bn256_vectors(eng, kats):
     adds = kats["g1_add"]
     out, st = eng.batch_g1_add(b"".join(H(v["x1"] + v["y1"]) for v in adds), b"".join(H(v["x2"] + v["y2"]) for v in adds), len(adds))

@@ -77,3 +77,36 @@ def test_reference_kats(kats):
     sigs = [hs.sign(ex["message"].encode(), H(k))[1] for k in ex["private_keys"]]
     pks = [hs.g2_mul(None, H(k), reduce=True)[1] for k in ex["private_keys"]]
     assert hs.verify(ex["message"].encode(), hs.g1_add(*sigs)[1], hs.g2_add(*pks)[1]) == 0
+
+
+def _codec_cases(kats, derived):
+    from oracle import bn254_model as m
+    g1 = [kats["sign"][0]["signature_compressed"], kats["g1_double_generator_compressed"]["hex"], kats["hash_to_g1"][0]["compressed"],
+          kats["hash_to_g1"][1]["compressed"], derived["example"]["agg_sig_compressed"]]
+    g2 = [kats["g2_compressed_roundtrip"]["hex"], kats["g2_double_generator_compressed"]["hex"], derived["g2_generator_compressed"],
+          derived["example"]["agg_pk_compressed"]]
+    x = 1
+    while m.fq_sqrt((x ** 3 + 3) % m.Q) is not None:
+        x += 1
+    off = H(derived["g2_not_in_subgroup"])
+    w = [int.from_bytes(off[i:i + 32], "big") for i in range(0, 128, 32)]
+    bad_g1 = [(b"\x04" + bytes(32), 3), (b"\x02" + m.Q.to_bytes(32, "big"), 6), (b"\x02" + x.to_bytes(32, "big"), 6)]
+    bad_g2 = [(b"\x0c" + H(derived["g2_generator_compressed"])[1:], 3), (m.g2_to_compressed(((w[0], w[1]), (w[2], w[3]))), 6),
+              (b"\x0a" + (m.Q * m.Q + 5).to_bytes(64, "big"), 3)]
+    return g1, g2, bad_g1, bad_g2
+
+
+def test_compressed_codecs(kats, derived):
+    """bn::G1/G2::from_compressed semantics (types.rs:91-93, :233-237) vs the big-integer model"""
+    from oracle import bn254_model as m
+    g1, g2, bad_g1, bad_g2 = _codec_cases(kats, derived)
+    for hx in g1:
+        for data in (H(hx), bytes([5 - H(hx)[0]]) + H(hx)[1:]):          # both signs
+            assert hs.g1_decompress(data) == (0, m.g1_to_uncompressed(m.g1_from_compressed(data)))
+    for hx in g2:
+        for data in (H(hx), bytes([0x15 - H(hx)[0]]) + H(hx)[1:]):
+            assert hs.g2_decompress(data) == (0, m.g2_to_uncompressed(m.g2_from_compressed(data)))
+    for data, st in bad_g1:
+        assert hs.g1_decompress(data)[0] == st
+    for data, st in bad_g2:
+        assert hs.g2_decompress(data)[0] == st
