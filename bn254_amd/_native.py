@@ -78,6 +78,8 @@ def load():
     L.bn254_batch_sign_device.argtypes = [vp, vp, vp, vp, sz, vp, vp, vp]
     L.bn254_batch_g1_sum.argtypes = [vp, vp, vp, sz, vp, vp]
     L.bn254_batch_g2_sum.argtypes = [vp, vp, vp, sz, vp, vp]
+    L.bn254_batch_aggregate_verify.argtypes = [vp, vp, vp, sz, vp, sz, vp, vp, vp, vp, sz, u32, vp]
+    L.bn254_batch_aggregate_verify_device.argtypes = [vp, vp, vp, sz, vp, sz, vp, vp, vp, vp, sz, u32, vp, vp]
     L.bn254_batch_g1_decompress.argtypes = [vp, vp, sz, vp, vp]
     L.bn254_batch_g2_decompress.argtypes = [vp, vp, sz, vp, vp]
     L.bn254_debug_fp_op.argtypes = [vp, i32, vp, vp, sz, vp, vp]
@@ -94,5 +96,5 @@ EXPORTED_SYMBOLS = [
     "bn254_batch_pairing_check", "bn254_batch_pairing", "bn254_batch_pairing_device", "bn254_batch_check_public_keys",
     "bn254_batch_g1_add", "bn254_batch_g2_add", "bn254_batch_g1_mul", "bn254_batch_g2_mul", "bn254_batch_g1_mul_device",
     "bn254_batch_g2_mul_device", "bn254_batch_sign", "bn254_batch_sign_device", "bn254_batch_g1_sum", "bn254_batch_g2_sum",
-    "bn254_batch_g1_decompress", "bn254_batch_g2_decompress", "bn254_debug_fp_op", "bn254_debug_fp12_op", "bn254_debug_miller_loop", "bn254_ctx_set_profiling", "bn254_ctx_last_kernel_ms", "bn254_ctx_set_option",
+    "bn254_batch_aggregate_verify", "bn254_batch_aggregate_verify_device", "bn254_batch_g1_decompress", "bn254_batch_g2_decompress", "bn254_debug_fp_op", "bn254_debug_fp12_op", "bn254_debug_miller_loop", "bn254_ctx_set_profiling", "bn254_ctx_last_kernel_ms", "bn254_ctx_set_option",
 ]

@@ -94,6 +94,33 @@ template <class F> BN_DEVN void jac_add(Jac<F>& r, const Jac<F>& p, const Jac<F>
   r = o;
 }
 
+// mixed addition P + (x2, y2) with an affine second operand (madd-2007-bl, 7M + 4S): the inner
+// operation of signature / public-key aggregation (/root/reference/src/types.rs:126-132, :264-270).
+// Exceptional cases by selects, as in jac_add: P = O -> Q, P = Q -> 2Q, P = -Q -> O; q_inf skips.
+template <class F> BN_DEVN void jac_madd(Jac<F>& r, const Jac<F>& p, const Affine<F>& q) {
+  F z1z1 = f_norm(f_sqr(p.z));
+  F u2 = f_norm(f_mul(q.x, z1z1));
+  F s2 = f_norm(f_mul(f_norm(f_mul(q.y, p.z)), z1z1));
+  F h = f_norm(f_sub(u2, p.x)), hh = f_norm(f_sqr(h));
+  F i = f_norm(f_dbl(f_dbl(hh))), j = f_norm(f_mul(h, i));
+  F rr = f_norm(f_dbl(f_sub(s2, p.y))), v = f_norm(f_mul(p.x, i));
+  Jac<F> o;
+  o.x = f_norm(f_sub(f_sub(f_sqr(rr), j), f_dbl(v)));
+  o.y = f_norm(f_sub(f_mul(rr, f_norm(f_sub(v, o.x))), f_dbl(f_mul(p.y, j))));
+  o.z = f_norm(f_sub(f_sub(f_sqr(f_add(p.z, h)), z1z1), hh));
+  bool p_inf = f_is_zero(p.z);
+  bool same_x = f_is_zero(h), same_y = f_is_zero(rr);
+  Jac<F> qj, d, id;
+  qj.x = q.x; qj.y = q.y; f_set_one(qj.z);
+  jac_dbl(d, qj);
+  jac_set_identity(id);
+  jac_select(o, same_x && same_y, d, o);
+  jac_select(o, same_x && !same_y, id, o);
+  jac_select(o, p_inf, qj, o);
+  jac_select(o, q.inf, p, o);
+  r = o;
+}
+
 // k * P for a per-lane 256-bit scalar (plain little-endian limbs, used as-is, not reduced —
 // /root/reference/src/bn256.json:54-159 has scalars up to 2^256-1).  Fixed 256-step ladder of
 // double + add-with-select: identical control flow in every lane.

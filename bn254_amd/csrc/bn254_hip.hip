@@ -470,6 +470,102 @@ KERNEL void k_g2_decompress(const uint8_t* in, size_t n, uint8_t* out, uint8_t* 
   encode_g2(out + 128 * i, p);
   status[i] = st;
 }
+// ---- aggregate verify (config 3): shared pools, per-tuple signer subsets -------------------------
+// Pools are decoded once into limb-major planes of their own: word k of coordinate e of entry j at
+// pool[(e*BN_LIMBS + k) * stride + j]; status byte per entry.
+struct Pool { int32_t* planes; uint8_t* st; size_t stride; };
+__device__ __forceinline__ Fp pool_load_fp(const Pool& p, int e, size_t j) {
+  Fp r;
+#pragma unroll
+  for (int k = 0; k < BN_LIMBS; ++k) r.v[k] = p.planes[((size_t)e * BN_LIMBS + k) * p.stride + j];
+  return r;
+}
+__device__ __forceinline__ void pool_store_fp(const Pool& p, int e, size_t j, const Fp& a) {
+#pragma unroll
+  for (int k = 0; k < BN_LIMBS; ++k) p.planes[((size_t)e * BN_LIMBS + k) * p.stride + j] = a.v[k];
+}
+KERNEL void k_pool_decode_g1(const uint8_t* pts, size_t n, uint32_t flags, Pool pool) {
+  size_t i = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
+  if (i >= n) return;
+  G1Affine p;
+  uint8_t st = decode_g1(p, pts + 64 * i, flags);
+  if (st != ST_OK) g1_set_generator(p);
+  pool_store_fp(pool, 0, i, p.x); pool_store_fp(pool, 1, i, p.y);
+  pool.st[i] = st | (p.inf ? 0x80 : 0);
+}
+KERNEL void k_pool_decode_g2(const uint8_t* pts, size_t n, uint32_t flags, Pool pool) {
+  size_t i = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
+  if (i >= n) return;
+  G2Affine q;
+  uint8_t st = decode_g2(q, pts + 128 * i, flags);
+  if (st != ST_OK) g2_set_generator(q);
+  if (flags & FLAG_G2_SUBGROUP_CHECK) {
+    bool in = g2_in_subgroup(q);
+    if (st == ST_OK && !in) { st = ST_INVALID_GROUP_POINT; g2_set_generator(q); }
+  }
+  pool_store_fp(pool, 0, i, q.x.c0); pool_store_fp(pool, 1, i, q.x.c1);
+  pool_store_fp(pool, 2, i, q.y.c0); pool_store_fp(pool, 3, i, q.y.c1);
+  pool.st[i] = st | (q.inf ? 0x80 : 0);
+}
+// tuple i: agg_sig = sum_s sig_pool[msg_i * S + s], agg_pk = sum_s pk_pool[s] over its signer list
+// (Add for Signature / PublicKey, types.rs:264-270, :126-132); results + H(msg_i) go to the verify planes.
+// A wave walks its lanes' lists in lockstep until the longest is exhausted.
+KERNEL void k_aggregate(const uint32_t* tuple_msg, const uint64_t* tuple_off, const uint32_t* signer_idx, size_t n, size_t n_signers,
+                        Pool pk_pool, Pool sig_pool, Pool h_pool, Ws ws) {
+  size_t i = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
+  if (i >= n) return;
+  uint32_t m = tuple_msg[i];
+  uint64_t lo = tuple_off[i], hi = tuple_off[i + 1];
+  G1Jac acc1;
+  G2Jac acc2;
+  jac_set_identity(acc1);
+  jac_set_identity(acc2);
+  uint8_t st = ST_OK;
+  uint64_t longest = hi - lo;
+  for (int off = 32; off > 0; off >>= 1) {
+    uint64_t other = __shfl_xor((unsigned long long)longest, off, BN_WAVE);
+    longest = other > longest ? other : longest;
+  }
+  for (uint64_t t = 0; t < longest; ++t) {
+    bool active = lo + t < hi;
+    uint32_t sgn = active ? signer_idx[lo + t] : 0u;
+    bool valid = active && sgn < n_signers;
+    if (active && !valid && st == ST_OK) st = ST_INDEX_OOB;             // IndexOutOfBounds
+    if (!valid) sgn = 0;
+    G1Affine sp;
+    G2Affine pp;
+    size_t sj = (size_t)m * n_signers + sgn;
+    sp.x = pool_load_fp(sig_pool, 0, sj); sp.y = pool_load_fp(sig_pool, 1, sj);
+    uint8_t s1 = sig_pool.st[sj];
+    pp.x.c0 = pool_load_fp(pk_pool, 0, sgn); pp.x.c1 = pool_load_fp(pk_pool, 1, sgn);
+    pp.y.c0 = pool_load_fp(pk_pool, 2, sgn); pp.y.c1 = pool_load_fp(pk_pool, 3, sgn);
+    uint8_t s2 = pk_pool.st[sgn];
+    if (valid && st == ST_OK && (s1 & 0x7f)) st = s1 & 0x7f;
+    if (valid && st == ST_OK && (s2 & 0x7f)) st = s2 & 0x7f;
+    sp.inf = !valid || (s1 & 0x80);
+    pp.inf = !valid || (s2 & 0x80);
+    jac_madd(acc1, acc1, sp);
+    jac_madd(acc2, acc2, pp);
+  }
+  G1Affine asig, h;
+  G2Affine apk;
+  jac_to_affine(asig, acc1);
+  jac_to_affine(apk, acc2);
+  h.x = pool_load_fp(h_pool, 0, m); h.y = pool_load_fp(h_pool, 1, m); h.inf = false;
+  ws_store_g1(ws, PL_P1X, BY_P1_INF, i, asig);
+  ws_store_g2(ws, i, apk);
+  ws_store_g1(ws, PL_P2X, BY_P2_INF, i, h);
+  ws_byte(ws, BY_ST_DECODE, i) = st;
+  ws_byte(ws, BY_ST_HASH, i) = h_pool.st[m];
+}
+// copy the hash planes of the M messages into a pool
+KERNEL void k_hash_to_pool(size_t n_msgs, Ws ws, Pool h_pool) {
+  size_t i = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
+  if (i >= n_msgs) return;
+  pool_store_fp(h_pool, 0, i, ws_load_fp(ws, PL_P2X, i));
+  pool_store_fp(h_pool, 1, i, ws_load_fp(ws, PL_P2X + 1, i));
+  h_pool.st[i] = ws_byte(ws, BY_ST_HASH, i);
+}
 // encode the G1 planes (px, px+1) as uncompressed bytes
 KERNEL void k_encode_g1(size_t n, Ws ws, int px, int inf_plane, uint8_t* out, uint8_t* status_out) {
   size_t i = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
@@ -539,6 +635,8 @@ struct bn254_ctx {
   size_t stage_cap[8];
   int profiling;
   int split_miller;  // A/B knob: one pairing per lane (k_miller_verify_split) instead of the fused 2-pair loop
+  Pool pool[3];       // aggregate verify: pk pool, sig pool, H(m) pool (grown on demand)
+  size_t pool_fp[3];  // coordinates per entry: 4, 2, 2
   int hash_max_tries; // test knob: counters tried before HashToPointError (0 = the reference's 255)
   hipEvent_t ev[5];
   int ev_valid;
@@ -594,6 +692,21 @@ static int stage_out(bn254_ctx* c, int slot, void* host, size_t bytes) {
   return 0;
 }
 static bool misaligned(const void* p) { return ((uintptr_t)p & 3u) != 0; }
+static int pool_reserve(bn254_ctx* c, int which, size_t n_fp, size_t entries) {
+  Pool& p = c->pool[which];
+  if (entries <= p.stride && c->pool_fp[which] == n_fp) return 0;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (p.planes) { HIP_TRY(hipFree(p.planes)); p.planes = nullptr; }
+  if (p.st) { HIP_TRY(hipFree(p.st)); p.st = nullptr; }
+  p.stride = 0;
+  size_t cap = (entries + 255) & ~(size_t)255;
+  HIP_TRY(hipMalloc((void**)&p.planes, n_fp * BN_LIMBS * sizeof(int32_t) * cap));
+  HIP_TRY(hipMalloc((void**)&p.st, cap));
+  p.stride = cap;
+  c->pool_fp[which] = n_fp;
+  return 0;
+}
 
 // Enqueue the hash-to-G1 rounds for n messages; points land in planes (px, px+1), statuses in BY_ST_HASH.
 // The schedule (widths, grid sizes) is fixed on the host from the EXPECTED survivor counts
@@ -656,6 +769,7 @@ void bn254_ctx_destroy(bn254_ctx* c) {
   if (c->ws.h_list) (void)hipFree(c->ws.h_list);
   if (c->ws.h_cnt) (void)hipFree(c->ws.h_cnt);
   if (c->ws.h_cand) (void)hipFree(c->ws.h_cand);
+  for (int i = 0; i < 3; ++i) { if (c->pool[i].planes) (void)hipFree(c->pool[i].planes); if (c->pool[i].st) (void)hipFree(c->pool[i].st); }
   for (int i = 0; i < 8; ++i) if (c->stage[i]) (void)hipFree(c->stage[i]);
   for (int i = 0; i < 5; ++i) (void)hipEventDestroy(c->ev[i]);
   (void)hipStreamDestroy(c->stream);
@@ -961,6 +1075,56 @@ static int sum_host(bn254_ctx* c, int g2, const uint8_t* pts, const uint64_t* se
 }
 int bn254_batch_g1_sum(bn254_ctx* c, const uint8_t* pts, const uint64_t* seg, size_t n, uint8_t* out, uint8_t* status) { return sum_host(c, 0, pts, seg, n, out, status); }
 int bn254_batch_g2_sum(bn254_ctx* c, const uint8_t* pts, const uint64_t* seg, size_t n, uint8_t* out, uint8_t* status) { return sum_host(c, 1, pts, seg, n, out, status); }
+
+int bn254_batch_aggregate_verify_device(bn254_ctx* c, const uint8_t* d_msgs, const uint64_t* d_msg_off, size_t n_msgs, const uint8_t* d_pk_pool,
+                                        size_t n_signers, const uint8_t* d_sig_pool, const uint32_t* d_tuple_msg, const uint64_t* d_tuple_off,
+                                        const uint32_t* d_signer_idx, size_t n, uint32_t flags, uint8_t* d_status, void* stream) {
+  if (!c || !n_msgs || !n_signers || (n && (!d_msgs || !d_msg_off || !d_pk_pool || !d_sig_pool || !d_tuple_msg || !d_tuple_off || !d_signer_idx || !d_status)))
+    return BN254_E_BAD_ARGUMENT;
+  if (n == 0) return 0;
+  if (misaligned(d_pk_pool) || misaligned(d_sig_pool) || misaligned(d_tuple_msg) || misaligned(d_signer_idx) || ((uintptr_t)d_msg_off & 7u) ||
+      ((uintptr_t)d_tuple_off & 7u))
+    return BN254_E_MISALIGNED;
+  HIP_TRY(hipSetDevice(c->device));
+  int rc;
+  if ((rc = ws_reserve(c, n > n_msgs ? n : n_msgs))) return rc;
+  if ((rc = pool_reserve(c, 0, 4, n_signers))) return rc;
+  if ((rc = pool_reserve(c, 1, 2, n_msgs * n_signers))) return rc;
+  if ((rc = pool_reserve(c, 2, 2, n_msgs))) return rc;
+  hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  k_pool_decode_g2<<<grid_for(n_signers), BN_WAVE, 0, s>>>(d_pk_pool, n_signers, flags, c->pool[0]);
+  k_pool_decode_g1<<<grid_for(n_msgs * n_signers), BN_WAVE, 0, s>>>(d_sig_pool, n_msgs * n_signers, flags, c->pool[1]);
+  if ((rc = launch_hash_rounds(c, s, d_msgs, d_msg_off, n_msgs, PL_P2X, BY_P2_INF, nullptr))) return rc;
+  k_hash_to_pool<<<grid_for(n_msgs), BN_WAVE, 0, s>>>(n_msgs, c->ws, c->pool[2]);
+  k_aggregate<<<grid_for(n), BN_WAVE, 0, s>>>(d_tuple_msg, d_tuple_off, d_signer_idx, n, n_signers, c->pool[0], c->pool[1], c->pool[2], c->ws);
+  k_miller_verify<<<grid_for(n), BN_WAVE, 0, s>>>(n, c->ws);
+  k_final_exp<<<grid_for(n), BN_WAVE, 0, s>>>(n, 1, 1, 1, c->ws, 1, nullptr, d_status, 0);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+int bn254_batch_aggregate_verify(bn254_ctx* c, const uint8_t* msgs, const uint64_t* msg_off, size_t n_msgs, const uint8_t* pk_pool, size_t n_signers,
+                                 const uint8_t* sig_pool, const uint32_t* tuple_msg, const uint64_t* tuple_off, const uint32_t* signer_idx, size_t n,
+                                 uint32_t flags, uint8_t* status) {
+  if (!c || !n_msgs || !n_signers || (n && (!msg_off || !pk_pool || !sig_pool || !tuple_msg || !tuple_off || !signer_idx || !status))) return BN254_E_BAD_ARGUMENT;
+  if (n == 0) return 0;
+  for (size_t i = 0; i < n; ++i) if (tuple_msg[i] >= n_msgs) return BN254_E_BAD_ARGUMENT;
+  HIP_TRY(hipSetDevice(c->device));
+  int rc;
+  if ((rc = stage_in(c, 0, msgs, (size_t)msg_off[n_msgs]))) return rc;
+  if ((rc = stage_in(c, 1, msg_off, (n_msgs + 1) * sizeof(uint64_t)))) return rc;
+  if ((rc = stage_in(c, 2, pk_pool, n_signers * 128))) return rc;
+  if ((rc = stage_in(c, 3, sig_pool, n_msgs * n_signers * 64))) return rc;
+  if ((rc = stage_in(c, 4, tuple_msg, n * sizeof(uint32_t)))) return rc;
+  if ((rc = stage_in(c, 5, tuple_off, (n + 1) * sizeof(uint64_t)))) return rc;
+  if ((rc = stage_in(c, 6, signer_idx, (size_t)tuple_off[n] * sizeof(uint32_t)))) return rc;
+  if ((rc = stage_reserve(c, 7, n))) return rc;
+  if ((rc = bn254_batch_aggregate_verify_device(c, c->stage[0], (const uint64_t*)c->stage[1], n_msgs, c->stage[2], n_signers, c->stage[3],
+                                                (const uint32_t*)c->stage[4], (const uint64_t*)c->stage[5], (const uint32_t*)c->stage[6], n, flags,
+                                                c->stage[7], nullptr))) return rc;
+  if ((rc = stage_out(c, 7, status, n))) return rc;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
 
 static int decompress_host(bn254_ctx* c, int g2, const uint8_t* in, size_t n, uint8_t* out, uint8_t* status) {
   if (!c || (n && (!in || !out || !status))) return BN254_E_BAD_ARGUMENT;

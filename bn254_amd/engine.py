@@ -164,6 +164,26 @@ class Engine:
     def batch_g2_sum(self, points, seg_off):
         return self._sum("bn254_batch_g2_sum", points, seg_off, G2_BYTES)
 
+    def batch_aggregate_verify(self, messages, pk_pool, sig_pool, tuple_msg, signer_lists, flags=0):
+        """messages: M byte strings; pk_pool: S*128 B; sig_pool: M*S*64 B (signer s on message m at m*S+s);
+        tuple i verifies messages[tuple_msg[i]] against the aggregate of signer_lists[i]."""
+        n, n_msgs = len(tuple_msg), len(messages)
+        n_signers = len(pk_pool) // G2_BYTES
+        assert len(sig_pool) == n_msgs * n_signers * G1_BYTES and len(signer_lists) == n
+        msgs, off = pack_messages(messages)
+        t_off = (ctypes.c_uint64 * (n + 1))()
+        flat = []
+        for i, lst in enumerate(signer_lists):
+            t_off[i] = len(flat)
+            flat.extend(lst)
+        t_off[n] = len(flat)
+        idx = (ctypes.c_uint32 * max(len(flat), 1))(*flat)
+        tm = (ctypes.c_uint32 * max(n, 1))(*tuple_msg)
+        status = ctypes.create_string_buffer(max(n, 1))
+        _check("bn254_batch_aggregate_verify",
+               self._lib.bn254_batch_aggregate_verify(self._h, msgs, off, n_msgs, bytes(pk_pool), n_signers, bytes(sig_pool), tm, t_off, idx, n, flags, status))
+        return status.raw[:n]
+
     def batch_g1_decompress(self, data, n):
         out = ctypes.create_string_buffer(max(n, 1) * G1_BYTES)
         status = ctypes.create_string_buffer(max(n, 1))

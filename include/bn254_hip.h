@@ -125,6 +125,21 @@ int bn254_batch_sign_device(bn254_ctx *ctx, const uint8_t *d_msgs, const uint64_
 int bn254_batch_g1_sum(bn254_ctx *ctx, const uint8_t *points, const uint64_t *seg_off /* n+1 */, size_t n, uint8_t *out /* n*64 */, uint8_t *status);
 int bn254_batch_g2_sum(bn254_ctx *ctx, const uint8_t *points, const uint64_t *seg_off /* n+1 */, size_t n, uint8_t *out /* n*128 */, uint8_t *status);
 
+/* aggregate verify over shared pools (BASELINE config 3): tuple i names a message tuple_msg[i] and a
+ * list of signers signer_idx[tuple_off[i] .. tuple_off[i+1]); status[i] = ECDSA::verify(msg, sum of the
+ * listed signers' signatures on that message, sum of their public keys) — aggregation is plain point
+ * addition (src/types.rs:126-132, :264-270) and only meaningful for one common message (src/lib.rs:34-38).
+ * sig_pool[(m * n_signers + s) * 64]: signature of signer s on message m; pk_pool[s * 128].
+ * An out-of-range signer index gives status 2 (IndexOutOfBounds); an undecodable pool entry gives its
+ * decode status to every tuple that uses it. */
+int bn254_batch_aggregate_verify(bn254_ctx *ctx, const uint8_t *msgs, const uint64_t *msg_off /* n_msgs+1 */, size_t n_msgs,
+                                 const uint8_t *pk_pool /* n_signers*128 */, size_t n_signers, const uint8_t *sig_pool /* n_msgs*n_signers*64 */,
+                                 const uint32_t *tuple_msg /* n */, const uint64_t *tuple_off /* n+1 */, const uint32_t *signer_idx, size_t n,
+                                 uint32_t flags, uint8_t *status /* n */);
+int bn254_batch_aggregate_verify_device(bn254_ctx *ctx, const uint8_t *d_msgs, const uint64_t *d_msg_off, size_t n_msgs, const uint8_t *d_pk_pool,
+                                        size_t n_signers, const uint8_t *d_sig_pool, const uint32_t *d_tuple_msg, const uint64_t *d_tuple_off,
+                                        const uint32_t *d_signer_idx, size_t n, uint32_t flags, uint8_t *d_status, void *stream);
+
 /* compressed wire formats (src/utils.rs:84-104, :130-158): out = uncompressed point, status as
  * bn::G1::from_compressed / bn::G2::from_compressed report through src/types.rs:91-93, :233-237:
  * bad prefix byte (G1: 0x02/0x03, G2: 0x0a/0x0b) or x.im >= q -> 3 InvalidEncoding; x >= q, no square

@@ -235,6 +235,31 @@ int hs_g2_decompress(const uint8_t* in65, uint8_t* out128) {
   memcpy(out128, tmp, 128);
   return st;
 }
+// sum of k points through the mixed-addition ladder used by k_aggregate
+int hs_g1_msum(const uint8_t* pts, uint64_t k, uint8_t* out) {
+  G1Jac acc;
+  jac_set_identity(acc);
+  uint8_t st = ST_OK;
+  for (uint64_t j = 0; j < k; ++j) { G1Affine p; uint8_t s = dec_g1(p, pts + 64 * j, 0); if (st == ST_OK) st = s; jac_madd(acc, acc, p); }
+  G1Affine r;
+  jac_to_affine(r, acc);
+  alignas(4) uint8_t tmp[64];
+  encode_g1(tmp, r);
+  memcpy(out, tmp, 64);
+  return st;
+}
+int hs_g2_msum(const uint8_t* pts, uint64_t k, uint8_t* out) {
+  G2Jac acc;
+  jac_set_identity(acc);
+  uint8_t st = ST_OK;
+  for (uint64_t j = 0; j < k; ++j) { G2Affine p; uint8_t s = dec_g2(p, pts + 128 * j, 0); if (st == ST_OK) st = s; jac_madd(acc, acc, p); }
+  G2Affine r;
+  jac_to_affine(r, acc);
+  alignas(4) uint8_t tmp[128];
+  encode_g2(tmp, r);
+  memcpy(out, tmp, 128);
+  return st;
+}
 // op codes as bn254_debug_fp_op
 int hs_fp_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
   alignas(4) uint8_t ta[32], tb[32], to[32];

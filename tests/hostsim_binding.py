@@ -24,6 +24,8 @@ def lib():
         L.hs_sign.argtypes = [cp, ctypes.c_uint64, cp, cp]
         L.hs_fp_op.argtypes = [ctypes.c_int, cp, cp, cp]
         L.hs_g1_decompress.argtypes = [cp, cp]
+        L.hs_g1_msum.argtypes = [cp, ctypes.c_uint64, cp]
+        L.hs_g2_msum.argtypes = [cp, ctypes.c_uint64, cp]
         L.hs_g2_decompress.argtypes = [cp, cp]
         _lib = L
     return _lib
@@ -83,3 +85,11 @@ def g1_decompress(c33):
 
 def g2_decompress(c65):
     o = _b(128); st = lib().hs_g2_decompress(bytes(c65), o); return st, o.raw
+
+
+def g1_msum(pts):
+    o = _b(64); st = lib().hs_g1_msum(b"".join(pts), len(pts), o); return st, o.raw
+
+
+def g2_msum(pts):
+    o = _b(128); st = lib().hs_g2_msum(b"".join(pts), len(pts), o); return st, o.raw

@@ -44,6 +44,9 @@ elif which == "group":
     v = k["public_key_from_private_key"][0]; o = buf(128); hs.hs_g2_mul(None, H(v["private_key"]), 1, o); assert o.raw.hex() == v["uncompressed"]
     o2 = buf(128); hs.hs_g2_add(o.raw, o.raw, o2)
     v = k["sign"][0]; o = buf(64); m = H(v["message_hex"]); hs.hs_sign(m, len(m), H(v["private_key"]), o)
+elif which == "msum":
+    g = H(d["g2_generator"]); o = buf(128); hs.hs_g2_msum(g + g + bytes(128) + g, 4, o)
+    g1 = (1).to_bytes(32, "big") + (2).to_bytes(32, "big"); o = buf(64); hs.hs_g1_msum(g1 * 5, 5, o)
 elif which == "codec":
     o = buf(64); assert hs.hs_g1_decompress(H(k["sign"][0]["signature_compressed"]), o) == 0
     o = buf(128); assert hs.hs_g2_decompress(H(k["g2_compressed_roundtrip"]["hex"]), o) == 0
@@ -59,7 +62,7 @@ def bounds_lib():
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "hostsim"), "libhostsim_bounds.so"], stdout=subprocess.DEVNULL)
 
 
-@pytest.mark.parametrize("flow", ["fp", "hash", "pairing", "verify", "group", "subgroup", "codec"])
+@pytest.mark.parametrize("flow", ["fp", "hash", "pairing", "verify", "group", "subgroup", "codec", "msum"])
 def test_bounds_hold(bounds_lib, flow):
     p = subprocess.run([sys.executable, "-c", DRIVER, ROOT, flow], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and p.stdout.strip() == "ok", (p.stdout[-500:], p.stderr[-2000:])

@@ -338,6 +338,39 @@ def test_group_ops_vs_oracle(eng, c):
     assert out2[256:384] == acc
 
 
+def test_aggregate_verify_vs_oracle(eng, c):
+    """config-3 shape in miniature: M messages, S signers, per-tuple signer subsets over shared pools."""
+    from tests.datagen import sk_bytes
+    M, S = 3, 9
+    msgs = [b"agg-msg-%d" % m for m in range(M)]
+    sks = [sk_bytes(100 + s) for s in range(S)]
+    pk_pool, st = eng.batch_g2_mul(None, b"".join(sks), S, reduce_scalar=True)
+    assert st == bytes(S)
+    sig_pool, st = eng.batch_sign([msgs[m] for m in range(M) for _ in range(S)], b"".join(sks * M))
+    assert st == bytes(M * S)
+    pk = lambda s: pk_pool[128 * s:128 * s + 128]                          # noqa: E731
+    sg = lambda m, s: sig_pool[64 * (m * S + s):64 * (m * S + s) + 64]     # noqa: E731
+    tuples = [(0, [0]), (1, list(range(S))), (2, [1, 3, 5, 7]), (0, []), (1, [4, 4]), (2, [8, 0, 2]), (0, [2, 99]), (1, [6])]
+    tuples += [(m % M, [s for s in range(S) if (m * 37 + s * 11) % 3]) for m in range(70)]
+    got = eng.batch_aggregate_verify(msgs, pk_pool, sig_pool, [t[0] for t in tuples], [t[1] for t in tuples])
+    for i, (m, lst) in enumerate(tuples):
+        if any(s >= S for s in lst):
+            assert got[i] == 2
+            continue
+        asig, apk = bytes(64), bytes(128)
+        for s in lst:
+            asig, apk = c.g1_add(asig, sg(m, s)), c.g2_add(apk, pk(s))
+        assert got[i] == c.verify(msgs[m], asig, apk, 0) == 0, (i, m, lst)
+    # a tuple whose signatures come from another message must fail: swap the pools' message rows
+    bad_pool = sig_pool[64 * S:128 * S] + sig_pool[:64 * S] + sig_pool[128 * S:]
+    got = eng.batch_aggregate_verify(msgs, pk_pool, bad_pool, [0, 2], [[1, 2], [1, 2]])
+    assert got == bytes([9, 0])
+    # an undecodable pool entry poisons exactly the tuples that use it
+    broken = bytearray(pk_pool); broken[128 * 3 + 127] ^= 1
+    got = eng.batch_aggregate_verify(msgs, bytes(broken), sig_pool, [0, 0], [[3, 4], [4, 5]])
+    assert got == bytes([4, 0])
+
+
 def test_full_size_batch_properties(eng):
     """config-2 size (65 536): expected-status pattern (valid except every 64th), and
     permutation-equivariance of the result — size-independent properties, no oracle needed."""

@@ -110,3 +110,20 @@ def test_compressed_codecs(kats, derived):
         assert hs.g1_decompress(data)[0] == st
     for data, st in bad_g2:
         assert hs.g2_decompress(data)[0] == st
+
+
+def test_mixed_addition_sums(kats):
+    """jac_madd ladder (aggregation) incl. its exceptional cases: O + P, P + P, P + (-P), identity operands"""
+    g1, g2 = c.g1_generator(), c.g2_generator()
+    p1 = [c.g1_mul(g1, (k + 2).to_bytes(32, "big")) for k in range(5)]
+    p2 = [c.g2_mul(g2, (k + 2).to_bytes(32, "big")) for k in range(5)]
+    neg1 = p1[0][:32] + (Q - int.from_bytes(p1[0][32:], "big")).to_bytes(32, "big")
+    for pts, add, msum, zero in ((p1, c.g1_add, hs.g1_msum, bytes(64)), (p2, c.g2_add, hs.g2_msum, bytes(128))):
+        acc = zero
+        for p in pts:
+            acc = add(acc, p)
+        assert msum(pts) == (0, acc)
+        assert msum([pts[1], pts[1]]) == (0, add(pts[1], pts[1]))            # doubling branch
+        assert msum([]) == (0, zero) and msum([zero, pts[2], zero]) == (0, pts[2])
+    assert hs.g1_msum([p1[0], neg1]) == (0, bytes(64))                         # P + (-P) = O
+    assert hs.g1_msum([p1[0], neg1, p1[3]]) == (0, p1[3])
