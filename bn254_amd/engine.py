@@ -225,6 +225,12 @@ class Engine:
     def batch_pairing_device(self, d_g1, d_g2, n, k, d_gt, d_status, flags=0, stream=None):
         _check("bn254_batch_pairing_device", self._lib.bn254_batch_pairing_device(self._h, d_g1, d_g2, n, k, flags, d_gt, d_status, stream))
 
+    def batch_aggregate_verify_device(self, d_msgs, d_msg_off, n_msgs, d_pk_pool, n_signers, d_sig_pool, d_tuple_msg, d_tuple_off, d_signer_idx, n,
+                                      d_status, flags=0, stream=None):
+        _check("bn254_batch_aggregate_verify_device",
+               self._lib.bn254_batch_aggregate_verify_device(self._h, d_msgs, d_msg_off, n_msgs, d_pk_pool, n_signers, d_sig_pool, d_tuple_msg,
+                                                             d_tuple_off, d_signer_idx, n, flags, d_status, stream))
+
     def batch_sign_device(self, d_msgs, d_off, d_sks, n, d_sigs, d_status, stream=None):
         _check("bn254_batch_sign_device", self._lib.bn254_batch_sign_device(self._h, d_msgs, d_off, d_sks, n, d_sigs, d_status, stream))
 
