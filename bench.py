@@ -47,6 +47,25 @@ def D(tag, i):
     return hashlib.sha256(tag.encode() + i.to_bytes(8, "little")).digest()
 
 
+def effective_cores():
+    """threads worth starting for the CPU baseline: the scheduler affinity, capped by a cgroup CPU quota"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.999)))
+            else:
+                quota = int(txt[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    n = min(n, max(1, int(quota / period + 0.999)))
+        except Exception:
+            pass
+    return n
+
+
 def measured_traffic(kernel):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC summary of this same command
     (profiles/pmc_latest.json, produced by tests/pmc_profile.sh + tests/pmc_to_json.py): FETCH_SIZE and
@@ -193,6 +212,9 @@ def main():
             "frac": achieved / (PEAK_MAC32_THEORETICAL / 1e12),
             "peak_measured_microbench": PEAK_MAC32_MEASURED / 1e12,
             "frac_of_measured_peak": achieved / (PEAK_MAC32_MEASURED / 1e12),
+            # register-resident chain of the same Fq product routine, one wave per SIMD
+            # (profiles/r01_fp_mul_chain_ceiling.jsonl): the ceiling of this code shape at occupancy 1
+            "frac_of_occupancy1_product_ceiling": (fp_mul * n / (k_avg[dom] * 1e-3)) / 8.16e10,
             "traffic": measured_traffic("k_miller_verify" if dom == "miller_loop" else "k_final_exp"),
             "multiplier_issue_frac": (fp_mul * MUL_INSTR_PER_FP_MUL * n / (k_avg[dom] * 1e-3)) / PEAK_MAC32_THEORETICAL,
             "kernel_ms": k_avg,
@@ -203,7 +225,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             from oracle import c_oracle
-            cores = os.cpu_count() or 1
+            cores = effective_cores()
             sample = min(n, max(256, 32 * cores))            # ~10-20 CPU-seconds of work in total
             t1 = time.perf_counter()
             st_cpu, _ = c_oracle.batch_verify(msgs[:sample], bytes(sigs[:64 * sample]), pks[:128 * sample], flags=0, nthreads=cores)
