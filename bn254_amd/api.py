@@ -264,3 +264,41 @@ def check_public_keys(public_key_g2, public_key_g1):
     """/root/reference/src/ecdsa.rs:78-93."""
     st = _eng().batch_check_public_keys(public_key_g2.raw, public_key_g1.raw, 1)
     _raise(st[0])
+
+
+def _le_chunks(data):
+    """each 32-byte big-endian chunk byte-reversed: zeropool-bn's Borsh (little-endian) affine coordinates"""
+    return b"".join(data[i:i + 32][::-1] for i in range(0, len(data), 32))
+
+
+_NEG_G2_ONE = None
+
+
+def _neg_g2_one():
+    global _NEG_G2_ONE
+    if _NEG_G2_ONE is None:
+        g2 = PublicKey.from_private_key(PrivateKey(1))
+        _NEG_G2_ONE = (-g2).raw
+    return _NEG_G2_ONE
+
+
+def format_pairing_check_uncompressed_values(message, signature, public_key):
+    """/root/reference/src/utils.rs:216-239: the two (G1, G2) tuples of the verification equation
+    e(H(m), pk) * e(sig, -G2::one()) as 64-/128-byte little-endian buffers for an on-chain alt_bn128
+    pairing precompile.  `signature` (64 B) and `public_key` (128 B) are the uncompressed big-endian
+    encodings; like the reference this does NOT validate them (it only re-orders bytes) and raises
+    IndexError-like InvalidLength on short input where the reference would panic."""
+    signature, public_key = bytes(signature), bytes(public_key)
+    if len(signature) < 64 or len(public_key) < 128:
+        raise Error(ErrorKind.InvalidLength)
+    pts, st, _ = _eng().batch_hash_to_g1([bytes(message)])
+    _raise(st[0])
+    return [(_le_chunks(pts), _le_chunks(public_key[:128])), (_le_chunks(signature[:64]), _le_chunks(_neg_g2_one()))]
+
+
+def format_pairing_check_values(message, signature, public_key):
+    """/root/reference/src/utils.rs:197-214: the same from COMPRESSED signature (33 B) and public key (65 B);
+    both are decoded (and thereby validated) first."""
+    sig = Signature.from_compressed(signature)
+    pk = PublicKey.from_compressed(public_key)
+    return format_pairing_check_uncompressed_values(message, sig.raw, pk.raw)

@@ -151,14 +151,45 @@ BN_DEV bool g1_on_curve(const G1Affine& p) {   // y^2 = x^3 + 3
 BN_DEV bool g2_on_curve(const G2Affine& p) {   // y^2 = x^3 + 3/xi
   return p.inf || fp2_eq(fp2_sqr(p.y), fp2_add(fp2_mul(fp2_sqr(p.x), p.x), fp2_load_const(C_TWIST_B)));
 }
-// order-r subgroup membership of a twist point: [r]P == O  (what AffineG2::new enforces)
+// psi = twist o Frobenius o untwist on Jacobian coordinates: (conj X * g_x, conj Y * g_y, conj Z)
+BN_DEV void g2_psi(G2Jac& r, const G2Jac& p) {
+  r.x = fp2_norm(fp2_mul(fp2_conj(p.x), fp2_load_const(C_TW_FROB_X1)));
+  r.y = fp2_norm(fp2_mul(fp2_conj(p.y), fp2_load_const(C_TW_FROB_Y1)));
+  r.z = fp2_norm(fp2_conj(p.z));
+}
+// equality of two Jacobian points (cross-multiplied; identity only equals identity)
+BN_DEV bool g2_jac_equal(const G2Jac& a, const G2Jac& b) {
+  bool ai = fp2_is_zero(a.z), bi = fp2_is_zero(b.z);
+  Fp2 za2 = fp2_norm(fp2_sqr(a.z)), zb2 = fp2_norm(fp2_sqr(b.z));
+  bool ex = fp2_eq(fp2_mul(a.x, zb2), fp2_mul(b.x, za2));
+  bool ey = fp2_eq(fp2_mul(a.y, fp2_norm(fp2_mul(zb2, b.z))), fp2_mul(b.y, fp2_norm(fp2_mul(za2, a.z))));
+  return (ai && bi) || (!ai && !bi && ex && ey);
+}
+// order-r subgroup membership of a twist point (what AffineG2::new enforces,
+// /root/reference/src/utils.rs:113).  Instead of the 254-bit ladder [r]P == O this uses the BN
+// endomorphism test  [u+1]P + psi([u]P) + psi^2([u]P) == psi^3([2u]P)  (Scott, "A note on group
+// membership tests for G1, G2 and GT on BLS pairing-friendly curves", BN case): one 63-bit ladder
+// (NAF of u, mixed additions).  tests/test_oracle_model.py checks the identity against [r]P == O on
+// random twist points in and out of the subgroup; the CPU suite also runs this implementation on them.
 BN_DEVN bool g2_in_subgroup(const G2Affine& p) {
-  G2Jac j, o;
-  jac_from_affine(j, p);
-  uint32_t k[8];
-  for (int i = 0; i < 8; ++i) k[i] = C_ORDER_R[i];
-  jac_mul(o, j, k);
-  return p.inf || jac_is_identity(o);
+  G2Affine pn = p;
+  pn.y = fp2_norm(fp2_neg(p.y));
+  G2Jac up, t, lhs, rhs;
+  jac_from_affine(up, p);
+  for (int i = 0; i < BN_U_NAF_LEN; ++i) {        // wave-uniform: u is a public constant
+    jac_dbl(up, up);
+    int d = C_U_NAF[i];
+    if (d > 0) jac_madd(up, up, p);
+    else if (d < 0) jac_madd(up, up, pn);
+  }
+  jac_madd(lhs, up, p);                            // [u+1]P
+  g2_psi(t, up);
+  jac_add(lhs, lhs, t);                            // + psi([u]P)
+  g2_psi(t, t);
+  jac_add(lhs, lhs, t);                            // + psi^2([u]P)
+  jac_dbl(rhs, up);
+  g2_psi(rhs, rhs); g2_psi(rhs, rhs); g2_psi(rhs, rhs);
+  return p.inf || g2_jac_equal(lhs, rhs);
 }
 
 }  // namespace bn254

@@ -262,6 +262,26 @@ def test_compressed_codecs(eng, kats, derived):
     assert e.value.kind == bn.ErrorKind.InvalidEncoding
 
 
+def test_pairing_check_formatters(eng, c, kats):
+    """src/utils.rs:197-239 (untested upstream): the two tuples are the little-endian images of
+    (H(m), pk) and (sig, -G2::one()); fed back through the pairing check they verify."""
+    import bn254_amd as bn
+    v = kats["sign"][0]
+    msg = H(v["message_hex"])
+    sk = bn.PrivateKey.try_from(v["private_key"])
+    sig, pk = bn.ECDSA.sign(msg, sk), bn.PublicKey.from_private_key(sk)
+    t1 = bn.format_pairing_check_values(msg, sig.to_compressed(), pk.to_compressed())
+    t2 = bn.format_pairing_check_uncompressed_values(msg, sig.to_uncompressed(), pk.to_uncompressed())
+    assert t1 == t2 and [len(x) for t in t1 for x in t] == [64, 128, 64, 128]
+    be = lambda b: b"".join(b[i:i + 32][::-1] for i in range(0, len(b), 32))     # noqa: E731
+    assert be(t1[0][0]) == c.hash_to_g1(msg)[1] and be(t1[0][1]) == pk.raw and be(t1[1][0]) == sig.raw
+    g2 = c.g2_generator()
+    assert be(t1[1][1]) == g2[:64] + b"".join((Q - int.from_bytes(g2[i:i + 32], "big")).to_bytes(32, "big") for i in (64, 96))
+    assert eng.batch_pairing_check(be(t1[0][0]) + be(t1[1][0]), be(t1[0][1]) + be(t1[1][1]), 1, 2) == b"\x00"
+    with pytest.raises(bn.Error):
+        bn.format_pairing_check_uncompressed_values(msg, sig.raw[:10], pk.raw)
+
+
 def test_bn256_vectors(eng, kats):
     adds = kats["g1_add"]
     out, st = eng.batch_g1_add(b"".join(H(v["x1"] + v["y1"]) for v in adds), b"".join(H(v["x2"] + v["y2"]) for v in adds), len(adds))

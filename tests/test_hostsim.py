@@ -127,3 +127,25 @@ def test_mixed_addition_sums(kats):
         assert msum([]) == (0, zero) and msum([zero, pts[2], zero]) == (0, pts[2])
     assert hs.g1_msum([p1[0], neg1]) == (0, bytes(64))                         # P + (-P) = O
     assert hs.g1_msum([p1[0], neg1, p1[3]]) == (0, p1[3])
+
+
+def test_g2_subgroup_check_device_source(derived):
+    """the endomorphism-based membership test of the decoders (flag bit0) on points in / out of G2"""
+    import random
+    from oracle import bn254_model as m
+    rnd = random.Random(9)
+    g1 = c.g1_generator()
+    pts = [(m.g2_mul(m.G2_GEN, rnd.randrange(1, m.R)), True) for _ in range(4)]
+    while len(pts) < 12:
+        x = (rnd.randrange(m.Q), rnd.randrange(m.Q))
+        y = m.f2_sqrt(m.f2_add(m.f2_mul(m.f2_mul(x, x), x), m.B2))
+        if y is None:
+            continue
+        p = (x, y)
+        pts.append((p, m.g2_in_subgroup(p)))
+        pts.append((m.g2_mul(p, 2 * m.Q - m.R), True))
+    for p, inside in pts:
+        st, _ = hs.pairing(g1, m.g2_to_uncompressed(p), flags=1)
+        assert (st != 4) == inside
+    off = H(derived["g2_not_in_subgroup"])
+    assert hs.pairing(g1, off, flags=1)[0] == 4 and hs.pairing(g1, off, flags=0)[0] == 9

@@ -108,3 +108,35 @@ def test_final_exponentiation_fast_path_agrees():
     assert m.f12_pow(e1, m.R) == m.F12_ONE and e1 != m.F12_ONE
     # bilinearity
     assert e1 == m.f12_pow(m.pairing(m.G1_GEN, m.G2_GEN), 33)
+
+
+def test_g2_endomorphism_subgroup_test_is_equivalent():
+    """[u+1]P + psi([u]P) + psi^2([u]P) == psi^3([2u]P)  <=>  [r]P == O, on twist points in and out of G2
+    (the product's decoder uses the left-hand test; this pins it to the definition)."""
+    import random
+    gx, gy = m.f2_pow(m.XI, (m.Q - 1) // 3), m.f2_pow(m.XI, (m.Q - 1) // 2)
+
+    def psi(p):
+        return None if p is None else (m.f2_mul(m.f2_conj(p[0]), gx), m.f2_mul(m.f2_conj(p[1]), gy))
+
+    def fast(p):
+        up = m.g2_mul(p, m.U)
+        lhs = m.g2_add(m.g2_add(m.g2_add(up, p), psi(up)), psi(psi(up)))
+        return lhs == psi(psi(psi(m.g2_add(up, up))))
+
+    rnd = random.Random(5)
+    for _ in range(3):
+        assert fast(m.g2_mul(m.G2_GEN, rnd.randrange(1, m.R)))
+    n = 0
+    while n < 6:
+        x = (rnd.randrange(m.Q), rnd.randrange(m.Q))
+        y = m.f2_sqrt(m.f2_add(m.f2_mul(m.f2_mul(x, x), x), m.B2))
+        if y is None:
+            continue
+        n += 1
+        p = (x, y)
+        assert fast(p) == m.g2_in_subgroup(p)
+        cleared = m.g2_mul(p, 2 * m.Q - m.R)
+        assert fast(cleared) and m.g2_in_subgroup(cleared)
+        mixed = m.g2_add(cleared, m.g2_mul(p, m.R))
+        assert fast(mixed) == m.g2_in_subgroup(mixed)
