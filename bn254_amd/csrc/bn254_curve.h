@@ -72,14 +72,14 @@ template <class F> BN_DEVN void jac_dbl(Jac<F>& r, const Jac<F>& p) {
 // P = O -> Q, Q = O -> P, P = Q -> 2P, P = -Q -> O
 template <class F> BN_DEVN void jac_add(Jac<F>& r, const Jac<F>& p, const Jac<F>& q) {
   F z1z1 = f_norm(f_sqr(p.z)), z2z2 = f_norm(f_sqr(q.z));
-  F u1 = f_norm(f_mul(p.x, z2z2)), u2 = f_norm(f_mul(q.x, z1z1));
-  F s1 = f_norm(f_mul(f_norm(f_mul(p.y, q.z)), z2z2)), s2 = f_norm(f_mul(f_norm(f_mul(q.y, p.z)), z1z1));
-  F h = f_norm(f_sub(u2, u1)), i = f_norm(f_sqr(f_dbl(h))), j = f_norm(f_mul(h, i));
-  F rr = f_norm(f_dbl(f_sub(s2, s1))), v = f_norm(f_mul(u1, i));
+  F u1 = f_mul(p.x, z2z2), u2 = f_mul(q.x, z1z1);
+  F s1 = f_mul(f_norm(f_mul(p.y, q.z)), z2z2), s2 = f_mul(f_norm(f_mul(q.y, p.z)), z1z1);
+  F h = f_norm(f_sub(u2, u1)), i = f_norm(f_sqr(f_dbl(h))), j = f_mul(h, i);
+  F rr = f_norm(f_dbl(f_sub(s2, s1))), v = f_mul(u1, i);
   Jac<F> o;
   o.x = f_norm(f_sub(f_sub(f_sqr(rr), j), f_dbl(v)));
   o.y = f_norm(f_sub(f_mul(rr, f_norm(f_sub(v, o.x))), f_dbl(f_mul(s1, j))));
-  o.z = f_norm(f_mul(f_norm(f_sub(f_sub(f_sqr(f_add(p.z, q.z)), z1z1), z2z2)), h));
+  o.z = f_mul(f_norm(f_sub(f_sub(f_sqr(f_add(p.z, q.z)), z1z1), z2z2)), h);
   bool p_inf = f_is_zero(p.z), q_inf = f_is_zero(q.z);
   bool same_x = f_is_zero(h), same_y = f_is_zero(rr);
   Jac<F> d;
@@ -99,11 +99,11 @@ template <class F> BN_DEVN void jac_add(Jac<F>& r, const Jac<F>& p, const Jac<F>
 // Exceptional cases by selects, as in jac_add: P = O -> Q, P = Q -> 2Q, P = -Q -> O; q_inf skips.
 template <class F> BN_DEVN void jac_madd(Jac<F>& r, const Jac<F>& p, const Affine<F>& q) {
   F z1z1 = f_norm(f_sqr(p.z));
-  F u2 = f_norm(f_mul(q.x, z1z1));
-  F s2 = f_norm(f_mul(f_norm(f_mul(q.y, p.z)), z1z1));
+  F u2 = f_mul(q.x, z1z1);
+  F s2 = f_mul(f_norm(f_mul(q.y, p.z)), z1z1);
   F h = f_norm(f_sub(u2, p.x)), hh = f_norm(f_sqr(h));
-  F i = f_norm(f_dbl(f_dbl(hh))), j = f_norm(f_mul(h, i));
-  F rr = f_norm(f_dbl(f_sub(s2, p.y))), v = f_norm(f_mul(p.x, i));
+  F i = f_norm(f_dbl(f_dbl(hh))), j = f_mul(h, i);
+  F rr = f_norm(f_dbl(f_sub(s2, p.y))), v = f_mul(p.x, i);
   Jac<F> o;
   o.x = f_norm(f_sub(f_sub(f_sqr(rr), j), f_dbl(v)));
   o.y = f_norm(f_sub(f_mul(rr, f_norm(f_sub(v, o.x))), f_dbl(f_mul(p.y, j))));
@@ -139,8 +139,8 @@ template <class F> BN_DEVN void jac_mul(Jac<F>& r, const Jac<F>& p, const uint32
 template <class F> BN_DEVN void jac_to_affine(Affine<F>& r, const Jac<F>& p) {
   bool inf = f_is_zero(p.z);
   F zi = f_norm(f_inv(p.z)), zi2 = f_norm(f_sqr(zi));
-  r.x = f_norm(f_mul(p.x, zi2));
-  r.y = f_norm(f_mul(p.y, f_norm(f_mul(zi2, zi))));
+  r.x = f_mul(p.x, zi2);
+  r.y = f_mul(p.y, f_norm(f_mul(zi2, zi)));
   r.inf = inf;
   if (inf) { f_set_zero(r.x); f_set_zero(r.y); }
 }
@@ -153,8 +153,8 @@ BN_DEV bool g2_on_curve(const G2Affine& p) {   // y^2 = x^3 + 3/xi
 }
 // psi = twist o Frobenius o untwist on Jacobian coordinates: (conj X * g_x, conj Y * g_y, conj Z)
 BN_DEV void g2_psi(G2Jac& r, const G2Jac& p) {
-  r.x = fp2_norm(fp2_mul(fp2_conj(p.x), fp2_load_const(C_TW_FROB_X1)));
-  r.y = fp2_norm(fp2_mul(fp2_conj(p.y), fp2_load_const(C_TW_FROB_Y1)));
+  r.x = fp2_mul(fp2_conj(p.x), fp2_load_const(C_TW_FROB_X1));
+  r.y = fp2_mul(fp2_conj(p.y), fp2_load_const(C_TW_FROB_Y1));
   r.z = fp2_norm(fp2_conj(p.z));
 }
 // equality of two Jacobian points (cross-multiplied; identity only equals identity)
@@ -162,7 +162,7 @@ BN_DEV bool g2_jac_equal(const G2Jac& a, const G2Jac& b) {
   bool ai = fp2_is_zero(a.z), bi = fp2_is_zero(b.z);
   Fp2 za2 = fp2_norm(fp2_sqr(a.z)), zb2 = fp2_norm(fp2_sqr(b.z));
   bool ex = fp2_eq(fp2_mul(a.x, zb2), fp2_mul(b.x, za2));
-  bool ey = fp2_eq(fp2_mul(a.y, fp2_norm(fp2_mul(zb2, b.z))), fp2_mul(b.y, fp2_norm(fp2_mul(za2, a.z))));
+  bool ey = fp2_eq(fp2_mul(a.y, fp2_mul(zb2, b.z)), fp2_mul(b.y, fp2_mul(za2, a.z)));
   return (ai && bi) || (!ai && !bi && ex && ey);
 }
 // order-r subgroup membership of a twist point (what AffineG2::new enforces,

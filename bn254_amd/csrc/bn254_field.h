@@ -324,11 +324,71 @@ BN_DEV Fp fp_sqr(const Fp& a) {
   return r;
 }
 
+// ---- lazy-reduction Fq2 product -------------------------------------------------------------------
+// (a0 + a1 i)(b0 + b1 i): both limb products of each output coefficient are accumulated into the same
+// 64-bit columns (re: a0*b0 + (-a1)*b1, im: a0*b1 + a1*b0) and reduced ONCE — 600 multiplies like a
+// 3-product Karatsuba, but no Karatsuba additions, no separate carry normalisation (outputs are tight)
+// and one call instead of three.  Column bound: 10*(A0*B0 + A1*B1) + 10*2^54 + 2^37 < 2^63.
+#if defined(__HIPCC__)
+typedef int32_t bn_i32x10 __attribute__((ext_vector_type(10)));
+typedef int32_t bn_i32x20 __attribute__((ext_vector_type(20)));
+#define BN_VEC10 bn_i32x10
+#define BN_VEC20 bn_i32x20
+#else
+struct bn_vec10 { int32_t e[10]; int32_t& operator[](int i) { return e[i]; } const int32_t& operator[](int i) const { return e[i]; } };
+struct bn_vec20 { int32_t e[20]; int32_t& operator[](int i) { return e[i]; } const int32_t& operator[](int i) const { return e[i]; } };
+#define BN_VEC10 bn_vec10
+#define BN_VEC20 bn_vec20
+#endif
+// r = Montgomery-reduce(x0*y0 + x1*y1), limbs as plain arrays
+BN_DEV void fp_dual_mul_reduce(int32_t* r, const int32_t* x0, const int32_t* y0, const int32_t* x1, const int32_t* y1) {
+  const int32_t q[BN_LIMBS] = BN_QL_ARRAY;
+  int64_t acc = 0;
+  int32_t m[BN_LIMBS];
+#pragma unroll
+  for (int k = 0; k < 2 * BN_LIMBS - 1; ++k) {
+#pragma unroll
+    for (int i = 0; i < BN_LIMBS; ++i) {
+      int j = k - i;
+      if (j < 0 || j >= BN_LIMBS) continue;
+      acc += (int64_t)x0[i] * y0[j];
+      acc += (int64_t)x1[i] * y1[j];
+    }
+#pragma unroll
+    for (int i = 0; i < BN_LIMBS; ++i) {
+      int j = k - i;
+      if (j < 0 || j >= BN_LIMBS) continue;
+      if (k < BN_LIMBS && i >= k) continue;
+      acc += (int64_t)m[i] * q[j];
+    }
+    if (k < BN_LIMBS) {
+      m[k] = (int32_t)(((uint32_t)acc * BN_N0) & BN_MASK);
+      acc += (int64_t)m[k] * q[0];
+    } else {
+      r[k - BN_LIMBS] = (int32_t)((uint32_t)acc & BN_MASK);
+    }
+    BN_COLUMN_SHIFT(acc);
+  }
+  r[BN_LIMBS - 1] = (int32_t)acc;
+}
+BN_DEVN BN_VEC20 fp2_mul_impl(BN_VEC10 a0, BN_VEC10 a1, BN_VEC10 b0, BN_VEC10 b1) {
+  BN_COUNT_MUL(); BN_COUNT_MUL(); BN_COUNT_MUL();   // algorithmic cost: a 3-product Karatsuba Fq2 multiplication
+  int32_t x0[BN_LIMBS], x1[BN_LIMBS], y0[BN_LIMBS], y1[BN_LIMBS], n1[BN_LIMBS], re[BN_LIMBS], im[BN_LIMBS];
+#pragma unroll
+  for (int i = 0; i < BN_LIMBS; ++i) { x0[i] = a0[i]; x1[i] = a1[i]; y0[i] = b0[i]; y1[i] = b1[i]; n1[i] = -a1[i]; }
+  fp_dual_mul_reduce(re, x0, y0, n1, y1);
+  fp_dual_mul_reduce(im, x0, y1, x1, y0);
+  BN_VEC20 r;
+#pragma unroll
+  for (int i = 0; i < BN_LIMBS; ++i) { r[i] = re[i]; r[BN_LIMBS + i] = im[i]; }
+  return r;
+}
+
 // the unique representative in [0, q) with canonical limbs (same Montgomery residue).
 // One product by the Montgomery one brings |value| into (-eps q, (1+eps) q); then at most one
 // correction by q either way.
 BN_DEVN Fp fp_canon(Fp a) {
-  Fp t = fp_norm(fp_mul(a, fp_one()));
+  Fp t = fp_mul(a, fp_one());
   Fp ql = fp_load_const(C_QL);
   Fp up = fp_norm(fp_add(t, ql));
   t = fp_select(t.v[BN_LIMBS - 1] < 0, up, t);
@@ -367,7 +427,7 @@ BN_DEVN U256 fp_to_u256(Fp a) {
   one.v[0] = 1;
   BN_TRK(bn_set_tight(one, 0, 1));
   // a * 1 / R is the plain residue; canonicalise it with the same +-q correction as fp_canon
-  Fp t = fp_norm(fp_mul(a, one));
+  Fp t = fp_mul(a, one);
   Fp ql = fp_load_const(C_QL);
   Fp up = fp_norm(fp_add(t, ql));
   t = fp_select(t.v[BN_LIMBS - 1] < 0, up, t);
@@ -417,12 +477,34 @@ BN_DEV Fp2 fp2_reduce_weak(const Fp2& a) { Fp2 r; r.c0 = fp_reduce_weak(a.c0); r
 BN_DEV bool fp2_is_zero(const Fp2& a) { return fp_is_zero(a.c0) && fp_is_zero(a.c1); }
 BN_DEV bool fp2_eq(const Fp2& a, const Fp2& b) { return fp_eq(a.c0, b.c0) && fp_eq(a.c1, b.c1); }
 BN_DEV Fp2 fp2_select(bool c, const Fp2& a, const Fp2& b) { Fp2 r; r.c0 = fp_select(c, a.c0, b.c0); r.c1 = fp_select(c, a.c1, b.c1); return r; }
-BN_DEV Fp2 fp2_mul(const Fp2& a, const Fp2& b) {   // Karatsuba, 3 Fq products
-  Fp t0 = fp_mul(a.c0, b.c0), t1 = fp_mul(a.c1, b.c1);
-  Fp t2 = fp_mul(fp_add(a.c0, a.c1), fp_add(b.c0, b.c1));
+#if defined(BN_TRACK_BOUNDS) && !defined(__HIPCC__)
+static inline void bn_trk_fp2mul(Fp2& r, const Fp2& a, const Fp2& b) {
+  double A0 = bn_absmax(a.c0), A1 = bn_absmax(a.c1), B0 = bn_absmax(b.c0), B1 = bn_absmax(b.c1);
+  double extra = 10.0 * 18014398509481984.0 + 137438953472.0;
+  double col_re = 10.0 * (A0 * B0 + A1 * B1) + extra, col_im = 10.0 * (A0 * B1 + A1 * B0) + extra;
+  if (col_re >= 9223372036854775808.0 || col_im >= 9223372036854775808.0) bn_bound_fail("fp2_mul column overflow", std::fmax(col_re, col_im));
+  auto prod = [](const Fp& x, const Fp& y, double& lo, double& hi) {
+    double c[4] = {x.bd.vlo * y.bd.vlo, x.bd.vlo * y.bd.vhi, x.bd.vhi * y.bd.vlo, x.bd.vhi * y.bd.vhi};
+    lo = std::fmin(std::fmin(c[0], c[1]), std::fmin(c[2], c[3])) / 86000.0;
+    hi = std::fmax(std::fmax(c[0], c[1]), std::fmax(c[2], c[3])) / 86000.0;
+  };
+  double l00, h00, l11, h11, l01, h01, l10, h10;
+  prod(a.c0, b.c0, l00, h00); prod(a.c1, b.c1, l11, h11); prod(a.c0, b.c1, l01, h01); prod(a.c1, b.c0, l10, h10);
+  double re_lo = l00 - h11, re_hi = h00 - l11, im_lo = l01 + l10, im_hi = h01 + h10;
+  if (std::fmax(std::fmax(std::fabs(re_lo), std::fabs(re_hi)), std::fmax(std::fabs(im_lo), std::fabs(im_hi))) > 64.0) bn_bound_fail("fp2_mul value bound", re_hi);
+  bn_set_tight(r.c0, re_lo, re_hi + 1.0);
+  bn_set_tight(r.c1, im_lo, im_hi + 1.0);
+}
+#endif
+BN_DEV Fp2 fp2_mul(const Fp2& a, const Fp2& b) {   // lazy-reduction product; outputs are tight
+  BN_VEC10 a0, a1, b0, b1;
+#pragma unroll
+  for (int i = 0; i < BN_LIMBS; ++i) { a0[i] = a.c0.v[i]; a1[i] = a.c1.v[i]; b0[i] = b.c0.v[i]; b1[i] = b.c1.v[i]; }
+  BN_VEC20 z = fp2_mul_impl(a0, a1, b0, b1);
   Fp2 r;
-  r.c0 = fp_sub(t0, t1);
-  r.c1 = fp_sub(fp_sub(t2, t0), t1);
+#pragma unroll
+  for (int i = 0; i < BN_LIMBS; ++i) { r.c0.v[i] = z[i]; r.c1.v[i] = z[BN_LIMBS + i]; }
+  BN_TRK(bn_trk_fp2mul(r, a, b));
   return r;
 }
 BN_DEV Fp2 fp2_sqr(const Fp2& a) {                 // 2 Fq products
@@ -456,7 +538,7 @@ BN_DEVN Fp2 fp2_pow_const(Fp2 a, const uint32_t* e) {
   a = fp2_norm(a);
   for (int i = 255; i >= 0; --i) {
     acc = fp2_norm(fp2_sqr(acc));
-    if ((e[i >> 5] >> (i & 31)) & 1) acc = fp2_norm(fp2_mul(acc, a));
+    if ((e[i >> 5] >> (i & 31)) & 1) acc = fp2_mul(acc, a);
   }
   return acc;
 }
@@ -466,12 +548,12 @@ BN_DEVN Fp2 fp2_pow_const(Fp2 a, const uint32_t* e) {
 BN_DEVN bool fp2_sqrt(Fp2& x, const Fp2& a_in) {
   Fp2 a = fp2_norm(a_in);
   Fp2 a1 = fp2_pow_const(a, C_EXP_QM3D4);
-  Fp2 alpha = fp2_norm(fp2_mul(fp2_norm(fp2_sqr(a1)), a));
-  Fp2 x0 = fp2_norm(fp2_mul(a1, a));
+  Fp2 alpha = fp2_mul(fp2_norm(fp2_sqr(a1)), a);
+  Fp2 x0 = fp2_mul(a1, a);
   Fp2 minus_one = fp2_norm(fp2_neg(fp2_one()));
   bool alpha_is_m1 = fp2_eq(alpha, minus_one);
   Fp2 b = fp2_pow_const(fp2_add(fp2_one(), alpha), C_EXP_QM1D2);
-  Fp2 xb = fp2_norm(fp2_mul(b, x0));
+  Fp2 xb = fp2_mul(b, x0);
   Fp2 xi_;                       // i * x0 = (-x0.c1, x0.c0)
   xi_.c0 = fp_norm(fp_neg(x0.c1));
   xi_.c1 = x0.c0;
@@ -506,18 +588,18 @@ BN_DEV void fp6_mul_fp2(Fp6& r, const Fp6& a, const Fp2& k) {
 // a * (b0 + b1 v)
 BN_DEV void fp6_mul_01(Fp6& r, const Fp6& a, const Fp2& b0, const Fp2& b1) {
   Fp2 v0 = fp2_mul(a.c0, b0), v1 = fp2_mul(a.c1, b1);
-  Fp2 c0 = fp2_add(fp2_mul_xi_n(fp2_mul(a.c2, b1)), v0);
+  Fp2 c0 = fp2_add(fp2_mul_xi(fp2_mul(a.c2, b1)), v0);
   Fp2 c1 = fp2_sub(fp2_sub(fp2_mul(fp2_add(a.c0, a.c1), fp2_add(b0, b1)), v0), v1);
   Fp2 c2 = fp2_add(fp2_mul(a.c2, b0), v1);
   r.c0 = fp2_norm(c0); r.c1 = fp2_norm(c1); r.c2 = fp2_norm(c2);
 }
 BN_DEVN void fp6_inv(Fp6& r, const Fp6& a) {
-  Fp2 t0 = fp2_norm(fp2_sub(fp2_sqr(a.c0), fp2_mul_xi_n(fp2_mul(a.c1, a.c2))));
+  Fp2 t0 = fp2_norm(fp2_sub(fp2_sqr(a.c0), fp2_mul_xi(fp2_mul(a.c1, a.c2))));
   Fp2 t1 = fp2_norm(fp2_sub(fp2_mul_xi_n(fp2_sqr(a.c2)), fp2_mul(a.c0, a.c1)));
   Fp2 t2 = fp2_norm(fp2_sub(fp2_sqr(a.c1), fp2_mul(a.c0, a.c2)));
   Fp2 d = fp2_add(fp2_mul_xi_n(fp2_add(fp2_mul(a.c2, t1), fp2_mul(a.c1, t2))), fp2_mul(a.c0, t0));
   d = fp2_norm(fp2_inv(fp2_norm(d)));
-  r.c0 = fp2_norm(fp2_mul(t0, d)); r.c1 = fp2_norm(fp2_mul(t1, d)); r.c2 = fp2_norm(fp2_mul(t2, d));
+  r.c0 = fp2_mul(t0, d); r.c1 = fp2_mul(t1, d); r.c2 = fp2_mul(t2, d);
 }
 
 BN_DEV void fp12_set_one(Fp12& r) {
@@ -594,7 +676,7 @@ BN_DEVN void fp12_frob(Fp12& r, const Fp12& a, int power) {
     Fp2& c = fp12_coef(t, k);
     Fp2 x = (power & 1) ? fp2_conj(c) : c;
     const int32_t (*g)[BN_LIMBS] = power == 1 ? C_FROB1[k] : power == 2 ? C_FROB2[k] : C_FROB3[k];
-    c = fp2_norm(fp2_mul(x, fp2_load_const(g)));
+    c = fp2_mul(x, fp2_load_const(g));
   }
   r = t;
 }

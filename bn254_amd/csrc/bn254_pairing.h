@@ -19,8 +19,8 @@ struct LineCoef { Fp2 c0, c1, c2; };
 
 // T <- 2T;  c0 = 2YZ, c1 = -3X^2, c2 = Y^2 - 3b'Z^2.   T and the line coefficients are tight.
 BN_DEVN void dbl_step(G2Proj& t, LineCoef& l) {
-  Fp2 xy = fp2_norm(fp2_mul(t.x, t.y)), b = fp2_norm(fp2_sqr(t.y)), c = fp2_norm(fp2_sqr(t.z));
-  Fp2 e = fp2_norm(fp2_mul(c, fp2_load_const(C_TWIST_3B)));
+  Fp2 xy = fp2_mul(t.x, t.y), b = fp2_norm(fp2_sqr(t.y)), c = fp2_norm(fp2_sqr(t.z));
+  Fp2 e = fp2_mul(c, fp2_load_const(C_TWIST_3B));
   Fp2 f = fp2_add(fp2_dbl(e), e);
   Fp2 h = fp2_norm(fp2_sub(fp2_sub(fp2_sqr(fp2_add(t.y, t.z)), b), c));
   Fp2 x2 = fp2_sqr(t.x);
@@ -40,13 +40,13 @@ BN_DEVN void dbl_step(G2Proj& t, LineCoef& l) {
 BN_DEVN void add_step(G2Proj& t, LineCoef& l, const Fp2& qx, const Fp2& qy) {
   Fp2 theta = fp2_norm(fp2_sub(t.y, fp2_mul(qy, t.z)));
   Fp2 mu = fp2_norm(fp2_sub(t.x, fp2_mul(qx, t.z)));
-  Fp2 c = fp2_norm(fp2_sqr(theta)), d = fp2_norm(fp2_sqr(mu)), e = fp2_norm(fp2_mul(mu, d));
-  Fp2 f = fp2_mul(t.z, c), g = fp2_norm(fp2_mul(t.x, d));
+  Fp2 c = fp2_norm(fp2_sqr(theta)), d = fp2_norm(fp2_sqr(mu)), e = fp2_mul(mu, d);
+  Fp2 f = fp2_mul(t.z, c), g = fp2_mul(t.x, d);
   Fp2 h = fp2_norm(fp2_sub(fp2_sub(fp2_add(e, f), g), g));
   G2Proj o;
-  o.x = fp2_norm(fp2_mul(mu, h));
+  o.x = fp2_mul(mu, h);
   o.y = fp2_norm(fp2_sub(fp2_mul(theta, fp2_norm(fp2_sub(g, h))), fp2_mul(e, t.y)));
-  o.z = fp2_norm(fp2_mul(t.z, e));
+  o.z = fp2_mul(t.z, e);
   l.c0 = mu;
   l.c1 = fp2_norm(fp2_neg(theta));
   l.c2 = fp2_norm(fp2_sub(fp2_mul(theta, qx), fp2_mul(mu, qy)));
@@ -54,7 +54,7 @@ BN_DEVN void add_step(G2Proj& t, LineCoef& l, const Fp2& qx, const Fp2& qy) {
 }
 // f <- f * line(P); a skipped pair multiplies by one
 BN_DEV void mul_by_line(Fp12& f, const LineCoef& l, const Fp& px, const Fp& py, bool skip) {
-  Fp2 l0 = fp2_norm(fp2_mul_fp(l.c0, py)), l1 = fp2_norm(fp2_mul_fp(l.c1, px)), l2 = l.c2;
+  Fp2 l0 = fp2_mul_fp(l.c0, py), l1 = fp2_mul_fp(l.c1, px), l2 = l.c2;
   l0 = fp2_select(skip, fp2_one(), l0);
   l1 = fp2_select(skip, fp2_zero(), l1);
   l2 = fp2_select(skip, fp2_zero(), l2);
@@ -93,14 +93,14 @@ BN_DEVN void miller_loop(Fp12& f, const G1Affine& pa, const G2Affine& qa, const 
   }
   // + pi(Q), - pi^2(Q)
   if constexpr (HAS_A) {
-    Fp2 q1x = fp2_norm(fp2_mul(fp2_conj(qa.x), fp2_load_const(C_TW_FROB_X1)));
-    Fp2 q1y = fp2_norm(fp2_mul(fp2_conj(qa.y), fp2_load_const(C_TW_FROB_Y1)));
+    Fp2 q1x = fp2_mul(fp2_conj(qa.x), fp2_load_const(C_TW_FROB_X1));
+    Fp2 q1y = fp2_mul(fp2_conj(qa.y), fp2_load_const(C_TW_FROB_Y1));
     add_step(t, l, q1x, q1y);
     mul_by_line(f, l, pa.x, pa.y, skip_a);
   }
   if constexpr (HAS_B) { fixed_line(l, idx++); mul_by_line(f, l, pb.x, pb.y, skip_b); }
   if constexpr (HAS_A) {
-    Fp2 q2x = fp2_norm(fp2_mul(qa.x, fp2_load_const(C_TW_FROB_X2)));
+    Fp2 q2x = fp2_mul(qa.x, fp2_load_const(C_TW_FROB_X2));
     add_step(t, l, q2x, qa.y);
     mul_by_line(f, l, pa.x, pa.y, skip_a);
   }
