@@ -75,6 +75,20 @@ struct Signature : PointBytes<64> {
     check_status(st);
     return s;
   }
+  static Signature from_compressed(const uint8_t* data, size_t len, Engine& e = Engine::default_engine()) {   // types.rs:233-237
+    if (len != 33) throw Error(ErrorKind::InvalidEncoding);
+    Signature s; uint8_t st = 0;
+    check_rc("bn254_batch_g1_decompress", bn254_batch_g1_decompress(e.raw(), data, 1, s.raw.data(), &st));
+    check_status(st);
+    return s;
+  }
+  std::array<uint8_t, 33> to_compressed() const {                  // utils.rs:84-104
+    if (is_identity()) throw Error(ErrorKind::PointInJacobian);
+    std::array<uint8_t, 33> o{};
+    o[0] = (raw[63] & 1) ? 3 : 2;
+    std::memcpy(o.data() + 1, raw.data(), 32);
+    return o;
+  }
   Signature operator+(const Signature& o) const {                  // types.rs:264-270
     Signature r; uint8_t st = 0;
     check_rc("bn254_batch_g1_add", bn254_batch_g1_add(Engine::default_engine().raw(), raw.data(), o.raw.data(), 1, r.raw.data(), &st));
@@ -95,6 +109,13 @@ struct PublicKey : PointBytes<128> {
   static PublicKey from_private_key(const PrivateKey& k, Engine& e = Engine::default_engine()) {     // types.rs:85-87
     PublicKey r; uint8_t st = 0;
     check_rc("bn254_batch_g2_mul", bn254_batch_g2_mul(e.raw(), nullptr, k.bytes.data(), 1, 1, r.raw.data(), &st));
+    check_status(st);
+    return r;
+  }
+  static PublicKey from_compressed(const uint8_t* data, size_t len, Engine& e = Engine::default_engine()) {   // types.rs:91-93
+    if (len != 65) throw Error(ErrorKind::InvalidEncoding);
+    PublicKey r; uint8_t st = 0;
+    check_rc("bn254_batch_g2_decompress", bn254_batch_g2_decompress(e.raw(), data, 1, r.raw.data(), &st));
     check_status(st);
     return r;
   }
