@@ -81,6 +81,101 @@ def measured_traffic(kernel):
         return None
 
 
+def other_workloads(args, torch, eng, dev):
+    """informational timings of configs 3-5 and of the host-buffer (PCIe-inclusive) verify; one JSON line"""
+    import numpy as np
+    from tests.datagen import KEY_POOL, make_verify_batch, sk_bytes
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps
+
+    def dev_bytes(b):
+        return torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+
+    out = {"workload": args.workload, "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "data": "synthetic"}
+    if args.workload == "verify-host":
+        n = args.batch
+        msgs, sigs, pks, expected = make_verify_batch(eng, n)
+        assert eng.batch_verify(msgs, sigs, pks) == expected
+        packed = bn254_pack(msgs)
+        st = __import__("ctypes").create_string_buffer(n)
+        lib, h = eng._lib, eng._h
+        dt = timed(lambda: lib.bn254_batch_verify(h, packed[0], packed[1], sigs, pks, n, 0, st), args.steps, args.warmup)
+        assert st.raw == expected
+        out.update(metric="BN254 pairings/sec (batch verify, host buffers: H2D + kernels + D2H + sync)", value=2 * n / dt, unit="pairings/s",
+                   ms_per_step=1e3 * dt, batch=n)
+    elif args.workload == "pairing":
+        n = args.batch if args.batch != BATCH else 1 << 19          # config 4: 4 Mi pairings over 8 GPUs
+        pool = 512
+        sc = [hashlib.sha256(b"cfg4-%d" % j).digest() for j in range(2 * pool)]
+        g1 = (1).to_bytes(32, "big") + (2).to_bytes(32, "big")
+        P, _ = eng.batch_g1_mul(g1 * pool, b"".join(sc[:pool]), pool, reduce_scalar=True)
+        Qs, _ = eng.batch_g2_mul(None, b"".join(sc[pool:]), pool, reduce_scalar=True)
+        i = np.arange(n)
+        d_g1 = torch.from_numpy(np.frombuffer(P, dtype=np.uint8).reshape(pool, 64)[(i * 7 + 3) % pool].reshape(-1).copy()).to(dev)
+        d_g2 = torch.from_numpy(np.frombuffer(Qs, dtype=np.uint8).reshape(pool, 128)[(i * 13 + 5) % pool].reshape(-1).copy()).to(dev)
+        d_gt = torch.empty(n * 384, dtype=torch.uint8, device=dev)
+        d_st = torch.empty(n, dtype=torch.uint8, device=dev)
+        eng.reserve(n)
+        dt = timed(lambda: eng.batch_pairing_device(d_g1.data_ptr(), d_g2.data_ptr(), n, 1, d_gt.data_ptr(), d_st.data_ptr(), stream=stream),
+                   args.steps, args.warmup)
+        out.update(metric="BN254 pairings/sec (independent pairings, canonical Gt out)", value=n / dt, unit="pairings/s", ms_per_step=1e3 * dt, batch=n)
+    elif args.workload == "hash":
+        n = args.batch if args.batch != BATCH else 1 << 24          # config 5: 16 Mi messages
+        g = torch.Generator(device=dev)
+        g.manual_seed(5)
+        d_msgs = torch.randint(0, 256, (n * 32,), dtype=torch.uint8, device=dev, generator=g)
+        d_off = torch.arange(0, 32 * (n + 1), 32, dtype=torch.int64, device=dev)
+        d_pts = torch.empty(n * 64, dtype=torch.uint8, device=dev)
+        d_st = torch.empty(n, dtype=torch.uint8, device=dev)
+        eng.reserve(n)
+        dt = timed(lambda: eng.batch_hash_to_g1_device(d_msgs.data_ptr(), d_off.data_ptr(), n, d_pts.data_ptr(), d_st.data_ptr(), None, stream=stream),
+                   args.steps, args.warmup)
+        assert int(d_st.max()) == 0
+        out.update(metric="hash_to_try_and_increment messages/sec", value=n / dt, unit="messages/s", ms_per_step=1e3 * dt, batch=n)
+    else:
+        n = args.batch if args.batch != BATCH else 1 << 20          # config 3: 1 Mi tuples, 1024 signers
+        M = S = 1024
+        sks = [sk_bytes(j) for j in range(S)]
+        msgs = [D("bn254/msg3", m) for m in range(M)]
+        pk_pool, _ = eng.batch_g2_mul(None, b"".join(sks), S, reduce_scalar=True)
+        sig_pool, _ = eng.batch_sign([msgs[m] for m in range(M) for _ in range(S)], b"".join(sks) * M)
+        g = torch.Generator(device=dev)
+        g.manual_seed(3)
+        tuple_msg = torch.randint(0, M, (n,), dtype=torch.int32, device=dev, generator=g)
+        counts, chunks = [], []
+        for lo in range(0, n, 1 << 17):
+            bits = torch.rand((min(1 << 17, n - lo), S), device=dev, generator=g) < 0.5
+            chunks.append(bits.nonzero()[:, 1].to(torch.int32))
+            counts.append(bits.sum(dim=1))
+        signer_idx = torch.cat(chunks)
+        tuple_off = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        tuple_off[1:] = torch.cumsum(torch.cat(counts).to(torch.int64), 0)
+        d_msgs, d_pk, d_sig = dev_bytes(b"".join(msgs)), dev_bytes(pk_pool), dev_bytes(sig_pool)
+        d_moff = torch.arange(0, 32 * (M + 1), 32, dtype=torch.int64, device=dev)
+        d_st = torch.empty(n, dtype=torch.uint8, device=dev)
+        dt = timed(lambda: eng.batch_aggregate_verify_device(d_msgs.data_ptr(), d_moff.data_ptr(), M, d_pk.data_ptr(), S, d_sig.data_ptr(),
+                                                             tuple_msg.data_ptr(), tuple_off.data_ptr(), signer_idx.data_ptr(), n, d_st.data_ptr(),
+                                                             stream=stream), args.steps, args.warmup)
+        assert int(d_st.max()) == 0
+        out.update(metric="aggregate verifies/sec (1024 signers, ~512 per tuple, pools decoded per step)", value=n / dt, unit="verifies/s",
+                   ms_per_step=1e3 * dt, batch=n, mean_signers_per_tuple=float(signer_idx.numel()) / n)
+    print(json.dumps(out))
+
+
+def bn254_pack(msgs):
+    from bn254_amd.engine import pack_messages
+    return pack_messages(msgs)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -89,6 +184,9 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH, help="tuples per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--split-miller", action="store_true", help="one pairing per lane instead of the fused 2-pair Miller loop (A/B)")
+    ap.add_argument("--workload", default="verify", choices=["verify", "verify-host", "pairing", "hash", "aggregate"],
+                    help="verify = the headline (configs[1]); the others time configs 4, 5, 3 or the host-buffer entry point "
+                         "(single GPU, informational — see DESIGN.md §4b)")
     args = ap.parse_args()
 
     import torch
@@ -111,6 +209,8 @@ def main():
     from tests.datagen import KEY_POOL, sk_bytes
 
     eng = bn254_amd.Engine(local_rank)
+    if args.workload != "verify":
+        return other_workloads(args, torch, eng, dev)
     n = args.batch
     eng.reserve(2 * n)
     if args.split_miller:

@@ -260,6 +260,21 @@ int hs_g2_msum(const uint8_t* pts, uint64_t k, uint8_t* out) {
   memcpy(out, tmp, 128);
   return st;
 }
+// deliberately unsafe sequences: the bound-tracking build must abort on them (tests/test_bounds.py)
+int hs_unsafe_sequence(int which) {
+  Fp a = fp_one(), b = fp_one();
+  if (which == 0) {                 // 40 lazy additions then a product: 10 * (41 T)^2 overflows a 64-bit column
+    for (int i = 0; i < 40; ++i) a = fp_add(a, fp_one());
+    a = fp_mul(a, a);
+  } else if (which == 1) {          // doubling 6 times: limbs leave int32
+    for (int i = 0; i < 6; ++i) a = fp_dbl(a);
+  } else {                          // xi-multiplication of an un-normalised value, twice
+    Fp2 x = fp2_one();
+    x = fp2_mul_xi(fp2_mul_xi(fp2_mul_xi(x)));
+    a = x.c0;
+  }
+  return a.v[0] + b.v[0];
+}
 // op codes as bn254_debug_fp_op
 int hs_fp_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
   alignas(4) uint8_t ta[32], tb[32], to[32];

@@ -51,6 +51,8 @@ elif which == "codec":
     o = buf(64); assert hs.hs_g1_decompress(H(k["sign"][0]["signature_compressed"]), o) == 0
     o = buf(128); assert hs.hs_g2_decompress(H(k["g2_compressed_roundtrip"]["hex"]), o) == 0
     assert hs.hs_g2_decompress(b"\x0c" + bytes(64), o) == 3
+elif which.startswith("unsafe"):
+    hs.hs_unsafe_sequence(int(which[-1]))
 elif which == "subgroup":
     v = d["verify_cases"][0]; m = H(v["message_hex"]); assert hs.hs_verify(m, len(m), H(v["sig"]), H(v["pk"]), 1) == 0
 print("ok")
@@ -66,3 +68,10 @@ def bounds_lib():
 def test_bounds_hold(bounds_lib, flow):
     p = subprocess.run([sys.executable, "-c", DRIVER, ROOT, flow], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and p.stdout.strip() == "ok", (p.stdout[-500:], p.stderr[-2000:])
+
+
+@pytest.mark.parametrize("which", [0, 1, 2])
+def test_tracker_catches_unsafe_sequences(bounds_lib, which):
+    """the checker is not vacuous: deliberately unsafe operation sequences abort with a BOUND VIOLATION"""
+    p = subprocess.run([sys.executable, "-c", DRIVER, ROOT, "unsafe%d" % which], capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "BOUND VIOLATION" in p.stderr
