@@ -209,14 +209,11 @@ struct bn_limbvec { int32_t e[16]; int32_t& operator[](int i) { return e[i]; } c
 #define BN_LIMB_VEC bn_limbvec
 #endif
 
-#define BN_COLUMN_SHIFT(acc)                                         \
-  do {                                                               \
-    uint32_t lo_ = (uint32_t)(acc);                                  \
-    int32_t hi_ = (int32_t)((acc) >> 32);                            \
-    uint32_t nlo_ = (lo_ >> BN_W) | ((uint32_t)hi_ << (32 - BN_W));  \
-    int32_t nhi_ = hi_ >> BN_W;                                      \
-    (acc) = (int64_t)(((uint64_t)(uint32_t)nhi_ << 32) | nlo_);      \
-  } while (0)
+// acc >>= 27 (arithmetic): one v_ashrrev_i64 — measured at the issue cost of a 32-bit VALU op on gfx950
+// (profiles/r01_issue_mix_microbench.jsonl), cheaper than an alignbit + ashr pair
+#define BN_COLUMN_SHIFT(acc) do { (acc) >>= BN_W; } while (0)
+
+#define BN_MAC(acc, x, y) do { (acc) += (int64_t)(x) * (y); } while (0)   // one v_mad_i64_i32 (no inline asm: it would make hipcc pad with s_nop)
 
 BN_DEVN BN_LIMB_VEC fp_mul_impl(BN_LIMB_VEC a, BN_LIMB_VEC b) {
   BN_COUNT_MUL();
@@ -351,8 +348,8 @@ BN_DEV void fp_dual_mul_reduce(int32_t* r, const int32_t* x0, const int32_t* y0,
     for (int i = 0; i < BN_LIMBS; ++i) {
       int j = k - i;
       if (j < 0 || j >= BN_LIMBS) continue;
-      acc += (int64_t)x0[i] * y0[j];
-      acc += (int64_t)x1[i] * y1[j];
+      BN_MAC(acc, x0[i], y0[j]);
+      BN_MAC(acc, x1[i], y1[j]);
     }
 #pragma unroll
     for (int i = 0; i < BN_LIMBS; ++i) {
