@@ -195,10 +195,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # test knobs (not used by the driver): run several ranks on ONE GPU over gloo to exercise the rank logic
+    backend = os.environ.get("BN254_BENCH_BACKEND", "nccl")
+    if os.environ.get("BN254_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (bn254_amd has no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -248,7 +255,10 @@ def main():
         eng.batch_verify_device(d_msgs.data_ptr(), d_off.data_ptr(), d_sigs.data_ptr(), d_pks.data_ptr(), n, d_status.data_ptr(),
                                 flags=0, stream=stream)
         if world > 1:
-            gather_status(d_status, out=d_all)               # RCCL all-gather over xGMI: the only collective
+            if backend == "nccl":
+                gather_status(d_status, out=d_all)           # RCCL all-gather over xGMI: the only collective
+            else:
+                d_all.copy_(gather_status(d_status.cpu()))   # gloo test mode: staged through the host
 
     for _ in range(args.warmup):
         step()
@@ -273,7 +283,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         assert bytes(d_all[rank * n:(rank + 1) * n].cpu().numpy()) == bytes(expected)
