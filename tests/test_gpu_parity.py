@@ -320,6 +320,51 @@ def test_fused_and_split_miller_agree(eng, derived):
         eng.set_option(OPT_SPLIT_MILLER, 0)
 
 
+def test_malformed_inputs_fuzz_vs_oracle(eng, c, derived):
+    """3000 verifies whose signature / public key bytes are valid, mutated (bit flips, coordinate >= q,
+    swapped coordinates, zeros) or random: every status byte must equal the oracle's, with and without the
+    G2 subgroup flag."""
+    from tests.datagen import make_verify_batch
+    rnd = random.Random(2024)
+    n = 3000
+    msgs, sigs, pks, _ = make_verify_batch(eng, n, corrupt_every=0)
+    sigs, pks = bytearray(sigs), bytearray(pks)
+    off_sub = H(derived["g2_not_in_subgroup"])
+    for i in range(n):
+        kind = rnd.randrange(12)
+        s, p = memoryview(sigs)[64 * i:64 * i + 64], memoryview(pks)[128 * i:128 * i + 128]
+        if kind == 0:
+            s[rnd.randrange(64)] ^= 1 << rnd.randrange(8)
+        elif kind == 1:
+            p[rnd.randrange(128)] ^= 1 << rnd.randrange(8)
+        elif kind == 2:
+            s[:32] = (Q + rnd.randrange(1000)).to_bytes(32, "big")
+        elif kind == 3:
+            j = 32 * rnd.randrange(4)
+            p[j:j + 32] = (Q + rnd.randrange(1 << 200)).to_bytes(32, "big")
+        elif kind == 4:
+            s[:] = bytes(64)
+        elif kind == 5:
+            p[:] = bytes(128)
+        elif kind == 6:
+            s[:] = bytes(rnd.randrange(256) for _ in range(64))
+        elif kind == 7:
+            p[:] = bytes(rnd.randrange(256) for _ in range(128))
+        elif kind == 8:
+            s[:32], s[32:] = bytes(s[32:]), bytes(s[:32])
+        elif kind == 9:
+            p[:] = off_sub
+        # kinds 10, 11: left valid
+    sigs, pks = bytes(sigs), bytes(pks)
+    for flags in (0, 1, 3):
+        got = eng.batch_verify(msgs, sigs, pks, flags=flags)
+        want, _ = c.batch_verify(msgs, sigs, pks, flags=flags, nthreads=8)
+        bad = [i for i in range(n) if got[i] != want[i]]
+        assert not bad, (flags, bad[:5], [(got[i], want[i]) for i in bad[:5]])
+        if flags == 0:
+            assert set(got) >= {0, 4, 6, 9}    # the corpus really exercises several status codes
+
+
 def test_pairing_check_k_pairs(eng, c):
     ps, qs = _rand_points(c, 6, b"kp")
     # e(aP, Q) * e(-aP, Q) == 1  and a 3-pair product that is not one
