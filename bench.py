@@ -30,8 +30,8 @@ CORRUPT_EVERY = 64                 # every 64th signature is wrong -> expected s
 # the host (tests/test_workcount.py keeps these in sync): Montgomery products per kernel stage.
 FP_MUL_DECODE = 19
 FP_MUL_HASH_PER_TRY = 370.3        # 371 on the first try (incl. conversions), 370 after; measured mean tries 2.12
-FP_MUL_MILLER = 12182
-FP_MUL_FINAL_EXP = 8587           # NAF exponentiations by u; incl. 12 canonicalisations for the == 1 test
+FP_MUL_MILLER = 11138
+FP_MUL_FINAL_EXP = 7507           # width-4 window exponentiations by u; incl. 12 canonicalisations for the == 1 test
 MAC32_PER_FP_MUL = 136             # ALGORITHMIC unit: an 8x32-bit Montgomery product = 2*8*8 + 8 MAC32.
 MUL_INSTR_PER_FP_MUL = 210         # what the kernels actually issue per product with 10x27-bit limbs: 200 v_mad_*64 + 10 v_mul_lo
 # VALU roofline: v_mad_u64_u32 issues once per 4 cycles per SIMD (half the 2-cycle full rate):

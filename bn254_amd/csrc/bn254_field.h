@@ -661,6 +661,21 @@ BN_DEVN void fp12_mul_line(Fp12& r, const Fp12& f, const Fp2& l0, const Fp2& l1,
   fp6_norm(r.c0, s);
   fp6_norm(r.c1, u);
 }
+// f * (b0 + b1 w): b0 a full Fq6, b1 = b10 + b11 v — the shape of a product of two lines
+BN_DEVN void fp12_mul_line2(Fp12& r, const Fp12& f, const Fp6& b0, const Fp2& b10, const Fp2& b11) {
+  Fp6 t0, t1, s, u, bs;
+  fp6_mul(t0, f.c0, b0);
+  fp6_mul_01(t1, f.c1, b10, b11);
+  fp6_add(s, f.c0, f.c1); fp6_norm(s, s);
+  bs.c0 = fp2_norm(fp2_add(b0.c0, b10)); bs.c1 = fp2_norm(fp2_add(b0.c1, b11)); bs.c2 = b0.c2;
+  fp6_mul(u, s, bs);
+  fp6_sub(u, u, t0);
+  fp6_sub(u, u, t1);
+  fp6_mul_v(s, t1);
+  fp6_add(s, t0, s);
+  fp6_norm(r.c0, s);
+  fp6_norm(r.c1, u);
+}
 // coefficient k of w^k in the polynomial basis: c[2i] = c0.c_i, c[2i+1] = c1.c_i
 BN_DEV Fp2& fp12_coef(Fp12& a, int k) {
   Fp6& h = (k & 1) ? a.c1 : a.c0;

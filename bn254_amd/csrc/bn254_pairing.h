@@ -60,6 +60,30 @@ BN_DEV void mul_by_line(Fp12& f, const LineCoef& l, const Fp& px, const Fp& py, 
   l2 = fp2_select(skip, fp2_zero(), l2);
   fp12_mul_line(f, f, l0, l1, l2);
 }
+// f <- f * lineA(pa) * lineB(pb), lineB = entry idx of the constant table (whose c2 is one).
+//   (l0 + l1 w + l2 w^3)(m0 + m1 w + w^3) =
+//     (l0 m0 + xi l2) + (l0 m1 + l1 m0) w + l1 m1 w^2 + (l0 + l2 m0) w^3 + (l1 + l2 m1) w^4
+// 5 Fq2 products for the line product and 17 for f * (5-term element), against 2 x 13.
+BN_DEV void mul_by_two_lines(Fp12& f, const LineCoef& l, const Fp& pax, const Fp& pay, bool skip_a, int idx, const Fp& pbx,
+                             const Fp& pby, bool skip_b) {
+  Fp2 l0 = fp2_mul_fp(l.c0, pay), l1 = fp2_mul_fp(l.c1, pax), l2 = l.c2;
+  l0 = fp2_select(skip_a, fp2_one(), l0);
+  l1 = fp2_select(skip_a, fp2_zero(), l1);
+  l2 = fp2_select(skip_a, fp2_zero(), l2);
+  Fp2 m0 = fp2_mul_fp(fp2_load_const(C_NEG_G2_LINES[idx][0]), pby), m1 = fp2_mul_fp(fp2_load_const(C_NEG_G2_LINES[idx][1]), pbx);
+  Fp2 v0 = fp2_mul(l0, m0), v1 = fp2_mul(l1, m1);
+  Fp2 x01 = fp2_sub(fp2_sub(fp2_mul(fp2_add(l0, l1), fp2_add(m0, m1)), v0), v1);
+  Fp2 w0 = fp2_add(v0, fp2_mul_xi(l2));
+  Fp2 w3 = fp2_add(l0, fp2_mul(l2, m0));
+  Fp2 w4 = fp2_add(l1, fp2_mul(l2, m1));
+  Fp6 b0;
+  b0.c0 = fp2_select(skip_b, l0, fp2_norm(w0));
+  b0.c1 = fp2_select(skip_b, fp2_zero(), fp2_norm(v1));
+  b0.c2 = fp2_select(skip_b, fp2_zero(), fp2_norm(w4));
+  Fp2 b10 = fp2_select(skip_b, l1, fp2_norm(x01));
+  Fp2 b11 = fp2_select(skip_b, l2, fp2_norm(w3));
+  fp12_mul_line2(f, f, b0, b10, b11);
+}
 BN_DEV void fixed_line(LineCoef& l, int idx) {
   l.c0 = fp2_load_const(C_NEG_G2_LINES[idx][0]);
   l.c1 = fp2_load_const(C_NEG_G2_LINES[idx][1]);
@@ -81,14 +105,21 @@ BN_DEVN void miller_loop(Fp12& f, const G1Affine& pa, const G2Affine& qa, const 
   bool skip_b = !HAS_B || pb.inf;
   if constexpr (HAS_A) { t.x = qa.x; t.y = qa.y; t.z = fp2_one(); qa_yneg = fp2_norm(fp2_neg(qa.y)); }
   int idx = 0;
+  constexpr bool BOTH = HAS_A && HAS_B;      // both pairs: one merged multiplication per step
   for (int d = 0; d < 64; ++d) {
     fp12_sqr(f, f);
-    if constexpr (HAS_A) { dbl_step(t, l); mul_by_line(f, l, pa.x, pa.y, skip_a); }
-    if constexpr (HAS_B) { fixed_line(l, idx++); mul_by_line(f, l, pb.x, pb.y, skip_b); }
+    if constexpr (HAS_A) { dbl_step(t, l); if constexpr (!BOTH) mul_by_line(f, l, pa.x, pa.y, skip_a); }
+    if constexpr (BOTH) mul_by_two_lines(f, l, pa.x, pa.y, skip_a, idx++, pb.x, pb.y, skip_b);
+    else if constexpr (HAS_B) { fixed_line(l, idx++); mul_by_line(f, l, pb.x, pb.y, skip_b); }
     int digit = C_ATE_NAF[d];
     if (digit != 0) {   // wave-uniform
-      if constexpr (HAS_A) { Fp2 qy = fp2_select(digit > 0, qa.y, qa_yneg); add_step(t, l, qa.x, qy); mul_by_line(f, l, pa.x, pa.y, skip_a); }
-      if constexpr (HAS_B) { fixed_line(l, idx++); mul_by_line(f, l, pb.x, pb.y, skip_b); }
+      if constexpr (HAS_A) {
+        Fp2 qy = fp2_select(digit > 0, qa.y, qa_yneg);
+        add_step(t, l, qa.x, qy);
+        if constexpr (!BOTH) mul_by_line(f, l, pa.x, pa.y, skip_a);
+      }
+      if constexpr (BOTH) mul_by_two_lines(f, l, pa.x, pa.y, skip_a, idx++, pb.x, pb.y, skip_b);
+      else if constexpr (HAS_B) { fixed_line(l, idx++); mul_by_line(f, l, pb.x, pb.y, skip_b); }
     }
   }
   // + pi(Q), - pi^2(Q)
@@ -96,30 +127,37 @@ BN_DEVN void miller_loop(Fp12& f, const G1Affine& pa, const G2Affine& qa, const 
     Fp2 q1x = fp2_mul(fp2_conj(qa.x), fp2_load_const(C_TW_FROB_X1));
     Fp2 q1y = fp2_mul(fp2_conj(qa.y), fp2_load_const(C_TW_FROB_Y1));
     add_step(t, l, q1x, q1y);
-    mul_by_line(f, l, pa.x, pa.y, skip_a);
+    if constexpr (!BOTH) mul_by_line(f, l, pa.x, pa.y, skip_a);
   }
-  if constexpr (HAS_B) { fixed_line(l, idx++); mul_by_line(f, l, pb.x, pb.y, skip_b); }
+  if constexpr (BOTH) mul_by_two_lines(f, l, pa.x, pa.y, skip_a, idx++, pb.x, pb.y, skip_b);
+  else if constexpr (HAS_B) { fixed_line(l, idx++); mul_by_line(f, l, pb.x, pb.y, skip_b); }
   if constexpr (HAS_A) {
     Fp2 q2x = fp2_mul(qa.x, fp2_load_const(C_TW_FROB_X2));
     add_step(t, l, q2x, qa.y);
-    mul_by_line(f, l, pa.x, pa.y, skip_a);
+    if constexpr (!BOTH) mul_by_line(f, l, pa.x, pa.y, skip_a);
   }
-  if constexpr (HAS_B) { fixed_line(l, idx++); mul_by_line(f, l, pb.x, pb.y, skip_b); }
+  if constexpr (BOTH) mul_by_two_lines(f, l, pa.x, pa.y, skip_a, idx++, pb.x, pb.y, skip_b);
+  else if constexpr (HAS_B) { fixed_line(l, idx++); mul_by_line(f, l, pb.x, pb.y, skip_b); }
 }
 
-// a^u for a in the cyclotomic subgroup (u = 4965661367192848881, 63 bits): signed-digit (NAF)
-// square-and-multiply, 24 multiplications instead of 28 — a^-1 is the conjugate there.
-// `acc` is caller-provided working storage (the kernels pass an LDS slot: the accumulator is read and
-// rewritten by every one of the 62 cyclotomic squarings).
+// a^u for a in the cyclotomic subgroup (u = 4965661367192848881, 63 bits): width-4 signed sliding
+// window over the odd powers a, a^3, a^5, a^7 (a^-1 is the conjugate there): 63 cyclotomic squarings
+// and 16 multiplications (3 for the table, 13 for the 14 non-zero digits) instead of the 28 of plain
+// square-and-multiply.  `acc` is caller-provided working storage (the kernels pass an LDS slot: the
+// accumulator is read and rewritten by every squaring).
 BN_DEVN void fp12_pow_u(Fp12& r, const Fp12& a, Fp12& acc) {
-  Fp12 a_inv;
-  fp12_conj(a_inv, a);
-  acc = a;
-  for (int i = 0; i < BN_U_NAF_LEN; ++i) {
+  Fp12 odd[4], t;
+  fp12_cyclotomic_sqr(t, a);
+  odd[0] = a;
+  fp12_mul(odd[1], a, t);
+  fp12_mul(odd[2], odd[1], t);
+  fp12_mul(odd[3], odd[2], t);
+  acc = odd[C_U_W4[0] >> 1];                        // leading digit is positive
+  for (int i = 1; i < BN_U_W4_LEN; ++i) {           // wave-uniform: u is a public constant
     fp12_cyclotomic_sqr(acc, acc);
-    int d = C_U_NAF[i];
-    if (d > 0) fp12_mul(acc, acc, a);
-    else if (d < 0) fp12_mul(acc, acc, a_inv);
+    int d = C_U_W4[i];
+    if (d > 0) fp12_mul(acc, acc, odd[d >> 1]);
+    else if (d < 0) { fp12_conj(t, odd[(-d) >> 1]); fp12_mul(acc, acc, t); }
   }
   r = acc;
 }

@@ -166,6 +166,13 @@ def main():
     q2 = (mul(qn[0], g_x2), qn[1])
     T, ln = add_step(T, q1); lines.append(ln)
     T, ln = add_step(T, q2); lines.append(ln)
+    # scale every line by 1/c2 (an Fq2 factor, killed by the final exponentiation) so that c2 == 1:
+    # the product of a variable line with a table line then takes 5 Fq2 products instead of 6
+    for i, ln in enumerate(lines):
+        assert ln[2] != (0, 0)
+        k = fpow(ln[2], Q * Q - 2)
+        lines[i] = (mul(ln[0], k), mul(ln[1], k), (1, 0))
+        assert mul(ln[2], k) == (1, 0)
 
     frob = {}
     for j in (1, 2, 3):
@@ -218,7 +225,23 @@ def main():
     o.append("#define BN_U_NAF_LEN %d" % len(unaf))
     o.append("BN_CONST signed char C_U_NAF[BN_U_NAF_LEN] = {%s};  /* NAF digits of u after the leading 1, MSB first (weight %d) */" %
              (", ".join(str(d) for d in unaf), sum(1 for d in unaf if d)))
-    o.append("/* line coefficients (c0 -> *yP, c1 -> *xP, c2) for Q = -G2::one(), in order of use */")
+    w4 = []
+    k = U
+    while k:
+        z = 0
+        if k & 1:
+            z = k % 16
+            if z >= 8:
+                z -= 16
+            k -= z
+        w4.append(z)
+        k >>= 1
+    w4.reverse()
+    assert sum(d << (len(w4) - 1 - i) for i, d in enumerate(w4)) == U and w4[0] > 0
+    o.append("#define BN_U_W4_LEN %d" % len(w4))
+    o.append("BN_CONST signed char C_U_W4[BN_U_W4_LEN] = {%s};  /* width-4 signed window digits of u (odd, |d| <= 7), MSB first, %d non-zero */" %
+             (", ".join(str(d) for d in w4), sum(1 for d in w4 if d)))
+    o.append("/* line coefficients (c0 -> *yP, c1 -> *xP, c2 == 1) for Q = -G2::one(), in order of use */")
     o.append("BN_CONST int32_t C_NEG_G2_LINES[BN_N_FIXED_LINES][3][2][10] = {")
     for ln in lines:
         o.append("  {%s, %s, %s}," % (c_fp2(ln[0]), c_fp2(ln[1]), c_fp2(ln[2])))
