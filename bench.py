@@ -112,6 +112,40 @@ def other_workloads(args, torch, eng, dev):
         assert st.raw == expected
         out.update(metric="BN254 pairings/sec (batch verify, host buffers: H2D + kernels + D2H + sync)", value=2 * n / dt, unit="pairings/s",
                    ms_per_step=1e3 * dt, batch=n)
+    elif args.workload == "verify-randomized":
+        # opt-in randomised batch verification against the exact path on the same inputs;
+        # generated in chunks so that the message list stays small on the host
+        n = args.batch if args.batch != BATCH else 1 << 20
+        seed = hashlib.sha256(b"bench-seed").digest()
+        chunk = 1 << 16
+        parts = [make_verify_batch(eng, min(chunk, n - lo), corrupt_every=0, tag="bn254/msgR%d" % lo) for lo in range(0, n, chunk)]
+        msgs = b"".join(b"".join(p[0]) for p in parts)
+        d_msgs, d_sigs, d_pks = dev_bytes(msgs), dev_bytes(b"".join(p[1] for p in parts)), dev_bytes(b"".join(p[2] for p in parts))
+        d_off = torch.arange(0, 32 * (n + 1), 32, dtype=torch.int64, device=dev)
+        d_st = torch.full((n,), 255, dtype=torch.uint8, device=dev)
+        d_gr = torch.zeros((n + 63) // 64, dtype=torch.uint8, device=dev)
+        eng.reserve(n + n // 64 + 512)
+        ptrs = (d_msgs.data_ptr(), d_off.data_ptr(), d_sigs.data_ptr(), d_pks.data_ptr(), n)
+        res = {}
+        for name, flags in (("rand128", 0), ("rand64", 0x100)):
+            dt = timed(lambda: eng.batch_verify_randomized_device(*ptrs, seed, d_st.data_ptr(), d_gr.data_ptr(), flags=flags, stream=stream),
+                       args.steps, args.warmup)
+            assert int(d_st.max()) == 0 and int(d_gr.min()) == 1
+            res[name] = {"verifies_per_s": n / dt, "ms_per_step": 1e3 * dt}
+        dt = timed(lambda: eng.batch_verify_device(*ptrs, d_st.data_ptr(), flags=0, stream=stream), args.steps, args.warmup)
+        assert int(d_st.max()) == 0
+        res["exact"] = {"verifies_per_s": n / dt, "ms_per_step": 1e3 * dt}
+        # worst case: one corrupted item in every group of 64 -> every group fails and is re-verified exactly
+        sig_view = d_sigs.view(n, 64)
+        saved = sig_view[63::64].clone()
+        sig_view[63::64] = sig_view[62::64]
+        dt = timed(lambda: eng.batch_verify_randomized_device(*ptrs, seed, d_st.data_ptr(), d_gr.data_ptr(), stream=stream), args.steps, args.warmup)
+        assert int(d_gr.max()) == 0 and int((d_st != 0).sum()) == n // 64 and int(d_st.view(-1)[63::64].min()) == 9
+        sig_view[63::64] = saved
+        res["rand128_every_group_fails"] = {"verifies_per_s": n / dt, "ms_per_step": 1e3 * dt}
+        out.update(metric="BN254 verifies/sec, randomised batch verification (groups of 64) vs exact, all-valid batch", unit="verifies/s",
+                   value=res["rand128"]["verifies_per_s"], ms_per_step=res["rand128"]["ms_per_step"], batch=n, modes=res,
+                   speedup_vs_exact=res["rand128"]["verifies_per_s"] / res["exact"]["verifies_per_s"])
     elif args.workload == "pairing":
         n = args.batch if args.batch != BATCH else 1 << 19          # config 4: 4 Mi pairings over 8 GPUs
         pool = 512
@@ -184,7 +218,7 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH, help="tuples per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--split-miller", action="store_true", help="one pairing per lane instead of the fused 2-pair Miller loop (A/B)")
-    ap.add_argument("--workload", default="verify", choices=["verify", "verify-host", "pairing", "hash", "aggregate"],
+    ap.add_argument("--workload", default="verify", choices=["verify", "verify-host", "verify-randomized", "pairing", "hash", "aggregate"],
                     help="verify = the headline (configs[1]); the others time configs 4, 5, 3 or the host-buffer entry point "
                          "(single GPU, informational — see DESIGN.md §4b)")
     args = ap.parse_args()

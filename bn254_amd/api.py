@@ -6,6 +6,7 @@ bn254_amd/host/bn254.hpp (C++); INTEGRATION.md holds the Rust shim a maintainer 
     ECDSA.sign(message, private_key) -> Signature               src/ecdsa.rs:26-35
     ECDSA.verify(message, signature, public_key) -> None/raise   src/ecdsa.rs:49-64
     ECDSA.batch_verify(messages, signatures, public_keys) -> [None | Error, ...]      (new)
+    ECDSA.batch_verify_randomized(messages, signatures, public_keys, seed) -> same    (new, opt-in, probabilistic)
     check_public_keys(public_key_g2, public_key_g1)              src/ecdsa.rs:78-93
     PrivateKey / PublicKey / PublicKeyG1 / Signature             src/types.rs:13,81,151,222
 
@@ -257,6 +258,22 @@ class ECDSA:
             raise Error(ErrorKind.InvalidLength)
         eng = engine or _eng()
         st = eng.batch_verify([bytes(m) for m in messages], b"".join(s.raw for s in signatures), b"".join(p.raw for p in public_keys))
+        return [None if s == 0 else Error(s) for s in st]
+
+
+    @staticmethod
+    def batch_verify_randomized(messages, signatures, public_keys, seed=None, engine=None, rand64=False):
+        """Same result shape as batch_verify through the randomised combined check (64 items per pairing
+        product, include/bn254_hip.h: bn254_batch_verify_randomized).  Errors are always exact; a None is wrong
+        with probability <= 2^-128 per group for a fresh secret `seed` (32 bytes; default os.urandom)."""
+        import os
+        n = len(messages)
+        if not (len(signatures) == n and len(public_keys) == n):
+            raise Error(ErrorKind.InvalidLength)
+        eng = engine or _eng()
+        st, _ = eng.batch_verify_randomized([bytes(m) for m in messages], b"".join(s.raw for s in signatures),
+                                            b"".join(p.raw for p in public_keys), seed if seed is not None else os.urandom(32),
+                                            flags=_engine.FLAG_RAND64 if rand64 else 0)
         return [None if s == 0 else Error(s) for s in st]
 
 

@@ -136,6 +136,58 @@ template <class F> BN_DEVN void jac_mul(Jac<F>& r, const Jac<F>& p, const uint32
   r = acc;
 }
 
+// P + Q for operands known to satisfy P != +-Q unless one of them is the identity (add-2007-bl without
+// the doubling / cancellation overrides of jac_add, which cost a jac_dbl per call).
+template <class F> BN_DEVN void jac_add_distinct(Jac<F>& r, const Jac<F>& p, const Jac<F>& q) {
+  F z1z1 = f_norm(f_sqr(p.z)), z2z2 = f_norm(f_sqr(q.z));
+  F u1 = f_mul(p.x, z2z2), u2 = f_mul(q.x, z1z1);
+  F s1 = f_mul(f_norm(f_mul(p.y, q.z)), z2z2), s2 = f_mul(f_norm(f_mul(q.y, p.z)), z1z1);
+  F h = f_norm(f_sub(u2, u1)), i = f_norm(f_sqr(f_dbl(h))), j = f_mul(h, i);
+  F rr = f_norm(f_dbl(f_sub(s2, s1))), v = f_mul(u1, i);
+  Jac<F> o;
+  o.x = f_norm(f_sub(f_sub(f_sqr(rr), j), f_dbl(v)));
+  o.y = f_norm(f_sub(f_mul(rr, f_norm(f_sub(v, o.x))), f_dbl(f_mul(s1, j))));
+  o.z = f_mul(f_norm(f_sub(f_sub(f_sqr(f_add(p.z, q.z)), z1z1), z2z2)), h);
+  bool p_inf = f_is_zero(p.z), q_inf = f_is_zero(q.z);
+  jac_select(o, q_inf, p, o);
+  jac_select(o, p_inf, q, o);
+  r = o;
+}
+
+// k * P for a per-lane scalar k < 2^(32*WORDS) (WORDS <= 4 little-endian words) and P in a group of prime
+// order r > 2^253 (G1: cofactor 1): signed fixed 4-bit windows (digits in [-8, 8]) over the table P..8P,
+// 32*WORDS doublings + 8*WORDS+1 additions with identical control flow in every lane.  While a window is added
+// the accumulator is 16 * (a prefix < 2^125) * P, never +-(digit * P) with digit <= 8 unless it is
+// the identity, so the additions cannot hit the doubling case and jac_add_distinct applies.
+// Used by the randomised batch verification (r_i * H(m_i), r_i * sig_i).
+template <int WORDS, class F> BN_DEVN void jac_mul_window(Jac<F>& r, const Affine<F>& p, const uint32_t* k) {
+  constexpr int NW = 8 * WORDS;
+  Jac<F> tab[8], acc, t;
+  jac_from_affine(tab[0], p);
+  jac_dbl(tab[1], tab[0]);
+  for (int j = 2; j < 8; ++j) jac_add_distinct(tab[j], tab[j - 1], tab[0]);
+  signed char digit[NW + 1];
+  int carry = 0;
+  for (int j = 0; j < NW; ++j) {
+    int v = (int)((k[j >> 3] >> (4 * (j & 7))) & 15u) + carry;
+    carry = v > 8;
+    digit[j] = (signed char)(v - 16 * carry);
+  }
+  digit[NW] = (signed char)carry;
+  jac_set_identity(acc);
+  for (int j = NW; j >= 0; --j) {
+    if (j != NW) { jac_dbl(acc, acc); jac_dbl(acc, acc); jac_dbl(acc, acc); jac_dbl(acc, acc); }
+    int d = digit[j], m = d < 0 ? -d : d;
+    jac_set_identity(t);
+    for (int e = 0; e < 8; ++e) jac_select(t, m == e + 1, tab[e], t);
+    t.y = f_select(d < 0, f_norm(f_neg(t.y)), t.y);
+    jac_add_distinct(acc, acc, t);
+  }
+  r = acc;
+}
+template <class F> BN_DEV void jac_mul_u128(Jac<F>& r, const Affine<F>& p, const uint32_t* k) { jac_mul_window<4>(r, p, k); }
+template <class F> BN_DEV void jac_mul_u64(Jac<F>& r, const Affine<F>& p, const uint32_t* k) { jac_mul_window<2>(r, p, k); }
+
 template <class F> BN_DEVN void jac_to_affine(Affine<F>& r, const Jac<F>& p) {
   bool inf = f_is_zero(p.z);
   F zi = f_norm(f_inv(p.z)), zi2 = f_norm(f_sqr(zi));

@@ -119,4 +119,22 @@ BN_DEV bool hash_try(G1Affine& out, const HashState& s, const uint8_t* msg, uint
   return true;
 }
 
+// Scalar of item i for the randomised batch verification (include/bn254_hip.h:
+// bn254_batch_verify_randomized): the first 16 bytes (rand64: 8) of SHA-256(seed || le64(i)) read as a
+// little-endian integer, 0 replaced by 1.  seed_be = the 32 seed bytes as big-endian words.
+BN_DEV void rand_scalar(uint32_t* k, const uint32_t* seed_be, uint64_t i, bool rand64) {
+  uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+  uint32_t blk[16];
+  for (int j = 0; j < 8; ++j) blk[j] = seed_be[j];
+  blk[8] = __builtin_bswap32((uint32_t)i);
+  blk[9] = __builtin_bswap32((uint32_t)(i >> 32));
+  blk[10] = 0x80000000u;
+  for (int j = 11; j < 15; ++j) blk[j] = 0;
+  blk[15] = 40 * 8;
+  sha256_compress(h, blk);
+  k[0] = __builtin_bswap32(h[0]); k[1] = __builtin_bswap32(h[1]);
+  k[2] = rand64 ? 0u : __builtin_bswap32(h[2]); k[3] = rand64 ? 0u : __builtin_bswap32(h[3]);
+  if ((k[0] | k[1] | k[2] | k[3]) == 0) k[0] = 1;
+}
+
 }  // namespace bn254

@@ -28,6 +28,7 @@ using namespace bn254;
 
 #define BN_WAVE 64
 #define BN_SPLIT_MAX_N ((size_t)98304)   // <= 1.5 waves per SIMD with one lane per verify
+#define RAND_TWO_PER_LANE_MIN_N ((size_t)131072)   // randomised verify: two items per lane once that still fills 1024 SIMDs
 // Register budget: amdgpu_waves_per_eu(W, W) on the kernels is propagated to every device function
 // they call (AMDGPU attributor), capping VGPR+AGPR at 512/W so that W waves fit on each SIMD.
 // In a pure-VALU microbenchmark two co-resident waves each keep the full single-wave issue rate
@@ -61,7 +62,7 @@ struct Ws {
 #define HASH_CAND_CAP ((size_t)1 << 18)        // speculative lanes per round (262 144)
 #define HASH_TARGET_LANES ((size_t)1 << 17)    // ~2 waves per SIMD
 enum { PL_P1X = 0, PL_P1Y, PL_QX0, PL_QX1, PL_QY0, PL_QY1, PL_P2X, PL_P2Y, PL_HASHX, PL_HASHY, PL_F0, N_PLANES = PL_F0 + 12 };
-enum { BY_ST_DECODE = 0, BY_ST_HASH, BY_P1_INF, BY_Q_INF, BY_P2_INF, N_BYTE_PLANES };
+enum { BY_ST_DECODE = 0, BY_ST_HASH, BY_P1_INF, BY_Q_INF, BY_P2_INF, BY_A_INF, N_BYTE_PLANES };
 
 __device__ __forceinline__ Fp ws_load_fp(const Ws& ws, int plane, size_t i) {
   Fp r;
@@ -240,9 +241,12 @@ KERNEL_SMALL void k_hash_resolve(Ws ws, int round, uint32_t width, uint32_t max_
 
 // ECDSA::verify Miller loop: f = miller(H(m), pk) * miller(sig, -G2)   (ecdsa.rs:53-57)
 // P1 planes hold sig, P2 planes hold H(m), Q planes hold pk.
-KERNEL void k_miller_verify(size_t n, Ws ws) {
+// With `map` (randomised batch verification, exact re-check of failed groups) lane j works on item
+// map[j] for j < *count and leaves at once otherwise.
+KERNEL void k_miller_verify(size_t n, Ws ws, const uint32_t* map, const uint32_t* count) {
   size_t i = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
   if (i >= n) return;
+  if (map) { if (i >= *count) return; i = map[i]; }
   G1Affine sig, h;
   G2Affine pk;
   ws_load_g1(ws, PL_P1X, BY_P1_INF, i, sig);
@@ -314,18 +318,21 @@ KERNEL void k_miller_cpk(size_t n, Ws ws) {
 // item i: product of the k Miller values f[i*k .. i*k+k), final exponentiation, compare with one.
 // status = first decode error among its pairs, else hash error (if use_hash), else 0 / 9.
 KERNEL void k_final_exp(size_t n, size_t k, size_t item_stride, size_t pair_stride, Ws ws, int use_hash, uint8_t* gt_out, uint8_t* status_out,
-                        int raw_only) {
+                        int raw_only, size_t base, const uint32_t* map, const uint32_t* count) {
   size_t i = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
   if (i >= n) return;
+  if (map) { if (i >= *count) return; i = map[i]; }   // see k_miller_verify
+  // `base`: the factors of item i start at workspace index base + i*item_stride (the per-group values of the
+  // randomised batch verification live behind the per-item region); outputs are indexed by i
   // factor j of item i sits at workspace index i*item_stride + j*pair_stride:
   //   pairing API  (k adjacent pairs per item): item_stride = k, pair_stride = 1
   //   split verify (f_A at i, f_B at half + i):  item_stride = 1, pair_stride = half
   // every factor slot carries its own decode status (slots of the B half hold 0)
   Fp12 f, g;
-  ws_load_f12(ws, i * item_stride, f);
-  uint8_t st = ws_byte(ws, BY_ST_DECODE, i * item_stride);
+  ws_load_f12(ws, base + i * item_stride, f);
+  uint8_t st = ws_byte(ws, BY_ST_DECODE, base + i * item_stride);
   for (size_t j = 1; j < k; ++j) {
-    size_t idx = i * item_stride + j * pair_stride;
+    size_t idx = base + i * item_stride + j * pair_stride;
     ws_load_f12(ws, idx, g);
     fp12_mul(f, f, g);
     uint8_t sj = ws_byte(ws, BY_ST_DECODE, idx);
@@ -336,6 +343,131 @@ KERNEL void k_final_exp(size_t n, size_t k, size_t item_stride, size_t pair_stri
   if (!raw_only) final_exponentiation(f, f, lds_acc[threadIdx.x].v);
   if (gt_out) encode_fp12(gt_out + 384 * i, f);
   if (status_out) status_out[i] = st != ST_OK ? st : (fp12_is_one(f) ? (uint8_t)ST_OK : (uint8_t)ST_VERIFICATION_FAILED);
+}
+
+// ------------------------------------------------------------------------------------------
+// Randomised batch verification: groups of 64 items = one wave.
+//   group passes  <=>  prod_i e(r_i H(m_i), pk_i) * e(sum_i r_i sig_i, -G2) == 1   over its valid items
+// N + N/64 Miller loops and N/64 final exponentiations instead of 2N and N.
+//   k_rand_scale  : A_i = r_i H(m_i) (affine, HASH planes), S_g = sum_i r_i sig_i (wave reduction in LDS)
+//   k_miller_rand : f_i = miller(A_i, pk_i), F_g = prod_i f_i (wave reduction in LDS)
+//   k_rand_tail   : F_g * miller(S_g, -G2)  ->  k_final_exp  ->  one byte per group
+//   k_rand_collect: statuses of passing groups; items of failing groups are queued for the exact kernels
+// Per-group values live at workspace index gbase + g, behind the per-item region.
+// ------------------------------------------------------------------------------------------
+struct Seed { uint32_t w[8]; };
+struct G1JacSlot { G1Jac v; int32_t pad; };   // 31 words: odd stride, no LDS bank conflicts
+
+KERNEL void k_rand_scale(size_t n, Ws ws, Seed seed, int rand64, size_t gbase) {
+  const unsigned t = threadIdx.x;
+  size_t i = (size_t)blockIdx.x * BN_WAVE + t;
+  const bool live = i < n;                       // no early return: every lane reaches the barriers
+  const size_t ii = live ? i : n - 1;
+  if (blockIdx.x == 0 && t == 0) ws.h_cnt[0] = 0;   // queue length of k_rand_collect (hash rounds are done)
+  G1Affine sig, h;
+  ws_load_g1(ws, PL_P1X, BY_P1_INF, ii, sig);
+  ws_load_g1(ws, PL_P2X, BY_P2_INF, ii, h);
+  const bool valid = live && ws_byte(ws, BY_ST_DECODE, ii) == ST_OK && ws_byte(ws, BY_ST_HASH, ii) == ST_OK;
+  uint32_t k[4];
+  rand_scalar(k, seed.w, (uint64_t)ii, rand64 != 0);
+  G1Jac a, sj, id;
+  if (rand64) jac_mul_u64(a, h, k); else jac_mul_u128(a, h, k);   // wave-uniform
+  G1Affine aa;
+  jac_to_affine(aa, a);
+  aa.inf = aa.inf || !valid;
+  if (live) ws_store_g1(ws, PL_HASHX, BY_A_INF, i, aa);
+  if (rand64) jac_mul_u64(sj, sig, k); else jac_mul_u128(sj, sig, k);
+  jac_set_identity(id);
+  jac_select(sj, !valid, id, sj);
+  __shared__ G1JacSlot lds_s[BN_WAVE];
+  lds_s[t].v = sj;
+  __syncthreads();
+  for (unsigned stride = BN_WAVE / 2; stride >= 1; stride >>= 1) {
+    if (t < stride) jac_add(lds_s[t].v, lds_s[t].v, lds_s[t + stride].v);
+    __syncthreads();
+  }
+  if (t == 0) {
+    G1Affine sa;
+    jac_to_affine(sa, lds_s[0].v);
+    ws_store_g1(ws, PL_P1X, BY_P1_INF, gbase + blockIdx.x, sa);
+    ws_byte(ws, BY_ST_DECODE, gbase + blockIdx.x) = ST_OK;
+  }
+}
+KERNEL void k_miller_rand(size_t n, Ws ws, size_t gbase) {
+  const unsigned t = threadIdx.x;
+  size_t i = (size_t)blockIdx.x * BN_WAVE + t;
+  const bool live = i < n;
+  const size_t ii = live ? i : n - 1;
+  G1Affine a;
+  G2Affine pk;
+  ws_load_g1(ws, PL_HASHX, BY_A_INF, ii, a);
+  if (!live) a.inf = true;
+  ws_load_g2(ws, ii, pk);
+  __shared__ Fp12Slot lds_f[BN_WAVE];
+  Fp12& f = lds_f[t].v;
+  miller_loop<true, false>(f, a, pk, a);
+  __syncthreads();
+  for (unsigned stride = BN_WAVE / 2; stride >= 1; stride >>= 1) {
+    if (t < stride) fp12_mul(f, f, lds_f[t + stride].v);
+    __syncthreads();
+  }
+  if (t == 0) ws_store_f12(ws, gbase + blockIdx.x, f);
+}
+// The same with TWO items per lane sharing f (one f^2 per loop step for both, merged line products): lanes
+// [32h, 32h+32) of block b hold group 2b+h, lane t of a half the items 2t and 2t+1 of its group.  Used when the
+// batch still fills the device at two items per lane.
+KERNEL void k_miller_rand2(size_t n, size_t n_groups, Ws ws, size_t gbase) {
+  const unsigned t = threadIdx.x, th = t & 31u;
+  const size_t group = (size_t)blockIdx.x * 2 + (t >> 5);
+  const size_t i0 = group * BN_WAVE + 2 * th, i1 = i0 + 1;
+  G1Affine a0, a1;
+  G2Affine pk0, pk1;
+  const size_t j0 = i0 < n ? i0 : n - 1, j1 = i1 < n ? i1 : n - 1;
+  ws_load_g1(ws, PL_HASHX, BY_A_INF, j0, a0);
+  ws_load_g1(ws, PL_HASHX, BY_A_INF, j1, a1);
+  if (i0 >= n) a0.inf = true;
+  if (i1 >= n) a1.inf = true;
+  ws_load_g2(ws, j0, pk0);
+  ws_load_g2(ws, j1, pk1);
+  __shared__ Fp12Slot lds_f[BN_WAVE];
+  Fp12& f = lds_f[t].v;
+  miller_loop_2var(f, a0, pk0, a1, pk1);
+  __syncthreads();
+  for (unsigned stride = 16; stride >= 1; stride >>= 1) {
+    if (th < stride) fp12_mul(f, f, lds_f[t + stride].v);
+    __syncthreads();
+  }
+  if (th == 0 && group < n_groups) ws_store_f12(ws, gbase + group, f);
+}
+KERNEL void k_rand_tail(size_t n_groups, Ws ws, size_t gbase) {
+  size_t g = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
+  if (g >= n_groups) return;
+  G1Affine s, unused_g1;
+  G2Affine unused_g2;
+  ws_load_g1(ws, PL_P1X, BY_P1_INF, gbase + g, s);
+  g1_set_generator(unused_g1);
+  g2_set_generator(unused_g2);
+  Fp12 fg;
+  ws_load_f12(ws, gbase + g, fg);
+  __shared__ Fp12Slot lds_f[BN_WAVE];
+  Fp12& f = lds_f[threadIdx.x].v;
+  miller_loop<false, true>(f, unused_g1, unused_g2, s);
+  fp12_mul(f, f, fg);
+  ws_store_f12(ws, gbase + g, f);
+}
+KERNEL_SMALL void k_rand_collect(size_t n, Ws ws, const uint8_t* group_st, uint8_t* status_out, uint8_t* group_ok_out) {
+  size_t i = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
+  if (i >= n) return;
+  uint8_t st = ws_byte(ws, BY_ST_DECODE, i);
+  if (st == ST_OK) st = ws_byte(ws, BY_ST_HASH, i);
+  const bool ok = group_st[i / BN_WAVE] == ST_OK;
+  if (ok || st != ST_OK) {
+    status_out[i] = st;
+  } else {
+    uint32_t pos = atomicAdd(&ws.h_cnt[0], 1u);
+    ws.h_list[pos] = (uint32_t)i;
+  }
+  if (group_ok_out && threadIdx.x == 0) group_ok_out[i / BN_WAVE] = ok ? 1 : 0;
 }
 
 // out[i] = a[i] + b[i]
@@ -640,6 +772,7 @@ struct bn254_ctx {
   int split_miller;  // A/B knob: one pairing per lane (k_miller_verify_split) instead of the fused 2-pair loop
   Pool pool[3];       // aggregate verify: pk pool, sig pool, H(m) pool (grown on demand)
   size_t pool_fp[3];  // coordinates per entry: 4, 2, 2
+  int rand_items_per_lane; // randomised verify: 0 = by batch size, 1 or 2 forced (A/B and tests)
   int hash_max_tries; // test knob: counters tried before HashToPointError (0 = the reference's 255)
   hipEvent_t ev[5];
   int ev_valid;
@@ -793,6 +926,7 @@ int bn254_ctx_set_profiling(bn254_ctx* c, int enabled) {
 int bn254_ctx_set_option(bn254_ctx* c, int option, int value) {
   if (!c) return BN254_E_BAD_ARGUMENT;
   if (option == BN254_OPT_SPLIT_MILLER) { c->split_miller = value; return 0; }
+  if (option == BN254_OPT_RAND_ITEMS_PER_LANE) { if (value < 0 || value > 2) return BN254_E_BAD_ARGUMENT; c->rand_items_per_lane = value; return 0; }
   if (option == BN254_OPT_HASH_MAX_TRIES) { if (value < 0 || value > 255) return BN254_E_BAD_ARGUMENT; c->hash_max_tries = value; return 0; }
   return BN254_E_BAD_ARGUMENT;
 }
@@ -828,11 +962,11 @@ int bn254_batch_verify_device(bn254_ctx* c, const uint8_t* d_msgs, const uint64_
   if (split) {
     k_miller_verify_split<<<2 * g, BN_WAVE, 0, s>>>(n, c->ws.stride / 2, g, c->ws);
     PROF_MARK(3);
-    k_final_exp<<<g, BN_WAVE, 0, s>>>(n, 2, 1, c->ws.stride / 2, c->ws, 1, nullptr, d_status, 0);
+    k_final_exp<<<g, BN_WAVE, 0, s>>>(n, 2, 1, c->ws.stride / 2, c->ws, 1, nullptr, d_status, 0, 0, nullptr, nullptr);
   } else {
-    k_miller_verify<<<g, BN_WAVE, 0, s>>>(n, c->ws);
+    k_miller_verify<<<g, BN_WAVE, 0, s>>>(n, c->ws, nullptr, nullptr);
     PROF_MARK(3);
-    k_final_exp<<<g, BN_WAVE, 0, s>>>(n, 1, 1, 1, c->ws, 1, nullptr, d_status, 0);
+    k_final_exp<<<g, BN_WAVE, 0, s>>>(n, 1, 1, 1, c->ws, 1, nullptr, d_status, 0, 0, nullptr, nullptr);
   }
   PROF_MARK(4);
   if (c->profiling) c->ev_valid = 1;
@@ -854,6 +988,69 @@ int bn254_batch_verify(bn254_ctx* c, const uint8_t* msgs, const uint64_t* off, c
   if ((rc = stage_reserve(c, 4, n))) return rc;
   if ((rc = bn254_batch_verify_device(c, c->stage[0], (const uint64_t*)c->stage[1], c->stage[2], c->stage[3], n, flags, c->stage[4], nullptr))) return rc;
   if ((rc = stage_out(c, 4, status, n))) return rc;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int bn254_batch_verify_randomized_device(bn254_ctx* c, const uint8_t* d_msgs, const uint64_t* d_off, const uint8_t* d_sigs,
+                                         const uint8_t* d_pks, size_t n, uint32_t flags, const uint8_t* seed32, uint8_t* d_status,
+                                         uint8_t* d_group_ok, void* stream) {
+  if (!c || !seed32 || (n && (!d_msgs || !d_off || !d_sigs || !d_pks || !d_status))) return BN254_E_BAD_ARGUMENT;
+  if (n == 0) return 0;
+  if (n > 0xFFFFFFFFu) return BN254_E_BAD_ARGUMENT;
+  if (misaligned(d_sigs) || misaligned(d_pks) || ((uintptr_t)d_off & 7u)) return BN254_E_MISALIGNED;
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t n_groups = (n + BN_WAVE - 1) / BN_WAVE;
+  const size_t gbase = (n + 255) & ~(size_t)255;
+  int rc = ws_reserve(c, gbase + n_groups);
+  if (rc) return rc;
+  hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  Seed seed;
+  for (int j = 0; j < 8; ++j)
+    seed.w[j] = ((uint32_t)seed32[4 * j] << 24) | ((uint32_t)seed32[4 * j + 1] << 16) | ((uint32_t)seed32[4 * j + 2] << 8) | seed32[4 * j + 3];
+  const unsigned g = grid_for(n), gg = grid_for(n_groups);
+  const uint32_t dflags = flags & (BN254_FLAG_G2_SUBGROUP_CHECK | BN254_FLAG_REJECT_IDENTITY);
+  uint8_t* d_group_st = c->ws.h_next;            // free once the hash rounds are done; n_groups <= stride
+  PROF_MARK(0);
+  k_decode_g1<<<g, BN_WAVE, 0, s>>>(d_sigs, n, dflags, c->ws, PL_P1X, BY_P1_INF, 0);
+  k_decode_g2<<<g, BN_WAVE, 0, s>>>(d_pks, n, dflags, c->ws, 1);
+  PROF_MARK(1);
+  if ((rc = launch_hash_rounds(c, s, d_msgs, d_off, n, PL_P2X, BY_P2_INF, nullptr))) return rc;
+  PROF_MARK(2);
+  k_rand_scale<<<g, BN_WAVE, 0, s>>>(n, c->ws, seed, (flags & BN254_FLAG_RAND64) ? 1 : 0, gbase);
+  const bool two = c->rand_items_per_lane ? c->rand_items_per_lane == 2 : n >= RAND_TWO_PER_LANE_MIN_N;
+  if (two) k_miller_rand2<<<(unsigned)((n_groups + 1) / 2), BN_WAVE, 0, s>>>(n, n_groups, c->ws, gbase);
+  else k_miller_rand<<<g, BN_WAVE, 0, s>>>(n, c->ws, gbase);
+  PROF_MARK(3);
+  k_rand_tail<<<gg, BN_WAVE, 0, s>>>(n_groups, c->ws, gbase);
+  k_final_exp<<<gg, BN_WAVE, 0, s>>>(n_groups, 1, 1, 1, c->ws, 0, nullptr, d_group_st, 0, gbase, nullptr, nullptr);
+  k_rand_collect<<<g, BN_WAVE, 0, s>>>(n, c->ws, d_group_st, d_status, d_group_ok);
+  // exact per-item check of the items of failed groups (none queued: both kernels leave at once)
+  k_miller_verify<<<g, BN_WAVE, 0, s>>>(n, c->ws, c->ws.h_list, c->ws.h_cnt);
+  k_final_exp<<<g, BN_WAVE, 0, s>>>(n, 1, 1, 1, c->ws, 1, nullptr, d_status, 0, 0, c->ws.h_list, c->ws.h_cnt);
+  PROF_MARK(4);
+  if (c->profiling) c->ev_valid = 1;
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int bn254_batch_verify_randomized(bn254_ctx* c, const uint8_t* msgs, const uint64_t* off, const uint8_t* sigs, const uint8_t* pks, size_t n,
+                                  uint32_t flags, const uint8_t* seed32, uint8_t* status, uint8_t* group_ok) {
+  if (!c || !seed32 || (n && (!off || !sigs || !pks || !status))) return BN254_E_BAD_ARGUMENT;
+  if (n == 0) return 0;
+  HIP_TRY(hipSetDevice(c->device));
+  size_t msg_bytes = (size_t)off[n], n_groups = (n + BN_WAVE - 1) / BN_WAVE;
+  int rc;
+  if ((rc = stage_in(c, 0, msgs, msg_bytes))) return rc;
+  if ((rc = stage_in(c, 1, off, (n + 1) * sizeof(uint64_t)))) return rc;
+  if ((rc = stage_in(c, 2, sigs, n * 64))) return rc;
+  if ((rc = stage_in(c, 3, pks, n * 128))) return rc;
+  if ((rc = stage_reserve(c, 4, n))) return rc;
+  if ((rc = stage_reserve(c, 5, n_groups))) return rc;
+  if ((rc = bn254_batch_verify_randomized_device(c, c->stage[0], (const uint64_t*)c->stage[1], c->stage[2], c->stage[3], n, flags, seed32,
+                                                 c->stage[4], c->stage[5], nullptr))) return rc;
+  if ((rc = stage_out(c, 4, status, n))) return rc;
+  if (group_ok && (rc = stage_out(c, 5, group_ok, n_groups))) return rc;
   HIP_TRY(hipStreamSynchronize(c->stream));
   return 0;
 }
@@ -905,7 +1102,7 @@ static int pairing_device(bn254_ctx* c, const uint8_t* d_g1, const uint8_t* d_g2
   k_decode_g1<<<grid_for(lanes), BN_WAVE, 0, s>>>(d_g1, lanes, flags, c->ws, PL_P1X, BY_P1_INF, 0);
   k_decode_g2<<<grid_for(lanes), BN_WAVE, 0, s>>>(d_g2, lanes, flags, c->ws, 1);
   k_miller_var<<<grid_for(lanes), BN_WAVE, 0, s>>>(lanes, c->ws);
-  k_final_exp<<<grid_for(n), BN_WAVE, 0, s>>>(n, k, k, 1, c->ws, 0, d_gt, d_status, raw_only);
+  k_final_exp<<<grid_for(n), BN_WAVE, 0, s>>>(n, k, k, 1, c->ws, 0, d_gt, d_status, raw_only, 0, nullptr, nullptr);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -956,7 +1153,7 @@ int bn254_batch_check_public_keys(bn254_ctx* c, const uint8_t* pk_g2, const uint
   k_decode_g2<<<g, BN_WAVE, 0, s>>>(c->stage[0], n, flags, c->ws, 0);       // ecdsa.rs:82: pk_g2 first
   k_decode_g1<<<g, BN_WAVE, 0, s>>>(c->stage[1], n, flags, c->ws, PL_P1X, BY_P1_INF, 1);
   k_miller_cpk<<<g, BN_WAVE, 0, s>>>(n, c->ws);
-  k_final_exp<<<g, BN_WAVE, 0, s>>>(n, 1, 1, 1, c->ws, 0, nullptr, c->stage[2], 0);
+  k_final_exp<<<g, BN_WAVE, 0, s>>>(n, 1, 1, 1, c->ws, 0, nullptr, c->stage[2], 0, 0, nullptr, nullptr);
   HIP_TRY(hipGetLastError());
   if ((rc = stage_out(c, 2, status, n))) return rc;
   HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1100,8 +1297,8 @@ int bn254_batch_aggregate_verify_device(bn254_ctx* c, const uint8_t* d_msgs, con
   if ((rc = launch_hash_rounds(c, s, d_msgs, d_msg_off, n_msgs, PL_P2X, BY_P2_INF, nullptr))) return rc;
   k_hash_to_pool<<<grid_for(n_msgs), BN_WAVE, 0, s>>>(n_msgs, c->ws, c->pool[2]);
   k_aggregate<<<grid_for(n), BN_WAVE, 0, s>>>(d_tuple_msg, d_tuple_off, d_signer_idx, n, n_signers, c->pool[0], c->pool[1], c->pool[2], c->ws);
-  k_miller_verify<<<grid_for(n), BN_WAVE, 0, s>>>(n, c->ws);
-  k_final_exp<<<grid_for(n), BN_WAVE, 0, s>>>(n, 1, 1, 1, c->ws, 1, nullptr, d_status, 0);
+  k_miller_verify<<<grid_for(n), BN_WAVE, 0, s>>>(n, c->ws, nullptr, nullptr);
+  k_final_exp<<<grid_for(n), BN_WAVE, 0, s>>>(n, 1, 1, 1, c->ws, 1, nullptr, d_status, 0, 0, nullptr, nullptr);
   HIP_TRY(hipGetLastError());
   return 0;
 }

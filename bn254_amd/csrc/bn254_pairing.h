@@ -140,6 +140,60 @@ BN_DEVN void miller_loop(Fp12& f, const G1Affine& pa, const G2Affine& qa, const 
   else if constexpr (HAS_B) { fixed_line(l, idx++); mul_by_line(f, l, pb.x, pb.y, skip_b); }
 }
 
+// f <- f * lineA(pa) * lineC(pc) for two variable lines: 6 Fq2 products for the line product (Karatsuba over
+// the three coefficients) + 17 for f * (5-term element), against 2 x 13 one line at a time.
+BN_DEV void mul_by_two_var_lines(Fp12& f, const LineCoef& la, const Fp& pax, const Fp& pay, bool skip_a, const LineCoef& lc, const Fp& pcx,
+                                 const Fp& pcy, bool skip_c) {
+  Fp2 l0 = fp2_mul_fp(la.c0, pay), l1 = fp2_mul_fp(la.c1, pax), l2 = la.c2;
+  l0 = fp2_select(skip_a, fp2_one(), l0);
+  l1 = fp2_select(skip_a, fp2_zero(), l1);
+  l2 = fp2_select(skip_a, fp2_zero(), l2);
+  Fp2 m0 = fp2_mul_fp(lc.c0, pcy), m1 = fp2_mul_fp(lc.c1, pcx), m2 = lc.c2;
+  m0 = fp2_select(skip_c, fp2_one(), m0);
+  m1 = fp2_select(skip_c, fp2_zero(), m1);
+  m2 = fp2_select(skip_c, fp2_zero(), m2);
+  Fp2 v0 = fp2_mul(l0, m0), v1 = fp2_mul(l1, m1), v2 = fp2_mul(l2, m2);
+  Fp2 x01 = fp2_sub(fp2_sub(fp2_mul(fp2_add(l0, l1), fp2_add(m0, m1)), v0), v1);
+  Fp2 x02 = fp2_sub(fp2_sub(fp2_mul(fp2_add(l0, l2), fp2_add(m0, m2)), v0), v2);
+  Fp2 x12 = fp2_sub(fp2_sub(fp2_mul(fp2_add(l1, l2), fp2_add(m1, m2)), v1), v2);
+  Fp6 b0;
+  b0.c0 = fp2_norm(fp2_add(v0, fp2_mul_xi(v2)));
+  b0.c1 = fp2_norm(v1);
+  b0.c2 = fp2_norm(x12);
+  fp12_mul_line2(f, f, b0, fp2_norm(x01), fp2_norm(x02));
+}
+
+// Miller loop over two pairs with variable twist points sharing f (randomised batch verification: two
+// items per lane).  A pair with an identity member contributes 1.
+BN_DEVN void miller_loop_2var(Fp12& f, const G1Affine& pa, const G2Affine& qa, const G1Affine& pc, const G2Affine& qc) {
+  fp12_set_one(f);
+  G2Proj ta, tc;
+  LineCoef la, lc;
+  const bool skip_a = pa.inf || qa.inf, skip_c = pc.inf || qc.inf;
+  ta.x = qa.x; ta.y = qa.y; ta.z = fp2_one();
+  tc.x = qc.x; tc.y = qc.y; tc.z = fp2_one();
+  const Fp2 qa_yneg = fp2_norm(fp2_neg(qa.y)), qc_yneg = fp2_norm(fp2_neg(qc.y));
+  for (int d = 0; d < 64; ++d) {
+    fp12_sqr(f, f);
+    dbl_step(ta, la);
+    dbl_step(tc, lc);
+    mul_by_two_var_lines(f, la, pa.x, pa.y, skip_a, lc, pc.x, pc.y, skip_c);
+    int digit = C_ATE_NAF[d];
+    if (digit != 0) {   // wave-uniform
+      add_step(ta, la, qa.x, fp2_select(digit > 0, qa.y, qa_yneg));
+      add_step(tc, lc, qc.x, fp2_select(digit > 0, qc.y, qc_yneg));
+      mul_by_two_var_lines(f, la, pa.x, pa.y, skip_a, lc, pc.x, pc.y, skip_c);
+    }
+  }
+  const Fp2 gx1 = fp2_load_const(C_TW_FROB_X1), gy1 = fp2_load_const(C_TW_FROB_Y1), gx2 = fp2_load_const(C_TW_FROB_X2);
+  add_step(ta, la, fp2_mul(fp2_conj(qa.x), gx1), fp2_mul(fp2_conj(qa.y), gy1));
+  add_step(tc, lc, fp2_mul(fp2_conj(qc.x), gx1), fp2_mul(fp2_conj(qc.y), gy1));
+  mul_by_two_var_lines(f, la, pa.x, pa.y, skip_a, lc, pc.x, pc.y, skip_c);
+  add_step(ta, la, fp2_mul(qa.x, gx2), qa.y);
+  add_step(tc, lc, fp2_mul(qc.x, gx2), qc.y);
+  mul_by_two_var_lines(f, la, pa.x, pa.y, skip_a, lc, pc.x, pc.y, skip_c);
+}
+
 // a^u for a in the cyclotomic subgroup (u = 4965661367192848881, 63 bits): width-4 signed sliding
 // window over the odd powers a, a^3, a^5, a^7 (a^-1 is the conjugate there): 63 cyclotomic squarings
 // and 16 multiplications (3 for the table, 13 for the 14 non-zero digits) instead of the 28 of plain

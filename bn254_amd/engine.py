@@ -10,8 +10,10 @@ from . import _native
 G1_BYTES, G2_BYTES, GT_BYTES, SCALAR_BYTES = 64, 128, 384, 32
 FLAG_G2_SUBGROUP_CHECK = 1
 FLAG_REJECT_IDENTITY = 2
+FLAG_RAND64 = 0x100
 OPT_SPLIT_MILLER = 1
 OPT_HASH_MAX_TRIES = 2
+OPT_RAND_ITEMS_PER_LANE = 3
 
 
 class NativeError(RuntimeError):
@@ -88,6 +90,18 @@ class Engine:
         status = ctypes.create_string_buffer(max(n, 1))
         _check("bn254_batch_verify", self._lib.bn254_batch_verify(self._h, msgs, off, bytes(sigs), bytes(pks), n, flags, status))
         return status.raw[:n]
+
+    def batch_verify_randomized(self, messages, sigs, pks, seed32, flags=0):
+        """opt-in randomised batch verification (include/bn254_hip.h) -> (status bytes, group_ok bytes)"""
+        n = len(messages)
+        assert len(sigs) == n * G1_BYTES and len(pks) == n * G2_BYTES and len(seed32) == 32
+        msgs, off = pack_messages(messages)
+        status = ctypes.create_string_buffer(max(n, 1))
+        ng = (n + 63) // 64
+        groups = ctypes.create_string_buffer(max(ng, 1))
+        _check("bn254_batch_verify_randomized",
+               self._lib.bn254_batch_verify_randomized(self._h, msgs, off, bytes(sigs), bytes(pks), n, flags, bytes(seed32), status, groups))
+        return status.raw[:n], groups.raw[:ng]
 
     def batch_hash_to_g1(self, messages):
         n = len(messages)
@@ -217,6 +231,11 @@ class Engine:
     def batch_verify_device(self, d_msgs, d_off, d_sigs, d_pks, n, d_status, flags=0, stream=None):
         _check("bn254_batch_verify_device",
                self._lib.bn254_batch_verify_device(self._h, d_msgs, d_off, d_sigs, d_pks, n, flags, d_status, stream))
+
+    def batch_verify_randomized_device(self, d_msgs, d_off, d_sigs, d_pks, n, seed32, d_status, d_group_ok=None, flags=0, stream=None):
+        assert len(seed32) == 32
+        _check("bn254_batch_verify_randomized_device",
+               self._lib.bn254_batch_verify_randomized_device(self._h, d_msgs, d_off, d_sigs, d_pks, n, flags, bytes(seed32), d_status, d_group_ok, stream))
 
     def batch_hash_to_g1_device(self, d_msgs, d_off, n, d_points, d_status, d_tries=None, stream=None):
         _check("bn254_batch_hash_to_g1_device",

@@ -48,6 +48,7 @@ typedef struct bn254_ctx bn254_ctx;
 
 #define BN254_FLAG_G2_SUBGROUP_CHECK 1u /* decode G2 inputs with the order-r check AffineG2::new performs */
 #define BN254_FLAG_REJECT_IDENTITY 2u   /* treat all-zero encodings as InvalidGroupPoint (from_uncompressed behaviour) */
+#define BN254_FLAG_RAND64 0x100u        /* bn254_batch_verify_randomized: 64-bit instead of 128-bit random scalars */
 
 #define BN254_E_BAD_ARGUMENT (-10001)
 #define BN254_E_MISALIGNED (-10002)
@@ -80,6 +81,27 @@ int bn254_batch_verify(bn254_ctx *ctx, const uint8_t *msgs, const uint64_t *msg_
                        const uint8_t *pks /* n*128 */, size_t n, uint32_t flags, uint8_t *status /* n */);
 int bn254_batch_verify_device(bn254_ctx *ctx, const uint8_t *d_msgs, const uint64_t *d_msg_off, const uint8_t *d_sigs,
                               const uint8_t *d_pks, size_t n, uint32_t flags, uint8_t *d_status, void *stream);
+
+/* Randomised batch verification — OPT-IN, probabilistic.  No counterpart in the
+ * reference, which verifies one tuple at a time (src/ecdsa.rs:49-64); same inputs and status bytes as
+ * bn254_batch_verify.  Items are taken 64 at a time; with r_i = the first 16 bytes (BN254_FLAG_RAND64: 8) of
+ * SHA-256(seed32 || le64(i)) read little-endian (0 -> 1), a group passes iff
+ *     prod_i e(r_i * H(m_i), pk_i) * e(sum_i r_i * sig_i, -G2::one()) == 1      (over its items that decode and hash)
+ * i.e. 64 + 1 Miller loops and ONE final exponentiation per 64 verifies.  Items of a passing group get status 0
+ * (or their decode / hash error); every item of a failing group is re-verified exactly (the kernels of
+ * bn254_batch_verify), so a non-zero status is always exact.  A zero status is wrong with probability <= 2^-128
+ * (2^-64) per group PROVIDED seed32 is fresh, unpredictable to whoever produced the signatures, and the public
+ * keys are in the order-r subgroup (validated earlier, or pass BN254_FLAG_G2_SUBGROUP_CHECK).  group_ok (optional,
+ * ceil(n/64) bytes): 1 = the group's combined check passed.  The combined check has a fixed latency of one
+ * Miller loop + one final exponentiation on n/64 lanes: it pays off for n >~ 4 x the lanes of the device
+ * (>~ 256 Ki items on an MI355X), see DESIGN.md.  Host variant synchronises; device variant only enqueues. */
+int bn254_batch_verify_randomized(bn254_ctx *ctx, const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *sigs,
+                                  const uint8_t *pks, size_t n, uint32_t flags, const uint8_t *seed32, uint8_t *status,
+                                  uint8_t *group_ok);
+int bn254_batch_verify_randomized_device(bn254_ctx *ctx, const uint8_t *d_msgs, const uint64_t *d_msg_off,
+                                         const uint8_t *d_sigs, const uint8_t *d_pks, size_t n, uint32_t flags,
+                                         const uint8_t *seed32 /* host memory */, uint8_t *d_status, uint8_t *d_group_ok,
+                                         void *stream);
 
 /* points[i] = hash_to_try_and_increment(msg_i) (src/hash.rs:29-63), uncompressed; status 1 =
  * HashToPointError; tries[i] (optional, may be NULL) = number of counters consumed (1..255). */
@@ -165,6 +187,7 @@ int bn254_ctx_set_profiling(bn254_ctx *ctx, int enabled);
  * different waves (one pairing per lane) instead of one lane sharing f^2 (default 0).  Results are
  * identical either way. */
 #define BN254_OPT_SPLIT_MILLER 1
+#define BN254_OPT_RAND_ITEMS_PER_LANE 3 /* randomised verify: items per lane in the Miller kernel; 0 = by batch size (default), 1, 2 */
 #define BN254_OPT_HASH_MAX_TRIES 2 /* test knob: counters tried before HashToPointError; 0 = 255 as in src/hash.rs:40 */
 int bn254_ctx_set_option(bn254_ctx *ctx, int option, int value);
 int bn254_ctx_last_kernel_ms(bn254_ctx *ctx, float ms[4]);

@@ -832,6 +832,57 @@ API u64 bn254o_batch_verify(const u8 *msgs, const u64 *off, const u8 *sigs, cons
   return total;
 }
 
+/* Randomised batch verification (no counterpart in the reference, which verifies
+ * one tuple at a time, src/ecdsa.rs:49-64).  Restates include/bn254_hip.h:bn254_batch_verify_randomized:
+ *   items are grouped 64 at a time; r_i = the first 16 (flag RAND64: 8) bytes of SHA-256(seed || le64(i)) read
+ *   little-endian (0 -> 1); a group passes iff
+ *       prod_{valid i} e(r_i H(m_i), pk_i) * e(sum_{valid i} r_i sig_i, -G2) == 1
+ *   where "valid" = decoded and hashed without error.  Items of a passing group get their decode / hash
+ *   status (0 if none); items of a failing group are verified one by one exactly as bn254o_verify. */
+#define FLAG_RAND64 0x100u
+static void rand_scalar(u64 *k, const u8 *seed32, u64 i, u32 flags) {
+  u8 buf[40], dg[32];
+  memcpy(buf, seed32, 32);
+  for (int b = 0; b < 8; ++b) buf[32 + b] = (u8)(i >> (8 * b));
+  sha256_msg_plus_byte(dg, buf, 39, buf[39]);
+  k[0] = k[1] = k[2] = k[3] = 0;
+  for (int b = 0; b < 8; ++b) k[0] |= (u64)dg[b] << (8 * b);
+  if (!(flags & FLAG_RAND64)) for (int b = 0; b < 8; ++b) k[1] |= (u64)dg[8 + b] << (8 * b);
+  if ((k[0] | k[1]) == 0) k[0] = 1;
+}
+API int bn254o_batch_verify_randomized(const u8 *msgs, const u64 *off, const u8 *sigs, const u8 *pks, size_t n, u32 flags,
+                                       const u8 *seed32, u8 *status, u8 *group_ok) {
+  ensure_init();
+  for (size_t g0 = 0; g0 < n; g0 += 64) {
+    size_t g1 = g0 + 64 > n ? n : g0 + 64;
+    fp12 f = FP12_ONE, part;
+    g1a ps[MAX_PAIRS]; g2a qs[MAX_PAIRS]; int np = 0;
+    g1j sum; g1j_from_affine(&sum, &(g1a){.inf = 1});
+    for (size_t i = g0; i < g1; ++i) {
+      g1a sig, h; g2a pk; int st;
+      if ((st = decode_g1(&sig, sigs + 64 * i, flags)) == ST_OK && (st = decode_g2(&pk, pks + 128 * i, flags)) == ST_OK)
+        st = hash_to_g1(&h, msgs + off[i], (size_t)(off[i + 1] - off[i]), NULL);
+      status[i] = (u8)st;
+      if (st != ST_OK) continue;
+      u64 k[4]; rand_scalar(k, seed32, (u64)i, flags);
+      g1j hj, sj, t;
+      g1j_from_affine(&hj, &h); g1j_mul(&t, &hj, k); g1j_to_affine(&ps[np], &t); qs[np] = pk; ++np;
+      g1j_from_affine(&sj, &sig); g1j_mul(&t, &sj, k); g1j_add(&sum, &sum, &t);
+      if (np == MAX_PAIRS) { miller_loop_multi(&part, ps, qs, np); fp12_mul(&f, &f, &part); np = 0; }
+    }
+    g1j_to_affine(&ps[np], &sum); qs[np] = G2_GEN_NEG; ++np;
+    miller_loop_multi(&part, ps, qs, np); fp12_mul(&f, &f, &part);
+    fp12 gt; final_exp(&gt, &f);
+    int ok = fp12_eq(&gt, &FP12_ONE);
+    if (group_ok) group_ok[g0 / 64] = (u8)ok;
+    if (!ok)
+      for (size_t i = g0; i < g1; ++i)
+        if (status[i] == ST_OK)
+          status[i] = (u8)bn254o_verify(msgs + off[i], (size_t)(off[i + 1] - off[i]), sigs + 64 * i, pks + 128 * i, flags);
+  }
+  return 0;
+}
+
 /* product of k pairings compared with one: bn::pairing_batch(..) == Gt::one() */
 API int bn254o_pairing_check(const u8 *g1s, const u8 *g2s, size_t k, u32 flags) {
   ensure_init();

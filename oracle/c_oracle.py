@@ -36,6 +36,7 @@ def lib():
         L.bn254o_check_public_keys.argtypes = [u8p, u8p, ctypes.c_uint32]
         L.bn254o_batch_verify.argtypes = [u8p, u64p, u8p, u8p, ctypes.c_size_t, ctypes.c_uint32, u8p, ctypes.c_int]
         L.bn254o_batch_verify.restype = ctypes.c_uint64
+        L.bn254o_batch_verify_randomized.argtypes = [u8p, u64p, u8p, u8p, ctypes.c_size_t, ctypes.c_uint32, u8p, u8p, u8p]
         L.bn254o_pairing_check.argtypes = [u8p, u8p, ctypes.c_size_t, ctypes.c_uint32]
         L.bn254o_pairing.argtypes = [u8p, u8p, ctypes.c_size_t, ctypes.c_uint32, u8p]
         L.bn254o_miller_loop.argtypes = [u8p, u8p, ctypes.c_size_t, u8p]
@@ -88,6 +89,25 @@ def batch_verify(msgs, sigs, pks, flags=FLAG_G2_SUBGROUP_CHECK, nthreads=1):
     status = _buf(max(n, 1))
     cnt = lib().bn254o_batch_verify(b"".join(msgs), offs, bytes(sigs), bytes(pks), n, flags, status, nthreads)
     return status.raw[:n], cnt
+
+
+FLAG_RAND64 = 0x100
+
+
+def batch_verify_randomized(msgs, sigs, pks, seed32, flags=FLAG_G2_SUBGROUP_CHECK):
+    """randomised batch verification in groups of 64 -> (status bytes, group_ok bytes)"""
+    n = len(msgs)
+    offs = (ctypes.c_uint64 * (n + 1))()
+    pos = 0
+    for i, m in enumerate(msgs):
+        offs[i] = pos
+        pos += len(m)
+    offs[n] = pos
+    status = _buf(max(n, 1))
+    groups = _buf(max((n + 63) // 64, 1))
+    assert len(seed32) == 32
+    lib().bn254o_batch_verify_randomized(b"".join(msgs), offs, bytes(sigs), bytes(pks), n, flags, bytes(seed32), status, groups)
+    return status.raw[:n], groups.raw[:(n + 63) // 64]
 
 
 def pairing_check(g1s, g2s, k, flags=0):

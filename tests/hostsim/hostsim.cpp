@@ -100,6 +100,74 @@ int hs_verify(const uint8_t* msg, uint64_t len, const uint8_t* sig64, const uint
   return st != ST_OK ? st : (fp12_is_one(f) ? ST_OK : ST_VERIFICATION_FAILED);
 }
 
+// mirrors bn254_batch_verify_randomized_device: k_decode_* + hash + k_rand_scale + k_miller_rand + k_rand_tail +
+// k_final_exp + k_rand_collect + the exact kernels for the items of failed groups (same wave tree reductions)
+int hs_verify_randomized(const uint8_t* msgs, const uint64_t* off, const uint8_t* sigs, const uint8_t* pks, uint64_t n, uint32_t flags,
+                         const uint8_t* seed32, uint8_t* status, uint8_t* group_ok) {
+  uint32_t seed[8];
+  for (int j = 0; j < 8; ++j)
+    seed[j] = ((uint32_t)seed32[4 * j] << 24) | ((uint32_t)seed32[4 * j + 1] << 16) | ((uint32_t)seed32[4 * j + 2] << 8) | seed32[4 * j + 3];
+  const uint32_t dflags = flags & 3u;
+  for (uint64_t g0 = 0; g0 < n; g0 += 64) {
+    static G1Jac s_lds[64];
+    static Fp12 f_lds[64];
+    static G1Affine a_ws[64];
+    static G2Affine pk_ws[64];
+    const bool two_per_lane = (flags & 0x80000000u) != 0;   // test knob: the k_miller_rand2 composition
+    uint8_t st[64];
+    for (unsigned t = 0; t < 64; ++t) {
+      uint64_t i = g0 + t;
+      bool live = i < n;
+      uint64_t ii = live ? i : n - 1;
+      G1Affine sig, h;
+      G2Affine pk;
+      uint8_t s1 = dec_g1(sig, sigs + 64 * ii, dflags), s2 = dec_g2(pk, pks + 128 * ii, dflags);
+      if (s1 == ST_OK) s1 = s2;
+      uint8_t sh = hash_item(h, msgs + off[ii], off[ii + 1] - off[ii], nullptr);
+      if (s1 == ST_OK) s1 = sh;
+      st[t] = s1;
+      bool valid = live && s1 == ST_OK;
+      uint32_t k[4];
+      rand_scalar(k, seed, ii, (flags & 0x100u) != 0);
+      G1Jac a, sj, id;
+      const bool rand64 = (flags & 0x100u) != 0;
+      if (rand64) jac_mul_u64(a, h, k); else jac_mul_u128(a, h, k);
+      G1Affine aa;
+      jac_to_affine(aa, a);
+      aa.inf = aa.inf || !valid;
+      if (rand64) jac_mul_u64(sj, sig, k); else jac_mul_u128(sj, sig, k);
+      jac_set_identity(id);
+      jac_select(sj, !valid, id, sj);
+      s_lds[t] = sj;
+      a_ws[t] = aa; pk_ws[t] = pk;
+      if (!two_per_lane) miller_loop<true, false>(f_lds[t], aa, pk, aa);
+    }
+    if (two_per_lane)
+      for (unsigned t = 0; t < 32; ++t) miller_loop_2var(f_lds[t], a_ws[2 * t], pk_ws[2 * t], a_ws[2 * t + 1], pk_ws[2 * t + 1]);
+    for (unsigned stride = 32; stride >= 1; stride >>= 1)
+      for (unsigned t = 0; t < stride; ++t) {
+        jac_add(s_lds[t], s_lds[t], s_lds[t + stride]);
+        if (!two_per_lane) fp12_mul(f_lds[t], f_lds[t], f_lds[t + stride]);
+        else if (stride <= 16) fp12_mul(f_lds[t], f_lds[t], f_lds[t + stride]);
+      }
+    G1Affine sa, ug1;
+    G2Affine ug2;
+    jac_to_affine(sa, s_lds[0]);
+    set_g1_gen(ug1); set_g2_gen(ug2);
+    Fp12 f;
+    miller_loop<false, true>(f, ug1, ug2, sa);
+    fp12_mul(f, f, f_lds[0]);
+    { Fp12 acc_; final_exponentiation(f, f, acc_); }
+    bool ok = fp12_is_one(f);
+    if (group_ok) group_ok[g0 / 64] = ok ? 1 : 0;
+    for (unsigned t = 0; t < 64 && g0 + t < n; ++t) {
+      uint64_t i = g0 + t;
+      status[i] = (ok || st[t] != ST_OK) ? st[t] : (uint8_t)hs_verify(msgs + off[i], off[i + 1] - off[i], sigs + 64 * i, pks + 128 * i, dflags);
+    }
+  }
+  return 0;
+}
+
 // mirrors pairing_device: k pairs, one Miller loop each, product, final exponentiation
 int hs_pairing(const uint8_t* g1s, const uint8_t* g2s, uint64_t k, uint32_t flags, uint8_t* gt384, int raw_only) {
   Fp12 f, g;
@@ -161,6 +229,21 @@ int hs_g2_add(const uint8_t* a, const uint8_t* b, uint8_t* out) {
   encode_g2(tmp, r);
   memcpy(out, tmp, 128);
   return st;
+}
+// k * P with the 128-bit windowed ladder of the randomised batch verification (k: 16 bytes little-endian)
+int hs_g1_mul_u128(const uint8_t* p, const uint8_t* k16, uint8_t* out) {
+  G1Affine a, o;
+  uint8_t st = dec_g1(a, p, 0);
+  if (st != ST_OK) return st;
+  uint32_t k[4];
+  for (int i = 0; i < 4; ++i) k[i] = (uint32_t)k16[4 * i] | ((uint32_t)k16[4 * i + 1] << 8) | ((uint32_t)k16[4 * i + 2] << 16) | ((uint32_t)k16[4 * i + 3] << 24);
+  G1Jac r;
+  jac_mul_u128(r, a, k);
+  jac_to_affine(o, r);
+  alignas(4) uint8_t tmp[64];
+  encode_g1(tmp, o);
+  memcpy(out, tmp, 64);
+  return 0;
 }
 int hs_g1_mul(const uint8_t* p, const uint8_t* scalar32, int reduce, uint8_t* out) {
   G1Affine pa, r;

@@ -27,6 +27,8 @@ def lib():
         L.hs_g1_msum.argtypes = [cp, ctypes.c_uint64, cp]
         L.hs_g2_msum.argtypes = [cp, ctypes.c_uint64, cp]
         L.hs_g2_decompress.argtypes = [cp, cp]
+        L.hs_g1_mul_u128.argtypes = [cp, cp, cp]
+        L.hs_verify_randomized.argtypes = [cp, ctypes.POINTER(ctypes.c_uint64), cp, cp, ctypes.c_uint64, ctypes.c_uint32, cp, cp, cp]
         _lib = L
     return _lib
 
@@ -93,3 +95,22 @@ def g1_msum(pts):
 
 def g2_msum(pts):
     o = _b(128); st = lib().hs_g2_msum(b"".join(pts), len(pts), o); return st, o.raw
+
+
+def g1_mul_u128(p, k):
+    o = _b(64)
+    st = lib().hs_g1_mul_u128(bytes(p), int(k).to_bytes(16, "little"), o)
+    return o.raw, st
+
+
+def verify_randomized(msgs, sigs, pks, seed32, flags=0):
+    n = len(msgs)
+    off = (ctypes.c_uint64 * (n + 1))()
+    pos = 0
+    for i, m in enumerate(msgs):
+        off[i] = pos
+        pos += len(m)
+    off[n] = pos
+    st, gr = _b(max(n, 1)), _b(max((n + 63) // 64, 1))
+    lib().hs_verify_randomized(b"".join(msgs), off, bytes(sigs), bytes(pks), n, flags, bytes(seed32), st, gr)
+    return st.raw[:n], gr.raw[:(n + 63) // 64]

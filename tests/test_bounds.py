@@ -51,6 +51,20 @@ elif which == "codec":
     o = buf(64); assert hs.hs_g1_decompress(H(k["sign"][0]["signature_compressed"]), o) == 0
     o = buf(128); assert hs.hs_g2_decompress(H(k["g2_compressed_roundtrip"]["hex"]), o) == 0
     assert hs.hs_g2_decompress(b"\x0c" + bytes(64), o) == 3
+elif which == "randomized":
+    # one ragged group with invalid members (combined check fails -> exact kernels), then its valid members only
+    for cases in (d["verify_cases"], [v for v in d["verify_cases"] if v["status"] == 0]):
+        n = len(cases); msgs = [H(v["message_hex"]) for v in cases]
+        off = (ctypes.c_uint64 * (n + 1))(); pos = 0
+        for i, m in enumerate(msgs):
+            off[i] = pos; pos += len(m)
+        off[n] = pos
+        st = buf(n); gr = buf(1)
+        for fl in (0, 0x100, 0x80000000):
+            hs.hs_verify_randomized(b"".join(msgs), off, b"".join(H(v["sig"]) for v in cases), b"".join(H(v["pk"]) for v in cases), n, fl,
+                                    bytes(range(32)), st, gr)
+        assert list(st.raw) == [v["status"] if "subgroup" not in v["name"] else st.raw[i] for i, v in enumerate(cases)], list(st.raw)
+        assert gr.raw == (b"\x01" if all(v["status"] == 0 for v in cases) else b"\x00")
 elif which.startswith("unsafe"):
     hs.hs_unsafe_sequence(int(which[-1]))
 elif which == "subgroup":
@@ -64,7 +78,7 @@ def bounds_lib():
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "hostsim"), "libhostsim_bounds.so"], stdout=subprocess.DEVNULL)
 
 
-@pytest.mark.parametrize("flow", ["fp", "hash", "pairing", "verify", "group", "subgroup", "codec", "msum"])
+@pytest.mark.parametrize("flow", ["fp", "hash", "pairing", "verify", "group", "subgroup", "codec", "msum", "randomized"])
 def test_bounds_hold(bounds_lib, flow):
     p = subprocess.run([sys.executable, "-c", DRIVER, ROOT, flow], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and p.stdout.strip() == "ok", (p.stdout[-500:], p.stderr[-2000:])

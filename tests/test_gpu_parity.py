@@ -450,3 +450,71 @@ def test_full_size_batch_properties(eng):
     rs = b"".join(sigs[64 * i:64 * i + 64] for i in range(n - 1, -1, -1))
     rp = b"".join(pks[128 * i:128 * i + 128] for i in range(n - 1, -1, -1))
     assert eng.batch_verify(rm, rs, rp, flags=0) == expected[::-1]
+
+
+# ---- randomised batch verification -------------------------------------
+RAND_SEED = hashlib.sha256(b"bn254/rand-seed").digest()
+
+
+def test_randomized_verify_vs_oracle(eng, c):
+    """statuses AND per-group verdicts equal the oracle's restatement (same seed-derived scalars): valid,
+    corrupted, undecodable, identity and wrong-key items, ragged last group, both scalar widths"""
+    from tests.datagen import make_verify_batch
+    n = 64 * 5 + 21
+    msgs, sigs, pks, expected = make_verify_batch(eng, n, corrupt_every=0, pool=7)
+    sigs, pks = bytearray(sigs), bytearray(pks)
+    assert eng.batch_verify_randomized(msgs, bytes(sigs), bytes(pks), RAND_SEED) == (bytes(n), b"\x01" * 6)
+    g = lambda i: bytes(sigs[64 * i:64 * i + 64])
+    sigs[64 * 70:64 * 71] = g(71)                                   # group 1: wrong signature
+    sigs[64 * 130:64 * 131] = b"\xff" * 64                          # group 2: undecodable (status 6), rest valid -> passes
+    sigs[64 * 200:64 * 201] = bytes(64)                             # group 3: identity signature
+    pks[128 * 260:128 * 261] = pks[128 * 261:128 * 262]             # group 4: wrong key
+    d = c.g1_mul(c.g1_generator(), (777).to_bytes(32, "big"))       # group 5: cancelling pair
+    dn = c.g1_mul(c.g1_generator(), (R - 777).to_bytes(32, "big"))
+    sigs[64 * 325:64 * 326] = c.g1_add(g(325), d)
+    sigs[64 * 330:64 * 331] = c.g1_add(g(330), dn)
+    from bn254_amd.engine import OPT_RAND_ITEMS_PER_LANE
+    for flags, per_lane in ((0, 1), (0x100, 1), (1, 1), (0, 2), (0x100, 2)):
+        eng.set_option(OPT_RAND_ITEMS_PER_LANE, per_lane)
+        try:
+            got = eng.batch_verify_randomized(msgs, bytes(sigs), bytes(pks), RAND_SEED, flags=flags)
+        finally:
+            eng.set_option(OPT_RAND_ITEMS_PER_LANE, 0)
+        want = c.batch_verify_randomized(msgs, bytes(sigs), bytes(pks), RAND_SEED, flags=flags)
+        assert got == want, (flags, per_lane)
+        assert got[1] == bytes([1, 0, 1, 0, 0, 0])
+        assert got[0] == eng.batch_verify(msgs, bytes(sigs), bytes(pks), flags=flags & 3)
+        assert [i for i in range(n) if got[0][i]] == [70, 130, 200, 260, 325, 330]
+
+
+def test_randomized_verify_golden_cases(eng, c, derived):
+    cs = derived["verify_cases"]
+    args = ([H(v["message_hex"]) for v in cs], b"".join(H(v["sig"]) for v in cs), b"".join(H(v["pk"]) for v in cs))
+    st, gr = eng.batch_verify_randomized(*args, RAND_SEED, flags=1)
+    assert list(st) == [v["status"] for v in cs] and gr == b"\x00"
+    assert (st, gr) == c.batch_verify_randomized(*args, RAND_SEED, flags=1)
+
+
+def test_randomized_verify_large_batch(eng):
+    """16 Ki + ragged tail: all-valid batch passes without touching the exact kernels; the config-2 pattern
+    (every 64th corrupted) fails every group and falls back to exact statuses; independent of the seed"""
+    from tests.datagen import make_verify_batch
+    n = 16384 + 45
+    msgs, sigs, pks, _ = make_verify_batch(eng, n, corrupt_every=0)
+    st, gr = eng.batch_verify_randomized(msgs, sigs, pks, RAND_SEED)
+    assert st == bytes(n) and gr == b"\x01" * ((n + 63) // 64)
+    msgs, sigs, pks, expected = make_verify_batch(eng, n)
+    for seed in (RAND_SEED, bytes(32)):
+        st, gr = eng.batch_verify_randomized(msgs, sigs, pks, seed)
+        assert st == expected and gr == b"\x00" * (n // 64) + b"\x01"
+    # one bad item in a large valid batch: only its group is re-verified (both Miller kernels)
+    from bn254_amd.engine import OPT_RAND_ITEMS_PER_LANE
+    bad = bytearray(make_verify_batch(eng, n, corrupt_every=0)[1])
+    bad[64 * 9000:64 * 9001] = bad[64 * 9001:64 * 9002]
+    for per_lane in (1, 2):
+        eng.set_option(OPT_RAND_ITEMS_PER_LANE, per_lane)
+        try:
+            st, gr = eng.batch_verify_randomized(msgs, bytes(bad), pks, RAND_SEED)
+        finally:
+            eng.set_option(OPT_RAND_ITEMS_PER_LANE, 0)
+        assert [i for i in range(n) if st[i]] == [9000] and st[9000] == 9 and gr.count(b"\x00") == 1 and gr[9000 // 64] == 0
