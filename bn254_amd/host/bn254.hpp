@@ -159,6 +159,26 @@ struct ECDSA {
     check_rc("bn254_batch_verify", bn254_batch_verify(e.raw(), msgs.data(), off.data(), sigs.data(), pks.data(), n, 0, status.data()));
     return status;
   }
+  // opt-in randomised mode (include/bn254_hip.h: bn254_batch_verify_randomized): same result shape; non-zero entries
+  // are exact, a zero is wrong with probability <= 2^-128 per group of 64 for a fresh secret 32-byte seed
+  static std::vector<uint8_t> batch_verify_randomized(const std::vector<std::vector<uint8_t>>& messages, const std::vector<Signature>& signatures,
+                                                      const std::vector<PublicKey>& public_keys, const std::array<uint8_t, 32>& seed,
+                                                      Engine& e = Engine::default_engine()) {
+    size_t n = messages.size();
+    if (signatures.size() != n || public_keys.size() != n) throw Error(ErrorKind::InvalidLength);
+    std::vector<uint64_t> off(n + 1, 0);
+    std::vector<uint8_t> msgs, sigs(n * 64), pks(n * 128), status(n, 0);
+    for (size_t i = 0; i < n; ++i) {
+      off[i] = msgs.size();
+      msgs.insert(msgs.end(), messages[i].begin(), messages[i].end());
+      std::memcpy(&sigs[64 * i], signatures[i].raw.data(), 64);
+      std::memcpy(&pks[128 * i], public_keys[i].raw.data(), 128);
+    }
+    off[n] = msgs.size();
+    check_rc("bn254_batch_verify_randomized",
+             bn254_batch_verify_randomized(e.raw(), msgs.data(), off.data(), sigs.data(), pks.data(), n, 0, seed.data(), status.data(), nullptr));
+    return status;
+  }
 };
 
 inline void check_public_keys(const PublicKey& pk_g2, const PublicKeyG1& pk_g1, Engine& e = Engine::default_engine()) {
