@@ -518,3 +518,25 @@ def test_randomized_verify_large_batch(eng):
         finally:
             eng.set_option(OPT_RAND_ITEMS_PER_LANE, 0)
         assert [i for i in range(n) if st[i]] == [9000] and st[9000] == 9 and gr.count(b"\x00") == 1 and gr[9000 // 64] == 0
+
+
+def test_randomized_verify_edge_sizes(eng, c):
+    """n = 0, 1, 63, 64, 65, 129 and messages of 0..130 bytes (SHA-256 padding boundaries) through the randomised path"""
+    from tests.datagen import sk_bytes
+    assert eng.batch_verify_randomized([], b"", b"", RAND_SEED) == (b"", b"")
+    sks = [sk_bytes(j) for j in range(5)]
+    pk_pool, _ = eng.batch_g2_mul(None, b"".join(sks), 5, reduce_scalar=True)
+    lens = [0, 1, 31, 32, 54, 55, 56, 63, 64, 65, 118, 119, 120, 127, 128, 130]
+    for n in (1, 63, 64, 65, 129):
+        msgs = [hashlib.sha256(b"edge%d" % i).digest() * 5 for i in range(n)]
+        msgs = [m[:lens[i % len(lens)]] for i, m in enumerate(msgs)]
+        sigs, st = eng.batch_sign(msgs, b"".join(sks[i % 5] for i in range(n)))
+        assert st == bytes(n)
+        pks = b"".join(pk_pool[128 * (i % 5):128 * (i % 5) + 128] for i in range(n))
+        assert eng.batch_verify_randomized(msgs, sigs, pks, RAND_SEED) == (bytes(n), b"\x01" * ((n + 63) // 64))
+        assert eng.batch_verify(msgs, sigs, pks) == bytes(n)
+        bad = bytearray(sigs)
+        bad[64 * (n - 1):64 * n] = c.g1_generator()
+        got = eng.batch_verify_randomized(msgs, bytes(bad), pks, RAND_SEED)
+        assert got == c.batch_verify_randomized(msgs, bytes(bad), pks, RAND_SEED, flags=0)
+        assert got[0] == bytes(n - 1) + b"\x09" and got[1][-1] == 0
