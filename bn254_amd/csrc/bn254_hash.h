@@ -80,17 +80,66 @@ BN_DEV void hash_state_init(HashState& s, const uint8_t* msg, uint64_t len) {
   }
 }
 
-// One try of /root/reference/src/hash.rs:40-59 for counter `ctr`; true iff it yields a point.
-BN_DEV bool hash_try(G1Affine& out, const HashState& s, const uint8_t* msg, uint64_t len, uint32_t ctr) {
+// Is a (0 <= a < q, plain integer) a square mod q?  Jacobi symbol (a/q) by the binary algorithm — shifts,
+// subtractions and the quadratic-reciprocity sign rules, no multiplications: ~190 iterations of ~70 simple
+// instructions against the ~370 Montgomery products of the square-root exponentiation it guards.  Zero counts
+// as a square (its root is 0), exactly like fp_sqrt.
+BN_DEVN bool u256_is_square_mod_q(const U256& a_in) {
+  uint32_t a[8], n[8];
+  uint32_t any = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { a[i] = a_in.w[i]; n[i] = C_Q[i]; any |= a[i]; }
+  if (any == 0) return true;
+  uint32_t t = 0;                                   // bit 0: parity of the sign flips
+  for (int iter = 0; iter < 600 && any != 0; ++iter) {   // each pass removes >= 1 bit of |a| + |n| (<= 508)
+    if (a[0] == 0) {                                // 32 trailing zeros: an even number of halvings, no sign change
+#pragma unroll
+      for (int i = 0; i < 7; ++i) a[i] = a[i + 1];
+      a[7] = 0;
+      continue;
+    }
+    const uint32_t s = (uint32_t)__builtin_ctz(a[0]);
+    // (2/n) = -1 iff n = 3, 5 (mod 8); applied s times
+    t ^= s & ((n[0] >> 1) ^ (n[0] >> 2));
+    if (s) {
+#pragma unroll
+      for (int i = 0; i < 7; ++i) a[i] = (a[i] >> s) | (a[i + 1] << (32 - s));
+      a[7] >>= s;
+    }
+    // a is odd: d1 = a - n, d2 = n - a
+    uint32_t d1[8], d2[8], b1 = 0, b2 = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      uint64_t x = (uint64_t)a[i] - n[i] - b1, y = (uint64_t)n[i] - a[i] - b2;
+      d1[i] = (uint32_t)x; b1 = (uint32_t)(x >> 63);
+      d2[i] = (uint32_t)y; b2 = (uint32_t)(y >> 63);
+    }
+    const bool lt = b1 != 0;                        // a < n: swap (reciprocity: flip iff both = 3 mod 4), then subtract
+    t ^= lt ? ((a[0] & n[0]) >> 1) : 0u;
+    any = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const uint32_t an = lt ? d2[i] : d1[i];
+      n[i] = lt ? a[i] : n[i];
+      a[i] = an;
+      any |= an;
+    }
+  }
+  // gcd(a_in, q) = n = 1 for a prime q and 0 < a_in < q
+  return (t & 1u) == 0;
+}
+
+// The candidate x of counter `ctr` (hash.rs:40-54): SHA-256(msg || ctr) read big-endian, rejected if >= 5q,
+// reduced by mod_u256's strict rule; false = this counter yields no x.
+BN_DEV bool hash_candidate(U256& x, const HashState& s, const uint8_t* msg, uint64_t len, uint32_t ctr) {
   uint32_t h[8], blk[16];
   for (int i = 0; i < 8; ++i) h[i] = s.mid[i];
   for (uint64_t b = s.first_block; b < s.n_blocks; ++b) {        // hash.rs:41-42  SHA256(msg || ctr)
     load_block(blk, msg, len, ctr, b, s.padded_len);
     sha256_compress(h, blk);
   }
-  U256 x;                                                        // hash.rs:44: digest read big-endian
 #pragma unroll
-  for (int i = 0; i < 8; ++i) x.w[i] = h[7 - i];
+  for (int i = 0; i < 8; ++i) x.w[i] = h[7 - i];                 // hash.rs:44: digest read big-endian
   if (u256_geq(x.w, C_QMULT[4])) return false;                   // hash.rs:49-51: h >= 5q -> next ctr
   // utils.rs:27-37 mod_u256: while x > q { x -= q } (strict), i.e. x mod q except exact multiples
   // k*q (k >= 1), which stop at q and are then rejected by Fq::from_slice
@@ -107,11 +156,27 @@ BN_DEV bool hash_try(G1Affine& out, const HashState& s, const uint8_t* msg, uint
   }
   uint32_t any = 0;
   for (int i = 0; i < 8; ++i) any |= x.w[i];
-  if (was_reduced && any == 0) return false;
-  // utils.rs:56-63 arbitrary_string_to_g1 -> G1::from_compressed(0x02 || x): even root of x^3 + 3
-  Fp xm = fp_from_u256(x);
-  Fp rhs = fp_add(fp_mul(fp_sqr(xm), xm), fp_load_const(C_THREE));
-  Fp y;
+  return !(was_reduced && any == 0);
+}
+// x^3 + 3 for a candidate (utils.rs:56-63 arbitrary_string_to_g1 -> G1::from_compressed(0x02 || x))
+BN_DEV void hash_curve_rhs(Fp& xm, Fp& rhs, const U256& x) {
+  xm = fp_from_u256(x);
+  rhs = fp_add(fp_mul(fp_sqr(xm), xm), fp_load_const(C_THREE));
+}
+// Cheap test of counter `ctr`: does it yield a point?  (candidate exists and x^3 + 3 is a square)
+BN_DEV bool hash_try_filter(const HashState& s, const uint8_t* msg, uint64_t len, uint32_t ctr) {
+  U256 x;
+  if (!hash_candidate(x, s, msg, len, ctr)) return false;
+  Fp xm, rhs;
+  hash_curve_rhs(xm, rhs, x);
+  return u256_is_square_mod_q(fp_to_u256(rhs));
+}
+// One try of /root/reference/src/hash.rs:40-59 for counter `ctr`; true iff it yields a point (the even root).
+BN_DEV bool hash_try(G1Affine& out, const HashState& s, const uint8_t* msg, uint64_t len, uint32_t ctr) {
+  U256 x;
+  if (!hash_candidate(x, s, msg, len, ctr)) return false;
+  Fp xm, rhs, y;
+  hash_curve_rhs(xm, rhs, x);
   if (!fp_sqrt(y, rhs)) return false;
   U256 yp = fp_to_u256(y);
   if (yp.w[0] & 1) y = fp_norm(fp_neg(y));

@@ -55,11 +55,10 @@ struct Ws {
   uint8_t* h_next;    // [stride]  first counter not yet tried
   uint32_t* h_list;   // [2][stride] compacted indices of the messages still without a point
   uint32_t* h_cnt;    // [HASH_MAX_ROUNDS + 1] number of entries of the list feeding round r
-  int32_t* h_cand;    // [2 * BN_LIMBS][HASH_CAND_CAP] candidate points of speculative lanes
 };
 #define HASH_NONE 0xFFFFFFFFu
 #define HASH_MAX_ROUNDS 64
-#define HASH_CAND_CAP ((size_t)1 << 18)        // speculative lanes per round (262 144)
+#define HASH_MAX_GRID_LANES ((size_t)1 << 24)   // lanes launched per round at most (grid-stride beyond)
 #define HASH_TARGET_LANES ((size_t)1 << 17)    // ~2 waves per SIMD
 enum { PL_P1X = 0, PL_P1Y, PL_QX0, PL_QX1, PL_QY0, PL_QY1, PL_P2X, PL_P2Y, PL_HASHX, PL_HASHY, PL_F0, N_PLANES = PL_F0 + 12 };
 enum { BY_ST_DECODE = 0, BY_ST_HASH, BY_P1_INF, BY_Q_INF, BY_P2_INF, BY_A_INF, N_BYTE_PLANES };
@@ -147,11 +146,15 @@ KERNEL void k_decode_g2(const uint8_t* pts, size_t n, uint32_t flags, Ws ws, int
 // hash_to_try_and_increment (hash.rs:29-63) in ROUNDS.  The reference tries counters 0,1,2,... per
 // message until one yields a point (p = 0.4726 per try, 2.12 tries on average, 20+ for the unluckiest
 // message of a 65 536 batch).  One-message-per-lane with a retry loop makes every wave wait for its
-// slowest lane and the kernel for the slowest message.  Instead:
-//   * a round handles only the messages that still have no point (compacted index list),
-//   * each of them tries `width` consecutive counters at once in `width` different lanes
-//     (speculation; width grows as the survivors thin out so every round fills the SIMDs),
-//   * atomicMin picks the SMALLEST successful counter, exactly the point the sequential loop returns.
+// slowest lane and the kernel for the slowest message, and every failed try pays for a square-root
+// exponentiation.  Instead:
+//   * a try is first only TESTED: SHA-256, range rules, x^3 + 3, and its Jacobi symbol (binary algorithm,
+//     no multiplications) — ~8 % of the cost of the exponentiation;
+//   * a round tests only the messages that still have no counter (compacted index list), `width`
+//     consecutive counters at once in `width` different lanes (speculation; width grows as the survivors
+//     thin out so every round fills the SIMDs); atomicMin keeps the SMALLEST passing counter, exactly the
+//     one the sequential loop stops at;
+//   * k_hash_finish then computes ONE square root per message, for the winning counter.
 // Lane w of a round: slot = w % n_act (message), j = w / n_act (counter offset) — consecutive lanes
 // work on consecutive messages with the same offset.
 KERNEL_SMALL void k_hash_init(size_t n, Ws ws) {
@@ -162,11 +165,8 @@ KERNEL_SMALL void k_hash_init(size_t n, Ws ws) {
 KERNEL_SMALL void k_hash_round(const uint8_t* msgs, const uint64_t* off, Ws ws, int round, uint32_t width, uint32_t max_ctr) {
   const uint32_t n_act = ws.h_cnt[round];
   if (n_act == 0) return;
-  uint32_t width_eff = width;
-  if ((size_t)n_act * width_eff > HASH_CAND_CAP) width_eff = (uint32_t)(HASH_CAND_CAP / n_act);
-  if (width_eff == 0) width_eff = 1;   // more survivors than candidate slots: plain one-try round (direct path below)
   const uint32_t* list = round == 0 ? nullptr : ws.h_list + (size_t)(round & 1) * ws.stride;
-  const size_t total = (size_t)n_act * width_eff;
+  const size_t total = (size_t)n_act * width;
   for (size_t w = (size_t)blockIdx.x * BN_WAVE + threadIdx.x; w < total; w += (size_t)gridDim.x * BN_WAVE) {
     uint32_t slot = (uint32_t)(w % n_act), j = (uint32_t)(w / n_act);
     uint32_t i = list ? list[slot] : slot;
@@ -176,67 +176,43 @@ KERNEL_SMALL void k_hash_round(const uint8_t* msgs, const uint64_t* off, Ws ws, 
     uint64_t len = off[i + 1] - off[i];
     HashState hs;
     hash_state_init(hs, msg, len);
-    G1Affine p;
-    if (hash_try(p, hs, msg, len, ctr)) {
-      atomicMin(&ws.h_best[i], ctr);
-      if (width_eff > 1) {
-#pragma unroll
-        for (int k = 0; k < BN_LIMBS; ++k) {
-          ws.h_cand[(size_t)k * HASH_CAND_CAP + w] = p.x.v[k];
-          ws.h_cand[(size_t)(BN_LIMBS + k) * HASH_CAND_CAP + w] = p.y.v[k];
-        }
-      } else {   // the only try of this message in this round: it IS the result (wave-uniform branch)
-        ws_store_fp(ws, PL_HASHX, i, p.x);
-        ws_store_fp(ws, PL_HASHX + 1, i, p.y);
-      }
-    }
+    if (hash_try_filter(hs, msg, len, ctr)) atomicMin(&ws.h_best[i], ctr);
   }
 }
-// after a round: commit the winning candidate or queue the message for the next round
-KERNEL_SMALL void k_hash_resolve(Ws ws, int round, uint32_t width, uint32_t max_ctr, int px, int inf_plane, uint8_t* tries_out) {
+// after a round: messages without a passing counter are queued for the next round (or give up at max_ctr)
+KERNEL_SMALL void k_hash_resolve(Ws ws, int round, uint32_t width, uint32_t max_ctr) {
   const uint32_t n_act = ws.h_cnt[round];
   if (n_act == 0) return;
-  uint32_t width_eff = width;
-  if ((size_t)n_act * width_eff > HASH_CAND_CAP) width_eff = (uint32_t)(HASH_CAND_CAP / n_act);
-  if (width_eff == 0) width_eff = 1;
   const uint32_t* list = round == 0 ? nullptr : ws.h_list + (size_t)(round & 1) * ws.stride;
   uint32_t* list_out = ws.h_list + (size_t)((round + 1) & 1) * ws.stride;
   for (size_t slot = (size_t)blockIdx.x * BN_WAVE + threadIdx.x; slot < n_act; slot += (size_t)gridDim.x * BN_WAVE) {
     uint32_t i = list ? list[slot] : (uint32_t)slot;
-    uint32_t best = ws.h_best[i];
-    uint32_t next = ws.h_next[i];
-    if (best != HASH_NONE) {
-      G1Affine p;
-      if (width_eff > 1) {
-        size_t w = (size_t)(best - next) * n_act + slot;
-#pragma unroll
-        for (int k = 0; k < BN_LIMBS; ++k) {
-          p.x.v[k] = ws.h_cand[(size_t)k * HASH_CAND_CAP + w];
-          p.y.v[k] = ws.h_cand[(size_t)(BN_LIMBS + k) * HASH_CAND_CAP + w];
-        }
-      } else {
-        p.x = ws_load_fp(ws, PL_HASHX, i);
-        p.y = ws_load_fp(ws, PL_HASHX + 1, i);
-      }
-      p.inf = false;
-      ws_store_g1(ws, px, inf_plane, i, p);
-      ws_byte(ws, BY_ST_HASH, i) = ST_OK;
-      if (tries_out) tries_out[i] = (uint8_t)(best + 1);
-    } else {
-      next += width_eff;
-      if (next >= max_ctr) {                                       // hash.rs:62: HashToPointError
-        G1Affine p;
-        g1_set_generator(p);
-        ws_store_g1(ws, px, inf_plane, i, p);
-        ws_byte(ws, BY_ST_HASH, i) = ST_HASH_TO_POINT;
-        if (tries_out) tries_out[i] = (uint8_t)max_ctr;
-      } else {
-        ws.h_next[i] = (uint8_t)next;
-        uint32_t pos = atomicAdd(&ws.h_cnt[round + 1], 1u);
-        list_out[pos] = i;
-      }
-    }
+    if (ws.h_best[i] != HASH_NONE) continue;
+    uint32_t next = (uint32_t)ws.h_next[i] + width;
+    if (next >= max_ctr) continue;                                 // hash.rs:62: HashToPointError (k_hash_finish)
+    ws.h_next[i] = (uint8_t)next;
+    uint32_t pos = atomicAdd(&ws.h_cnt[round + 1], 1u);
+    list_out[pos] = i;
   }
+}
+// the point of every message: the even root for its winning counter (or the error status)
+KERNEL_SMALL void k_hash_finish(const uint8_t* msgs, const uint64_t* off, size_t n, Ws ws, uint32_t max_ctr, int px, int inf_plane,
+                                uint8_t* tries_out) {
+  size_t i = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t best = ws.h_best[i];
+  const uint8_t* msg = msgs + off[i];
+  uint64_t len = off[i + 1] - off[i];
+  HashState hs;
+  hash_state_init(hs, msg, len);
+  G1Affine p;
+  // the filter and the exponentiation agree by construction (Euler's criterion); a disagreement would be
+  // reported as an error status, never as a wrong point
+  bool ok = best != HASH_NONE && hash_try(p, hs, msg, len, best);
+  if (!ok) g1_set_generator(p);
+  ws_store_g1(ws, px, inf_plane, i, p);
+  ws_byte(ws, BY_ST_HASH, i) = ok ? (uint8_t)ST_OK : (uint8_t)ST_HASH_TO_POINT;
+  if (tries_out) tries_out[i] = ok ? (uint8_t)(best + 1) : (uint8_t)max_ctr;
 }
 
 // ECDSA::verify Miller loop: f = miller(H(m), pk) * miller(sig, -G2)   (ecdsa.rs:53-57)
@@ -803,7 +779,6 @@ static int ws_reserve(bn254_ctx* c, size_t n) {
   HIP_TRY(hipMalloc((void**)&c->ws.h_next, cap));
   HIP_TRY(hipMalloc((void**)&c->ws.h_list, 2 * sizeof(uint32_t) * cap));
   if (!c->ws.h_cnt) HIP_TRY(hipMalloc((void**)&c->ws.h_cnt, sizeof(uint32_t) * (HASH_MAX_ROUNDS + 1)));
-  if (!c->ws.h_cand) HIP_TRY(hipMalloc((void**)&c->ws.h_cand, (size_t)2 * BN_LIMBS * sizeof(int32_t) * HASH_CAND_CAP));
   c->ws.stride = cap;
   return 0;
 }
@@ -862,14 +837,15 @@ static int launch_hash_rounds(bn254_ctx* c, hipStream_t s, const uint8_t* d_msgs
     double bound = expect * 1.25 + 256.0;                 // generous estimate of the survivors
     if (bound > (double)n) bound = (double)n;
     size_t lanes = (size_t)(bound * width);
-    if (lanes > HASH_CAND_CAP && width > 1) lanes = HASH_CAND_CAP;
+    if (lanes > HASH_MAX_GRID_LANES) lanes = HASH_MAX_GRID_LANES;   // grid-stride loops cover the rest
     k_hash_round<<<grid_for(lanes), BN_WAVE, 0, s>>>(d_msgs, d_off, c->ws, round, width, max_ctr);
-    k_hash_resolve<<<grid_for((size_t)bound), BN_WAVE, 0, s>>>(c->ws, round, width, max_ctr, px, inf_plane, d_tries);
+    k_hash_resolve<<<grid_for((size_t)bound), BN_WAVE, 0, s>>>(c->ws, round, width, max_ctr);
     consumed += width;
     double pf = 1.0;
     for (uint32_t t = 0; t < width && pf > 1e-12; ++t) pf *= 0.5274;
     expect *= pf;
   }
+  k_hash_finish<<<grid_for(n), BN_WAVE, 0, s>>>(d_msgs, d_off, n, c->ws, max_ctr, px, inf_plane, d_tries);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -904,7 +880,6 @@ void bn254_ctx_destroy(bn254_ctx* c) {
   if (c->ws.h_next) (void)hipFree(c->ws.h_next);
   if (c->ws.h_list) (void)hipFree(c->ws.h_list);
   if (c->ws.h_cnt) (void)hipFree(c->ws.h_cnt);
-  if (c->ws.h_cand) (void)hipFree(c->ws.h_cand);
   for (int i = 0; i < 3; ++i) { if (c->pool[i].planes) (void)hipFree(c->pool[i].planes); if (c->pool[i].st) (void)hipFree(c->pool[i].st); }
   for (int i = 0; i < 8; ++i) if (c->stage[i]) (void)hipFree(c->stage[i]);
   for (int i = 0; i < 5; ++i) (void)hipEventDestroy(c->ev[i]);

@@ -39,12 +39,17 @@ static uint8_t dec_g2(G2Affine& q, const uint8_t* b, uint32_t flags) {
   }
   return st;
 }
+// mirrors k_hash_round (filter: candidate + Jacobi symbol) and k_hash_finish (one square root, for the winner)
 static uint8_t hash_item(G1Affine& p, const uint8_t* msg, uint64_t len, int* tries) {
   HashState hs;
   hash_state_init(hs, msg, len);
   set_g1_gen(p);
   for (uint32_t ctr = 0; ctr < 255; ++ctr) {
-    if (hash_try(p, hs, msg, len, ctr)) { if (tries) *tries = (int)ctr + 1; return ST_OK; }
+    if (!hash_try_filter(hs, msg, len, ctr)) continue;
+    if (tries) *tries = (int)ctr + 1;
+    if (hash_try(p, hs, msg, len, ctr)) return ST_OK;
+    set_g1_gen(p);                       // filter and exponentiation disagree: cannot happen (reported as an error)
+    return ST_HASH_TO_POINT;
   }
   if (tries) *tries = 255;
   set_g1_gen(p);
@@ -374,6 +379,11 @@ int hs_fp_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
     case 2: r = fp_sub(x, y); break;
     case 3: r = fp_inv(x); break;
     case 4: r = fp_sqr(x); break;
+    case 6: {                                   // Jacobi-symbol square test of the hash pre-filter
+      bool sq = u256_is_square_mod_q(fp_to_u256(x));
+      memset(out, 0, 32); out[31] = sq ? 1 : 0;
+      return st;
+    }
     default: if (!fp_sqrt(r, x) && st == ST_OK) st = ST_NOT_MEMBER; break;
   }
   fp_to_be(to, r);
