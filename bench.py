@@ -30,9 +30,9 @@ CORRUPT_EVERY = 64                 # every 64th signature is wrong -> expected s
 # the host (tests/test_workcount.py keeps these in sync): Montgomery products per kernel stage.
 FP_MUL_DECODE = 19
 FP_MUL_HASH_FILTER = 4             # per tested counter: x -> Montgomery, x^3 + 3, back to an integer for the Jacobi symbol
-FP_MUL_HASH_FINISH = 371           # once per message: the square-root exponentiation of the winning counter + checks
+FP_MUL_HASH_FINISH = 311           # once per message: the square-root exponentiation of the winning counter + checks
 FP_MUL_MILLER = 11138
-FP_MUL_FINAL_EXP = 7507           # width-4 window exponentiations by u; incl. 12 canonicalisations for the == 1 test
+FP_MUL_FINAL_EXP = 7449           # width-4 window exponentiations by u; incl. 12 canonicalisations for the == 1 test
 MAC32_PER_FP_MUL = 136             # ALGORITHMIC unit: an 8x32-bit Montgomery product = 2*8*8 + 8 MAC32.
 MUL_INSTR_PER_FP_MUL = 210         # what the kernels actually issue per product with 10x27-bit limbs: 200 v_mad_*64 + 10 v_mul_lo
 # VALU roofline: v_mad_u64_u32 issues once per 4 cycles per SIMD (half the 2-cycle full rate):

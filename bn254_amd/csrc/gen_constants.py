@@ -74,6 +74,29 @@ def naf_digits(s):
     return d[-2::-1]
 
 
+def pow_schedule(e, w):
+    """left-to-right sliding window over the odd powers below 2^w: list of (squarings, multiplier)"""
+    bits = bin(e)[2:]
+    i, nsq, ops = 0, 0, []
+    while i < len(bits):
+        if bits[i] == "0":
+            nsq += 1
+            i += 1
+            continue
+        j = min(i + w, len(bits))
+        while bits[j - 1] == "0":
+            j -= 1
+        ops.append((0 if not ops else nsq + (j - i), int(bits[i:j], 2)))
+        nsq, i = 0, j
+    if nsq:
+        ops.append((nsq, 0))
+    acc = 0
+    for n, v in ops:
+        acc = (acc << n) + v
+    assert acc == e and all(v < (1 << w) and (v & 1 or v == 0) for _, v in ops)
+    return ops
+
+
 def naf_plain(s):
     """canonical NAF, most-significant first, without the leading 1"""
     d = []
@@ -207,6 +230,13 @@ def main():
     o.append("BN_CONST uint32_t C_EXP_QP1D4[8] = %s;    /* (q+1)/4, plain U256 */" % c_u256((Q + 1) // 4))
     o.append("BN_CONST uint32_t C_EXP_QM3D4[8] = %s;    /* (q-3)/4, plain U256 */" % c_u256((Q - 3) // 4))
     o.append("BN_CONST uint32_t C_EXP_QM1D2[8] = %s;    /* (q-1)/2, plain U256 */" % c_u256((Q - 1) // 2))
+    o.append("/* width-4 sliding-window schedules for the fixed exponents: {squarings, odd multiplier} steps, MSB first;")
+    o.append("   the first step only selects its multiplier, a multiplier of 0 means squarings only */")
+    for name, e in (("QM2", Q - 2), ("QP1D4", (Q + 1) // 4), ("QM3D4", (Q - 3) // 4), ("QM1D2", (Q - 1) // 2)):
+        ops = pow_schedule(e, 4)
+        o.append("#define BN_SCHED_%s_LEN %d" % (name, len(ops)))
+        o.append("BN_CONST unsigned char C_SCHED_%s[BN_SCHED_%s_LEN][2] = {%s};  /* %d squarings, %d multiplications */" %
+                 (name, name, ", ".join("{%d, %d}" % op for op in ops), sum(op[0] for op in ops), sum(1 for op in ops[1:] if op[1])))
     o.append("BN_CONST int32_t C_QL[10] = %s;           /* q as 27-bit limbs (plain) */" % c_fp(Q, False))
     o.append("BN_CONST int32_t C_R2[10] = %s;           /* R^2 mod q, plain limbs: to_mont(x) = mul(x, R2) */" % c_fp(MONT_R * MONT_R % Q, False))
     o.append("BN_CONST int32_t C_ONE[10] = %s;          /* 1 (Montgomery) */" % c_fp(1))
