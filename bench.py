@@ -218,6 +218,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=BATCH, help="tuples per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pair-lanes", action="store_true", help="one lane per verify instead of lane pairs (A/B)")
     ap.add_argument("--split-miller", action="store_true", help="one pairing per lane instead of the fused 2-pair Miller loop (A/B)")
     ap.add_argument("--workload", default="verify", choices=["verify", "verify-host", "verify-randomized", "pairing", "hash", "aggregate"],
                     help="verify = the headline (configs[1]); the others time configs 4, 5, 3 or the host-buffer entry point "
@@ -257,6 +258,8 @@ def main():
     eng.reserve(2 * n)
     if args.split_miller:
         eng.set_option(1, 1)
+    if args.no_pair_lanes:
+        eng.set_option(4, 0)
 
     # ---- synthetic inputs, generated on the GPU by the product's own sign / keygen kernels -------
     base = rank * n                                          # each rank owns a distinct shard

@@ -9,6 +9,13 @@
 
 namespace bn254 {
 
+enum Status : uint8_t {   // 1 + index of the variant in /root/reference/src/error.rs:6-29
+  ST_OK = 0, ST_HASH_TO_POINT = 1, ST_INDEX_OOB = 2, ST_INVALID_ENCODING = 3, ST_INVALID_GROUP_POINT = 4,
+  ST_INVALID_LENGTH = 5, ST_NOT_MEMBER = 6, ST_TO_AFFINE = 7, ST_POINT_IN_JACOBIAN = 8,
+  ST_VERIFICATION_FAILED = 9, ST_SERIALIZATION = 10, ST_HEX_DECODE = 11
+};
+enum Flags : uint32_t { FLAG_G2_SUBGROUP_CHECK = 1u, FLAG_REJECT_IDENTITY = 2u };
+
 // field traits so one template serves G1 (Fq) and G2 (Fq2)
 BN_DEV Fp f_add(const Fp& a, const Fp& b) { return fp_add(a, b); }
 BN_DEV Fp f_sub(const Fp& a, const Fp& b) { return fp_sub(a, b); }

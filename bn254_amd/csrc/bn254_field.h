@@ -86,7 +86,18 @@ static inline void bn_bound_fail(const char* what, double x) {
 #endif
 
 struct Fp { int32_t v[BN_LIMBS]; BN_BOUNDS_MEMBER };
+#if defined(BN_SPLIT_FP2)
+// "pair" layout (bn254_fp2_pair.h): on the device a lane holds ONE coefficient of every Fq2 element and the
+// adjacent lane the other; the host build keeps both and runs the two roles one after the other.
+#if defined(__HIPCC__)
+#define BN_PAIR_ROLES 1
+#else
+#define BN_PAIR_ROLES 2
+#endif
+struct Fp2 { Fp c[BN_PAIR_ROLES]; };
+#else
 struct Fp2 { Fp c0, c1; };
+#endif
 struct Fp6 { Fp2 c0, c1, c2; };
 struct Fp12 { Fp6 c0, c1; };
 struct U256 { uint32_t w[8]; };   // plain 256-bit integer
@@ -213,7 +224,12 @@ struct bn_limbvec { int32_t e[16]; int32_t& operator[](int i) { return e[i]; } c
 // (profiles/r01_issue_mix_microbench.jsonl), cheaper than an alignbit + ashr pair
 #define BN_COLUMN_SHIFT(acc) do { (acc) >>= BN_W; } while (0)
 
-#define BN_MAC(acc, x, y) do { (acc) += (int64_t)(x) * (y); } while (0)   // one v_mad_i64_i32 (no inline asm: it would make hipcc pad with s_nop)
+// acc += x * y: one v_mad_i64_i32 per limb product, left to the compiler.  Measured and rejected: spelling the
+// instruction out with the (unused) carry-out alternating between two SGPR pairs.  In a synthetic stream that
+// lifts a lone wave from 4.0 to 2.2 ns per multiply-add (profiles/r01_mad_latency_microbench.jsonl), but in the
+// real routines, where every multiply-add reads four fresh VGPR words, it changes nothing (793 vs 774 ns per
+// product) and the asm statements cost scheduling freedom.
+#define BN_MAC(acc, x, y) do { (acc) += (int64_t)(x) * (y); } while (0)
 
 BN_DEVN BN_LIMB_VEC fp_mul_impl(BN_LIMB_VEC a, BN_LIMB_VEC b) {
   BN_COUNT_MUL();
@@ -227,18 +243,18 @@ BN_DEVN BN_LIMB_VEC fp_mul_impl(BN_LIMB_VEC a, BN_LIMB_VEC b) {
     for (int i = 0; i < BN_LIMBS; ++i) {
       int j = k - i;
       if (j < 0 || j >= BN_LIMBS) continue;
-      acc += (int64_t)a[i] * b[j];
+      BN_MAC(acc, a[i], b[j]);
     }
 #pragma unroll
     for (int i = 0; i < BN_LIMBS; ++i) {
       int j = k - i;
       if (j < 0 || j >= BN_LIMBS) continue;
       if (k < BN_LIMBS && i >= k) continue;     // m_k itself is added below, once it is known
-      acc += (int64_t)m[i] * q[j];
+      BN_MAC(acc, m[i], q[j]);
     }
     if (k < BN_LIMBS) {
       m[k] = (int32_t)(((uint32_t)acc * BN_N0) & BN_MASK);
-      acc += (int64_t)m[k] * q[0];
+      BN_MAC(acc, m[k], q[0]);
     } else {
       r[k - BN_LIMBS] = (int32_t)((uint32_t)acc & BN_MASK);
     }
@@ -263,18 +279,18 @@ BN_DEVN BN_LIMB_VEC fp_sqr_impl(BN_LIMB_VEC a) {
     for (int i = 0; i < BN_LIMBS; ++i) {
       int j = k - i;
       if (j < 0 || j >= BN_LIMBS || i > j) continue;
-      if (i == j) acc += (int64_t)a[i] * a[i]; else acc += (int64_t)a2[i] * a[j];
+      if (i == j) BN_MAC(acc, a[i], a[i]); else BN_MAC(acc, a2[i], a[j]);
     }
 #pragma unroll
     for (int i = 0; i < BN_LIMBS; ++i) {
       int j = k - i;
       if (j < 0 || j >= BN_LIMBS) continue;
       if (k < BN_LIMBS && i >= k) continue;
-      acc += (int64_t)m[i] * q[j];
+      BN_MAC(acc, m[i], q[j]);
     }
     if (k < BN_LIMBS) {
       m[k] = (int32_t)(((uint32_t)acc * BN_N0) & BN_MASK);
-      acc += (int64_t)m[k] * q[0];
+      BN_MAC(acc, m[k], q[0]);
     } else {
       r[k - BN_LIMBS] = (int32_t)((uint32_t)acc & BN_MASK);
     }
@@ -356,11 +372,11 @@ BN_DEV void fp_dual_mul_reduce(int32_t* r, const int32_t* x0, const int32_t* y0,
       int j = k - i;
       if (j < 0 || j >= BN_LIMBS) continue;
       if (k < BN_LIMBS && i >= k) continue;
-      acc += (int64_t)m[i] * q[j];
+      BN_MAC(acc, m[i], q[j]);
     }
     if (k < BN_LIMBS) {
       m[k] = (int32_t)(((uint32_t)acc * BN_N0) & BN_MASK);
-      acc += (int64_t)m[k] * q[0];
+      BN_MAC(acc, m[k], q[0]);
     } else {
       r[k - BN_LIMBS] = (int32_t)((uint32_t)acc & BN_MASK);
     }
@@ -368,6 +384,7 @@ BN_DEV void fp_dual_mul_reduce(int32_t* r, const int32_t* x0, const int32_t* y0,
   }
   r[BN_LIMBS - 1] = (int32_t)acc;
 }
+#if !defined(BN_SPLIT_FP2)
 BN_DEVN BN_VEC20 fp2_mul_impl(BN_VEC10 a0, BN_VEC10 a1, BN_VEC10 b0, BN_VEC10 b1) {
   BN_COUNT_MUL(); BN_COUNT_MUL(); BN_COUNT_MUL();   // algorithmic cost: a 3-product Karatsuba Fq2 multiplication
   int32_t x0[BN_LIMBS], x1[BN_LIMBS], y0[BN_LIMBS], y1[BN_LIMBS], n1[BN_LIMBS], re[BN_LIMBS], im[BN_LIMBS];
@@ -380,6 +397,7 @@ BN_DEVN BN_VEC20 fp2_mul_impl(BN_VEC10 a0, BN_VEC10 a1, BN_VEC10 b0, BN_VEC10 b1
   for (int i = 0; i < BN_LIMBS; ++i) { r[i] = re[i]; r[BN_LIMBS + i] = im[i]; }
   return r;
 }
+#endif
 
 // the unique representative in [0, q) with canonical limbs (same Montgomery residue).
 // One product by the Montgomery one brings |value| into (-eps q, (1+eps) q); then at most one
@@ -464,6 +482,11 @@ BN_DEV bool fp_sqrt(Fp& y, const Fp& a) {
   return fp_eq(fp_sqr(y), a);
 }
 
+#if defined(BN_SPLIT_FP2)
+}  // namespace bn254
+#include "bn254_fp2_pair.h"
+namespace bn254 {
+#else
 // ------------------------------------------------------------------------------------------
 // Fq2.  Inline helpers are LAZY: results of add/sub/mul_xi/mul carry whatever limb bounds their
 // inputs imply; callers place fp2_norm where the next product needs it (tests/test_bounds.py).
@@ -568,6 +591,8 @@ BN_DEVN bool fp2_sqrt(Fp2& x, const Fp2& a_in) {
   x = fp2_select(alpha_is_m1, xi_, xb);
   return fp2_eq(fp2_sqr(x), a);
 }
+
+#endif  // BN_SPLIT_FP2
 
 // ------------------------------------------------------------------------------------------
 // Fq6, Fq12.  Fq12-level operations are real (non-inlined) functions on the per-lane private segment;

@@ -1,0 +1,136 @@
+// Fq2 in the "pair" layout: the two coefficients of every Fq2 element live in two ADJACENT LANES (even lane:
+// real part, odd lane: imaginary part), so a verify is carried by a lane pair.  Every tower level above
+// (Fq6, Fq12, twist-point steps, Miller loop, final exponentiation — bn254_field.h / bn254_pairing.h) is
+// written against the fp2_* interface only and compiles unchanged for this layout.  Per lane that halves the
+// multiplications, the live registers (an Fq12 is 60 words instead of 120) and the LDS footprint of the
+// accumulators, which is what lets TWO waves share a SIMD (256 registers each): a lone wave can only issue a
+// v_mad_u64_u32 every 8 cycles, two co-resident waves overlap (profiles/r01_issue_mix_microbench.jsonl).
+//   product:  re lane  a0*b0 + (-a1)*b1      im lane  a1*b0 + a0*b1     one dual-accumulated Montgomery
+//             product each (300 multiply instructions), operands of the partner fetched by DPP quad_perm
+//   square:   re lane  (a0+a1)(a0-a1)        im lane  2*a0*a1           one product each
+// On the host (tests/hostsim, bound tracker) an element keeps both coefficients and every primitive runs the
+// two roles in sequence through the same per-role code.
+#pragma once
+
+namespace bn254 {
+
+#if defined(__HIPCC__)
+#define BN_FOR_ROLES(k) for (int k = 0; k < 1; ++k)
+BN_DEV bool bn_role_im(int) { return (threadIdx.x & 1u) != 0; }
+BN_DEV int bn_role_index(int) { return (int)(threadIdx.x & 1u); }
+// the same word of the partner lane (quad_perm [1,0,3,2]); both lanes of a pair are always active together
+BN_DEV int32_t bn_partner_word(int32_t v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true); }
+BN_DEV Fp bn_partner(const Fp2& a, int) {
+  Fp r;
+#pragma unroll
+  for (int i = 0; i < BN_LIMBS; ++i) r.v[i] = bn_partner_word(a.c[0].v[i]);
+  return r;
+}
+BN_DEV bool bn_pair_and(bool x) { return x && (bn_partner_word(x ? 1 : 0) != 0); }
+#else
+#define BN_FOR_ROLES(k) for (int k = 0; k < 2; ++k)
+BN_DEV bool bn_role_im(int k) { return k == 1; }
+BN_DEV int bn_role_index(int k) { return k; }
+BN_DEV Fp bn_partner(const Fp2& a, int k) { return a.c[k ^ 1]; }
+BN_DEV bool bn_pair_and(bool x) { return x; }
+#endif
+
+// r = Montgomery-reduce(x0*y0 + x1*y1): the per-lane half of an Fq2 product
+#if defined(BN_TRACK_BOUNDS) && !defined(__HIPCC__)
+static inline void bn_trk_dual(Fp& r, const Fp& x0, const Fp& y0, const Fp& x1, const Fp& y1) {
+  double col = 10.0 * (bn_absmax(x0) * bn_absmax(y0) + bn_absmax(x1) * bn_absmax(y1)) + 10.0 * 18014398509481984.0 + 137438953472.0;
+  if (col >= 9223372036854775808.0) bn_bound_fail("pair product column overflow", col);
+  auto prod = [](const Fp& x, const Fp& y, double& lo, double& hi) {
+    double c[4] = {x.bd.vlo * y.bd.vlo, x.bd.vlo * y.bd.vhi, x.bd.vhi * y.bd.vlo, x.bd.vhi * y.bd.vhi};
+    lo = std::fmin(std::fmin(c[0], c[1]), std::fmin(c[2], c[3])) / 86000.0;
+    hi = std::fmax(std::fmax(c[0], c[1]), std::fmax(c[2], c[3])) / 86000.0;
+  };
+  double l0, h0, l1, h1;
+  prod(x0, y0, l0, h0); prod(x1, y1, l1, h1);
+  if (std::fmax(std::fabs(l0 + l1), std::fabs(h0 + h1)) > 64.0) bn_bound_fail("pair product value bound", h0 + h1);
+  bn_set_tight(r, l0 + l1 - 1.0, h0 + h1 + 1.0);
+}
+#endif
+BN_DEVN BN_VEC10 fp_dual_impl(BN_VEC10 x0, BN_VEC10 y0, BN_VEC10 x1, BN_VEC10 y1) {
+  BN_COUNT_MUL();   // a lane pair spends 2 x 1.5 = the 3 algorithmic products of a Karatsuba Fq2 multiplication;
+                    // counted per lane as 1 (host emulation: 2 per Fq2 product)
+  int32_t a[BN_LIMBS], b[BN_LIMBS], c[BN_LIMBS], d[BN_LIMBS], r[BN_LIMBS];
+#pragma unroll
+  for (int i = 0; i < BN_LIMBS; ++i) { a[i] = x0[i]; b[i] = y0[i]; c[i] = x1[i]; d[i] = y1[i]; }
+  fp_dual_mul_reduce(r, a, b, c, d);
+  BN_VEC10 z;
+#pragma unroll
+  for (int i = 0; i < BN_LIMBS; ++i) z[i] = r[i];
+  return z;
+}
+BN_DEV Fp fp_dual(const Fp& x0, const Fp& y0, const Fp& x1, const Fp& y1) {
+  BN_VEC10 a, b, c, d;
+#pragma unroll
+  for (int i = 0; i < BN_LIMBS; ++i) { a[i] = x0.v[i]; b[i] = y0.v[i]; c[i] = x1.v[i]; d[i] = y1.v[i]; }
+  BN_VEC10 z = fp_dual_impl(a, b, c, d);
+  Fp r;
+#pragma unroll
+  for (int i = 0; i < BN_LIMBS; ++i) r.v[i] = z[i];
+  BN_TRK(bn_trk_dual(r, x0, y0, x1, y1));
+  return r;
+}
+
+BN_DEV Fp2 fp2_zero() { Fp2 r; BN_FOR_ROLES(k) r.c[k] = fp_zero(); return r; }
+BN_DEV Fp2 fp2_one() { Fp2 r; BN_FOR_ROLES(k) r.c[k] = fp_select(bn_role_im(k), fp_zero(), fp_one()); return r; }
+BN_DEV Fp2 fp2_load_const(const int32_t (*c)[BN_LIMBS]) { Fp2 r; BN_FOR_ROLES(k) r.c[k] = fp_load_const(c[bn_role_index(k)]); return r; }
+BN_DEV Fp2 fp2_add(const Fp2& a, const Fp2& b) { Fp2 r; BN_FOR_ROLES(k) r.c[k] = fp_add(a.c[k], b.c[k]); return r; }
+BN_DEV Fp2 fp2_sub(const Fp2& a, const Fp2& b) { Fp2 r; BN_FOR_ROLES(k) r.c[k] = fp_sub(a.c[k], b.c[k]); return r; }
+BN_DEV Fp2 fp2_neg(const Fp2& a) { Fp2 r; BN_FOR_ROLES(k) r.c[k] = fp_neg(a.c[k]); return r; }
+BN_DEV Fp2 fp2_dbl(const Fp2& a) { return fp2_add(a, a); }
+BN_DEV Fp2 fp2_conj(const Fp2& a) { Fp2 r; BN_FOR_ROLES(k) r.c[k] = fp_select(bn_role_im(k), fp_neg(a.c[k]), a.c[k]); return r; }
+BN_DEV Fp2 fp2_norm(const Fp2& a) { Fp2 r; BN_FOR_ROLES(k) r.c[k] = fp_norm(a.c[k]); return r; }
+BN_DEV Fp2 fp2_reduce_weak(const Fp2& a) { Fp2 r; BN_FOR_ROLES(k) r.c[k] = fp_reduce_weak(a.c[k]); return r; }
+BN_DEV bool fp2_is_zero(const Fp2& a) { bool z = true; BN_FOR_ROLES(k) z = fp_is_zero(a.c[k]) && z; return bn_pair_and(z); }
+BN_DEV bool fp2_eq(const Fp2& a, const Fp2& b) { return fp2_is_zero(fp2_sub(a, b)); }
+BN_DEV Fp2 fp2_select(bool c, const Fp2& a, const Fp2& b) { Fp2 r; BN_FOR_ROLES(k) r.c[k] = fp_select(c, a.c[k], b.c[k]); return r; }
+
+BN_DEV Fp2 fp2_mul(const Fp2& a, const Fp2& b) {   // outputs are tight
+  Fp2 r;
+  BN_FOR_ROLES(k) {
+    const bool im = bn_role_im(k);
+    const Fp ap = bn_partner(a, k), bp = bn_partner(b, k);
+    // re: a0*b0 + a1*(-b1)   im: a1*b0 + a0*b1   (own = a.c[k], partner = ap)
+    r.c[k] = fp_dual(a.c[k], fp_select(im, bp, b.c[k]), ap, fp_select(im, b.c[k], fp_neg(bp)));
+  }
+  return r;
+}
+BN_DEV Fp2 fp2_sqr(const Fp2& a) {
+  Fp2 r;
+  BN_FOR_ROLES(k) {
+    const bool im = bn_role_im(k);
+    const Fp ap = bn_partner(a, k);
+    // re: (a0 + a1)(a0 - a1)   im: 2 * (a1 * a0)
+    Fp p = fp_mul(fp_select(im, a.c[k], fp_add(a.c[k], ap)), fp_select(im, ap, fp_sub(a.c[k], ap)));
+    r.c[k] = fp_select(im, fp_dbl(p), p);
+  }
+  return r;
+}
+BN_DEV Fp2 fp2_mul_fp(const Fp2& a, const Fp& s) { Fp2 r; BN_FOR_ROLES(k) r.c[k] = fp_mul(a.c[k], s); return r; }
+BN_DEV Fp2 fp2_mul_xi(const Fp2& a) {              // (9 + i) * a; limb bounds grow 10x: input must be (near) tight
+  Fp2 r;
+  BN_FOR_ROLES(k) {
+    const Fp ap = bn_partner(a, k);
+    Fp a2 = fp_dbl(a.c[k]), a4 = fp_dbl(a2), a8 = fp_dbl(a4);
+    // re: 9 a0 - a1   im: 9 a1 + a0
+    r.c[k] = fp_add(fp_add(a8, a.c[k]), fp_select(bn_role_im(k), ap, fp_neg(ap)));
+  }
+  return r;
+}
+BN_DEV Fp2 fp2_mul_xi_n(const Fp2& a) { return fp2_mul_xi(fp2_norm(a)); }
+BN_DEV Fp2 fp2_inv(const Fp2& a) {
+  Fp2 t, r;
+  BN_FOR_ROLES(k) t.c[k] = fp_sqr(a.c[k]);
+  BN_FOR_ROLES(k) {
+    Fp n = fp_inv(fp_add(t.c[k], bn_partner(t, k)));   // both lanes invert the norm (the one duplicated step)
+    Fp m = fp_mul(a.c[k], n);
+    r.c[k] = fp_select(bn_role_im(k), fp_neg(m), m);
+  }
+  return r;
+}
+
+}  // namespace bn254

@@ -26,54 +26,7 @@
 
 using namespace bn254;
 
-#define BN_WAVE 64
-#define BN_SPLIT_MAX_N ((size_t)98304)   // <= 1.5 waves per SIMD with one lane per verify
-#define RAND_TWO_PER_LANE_MIN_N ((size_t)131072)   // randomised verify: two items per lane once that still fills 1024 SIMDs
-// Register budget: amdgpu_waves_per_eu(W, W) on the kernels is propagated to every device function
-// they call (AMDGPU attributor), capping VGPR+AGPR at 512/W so that W waves fit on each SIMD.
-// In a pure-VALU microbenchmark two co-resident waves each keep the full single-wave issue rate
-// (profiles/r01_issue_mix_microbench.jsonl), but the Fq12 bodies need ~400 live registers: at W = 2
-// they spill to the private segment and every kernel got slower (profiles/r01_c_ab_occupancy.log).
-// W = 1 (512 registers per lane) is the measured optimum for this code shape.
-#ifndef BN_WAVES_PER_EU
-#define BN_WAVES_PER_EU 1
-#endif
-#define KERNEL __global__ __launch_bounds__(BN_WAVE) __attribute__((amdgpu_waves_per_eu(BN_WAVES_PER_EU, BN_WAVES_PER_EU)))
-// kernels whose per-lane state is a few field elements (hash rounds, decoders, encoders) fit 256
-// registers without spilling and gain from a second wave per SIMD (hash: 1.34 -> 1.15 ms per 65 536)
-#define KERNEL_SMALL __global__ __launch_bounds__(BN_WAVE) __attribute__((amdgpu_waves_per_eu(2, 2)))
-
-// ------------------------------------------------------------------------------------------
-// workspace planes
-// ------------------------------------------------------------------------------------------
-struct Ws {
-  int32_t* planes;    // [N_PLANES * BN_LIMBS][stride] i32
-  uint8_t* bytes;     // [N_BYTE_PLANES][stride]
-  size_t stride;
-  // hash-to-G1 round state (see k_hash_round)
-  uint32_t* h_best;   // [stride]  smallest successful counter of the current round, or HASH_NONE
-  uint8_t* h_next;    // [stride]  first counter not yet tried
-  uint32_t* h_list;   // [2][stride] compacted indices of the messages still without a point
-  uint32_t* h_cnt;    // [HASH_MAX_ROUNDS + 1] number of entries of the list feeding round r
-};
-#define HASH_NONE 0xFFFFFFFFu
-#define HASH_MAX_ROUNDS 64
-#define HASH_MAX_GRID_LANES ((size_t)1 << 24)   // lanes launched per round at most (grid-stride beyond)
-#define HASH_TARGET_LANES ((size_t)1 << 17)    // ~2 waves per SIMD
-enum { PL_P1X = 0, PL_P1Y, PL_QX0, PL_QX1, PL_QY0, PL_QY1, PL_P2X, PL_P2Y, PL_HASHX, PL_HASHY, PL_F0, N_PLANES = PL_F0 + 12 };
-enum { BY_ST_DECODE = 0, BY_ST_HASH, BY_P1_INF, BY_Q_INF, BY_P2_INF, BY_A_INF, N_BYTE_PLANES };
-
-__device__ __forceinline__ Fp ws_load_fp(const Ws& ws, int plane, size_t i) {
-  Fp r;
-#pragma unroll
-  for (int k = 0; k < BN_LIMBS; ++k) r.v[k] = ws.planes[((size_t)plane * BN_LIMBS + k) * ws.stride + i];
-  return r;
-}
-__device__ __forceinline__ void ws_store_fp(const Ws& ws, int plane, size_t i, const Fp& a) {
-#pragma unroll
-  for (int k = 0; k < BN_LIMBS; ++k) ws.planes[((size_t)plane * BN_LIMBS + k) * ws.stride + i] = a.v[k];
-}
-__device__ __forceinline__ uint8_t& ws_byte(const Ws& ws, int plane, size_t i) { return ws.bytes[(size_t)plane * ws.stride + i]; }
+#include "bn254_ws.h"
 
 __device__ __forceinline__ void ws_store_f12(const Ws& ws, size_t i, const Fp12& f) {
   const Fp2* c[6] = {&f.c0.c0, &f.c0.c1, &f.c0.c2, &f.c1.c0, &f.c1.c1, &f.c1.c2};
@@ -84,12 +37,6 @@ __device__ __forceinline__ void ws_load_f12(const Ws& ws, size_t i, Fp12& f) {
   Fp2* c[6] = {&f.c0.c0, &f.c0.c1, &f.c0.c2, &f.c1.c0, &f.c1.c1, &f.c1.c2};
 #pragma unroll
   for (int k = 0; k < 6; ++k) { c[k]->c0 = ws_load_fp(ws, PL_F0 + 2 * k, i); c[k]->c1 = ws_load_fp(ws, PL_F0 + 2 * k + 1, i); }
-}
-__device__ __forceinline__ void ws_store_g1(const Ws& ws, int px, int inf_plane, size_t i, const G1Affine& p) {
-  ws_store_fp(ws, px, i, p.x); ws_store_fp(ws, px + 1, i, p.y); ws_byte(ws, inf_plane, i) = p.inf;
-}
-__device__ __forceinline__ void ws_load_g1(const Ws& ws, int px, int inf_plane, size_t i, G1Affine& p) {
-  p.x = ws_load_fp(ws, px, i); p.y = ws_load_fp(ws, px + 1, i); p.inf = ws_byte(ws, inf_plane, i) != 0;
 }
 __device__ __forceinline__ void ws_store_g2(const Ws& ws, size_t i, const G2Affine& q) {
   ws_store_fp(ws, PL_QX0, i, q.x.c0); ws_store_fp(ws, PL_QX1, i, q.x.c1);
@@ -748,17 +695,14 @@ struct bn254_ctx {
   int split_miller;  // A/B knob: one pairing per lane (k_miller_verify_split) instead of the fused 2-pair loop
   Pool pool[3];       // aggregate verify: pk pool, sig pool, H(m) pool (grown on demand)
   size_t pool_fp[3];  // coordinates per entry: 4, 2, 2
+  int pair_lanes;    // verify: Miller loop + final exponentiation on lane pairs (bn254_pair.hip); default on
   int rand_items_per_lane; // randomised verify: 0 = by batch size, 1 or 2 forced (A/B and tests)
   int hash_max_tries; // test knob: counters tried before HashToPointError (0 = the reference's 255)
   hipEvent_t ev[5];
   int ev_valid;
 };
 
-#define HIP_TRY(expr)                                      \
-  do {                                                     \
-    hipError_t e_ = (expr);                                \
-    if (e_ != hipSuccess) return -(int)e_;                 \
-  } while (0)
+
 
 static inline unsigned grid_for(size_t n) { return (unsigned)((n + BN_WAVE - 1) / BN_WAVE); }
 
@@ -852,7 +796,7 @@ static int launch_hash_rounds(bn254_ctx* c, hipStream_t s, const uint8_t* d_msgs
 
 extern "C" {
 
-const char* bn254_version(void) { return "bn254-mi355x 0.2 (gfx950; 10x27-bit signed Montgomery limbs, one item per lane)"; }
+const char* bn254_version(void) { return "bn254-mi355x 0.3 (gfx950; 10x27-bit signed Montgomery limbs; verify on lane pairs)"; }
 
 int bn254_ctx_create(int hip_device, bn254_ctx** out) {
   if (!out) return BN254_E_BAD_ARGUMENT;
@@ -864,6 +808,7 @@ int bn254_ctx_create(int hip_device, bn254_ctx** out) {
   bn254_ctx* c = new (std::nothrow) bn254_ctx();
   if (!c) return BN254_E_BAD_ARGUMENT;
   memset(c, 0, sizeof *c);
+  c->pair_lanes = 1;
   c->device = hip_device;
   HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   for (int i = 0; i < 5; ++i) HIP_TRY(hipEventCreate(&c->ev[i]));
@@ -901,6 +846,7 @@ int bn254_ctx_set_profiling(bn254_ctx* c, int enabled) {
 int bn254_ctx_set_option(bn254_ctx* c, int option, int value) {
   if (!c) return BN254_E_BAD_ARGUMENT;
   if (option == BN254_OPT_SPLIT_MILLER) { c->split_miller = value; return 0; }
+  if (option == BN254_OPT_PAIR_LANES) { c->pair_lanes = value != 0; return 0; }
   if (option == BN254_OPT_RAND_ITEMS_PER_LANE) { if (value < 0 || value > 2) return BN254_E_BAD_ARGUMENT; c->rand_items_per_lane = value; return 0; }
   if (option == BN254_OPT_HASH_MAX_TRIES) { if (value < 0 || value > 255) return BN254_E_BAD_ARGUMENT; c->hash_max_tries = value; return 0; }
   return BN254_E_BAD_ARGUMENT;
@@ -938,6 +884,10 @@ int bn254_batch_verify_device(bn254_ctx* c, const uint8_t* d_msgs, const uint64_
     k_miller_verify_split<<<2 * g, BN_WAVE, 0, s>>>(n, c->ws.stride / 2, g, c->ws);
     PROF_MARK(3);
     k_final_exp<<<g, BN_WAVE, 0, s>>>(n, 2, 1, c->ws.stride / 2, c->ws, 1, nullptr, d_status, 0, 0, nullptr, nullptr);
+  } else if (c->pair_lanes) {
+    if ((rc = bn254_pair_miller_verify(n, c->ws, nullptr, nullptr, s))) return rc;
+    PROF_MARK(3);
+    if ((rc = bn254_pair_final_exp(n, c->ws, 1, d_status, nullptr, nullptr, s))) return rc;
   } else {
     k_miller_verify<<<g, BN_WAVE, 0, s>>>(n, c->ws, nullptr, nullptr);
     PROF_MARK(3);

@@ -13,13 +13,6 @@
 
 namespace bn254 {
 
-enum Status : uint8_t {   // 1 + index of the variant in /root/reference/src/error.rs:6-29
-  ST_OK = 0, ST_HASH_TO_POINT = 1, ST_INDEX_OOB = 2, ST_INVALID_ENCODING = 3, ST_INVALID_GROUP_POINT = 4,
-  ST_INVALID_LENGTH = 5, ST_NOT_MEMBER = 6, ST_TO_AFFINE = 7, ST_POINT_IN_JACOBIAN = 8,
-  ST_VERIFICATION_FAILED = 9, ST_SERIALIZATION = 10, ST_HEX_DECODE = 11
-};
-enum Flags : uint32_t { FLAG_G2_SUBGROUP_CHECK = 1u, FLAG_REJECT_IDENTITY = 2u };
-
 // 32 big-endian bytes (4-byte aligned) -> plain limbs
 BN_DEV void u256_from_be(uint32_t* v, const uint8_t* p) {
   const uint32_t* w = (const uint32_t*)p;

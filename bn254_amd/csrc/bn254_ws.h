@@ -1,0 +1,70 @@
+// Workspace layout shared by the two device translation units of libbn254hip.so (bn254_hip.hip: one item per
+// lane; bn254_pair.hip: one verify per lane PAIR).  Device-side only; include after the field headers.
+#pragma once
+
+#define BN_WAVE 64
+#define BN_SPLIT_MAX_N ((size_t)98304)   // <= 1.5 waves per SIMD with one lane per verify
+#define RAND_TWO_PER_LANE_MIN_N ((size_t)131072)   // randomised verify: two items per lane once that still fills 1024 SIMDs
+// Register budget: amdgpu_waves_per_eu(W, W) on the kernels is propagated to every device function
+// they call (AMDGPU attributor), capping VGPR+AGPR at 512/W so that W waves fit on each SIMD.
+// In a pure-VALU microbenchmark two co-resident waves each keep the full single-wave issue rate
+// (profiles/r01_issue_mix_microbench.jsonl), but the Fq12 bodies need ~400 live registers: at W = 2
+// they spill to the private segment and every kernel got slower (profiles/r01_c_ab_occupancy.log).
+// W = 1 (512 registers per lane) is the measured optimum for this code shape.
+#ifndef BN_WAVES_PER_EU
+#define BN_WAVES_PER_EU 1
+#endif
+#define KERNEL __global__ __launch_bounds__(BN_WAVE) __attribute__((amdgpu_waves_per_eu(BN_WAVES_PER_EU, BN_WAVES_PER_EU)))
+// kernels whose per-lane state is a few field elements (hash rounds, decoders, encoders) fit 256
+// registers without spilling and gain from a second wave per SIMD (hash: 1.34 -> 1.15 ms per 65 536)
+#define KERNEL_SMALL __global__ __launch_bounds__(BN_WAVE) __attribute__((amdgpu_waves_per_eu(2, 2)))
+
+// ------------------------------------------------------------------------------------------
+// workspace planes
+// ------------------------------------------------------------------------------------------
+struct Ws {
+  int32_t* planes;    // [N_PLANES * BN_LIMBS][stride] i32
+  uint8_t* bytes;     // [N_BYTE_PLANES][stride]
+  size_t stride;
+  // hash-to-G1 round state (see k_hash_round)
+  uint32_t* h_best;   // [stride]  smallest successful counter of the current round, or HASH_NONE
+  uint8_t* h_next;    // [stride]  first counter not yet tried
+  uint32_t* h_list;   // [2][stride] compacted indices of the messages still without a point
+  uint32_t* h_cnt;    // [HASH_MAX_ROUNDS + 1] number of entries of the list feeding round r
+};
+#define HASH_NONE 0xFFFFFFFFu
+#define HASH_MAX_ROUNDS 64
+#define HASH_MAX_GRID_LANES ((size_t)1 << 24)   // lanes launched per round at most (grid-stride beyond)
+#define HASH_TARGET_LANES ((size_t)1 << 17)    // ~2 waves per SIMD
+enum { PL_P1X = 0, PL_P1Y, PL_QX0, PL_QX1, PL_QY0, PL_QY1, PL_P2X, PL_P2Y, PL_HASHX, PL_HASHY, PL_F0, N_PLANES = PL_F0 + 12 };
+enum { BY_ST_DECODE = 0, BY_ST_HASH, BY_P1_INF, BY_Q_INF, BY_P2_INF, BY_A_INF, N_BYTE_PLANES };
+
+__device__ __forceinline__ Fp ws_load_fp(const Ws& ws, int plane, size_t i) {
+  Fp r;
+#pragma unroll
+  for (int k = 0; k < BN_LIMBS; ++k) r.v[k] = ws.planes[((size_t)plane * BN_LIMBS + k) * ws.stride + i];
+  return r;
+}
+__device__ __forceinline__ void ws_store_fp(const Ws& ws, int plane, size_t i, const Fp& a) {
+#pragma unroll
+  for (int k = 0; k < BN_LIMBS; ++k) ws.planes[((size_t)plane * BN_LIMBS + k) * ws.stride + i] = a.v[k];
+}
+__device__ __forceinline__ uint8_t& ws_byte(const Ws& ws, int plane, size_t i) { return ws.bytes[(size_t)plane * ws.stride + i]; }
+
+__device__ __forceinline__ void ws_store_g1(const Ws& ws, int px, int inf_plane, size_t i, const G1Affine& p) {
+  ws_store_fp(ws, px, i, p.x); ws_store_fp(ws, px + 1, i, p.y); ws_byte(ws, inf_plane, i) = p.inf;
+}
+__device__ __forceinline__ void ws_load_g1(const Ws& ws, int px, int inf_plane, size_t i, G1Affine& p) {
+  p.x = ws_load_fp(ws, px, i); p.y = ws_load_fp(ws, px + 1, i); p.inf = ws_byte(ws, inf_plane, i) != 0;
+}
+
+#define HIP_TRY(expr)                                      \
+  do {                                                     \
+    hipError_t e_ = (expr);                                \
+    if (e_ != hipSuccess) return -(int)e_;                 \
+  } while (0)
+
+// entry points of bn254_pair.hip (internal to the library)
+__attribute__((visibility("hidden"))) int bn254_pair_miller_verify(size_t n, Ws ws, const uint32_t* map, const uint32_t* count, hipStream_t s);
+__attribute__((visibility("hidden"))) int bn254_pair_final_exp(size_t n, Ws ws, int use_hash, uint8_t* status_out, const uint32_t* map,
+                                                               const uint32_t* count, hipStream_t s);

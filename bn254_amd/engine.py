@@ -14,6 +14,7 @@ FLAG_RAND64 = 0x100
 OPT_SPLIT_MILLER = 1
 OPT_HASH_MAX_TRIES = 2
 OPT_RAND_ITEMS_PER_LANE = 3
+OPT_PAIR_LANES = 4
 
 
 class NativeError(RuntimeError):

@@ -187,6 +187,7 @@ int bn254_ctx_set_profiling(bn254_ctx *ctx, int enabled);
  * different waves (one pairing per lane) instead of one lane sharing f^2 (default 0).  Results are
  * identical either way. */
 #define BN254_OPT_SPLIT_MILLER 1
+#define BN254_OPT_PAIR_LANES 4 /* verify: Miller loop + final exponentiation on lane pairs, two waves per SIMD (default 1); 0 = one lane per verify */
 #define BN254_OPT_RAND_ITEMS_PER_LANE 3 /* randomised verify: items per lane in the Miller kernel; 0 = by batch size (default), 1, 2 */
 #define BN254_OPT_HASH_MAX_TRIES 2 /* test knob: counters tried before HashToPointError; 0 = 255 as in src/hash.rs:40 */
 int bn254_ctx_set_option(bn254_ctx *ctx, int option, int value);

@@ -1,0 +1,61 @@
+// hostsim_pair — TEST INFRASTRUCTURE ONLY.
+//
+// Host compilation of the PAIR layout of the Fq2 tower (bn254_amd/csrc/bn254_fp2_pair.h, the code of
+// bn254_pair.hip): an Fq2 element keeps both coefficients and every primitive runs the two lane roles in
+// sequence through the same per-role code the device executes with a DPP exchange.  Used by the CPU suite for
+// parity against the oracle and, built with -DBN_TRACK_BOUNDS, for the limb / value bound proof of this layout.
+#include <cstdint>
+#include <cstring>
+
+#define BN_SPLIT_FP2 1
+#define BN_COUNT_FP_MUL 1
+extern "C" { unsigned long long bn_fp_mul_counter = 0; }
+
+#include "../../bn254_amd/csrc/bn254_pairing.h"
+
+using namespace bn254;
+
+static Fp fp_from_be32(const uint8_t* b) {   // inputs are valid field elements (decoding is tested elsewhere)
+  U256 x;
+  for (int i = 0; i < 8; ++i) x.w[i] = ((uint32_t)b[28 - 4 * i] << 24) | ((uint32_t)b[29 - 4 * i] << 16) | ((uint32_t)b[30 - 4 * i] << 8) | b[31 - 4 * i];
+  return fp_from_u256(x);
+}
+static void fp_to_be32(uint8_t* b, const Fp& a) {
+  U256 x = fp_to_u256(a);
+  for (int i = 0; i < 8; ++i) { b[28 - 4 * i] = (uint8_t)(x.w[i] >> 24); b[29 - 4 * i] = (uint8_t)(x.w[i] >> 16); b[30 - 4 * i] = (uint8_t)(x.w[i] >> 8); b[31 - 4 * i] = (uint8_t)x.w[i]; }
+}
+static bool all_zero(const uint8_t* b, int n) { uint8_t o = 0; for (int i = 0; i < n; ++i) o |= b[i]; return o == 0; }
+static void load_g1(G1Affine& p, const uint8_t* b) { p.inf = all_zero(b, 64); p.x = fp_from_be32(b); p.y = fp_from_be32(b + 32); if (p.inf) { p.x = fp_load_const(C_G1_GEN[0]); p.y = fp_load_const(C_G1_GEN[1]); } }
+static void load_g2(G2Affine& q, const uint8_t* b) {
+  q.inf = all_zero(b, 128);
+  if (q.inf) { q.x = fp2_load_const(C_G2_GEN[0]); q.y = fp2_load_const(C_G2_GEN[1]); return; }
+  q.x.c[0] = fp_from_be32(b); q.x.c[1] = fp_from_be32(b + 32); q.y.c[0] = fp_from_be32(b + 64); q.y.c[1] = fp_from_be32(b + 96);
+}
+
+extern "C" {
+
+unsigned long long hp_fp_mul_count(void) { return bn_fp_mul_counter; }
+void hp_fp_mul_count_reset(void) { bn_fp_mul_counter = 0; }
+
+// mirrors k_miller_verify_pair + k_final_exp_pair on decoded inputs: 0 = the pairing product is one, 9 = it is not
+int hp_verify_decoded(const uint8_t* h64, const uint8_t* sig64, const uint8_t* pk128) {
+  G1Affine h, sig;
+  G2Affine pk;
+  load_g1(h, h64); load_g1(sig, sig64); load_g2(pk, pk128);
+  Fp12 f, acc;
+  miller_loop<true, true>(f, h, pk, sig);
+  final_exponentiation(f, f, acc);
+  return fp12_is_one(f) ? 0 : 9;
+}
+// canonical Gt of one pairing through the pair layout
+void hp_pairing(const uint8_t* g1, const uint8_t* g2, uint8_t* gt384) {
+  G1Affine p;
+  G2Affine q;
+  load_g1(p, g1); load_g2(q, g2);
+  Fp12 f, acc;
+  miller_loop<true, false>(f, p, q, p);
+  final_exponentiation(f, f, acc);
+  const Fp2* c[6] = {&f.c0.c0, &f.c0.c1, &f.c0.c2, &f.c1.c0, &f.c1.c1, &f.c1.c2};
+  for (int k = 0; k < 6; ++k) { fp_to_be32(gt384 + 64 * k, c[k]->c[0]); fp_to_be32(gt384 + 64 * k + 32, c[k]->c[1]); }
+}
+}  // extern "C"

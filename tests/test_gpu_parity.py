@@ -320,6 +320,23 @@ def test_fused_and_split_miller_agree(eng, derived):
         eng.set_option(OPT_SPLIT_MILLER, 0)
 
 
+def test_pair_lanes_and_single_lane_agree(eng, derived):
+    """verify on lane pairs (default, bn254_pair.hip) and on one lane per verify give the same statuses"""
+    from bn254_amd.engine import OPT_PAIR_LANES
+    from tests.datagen import make_verify_batch
+    cs = derived["verify_cases"]
+    args = ([H(v["message_hex"]) for v in cs], b"".join(H(v["sig"]) for v in cs), b"".join(H(v["pk"]) for v in cs))
+    want = [v["status"] for v in cs]
+    big = make_verify_batch(eng, 2048 + 33)
+    for mode in (1, 0):
+        eng.set_option(OPT_PAIR_LANES, mode)
+        try:
+            assert list(eng.batch_verify(*args, flags=1)) == want, mode
+            assert eng.batch_verify(big[0], big[1], big[2]) == big[3], mode
+        finally:
+            eng.set_option(OPT_PAIR_LANES, 1)
+
+
 def test_malformed_inputs_fuzz_vs_oracle(eng, c, derived):
     """3000 verifies whose signature / public key bytes are valid, mutated (bit flips, coordinate >= q,
     swapped coordinates, zeros) or random: every status byte must equal the oracle's, with and without the
