@@ -14,7 +14,13 @@ using namespace bn254;
 
 #include "bn254_ws.h"
 
-#define KERNEL_PAIR __global__ __launch_bounds__(BN_WAVE) __attribute__((amdgpu_waves_per_eu(2, 2)))
+// 256-thread workgroups: the four waves of a workgroup land on the four SIMDs of a CU, so two workgroups per CU
+// give exactly two waves per SIMD.  With one-wave workgroups the dispatcher filled the SIMDs unevenly (1.54 resident
+// waves per SIMD on average, rocprofv3 SQ_WAVE_CYCLES) and the pair layout gained nothing.
+#ifndef BN_PAIR_WG
+#define BN_PAIR_WG 256
+#endif
+#define KERNEL_PAIR __global__ __launch_bounds__(BN_PAIR_WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
 struct Fp12PairSlot { Fp12 v; int32_t pad; };
 static_assert(sizeof(Fp12PairSlot) == 61 * 4, "LDS slot must be 61 words (odd stride: conflict-free)");
@@ -38,7 +44,7 @@ __device__ __forceinline__ void ws_store_f12_own(const Ws& ws, size_t i, const F
 // f = miller(H(m), pk) * miller(sig, -G2); item = lane >> 1.  Both lanes of a pair take every branch together
 // (item-level conditions only), so the DPP exchanges always find their partner active.
 KERNEL_PAIR void k_miller_verify_pair(size_t n, Ws ws, const uint32_t* map, const uint32_t* count) {
-  size_t i = ((size_t)blockIdx.x * BN_WAVE + threadIdx.x) >> 1;
+  size_t i = ((size_t)blockIdx.x * BN_PAIR_WG + threadIdx.x) >> 1;
   if (i >= n) return;
   if (map) { if (i >= *count) return; i = map[i]; }
   G1Affine sig, h;
@@ -48,32 +54,32 @@ KERNEL_PAIR void k_miller_verify_pair(size_t n, Ws ws, const uint32_t* map, cons
   pk.x = ws_load_fp2_own(ws, PL_QX0, i);
   pk.y = ws_load_fp2_own(ws, PL_QY0, i);
   pk.inf = ws_byte(ws, BY_Q_INF, i) != 0;
-  __shared__ Fp12PairSlot lds_f[BN_WAVE];
+  __shared__ Fp12PairSlot lds_f[BN_PAIR_WG];
   Fp12& f = lds_f[threadIdx.x].v;
   miller_loop<true, true>(f, h, pk, sig);
   ws_store_f12_own(ws, i, f);
 }
 KERNEL_PAIR void k_final_exp_pair(size_t n, Ws ws, int use_hash, uint8_t* status_out, const uint32_t* map, const uint32_t* count) {
-  size_t i = ((size_t)blockIdx.x * BN_WAVE + threadIdx.x) >> 1;
+  size_t i = ((size_t)blockIdx.x * BN_PAIR_WG + threadIdx.x) >> 1;
   if (i >= n) return;
   if (map) { if (i >= *count) return; i = map[i]; }
   Fp12 f;
   ws_load_f12_own(ws, i, f);
   uint8_t st = ws_byte(ws, BY_ST_DECODE, i);
   if (st == ST_OK && use_hash) st = ws_byte(ws, BY_ST_HASH, i);
-  __shared__ Fp12PairSlot lds_acc[BN_WAVE];
+  __shared__ Fp12PairSlot lds_acc[BN_PAIR_WG];
   final_exponentiation(f, f, lds_acc[threadIdx.x].v);
   const bool one = fp12_is_one(f);   // combined over the pair
   if ((threadIdx.x & 1u) == 0) status_out[i] = st != ST_OK ? st : (one ? (uint8_t)ST_OK : (uint8_t)ST_VERIFICATION_FAILED);
 }
 
 int bn254_pair_miller_verify(size_t n, Ws ws, const uint32_t* map, const uint32_t* count, hipStream_t s) {
-  k_miller_verify_pair<<<(unsigned)((2 * n + BN_WAVE - 1) / BN_WAVE), BN_WAVE, 0, s>>>(n, ws, map, count);
+  k_miller_verify_pair<<<(unsigned)((2 * n + BN_PAIR_WG - 1) / BN_PAIR_WG), BN_PAIR_WG, 0, s>>>(n, ws, map, count);
   HIP_TRY(hipGetLastError());
   return 0;
 }
 int bn254_pair_final_exp(size_t n, Ws ws, int use_hash, uint8_t* status_out, const uint32_t* map, const uint32_t* count, hipStream_t s) {
-  k_final_exp_pair<<<(unsigned)((2 * n + BN_WAVE - 1) / BN_WAVE), BN_WAVE, 0, s>>>(n, ws, use_hash, status_out, map, count);
+  k_final_exp_pair<<<(unsigned)((2 * n + BN_PAIR_WG - 1) / BN_PAIR_WG), BN_PAIR_WG, 0, s>>>(n, ws, use_hash, status_out, map, count);
   HIP_TRY(hipGetLastError());
   return 0;
 }
