@@ -261,6 +261,7 @@ def main():
     if args.no_pair_lanes:
         eng.set_option(4, 0)
 
+
     # ---- synthetic inputs, generated on the GPU by the product's own sign / keygen kernels -------
     base = rank * n                                          # each rank owns a distinct shard
     msgs = [D("bn254/msg2", base + i) for i in range(n)]

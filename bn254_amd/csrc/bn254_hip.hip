@@ -951,8 +951,13 @@ int bn254_batch_verify_randomized_device(bn254_ctx* c, const uint8_t* d_msgs, co
   k_final_exp<<<gg, BN_WAVE, 0, s>>>(n_groups, 1, 1, 1, c->ws, 0, nullptr, d_group_st, 0, gbase, nullptr, nullptr);
   k_rand_collect<<<g, BN_WAVE, 0, s>>>(n, c->ws, d_group_st, d_status, d_group_ok);
   // exact per-item check of the items of failed groups (none queued: both kernels leave at once)
-  k_miller_verify<<<g, BN_WAVE, 0, s>>>(n, c->ws, c->ws.h_list, c->ws.h_cnt);
-  k_final_exp<<<g, BN_WAVE, 0, s>>>(n, 1, 1, 1, c->ws, 1, nullptr, d_status, 0, 0, c->ws.h_list, c->ws.h_cnt);
+  if (c->pair_lanes) {
+    if ((rc = bn254_pair_miller_verify(n, c->ws, c->ws.h_list, c->ws.h_cnt, s))) return rc;
+    if ((rc = bn254_pair_final_exp(n, c->ws, 1, d_status, c->ws.h_list, c->ws.h_cnt, s))) return rc;
+  } else {
+    k_miller_verify<<<g, BN_WAVE, 0, s>>>(n, c->ws, c->ws.h_list, c->ws.h_cnt);
+    k_final_exp<<<g, BN_WAVE, 0, s>>>(n, 1, 1, 1, c->ws, 1, nullptr, d_status, 0, 0, c->ws.h_list, c->ws.h_cnt);
+  }
   PROF_MARK(4);
   if (c->profiling) c->ev_valid = 1;
   HIP_TRY(hipGetLastError());
@@ -1222,8 +1227,13 @@ int bn254_batch_aggregate_verify_device(bn254_ctx* c, const uint8_t* d_msgs, con
   if ((rc = launch_hash_rounds(c, s, d_msgs, d_msg_off, n_msgs, PL_P2X, BY_P2_INF, nullptr))) return rc;
   k_hash_to_pool<<<grid_for(n_msgs), BN_WAVE, 0, s>>>(n_msgs, c->ws, c->pool[2]);
   k_aggregate<<<grid_for(n), BN_WAVE, 0, s>>>(d_tuple_msg, d_tuple_off, d_signer_idx, n, n_signers, c->pool[0], c->pool[1], c->pool[2], c->ws);
-  k_miller_verify<<<grid_for(n), BN_WAVE, 0, s>>>(n, c->ws, nullptr, nullptr);
-  k_final_exp<<<grid_for(n), BN_WAVE, 0, s>>>(n, 1, 1, 1, c->ws, 1, nullptr, d_status, 0, 0, nullptr, nullptr);
+  if (c->pair_lanes) {
+    if ((rc = bn254_pair_miller_verify(n, c->ws, nullptr, nullptr, s))) return rc;
+    if ((rc = bn254_pair_final_exp(n, c->ws, 1, d_status, nullptr, nullptr, s))) return rc;
+  } else {
+    k_miller_verify<<<grid_for(n), BN_WAVE, 0, s>>>(n, c->ws, nullptr, nullptr);
+    k_final_exp<<<grid_for(n), BN_WAVE, 0, s>>>(n, 1, 1, 1, c->ws, 1, nullptr, d_status, 0, 0, nullptr, nullptr);
+  }
   HIP_TRY(hipGetLastError());
   return 0;
 }
