@@ -350,21 +350,26 @@ def main():
     if rank == 0:
         k_avg = {k: v / args.steps for k, v in kernel_ms.items()}
         dom = max(("miller_loop", "final_exp"), key=lambda k: k_avg[k])
+        pair = not (args.no_pair_lanes or args.split_miller)
+        kname = {("miller_loop", True): "k_miller_verify_pair", ("miller_loop", False): "k_miller_verify",
+                 ("final_exp", True): "k_final_exp_pair", ("final_exp", False): "k_final_exp"}[(dom, pair)]
         fp_mul = FP_MUL_MILLER if dom == "miller_loop" else FP_MUL_FINAL_EXP
         mac_per_launch = fp_mul * MAC32_PER_FP_MUL * n
         achieved = mac_per_launch / (k_avg[dom] * 1e-3) / 1e12
         io_bytes = BYTES_PER_VERIFY_IO * n
         result["roofline"] = {
             "bound": "valu",                       # integer multiply issue (v_mad_u64_u32); not HBM, not MFMA
-            "kernel": "k_miller_verify" if dom == "miller_loop" else "k_final_exp",
+            "kernel": kname,
+            "layout": "one verify per lane pair (Fq2 coefficients in adjacent lanes), two waves per SIMD" if pair else "one verify per lane",
             "achieved": achieved, "peak": PEAK_MAC32_THEORETICAL / 1e12, "unit": "TMAC32/s",
             "frac": achieved / (PEAK_MAC32_THEORETICAL / 1e12),
             "peak_measured_microbench": PEAK_MAC32_MEASURED / 1e12,
             "frac_of_measured_peak": achieved / (PEAK_MAC32_MEASURED / 1e12),
-            # register-resident chain of the same Fq product routine, one wave per SIMD
-            # (profiles/r01_fp_mul_chain_ceiling.jsonl): the ceiling of this code shape at occupancy 1
+            # register-resident chains of the same product routines (profiles/r01_fp_mul_chain_ceiling.jsonl):
+            # 8.16e10 Fq products/s with one wave per SIMD, 1.37e11 when the multiplier pipe is saturated
             "frac_of_occupancy1_product_ceiling": (fp_mul * n / (k_avg[dom] * 1e-3)) / 8.16e10,
-            "traffic": measured_traffic("k_miller_verify" if dom == "miller_loop" else "k_final_exp"),
+            "frac_of_saturated_product_rate": (fp_mul * n / (k_avg[dom] * 1e-3)) / 1.37e11,
+            "traffic": measured_traffic(kname),
             "multiplier_issue_frac": (fp_mul * MUL_INSTR_PER_FP_MUL * n / (k_avg[dom] * 1e-3)) / PEAK_MAC32_THEORETICAL,
             "kernel_ms": k_avg,
             "mac32_per_verify": {"miller_loop": FP_MUL_MILLER * MAC32_PER_FP_MUL, "final_exp": FP_MUL_FINAL_EXP * MAC32_PER_FP_MUL,
