@@ -89,8 +89,39 @@ BN_DEV bool fp2_is_zero(const Fp2& a) { bool z = true; BN_FOR_ROLES(k) z = fp_is
 BN_DEV bool fp2_eq(const Fp2& a, const Fp2& b) { return fp2_is_zero(fp2_sub(a, b)); }
 BN_DEV Fp2 fp2_select(bool c, const Fp2& a, const Fp2& b) { Fp2 r; BN_FOR_ROLES(k) r.c[k] = fp_select(c, a.c[k], b.c[k]); return r; }
 
+#if defined(__HIPCC__)
+// Device form of fp2_mul: the callee fetches the partner's operands itself (DPP) and picks its role's operand
+// pairing, so a call passes 20 words in registers (a 40-word call spills 8 argument words to the stack) and the
+// exchange / select code exists once instead of at every call site.
+BN_DEVN BN_VEC10 fp_pair_mul_impl(BN_VEC10 a, BN_VEC10 b) {
+  const bool im = (threadIdx.x & 1u) != 0;
+  int32_t ao[BN_LIMBS], ap[BN_LIMBS], x[BN_LIMBS], y[BN_LIMBS], r[BN_LIMBS];
+#pragma unroll
+  for (int i = 0; i < BN_LIMBS; ++i) {
+    const int32_t bo = b[i], bp = bn_partner_word(b[i]);
+    ao[i] = a[i];
+    ap[i] = bn_partner_word(a[i]);
+    x[i] = im ? bp : bo;          // re: a0*b0 + a1*(-b1)   im: a1*b0 + a0*b1
+    y[i] = im ? bo : -bp;
+  }
+  fp_dual_mul_reduce(r, ao, x, ap, y);
+  BN_VEC10 z;
+#pragma unroll
+  for (int i = 0; i < BN_LIMBS; ++i) z[i] = r[i];
+  return z;
+}
+#endif
 BN_DEV Fp2 fp2_mul(const Fp2& a, const Fp2& b) {   // outputs are tight
   Fp2 r;
+#if defined(__HIPCC__)
+  BN_VEC10 x, y;
+#pragma unroll
+  for (int i = 0; i < BN_LIMBS; ++i) { x[i] = a.c[0].v[i]; y[i] = b.c[0].v[i]; }
+  BN_VEC10 z = fp_pair_mul_impl(x, y);
+#pragma unroll
+  for (int i = 0; i < BN_LIMBS; ++i) r.c[0].v[i] = z[i];
+  return r;
+#endif
   BN_FOR_ROLES(k) {
     const bool im = bn_role_im(k);
     const Fp ap = bn_partner(a, k), bp = bn_partner(b, k);
@@ -99,14 +130,43 @@ BN_DEV Fp2 fp2_mul(const Fp2& a, const Fp2& b) {   // outputs are tight
   }
   return r;
 }
+#if defined(__HIPCC__)
+// Device form of fp2_sqr, same idea: re (a0 + a1)(a0 - a1), im 2 * (a1 * a0) — one product per lane
+BN_DEVN BN_VEC10 fp_pair_sqr_impl(BN_VEC10 a) {
+  const bool im = (threadIdx.x & 1u) != 0;
+  int32_t u[BN_LIMBS], v[BN_LIMBS];
+#pragma unroll
+  for (int i = 0; i < BN_LIMBS; ++i) {
+    const int32_t ao = a[i], ap = bn_partner_word(a[i]);
+    u[i] = im ? ao + ao : ao + ap;
+    v[i] = im ? ap : ao - ap;
+  }
+  BN_LIMB_VEC x, y;
+#pragma unroll
+  for (int i = 0; i < BN_LIMBS; ++i) { x[i] = u[i]; y[i] = v[i]; }
+  BN_LIMB_VEC p = fp_mul_impl(x, y);
+  BN_VEC10 z;
+#pragma unroll
+  for (int i = 0; i < BN_LIMBS; ++i) z[i] = p[i];
+  return z;
+}
+#endif
 BN_DEV Fp2 fp2_sqr(const Fp2& a) {
   Fp2 r;
+#if defined(__HIPCC__)
+  BN_VEC10 x;
+#pragma unroll
+  for (int i = 0; i < BN_LIMBS; ++i) x[i] = a.c[0].v[i];
+  BN_VEC10 z = fp_pair_sqr_impl(x);
+#pragma unroll
+  for (int i = 0; i < BN_LIMBS; ++i) r.c[0].v[i] = z[i];
+  return r;
+#endif
   BN_FOR_ROLES(k) {
     const bool im = bn_role_im(k);
     const Fp ap = bn_partner(a, k);
-    // re: (a0 + a1)(a0 - a1)   im: 2 * (a1 * a0)
-    Fp p = fp_mul(fp_select(im, a.c[k], fp_add(a.c[k], ap)), fp_select(im, ap, fp_sub(a.c[k], ap)));
-    r.c[k] = fp_select(im, fp_dbl(p), p);
+    // re: (a0 + a1)(a0 - a1)   im: (2 a1) * a0
+    r.c[k] = fp_mul(fp_select(im, fp_dbl(a.c[k]), fp_add(a.c[k], ap)), fp_select(im, ap, fp_sub(a.c[k], ap)));
   }
   return r;
 }
