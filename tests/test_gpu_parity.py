@@ -557,3 +557,28 @@ def test_randomized_verify_edge_sizes(eng, c):
         got = eng.batch_verify_randomized(msgs, bytes(bad), pks, RAND_SEED)
         assert got == c.batch_verify_randomized(msgs, bytes(bad), pks, RAND_SEED, flags=0)
         assert got[0] == bytes(n - 1) + b"\x09" and got[1][-1] == 0
+
+
+def test_argument_validation_and_empty_batches(eng):
+    """error behaviour at the C ABI: empty batches succeed, NULL / misaligned device pointers are refused with
+    BN254_E_BAD_ARGUMENT / BN254_E_MISALIGNED (never a fault), bad option values are refused"""
+    import ctypes
+    L, h = eng._lib, eng._h
+    assert eng.batch_verify([], b"", b"") == b""
+    assert eng.batch_hash_to_g1([]) == (b"", b"", b"")
+    assert eng.batch_pairing_check(b"", b"", 0, 2) == b""
+    assert eng.batch_g1_add(b"", b"", 0)[0] == b""
+    st = ctypes.create_string_buffer(8)
+    assert L.bn254_batch_verify(h, None, None, None, None, 4, 0, st) == -10001
+    assert L.bn254_batch_verify(None, None, None, None, None, 0, 0, st) == -10001
+    assert L.bn254_batch_verify_randomized(h, b"", (ctypes.c_uint64 * 1)(0), b"", b"", 0, 0, None, st, None) == -10001   # no seed
+    p, off = 0x7F0000001000, 0x7F0000100000        # pointer VALUES only: every call below is refused before any access
+    assert L.bn254_batch_verify_device(h, p, off, p + 1, p + 1024, 2, 0, p + 2048, None) == -10002        # sigs not 4-byte aligned
+    assert L.bn254_batch_verify_device(h, p, off + 4, p, p + 1024, 2, 0, p + 2048, None) == -10002        # offsets not 8-byte aligned
+    assert L.bn254_batch_verify_device(h, p, off, p, None, 2, 0, p + 2048, None) == -10001
+    assert L.bn254_ctx_set_option(h, 3, 7) == -10001 and L.bn254_ctx_set_option(h, 2, 300) == -10001
+    assert L.bn254_ctx_set_option(h, 99, 0) == -10001
+    # the context is still usable afterwards
+    from tests.datagen import make_verify_batch
+    msgs, sigs, pks, expected = make_verify_batch(eng, 130)
+    assert eng.batch_verify(msgs, sigs, pks) == expected
