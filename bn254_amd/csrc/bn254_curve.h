@@ -128,21 +128,6 @@ template <class F> BN_DEVN void jac_madd(Jac<F>& r, const Jac<F>& p, const Affin
   r = o;
 }
 
-// k * P for a per-lane 256-bit scalar (plain little-endian limbs, used as-is, not reduced —
-// /root/reference/src/bn256.json:54-159 has scalars up to 2^256-1).  Fixed 256-step ladder of
-// double + add-with-select: identical control flow in every lane.
-template <class F> BN_DEVN void jac_mul(Jac<F>& r, const Jac<F>& p, const uint32_t* k) {
-  Jac<F> acc, t;
-  jac_set_identity(acc);
-  for (int i = 255; i >= 0; --i) {
-    jac_dbl(acc, acc);
-    jac_add(t, acc, p);
-    bool bit = (k[i >> 5] >> (i & 31)) & 1;
-    jac_select(acc, bit, t, acc);
-  }
-  r = acc;
-}
-
 // P + Q for operands known to satisfy P != +-Q unless one of them is the identity (add-2007-bl without
 // the doubling / cancellation overrides of jac_add, which cost a jac_dbl per call).
 template <class F> BN_DEVN void jac_add_distinct(Jac<F>& r, const Jac<F>& p, const Jac<F>& q) {
@@ -161,18 +146,24 @@ template <class F> BN_DEVN void jac_add_distinct(Jac<F>& r, const Jac<F>& p, con
   r = o;
 }
 
-// k * P for a per-lane scalar k < 2^(32*WORDS) (WORDS <= 4 little-endian words) and P in a group of prime
-// order r > 2^253 (G1: cofactor 1): signed fixed 4-bit windows (digits in [-8, 8]) over the table P..8P,
-// 32*WORDS doublings + 8*WORDS+1 additions with identical control flow in every lane.  While a window is added
-// the accumulator is 16 * (a prefix < 2^125) * P, never +-(digit * P) with digit <= 8 unless it is
-// the identity, so the additions cannot hit the doubling case and jac_add_distinct applies.
-// Used by the randomised batch verification (r_i * H(m_i), r_i * sig_i).
-template <int WORDS, class F> BN_DEVN void jac_mul_window(Jac<F>& r, const Affine<F>& p, const uint32_t* k) {
+// k * P for a per-lane scalar k < 2^(32*WORDS) (little-endian words): signed fixed 4-bit windows (digits in
+// [-8, 8]) over the table P..8P — 32*WORDS doublings + 8*WORDS+1 additions, identical control flow in every lane.
+// COMPLETE = false: P in a group of prime order r > 2^253 (G1: cofactor 1) and k < 2^128.  While a window is
+//   added the accumulator is 16 * (a prefix < 2^125) * P, never +-(digit * P) with digit <= 8 unless it is the
+//   identity, so the additions cannot hit the doubling case and jac_add_distinct applies (randomised batch
+//   verification: r_i * H(m_i), r_i * sig_i).
+// COMPLETE = true: any point, any scalar (used as-is, not reduced — /root/reference/src/bn256.json:54-159 has
+//   scalars up to 2^256-1): every addition is the complete jac_add.  Signing and key derivation
+//   (/root/reference/src/ecdsa.rs:31, src/types.rs:86, :156): 3.7 k products against 8.2 k for the
+//   bit-by-bit ladder this replaces.
+template <int WORDS, bool COMPLETE, class F> BN_DEVN void jac_mul_window(Jac<F>& r, const Affine<F>& p, const uint32_t* k) {
   constexpr int NW = 8 * WORDS;
   Jac<F> tab[8], acc, t;
   jac_from_affine(tab[0], p);
   jac_dbl(tab[1], tab[0]);
-  for (int j = 2; j < 8; ++j) jac_add_distinct(tab[j], tab[j - 1], tab[0]);
+  for (int j = 2; j < 8; ++j) {
+    if constexpr (COMPLETE) jac_add(tab[j], tab[j - 1], tab[0]); else jac_add_distinct(tab[j], tab[j - 1], tab[0]);
+  }
   signed char digit[NW + 1];
   int carry = 0;
   for (int j = 0; j < NW; ++j) {
@@ -188,12 +179,14 @@ template <int WORDS, class F> BN_DEVN void jac_mul_window(Jac<F>& r, const Affin
     jac_set_identity(t);
     for (int e = 0; e < 8; ++e) jac_select(t, m == e + 1, tab[e], t);
     t.y = f_select(d < 0, f_norm(f_neg(t.y)), t.y);
-    jac_add_distinct(acc, acc, t);
+    if constexpr (COMPLETE) jac_add(acc, acc, t); else jac_add_distinct(acc, acc, t);
   }
   r = acc;
 }
-template <class F> BN_DEV void jac_mul_u128(Jac<F>& r, const Affine<F>& p, const uint32_t* k) { jac_mul_window<4>(r, p, k); }
-template <class F> BN_DEV void jac_mul_u64(Jac<F>& r, const Affine<F>& p, const uint32_t* k) { jac_mul_window<2>(r, p, k); }
+template <class F> BN_DEV void jac_mul_u128(Jac<F>& r, const Affine<F>& p, const uint32_t* k) { jac_mul_window<4, false>(r, p, k); }
+template <class F> BN_DEV void jac_mul_u64(Jac<F>& r, const Affine<F>& p, const uint32_t* k) { jac_mul_window<2, false>(r, p, k); }
+// k * P, 256-bit scalar, any point
+template <class F> BN_DEV void jac_mul(Jac<F>& r, const Affine<F>& p, const uint32_t* k) { jac_mul_window<8, true>(r, p, k); }
 
 template <class F> BN_DEVN void jac_to_affine(Affine<F>& r, const Jac<F>& p) {
   bool inf = f_is_zero(p.z);

@@ -441,9 +441,8 @@ KERNEL void k_g1_mul(const uint8_t* p, const uint8_t* scalars, size_t n, int red
   if (st != ST_OK) g1_set_generator(pa);
   uint32_t k[8];
   scalar_from_be(k, scalars + 32 * i, reduce != 0);
-  G1Jac ja, jo;
-  jac_from_affine(ja, pa);
-  jac_mul(jo, ja, k);
+  G1Jac jo;
+  jac_mul(jo, pa, k);
   jac_to_affine(r, jo);
   if (st != ST_OK) r.inf = true;
   encode_g1(out + 64 * i, r);
@@ -459,9 +458,8 @@ KERNEL void k_g2_mul(const uint8_t* p, const uint8_t* scalars, size_t n, int red
   if (st != ST_OK) g2_set_generator(pa);
   uint32_t k[8];
   scalar_from_be(k, scalars + 32 * i, reduce != 0);
-  G2Jac ja, jo;
-  jac_from_affine(ja, pa);
-  jac_mul(jo, ja, k);
+  G2Jac jo;
+  jac_mul(jo, pa, k);
   jac_to_affine(r, jo);
   if (st != ST_OK) r.inf = true;
   encode_g2(out + 128 * i, r);

@@ -257,9 +257,8 @@ int hs_g1_mul(const uint8_t* p, const uint8_t* scalar32, int reduce, uint8_t* ou
   memcpy(sc, scalar32, 32);
   uint32_t k[8];
   scalar_from_be(k, sc, reduce != 0);
-  G1Jac ja, jo;
-  jac_from_affine(ja, pa);
-  jac_mul(jo, ja, k);
+  G1Jac jo;
+  jac_mul(jo, pa, k);
   jac_to_affine(r, jo);
   if (st != ST_OK) r.inf = true;
   alignas(4) uint8_t tmp[64];
@@ -275,9 +274,8 @@ int hs_g2_mul(const uint8_t* p, const uint8_t* scalar32, int reduce, uint8_t* ou
   memcpy(sc, scalar32, 32);
   uint32_t k[8];
   scalar_from_be(k, sc, reduce != 0);
-  G2Jac ja, jo;
-  jac_from_affine(ja, pa);
-  jac_mul(jo, ja, k);
+  G2Jac jo;
+  jac_mul(jo, pa, k);
   jac_to_affine(r, jo);
   if (st != ST_OK) r.inf = true;
   alignas(4) uint8_t tmp[128];
@@ -292,9 +290,8 @@ int hs_sign(const uint8_t* msg, uint64_t len, const uint8_t* sk32, uint8_t* sig6
   memcpy(sc, sk32, 32);
   uint32_t k[8];
   scalar_from_be(k, sc, true);
-  G1Jac ja, jo;
-  jac_from_affine(ja, h);
-  jac_mul(jo, ja, k);
+  G1Jac jo;
+  jac_mul(jo, h, k);
   jac_to_affine(r, jo);
   if (st != ST_OK) r.inf = true;
   alignas(4) uint8_t tmp[64];
