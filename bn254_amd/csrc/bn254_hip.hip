@@ -942,11 +942,18 @@ int bn254_batch_verify_randomized_device(bn254_ctx* c, const uint8_t* d_msgs, co
   PROF_MARK(2);
   k_rand_scale<<<g, BN_WAVE, 0, s>>>(n, c->ws, seed, (flags & BN254_FLAG_RAND64) ? 1 : 0, gbase);
   const bool two = c->rand_items_per_lane ? c->rand_items_per_lane == 2 : n >= RAND_TWO_PER_LANE_MIN_N;
-  if (two) k_miller_rand2<<<(unsigned)((n_groups + 1) / 2), BN_WAVE, 0, s>>>(n, n_groups, c->ws, gbase);
-  else k_miller_rand<<<g, BN_WAVE, 0, s>>>(n, c->ws, gbase);
-  PROF_MARK(3);
-  k_rand_tail<<<gg, BN_WAVE, 0, s>>>(n_groups, c->ws, gbase);
-  k_final_exp<<<gg, BN_WAVE, 0, s>>>(n_groups, 1, 1, 1, c->ws, 0, nullptr, d_group_st, 0, gbase, nullptr, nullptr);
+  if (c->pair_lanes) {
+    if ((rc = bn254_pair_miller_rand(n, n_groups, two ? 2 : 1, c->ws, gbase, s))) return rc;
+    PROF_MARK(3);
+    if ((rc = bn254_pair_rand_tail(n_groups, c->ws, gbase, s))) return rc;
+    if ((rc = bn254_pair_final_exp(n_groups, c->ws, 0, d_group_st, nullptr, nullptr, s, gbase))) return rc;
+  } else {
+    if (two) k_miller_rand2<<<(unsigned)((n_groups + 1) / 2), BN_WAVE, 0, s>>>(n, n_groups, c->ws, gbase);
+    else k_miller_rand<<<g, BN_WAVE, 0, s>>>(n, c->ws, gbase);
+    PROF_MARK(3);
+    k_rand_tail<<<gg, BN_WAVE, 0, s>>>(n_groups, c->ws, gbase);
+    k_final_exp<<<gg, BN_WAVE, 0, s>>>(n_groups, 1, 1, 1, c->ws, 0, nullptr, d_group_st, 0, gbase, nullptr, nullptr);
+  }
   k_rand_collect<<<g, BN_WAVE, 0, s>>>(n, c->ws, d_group_st, d_status, d_group_ok);
   // exact per-item check of the items of failed groups (none queued: both kernels leave at once)
   if (c->pair_lanes) {

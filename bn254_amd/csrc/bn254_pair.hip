@@ -59,13 +59,14 @@ KERNEL_PAIR void k_miller_verify_pair(size_t n, Ws ws, const uint32_t* map, cons
   miller_loop<true, true>(f, h, pk, sig);
   ws_store_f12_own(ws, i, f);
 }
-KERNEL_PAIR void k_final_exp_pair(size_t n, Ws ws, int use_hash, uint8_t* status_out, const uint32_t* map, const uint32_t* count) {
+// `base`: item i reads its factor and decode status at workspace index base + i (per-group values of the randomised mode)
+KERNEL_PAIR void k_final_exp_pair(size_t n, Ws ws, int use_hash, uint8_t* status_out, const uint32_t* map, const uint32_t* count, size_t base) {
   size_t i = ((size_t)blockIdx.x * BN_PAIR_WG + threadIdx.x) >> 1;
   if (i >= n) return;
   if (map) { if (i >= *count) return; i = map[i]; }
   Fp12 f;
-  ws_load_f12_own(ws, i, f);
-  uint8_t st = ws_byte(ws, BY_ST_DECODE, i);
+  ws_load_f12_own(ws, base + i, f);
+  uint8_t st = ws_byte(ws, BY_ST_DECODE, base + i);
   if (st == ST_OK && use_hash) st = ws_byte(ws, BY_ST_HASH, i);
   __shared__ Fp12PairSlot lds_acc[BN_PAIR_WG];
   final_exponentiation(f, f, lds_acc[threadIdx.x].v);
@@ -73,13 +74,81 @@ KERNEL_PAIR void k_final_exp_pair(size_t n, Ws ws, int use_hash, uint8_t* status
   if ((threadIdx.x & 1u) == 0) status_out[i] = st != ST_OK ? st : (one ? (uint8_t)ST_OK : (uint8_t)ST_VERIFICATION_FAILED);
 }
 
+// ---- randomised batch verification (see bn254_hip.hip) on lane pairs -------------------------------------------
+// A 256-lane workgroup = 128 lane pairs.  k_miller_rand_pair: one item per pair -> 2 groups of 64 items per
+// workgroup; k_miller_rand2_pair: two items per pair (shared f^2, merged lines) -> 4 groups per workgroup.
+// The Miller values of a group are multiplied by an LDS tree; both lanes of a pair take every branch together.
+template <int ITEMS_PER_PAIR>
+__device__ __forceinline__ void miller_rand_pair_body(size_t n, size_t n_groups, Ws ws, size_t gbase) {
+  constexpr unsigned PAIRS_PER_GROUP = BN_WAVE / ITEMS_PER_PAIR;                 // 64 or 32
+  constexpr unsigned GROUPS_PER_WG = (BN_PAIR_WG / 2) / PAIRS_PER_GROUP;           // 2 or 4
+  const unsigned pair = threadIdx.x >> 1, gp = pair / PAIRS_PER_GROUP, tp = pair % PAIRS_PER_GROUP;
+  const size_t group = (size_t)blockIdx.x * GROUPS_PER_WG + gp;
+  const size_t i0 = group * BN_WAVE + (size_t)tp * ITEMS_PER_PAIR;
+  __shared__ Fp12PairSlot lds_f[BN_PAIR_WG];
+  Fp12& f = lds_f[threadIdx.x].v;
+  G1Affine a0;
+  G2Affine pk0;
+  const size_t j0 = i0 < n ? i0 : n - 1;
+  ws_load_g1(ws, PL_HASHX, BY_A_INF, j0, a0);
+  if (i0 >= n) a0.inf = true;
+  pk0.x = ws_load_fp2_own(ws, PL_QX0, j0); pk0.y = ws_load_fp2_own(ws, PL_QY0, j0); pk0.inf = ws_byte(ws, BY_Q_INF, j0) != 0;
+  if constexpr (ITEMS_PER_PAIR == 2) {
+    G1Affine a1;
+    G2Affine pk1;
+    const size_t i1 = i0 + 1, j1 = i1 < n ? i1 : n - 1;
+    ws_load_g1(ws, PL_HASHX, BY_A_INF, j1, a1);
+    if (i1 >= n) a1.inf = true;
+    pk1.x = ws_load_fp2_own(ws, PL_QX0, j1); pk1.y = ws_load_fp2_own(ws, PL_QY0, j1); pk1.inf = ws_byte(ws, BY_Q_INF, j1) != 0;
+    miller_loop_2var(f, a0, pk0, a1, pk1);
+  } else {
+    miller_loop<true, false>(f, a0, pk0, a0);
+  }
+  __syncthreads();
+  for (unsigned stride = PAIRS_PER_GROUP / 2; stride >= 1; stride >>= 1) {
+    if (tp < stride) fp12_mul(f, f, lds_f[threadIdx.x + 2 * stride].v);
+    __syncthreads();
+  }
+  if (tp == 0 && group < n_groups) ws_store_f12_own(ws, gbase + group, f);
+}
+KERNEL_PAIR void k_miller_rand_pair(size_t n, size_t n_groups, Ws ws, size_t gbase) { miller_rand_pair_body<1>(n, n_groups, ws, gbase); }
+KERNEL_PAIR void k_miller_rand2_pair(size_t n, size_t n_groups, Ws ws, size_t gbase) { miller_rand_pair_body<2>(n, n_groups, ws, gbase); }
+// per group: F_g * miller(S_g, -G2) through the line table
+KERNEL_PAIR void k_rand_tail_pair(size_t n_groups, Ws ws, size_t gbase) {
+  size_t g = ((size_t)blockIdx.x * BN_PAIR_WG + threadIdx.x) >> 1;
+  if (g >= n_groups) return;
+  G1Affine s, unused_g1;
+  G2Affine unused_g2;
+  ws_load_g1(ws, PL_P1X, BY_P1_INF, gbase + g, s);
+  unused_g1.x = fp_load_const(C_G1_GEN[0]); unused_g1.y = fp_load_const(C_G1_GEN[1]); unused_g1.inf = false;
+  unused_g2.x = fp2_load_const(C_G2_GEN[0]); unused_g2.y = fp2_load_const(C_G2_GEN[1]); unused_g2.inf = false;
+  Fp12 fg;
+  ws_load_f12_own(ws, gbase + g, fg);
+  __shared__ Fp12PairSlot lds_f[BN_PAIR_WG];
+  Fp12& f = lds_f[threadIdx.x].v;
+  miller_loop<false, true>(f, unused_g1, unused_g2, s);
+  fp12_mul(f, f, fg);
+  ws_store_f12_own(ws, gbase + g, f);
+}
+int bn254_pair_miller_rand(size_t n, size_t n_groups, int items_per_pair, Ws ws, size_t gbase, hipStream_t s) {
+  if (items_per_pair == 2) k_miller_rand2_pair<<<(unsigned)((n_groups + 3) / 4), BN_PAIR_WG, 0, s>>>(n, n_groups, ws, gbase);
+  else k_miller_rand_pair<<<(unsigned)((n_groups + 1) / 2), BN_PAIR_WG, 0, s>>>(n, n_groups, ws, gbase);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+int bn254_pair_rand_tail(size_t n_groups, Ws ws, size_t gbase, hipStream_t s) {
+  k_rand_tail_pair<<<(unsigned)((2 * n_groups + BN_PAIR_WG - 1) / BN_PAIR_WG), BN_PAIR_WG, 0, s>>>(n_groups, ws, gbase);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 int bn254_pair_miller_verify(size_t n, Ws ws, const uint32_t* map, const uint32_t* count, hipStream_t s) {
   k_miller_verify_pair<<<(unsigned)((2 * n + BN_PAIR_WG - 1) / BN_PAIR_WG), BN_PAIR_WG, 0, s>>>(n, ws, map, count);
   HIP_TRY(hipGetLastError());
   return 0;
 }
-int bn254_pair_final_exp(size_t n, Ws ws, int use_hash, uint8_t* status_out, const uint32_t* map, const uint32_t* count, hipStream_t s) {
-  k_final_exp_pair<<<(unsigned)((2 * n + BN_PAIR_WG - 1) / BN_PAIR_WG), BN_PAIR_WG, 0, s>>>(n, ws, use_hash, status_out, map, count);
+int bn254_pair_final_exp(size_t n, Ws ws, int use_hash, uint8_t* status_out, const uint32_t* map, const uint32_t* count, hipStream_t s, size_t base) {
+  k_final_exp_pair<<<(unsigned)((2 * n + BN_PAIR_WG - 1) / BN_PAIR_WG), BN_PAIR_WG, 0, s>>>(n, ws, use_hash, status_out, map, count, base);
   HIP_TRY(hipGetLastError());
   return 0;
 }

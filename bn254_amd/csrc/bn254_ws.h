@@ -67,4 +67,6 @@ __device__ __forceinline__ void ws_load_g1(const Ws& ws, int px, int inf_plane, 
 // entry points of bn254_pair.hip (internal to the library)
 __attribute__((visibility("hidden"))) int bn254_pair_miller_verify(size_t n, Ws ws, const uint32_t* map, const uint32_t* count, hipStream_t s);
 __attribute__((visibility("hidden"))) int bn254_pair_final_exp(size_t n, Ws ws, int use_hash, uint8_t* status_out, const uint32_t* map,
-                                                               const uint32_t* count, hipStream_t s);
+                                                               const uint32_t* count, hipStream_t s, size_t base = 0);
+__attribute__((visibility("hidden"))) int bn254_pair_miller_rand(size_t n, size_t n_groups, int items_per_pair, Ws ws, size_t gbase, hipStream_t s);
+__attribute__((visibility("hidden"))) int bn254_pair_rand_tail(size_t n_groups, Ws ws, size_t gbase, hipStream_t s);
