@@ -1036,8 +1036,13 @@ static int pairing_device(bn254_ctx* c, const uint8_t* d_g1, const uint8_t* d_g2
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
   k_decode_g1<<<grid_for(lanes), BN_WAVE, 0, s>>>(d_g1, lanes, flags, c->ws, PL_P1X, BY_P1_INF, 0);
   k_decode_g2<<<grid_for(lanes), BN_WAVE, 0, s>>>(d_g2, lanes, flags, c->ws, 1);
-  k_miller_var<<<grid_for(lanes), BN_WAVE, 0, s>>>(lanes, c->ws);
-  k_final_exp<<<grid_for(n), BN_WAVE, 0, s>>>(n, k, k, 1, c->ws, 0, d_gt, d_status, raw_only, 0, nullptr, nullptr);
+  if (c->pair_lanes) {
+    if ((rc = bn254_pair_miller_var(lanes, c->ws, s))) return rc;
+    if ((rc = bn254_pair_final_exp_product(n, k, c->ws, d_gt, d_status, raw_only, s))) return rc;
+  } else {
+    k_miller_var<<<grid_for(lanes), BN_WAVE, 0, s>>>(lanes, c->ws);
+    k_final_exp<<<grid_for(n), BN_WAVE, 0, s>>>(n, k, k, 1, c->ws, 0, d_gt, d_status, raw_only, 0, nullptr, nullptr);
+  }
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -1087,8 +1092,13 @@ int bn254_batch_check_public_keys(bn254_ctx* c, const uint8_t* pk_g2, const uint
   unsigned g = grid_for(n);
   k_decode_g2<<<g, BN_WAVE, 0, s>>>(c->stage[0], n, flags, c->ws, 0);       // ecdsa.rs:82: pk_g2 first
   k_decode_g1<<<g, BN_WAVE, 0, s>>>(c->stage[1], n, flags, c->ws, PL_P1X, BY_P1_INF, 1);
-  k_miller_cpk<<<g, BN_WAVE, 0, s>>>(n, c->ws);
-  k_final_exp<<<g, BN_WAVE, 0, s>>>(n, 1, 1, 1, c->ws, 0, nullptr, c->stage[2], 0, 0, nullptr, nullptr);
+  if (c->pair_lanes) {
+    if ((rc = bn254_pair_miller_verify(n, c->ws, nullptr, nullptr, s, 1))) return rc;
+    if ((rc = bn254_pair_final_exp(n, c->ws, 0, c->stage[2], nullptr, nullptr, s))) return rc;
+  } else {
+    k_miller_cpk<<<g, BN_WAVE, 0, s>>>(n, c->ws);
+    k_final_exp<<<g, BN_WAVE, 0, s>>>(n, 1, 1, 1, c->ws, 0, nullptr, c->stage[2], 0, 0, nullptr, nullptr);
+  }
   HIP_TRY(hipGetLastError());
   if ((rc = stage_out(c, 2, status, n))) return rc;
   HIP_TRY(hipStreamSynchronize(c->stream));

@@ -43,14 +43,17 @@ __device__ __forceinline__ void ws_store_f12_own(const Ws& ws, size_t i, const F
 
 // f = miller(H(m), pk) * miller(sig, -G2); item = lane >> 1.  Both lanes of a pair take every branch together
 // (item-level conditions only), so the DPP exchanges always find their partner active.
-KERNEL_PAIR void k_miller_verify_pair(size_t n, Ws ws, const uint32_t* map, const uint32_t* count) {
+// mode 1 = check_public_keys (/root/reference/src/ecdsa.rs:80-86): miller(G1::one(), pk_g2) * miller(pk_g1, -G2) with
+// pk_g1 in the P1 planes
+KERNEL_PAIR void k_miller_verify_pair(size_t n, Ws ws, const uint32_t* map, const uint32_t* count, int mode) {
   size_t i = ((size_t)blockIdx.x * BN_PAIR_WG + threadIdx.x) >> 1;
   if (i >= n) return;
   if (map) { if (i >= *count) return; i = map[i]; }
   G1Affine sig, h;
   G2Affine pk;
   ws_load_g1(ws, PL_P1X, BY_P1_INF, i, sig);
-  ws_load_g1(ws, PL_P2X, BY_P2_INF, i, h);
+  if (mode == 1) { h.x = fp_load_const(C_G1_GEN[0]); h.y = fp_load_const(C_G1_GEN[1]); h.inf = false; }   // wave-uniform
+  else ws_load_g1(ws, PL_P2X, BY_P2_INF, i, h);
   pk.x = ws_load_fp2_own(ws, PL_QX0, i);
   pk.y = ws_load_fp2_own(ws, PL_QY0, i);
   pk.inf = ws_byte(ws, BY_Q_INF, i) != 0;
@@ -59,19 +62,56 @@ KERNEL_PAIR void k_miller_verify_pair(size_t n, Ws ws, const uint32_t* map, cons
   miller_loop<true, true>(f, h, pk, sig);
   ws_store_f12_own(ws, i, f);
 }
-// `base`: item i reads its factor and decode status at workspace index base + i (per-group values of the randomised mode)
-KERNEL_PAIR void k_final_exp_pair(size_t n, Ws ws, int use_hash, uint8_t* status_out, const uint32_t* map, const uint32_t* count, size_t base) {
+// generic single pair per lane pair: f = miller(P1, Q)   (bn254_batch_pairing*)
+KERNEL_PAIR void k_miller_var_pair(size_t n, Ws ws) {
+  size_t i = ((size_t)blockIdx.x * BN_PAIR_WG + threadIdx.x) >> 1;
+  if (i >= n) return;
+  G1Affine p;
+  G2Affine q;
+  ws_load_g1(ws, PL_P1X, BY_P1_INF, i, p);
+  q.x = ws_load_fp2_own(ws, PL_QX0, i);
+  q.y = ws_load_fp2_own(ws, PL_QY0, i);
+  q.inf = ws_byte(ws, BY_Q_INF, i) != 0;
+  __shared__ Fp12PairSlot lds_f[BN_PAIR_WG];
+  Fp12& f = lds_f[threadIdx.x].v;
+  miller_loop<true, false>(f, p, q, p);
+  ws_store_f12_own(ws, i, f);
+}
+// 32 big-endian bytes of the canonical value (4-byte aligned destination)
+__device__ __forceinline__ void store_fp_be(uint8_t* b, const Fp& a) {
+  U256 x = fp_to_u256(a);
+  uint32_t* w = (uint32_t*)b;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) w[k] = __builtin_bswap32(x.w[7 - k]);
+}
+// item i: product of the k Miller values at workspace indices base + i*item_stride + j*pair_stride, final
+// exponentiation, comparison with one (status) and / or the canonical Gt bytes (each lane writes the 32-byte halves
+// of its role).  Same contract as k_final_exp of bn254_hip.hip.
+KERNEL_PAIR void k_final_exp_pair(size_t n, size_t k, size_t item_stride, size_t pair_stride, Ws ws, int use_hash, uint8_t* gt_out,
+                                  uint8_t* status_out, int raw_only, size_t base, const uint32_t* map, const uint32_t* count) {
   size_t i = ((size_t)blockIdx.x * BN_PAIR_WG + threadIdx.x) >> 1;
   if (i >= n) return;
   if (map) { if (i >= *count) return; i = map[i]; }
-  Fp12 f;
-  ws_load_f12_own(ws, base + i, f);
-  uint8_t st = ws_byte(ws, BY_ST_DECODE, base + i);
+  Fp12 f, g;
+  ws_load_f12_own(ws, base + i * item_stride, f);
+  uint8_t st = ws_byte(ws, BY_ST_DECODE, base + i * item_stride);
+  for (size_t j = 1; j < k; ++j) {
+    size_t idx = base + i * item_stride + j * pair_stride;
+    ws_load_f12_own(ws, idx, g);
+    fp12_mul(f, f, g);
+    uint8_t sj = ws_byte(ws, BY_ST_DECODE, idx);
+    if (st == ST_OK) st = sj;
+  }
   if (st == ST_OK && use_hash) st = ws_byte(ws, BY_ST_HASH, i);
   __shared__ Fp12PairSlot lds_acc[BN_PAIR_WG];
-  final_exponentiation(f, f, lds_acc[threadIdx.x].v);
+  if (!raw_only) final_exponentiation(f, f, lds_acc[threadIdx.x].v);
+  const unsigned role = threadIdx.x & 1u;
+  if (gt_out) {
+    const Fp2* c[6] = {&f.c0.c0, &f.c0.c1, &f.c0.c2, &f.c1.c0, &f.c1.c1, &f.c1.c2};
+    for (int e = 0; e < 6; ++e) store_fp_be(gt_out + 384 * i + 64 * e + 32 * role, c[e]->c[0]);
+  }
   const bool one = fp12_is_one(f);   // combined over the pair
-  if ((threadIdx.x & 1u) == 0) status_out[i] = st != ST_OK ? st : (one ? (uint8_t)ST_OK : (uint8_t)ST_VERIFICATION_FAILED);
+  if (status_out && role == 0) status_out[i] = st != ST_OK ? st : (one ? (uint8_t)ST_OK : (uint8_t)ST_VERIFICATION_FAILED);
 }
 
 // ---- randomised batch verification (see bn254_hip.hip) on lane pairs -------------------------------------------
@@ -142,13 +182,23 @@ int bn254_pair_rand_tail(size_t n_groups, Ws ws, size_t gbase, hipStream_t s) {
   return 0;
 }
 
-int bn254_pair_miller_verify(size_t n, Ws ws, const uint32_t* map, const uint32_t* count, hipStream_t s) {
-  k_miller_verify_pair<<<(unsigned)((2 * n + BN_PAIR_WG - 1) / BN_PAIR_WG), BN_PAIR_WG, 0, s>>>(n, ws, map, count);
+int bn254_pair_miller_verify(size_t n, Ws ws, const uint32_t* map, const uint32_t* count, hipStream_t s, int mode) {
+  k_miller_verify_pair<<<(unsigned)((2 * n + BN_PAIR_WG - 1) / BN_PAIR_WG), BN_PAIR_WG, 0, s>>>(n, ws, map, count, mode);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+int bn254_pair_miller_var(size_t n, Ws ws, hipStream_t s) {
+  k_miller_var_pair<<<(unsigned)((2 * n + BN_PAIR_WG - 1) / BN_PAIR_WG), BN_PAIR_WG, 0, s>>>(n, ws);
   HIP_TRY(hipGetLastError());
   return 0;
 }
 int bn254_pair_final_exp(size_t n, Ws ws, int use_hash, uint8_t* status_out, const uint32_t* map, const uint32_t* count, hipStream_t s, size_t base) {
-  k_final_exp_pair<<<(unsigned)((2 * n + BN_PAIR_WG - 1) / BN_PAIR_WG), BN_PAIR_WG, 0, s>>>(n, ws, use_hash, status_out, map, count, base);
+  k_final_exp_pair<<<(unsigned)((2 * n + BN_PAIR_WG - 1) / BN_PAIR_WG), BN_PAIR_WG, 0, s>>>(n, 1, 1, 1, ws, use_hash, nullptr, status_out, 0, base, map, count);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+int bn254_pair_final_exp_product(size_t n, size_t k, Ws ws, uint8_t* gt_out, uint8_t* status_out, int raw_only, hipStream_t s) {
+  k_final_exp_pair<<<(unsigned)((2 * n + BN_PAIR_WG - 1) / BN_PAIR_WG), BN_PAIR_WG, 0, s>>>(n, k, k, 1, ws, 0, gt_out, status_out, raw_only, 0, nullptr, nullptr);
   HIP_TRY(hipGetLastError());
   return 0;
 }

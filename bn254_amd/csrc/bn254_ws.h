@@ -65,7 +65,11 @@ __device__ __forceinline__ void ws_load_g1(const Ws& ws, int px, int inf_plane, 
   } while (0)
 
 // entry points of bn254_pair.hip (internal to the library)
-__attribute__((visibility("hidden"))) int bn254_pair_miller_verify(size_t n, Ws ws, const uint32_t* map, const uint32_t* count, hipStream_t s);
+__attribute__((visibility("hidden"))) int bn254_pair_miller_verify(size_t n, Ws ws, const uint32_t* map, const uint32_t* count, hipStream_t s,
+                                                                   int mode = 0);
+__attribute__((visibility("hidden"))) int bn254_pair_miller_var(size_t n, Ws ws, hipStream_t s);
+__attribute__((visibility("hidden"))) int bn254_pair_final_exp_product(size_t n, size_t k, Ws ws, uint8_t* gt_out, uint8_t* status_out, int raw_only,
+                                                                       hipStream_t s);
 __attribute__((visibility("hidden"))) int bn254_pair_final_exp(size_t n, Ws ws, int use_hash, uint8_t* status_out, const uint32_t* map,
                                                                const uint32_t* count, hipStream_t s, size_t base = 0);
 __attribute__((visibility("hidden"))) int bn254_pair_miller_rand(size_t n, size_t n_groups, int items_per_pair, Ws ws, size_t gbase, hipStream_t s);
