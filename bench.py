@@ -128,7 +128,7 @@ def other_workloads(args, torch, eng, dev):
         eng.reserve(n + n // 64 + 512)
         ptrs = (d_msgs.data_ptr(), d_off.data_ptr(), d_sigs.data_ptr(), d_pks.data_ptr(), n)
         res = {}
-        for name, flags in (("rand128", 0), ("rand64", 0x100)):
+        for name, flags in (("rand128", 0), ("rand128_glv", 0x200), ("rand64", 0x100)):
             dt = timed(lambda: eng.batch_verify_randomized_device(*ptrs, seed, d_st.data_ptr(), d_gr.data_ptr(), flags=flags, stream=stream),
                        args.steps, args.warmup)
             assert int(d_st.max()) == 0 and int(d_gr.min()) == 1

@@ -281,7 +281,8 @@ KERNEL void k_final_exp(size_t n, size_t k, size_t item_stride, size_t pair_stri
 struct Seed { uint32_t w[8]; };
 struct G1JacSlot { G1Jac v; int32_t pad; };   // 31 words: odd stride, no LDS bank conflicts
 
-KERNEL void k_rand_scale(size_t n, Ws ws, Seed seed, int rand64, size_t gbase) {
+// mode: 0 = 128-bit scalar, 1 = 64-bit scalar, 2 = k1 + k2*lambda with 64-bit k1, k2 (BN254_FLAG_RAND_GLV)
+KERNEL void k_rand_scale(size_t n, Ws ws, Seed seed, int mode, size_t gbase) {
   const unsigned t = threadIdx.x;
   size_t i = (size_t)blockIdx.x * BN_WAVE + t;
   const bool live = i < n;                       // no early return: every lane reaches the barriers
@@ -292,14 +293,14 @@ KERNEL void k_rand_scale(size_t n, Ws ws, Seed seed, int rand64, size_t gbase) {
   ws_load_g1(ws, PL_P2X, BY_P2_INF, ii, h);
   const bool valid = live && ws_byte(ws, BY_ST_DECODE, ii) == ST_OK && ws_byte(ws, BY_ST_HASH, ii) == ST_OK;
   uint32_t k[4];
-  rand_scalar(k, seed.w, (uint64_t)ii, rand64 != 0);
+  rand_scalar(k, seed.w, (uint64_t)ii, mode == 1);
   G1Jac a, sj, id;
-  if (rand64) jac_mul_u64(a, h, k); else jac_mul_u128(a, h, k);   // wave-uniform
+  if (mode == 2) g1_mul_glv(a, h, k, k + 2); else if (mode == 1) jac_mul_u64(a, h, k); else jac_mul_u128(a, h, k);   // wave-uniform
   G1Affine aa;
   jac_to_affine(aa, a);
   aa.inf = aa.inf || !valid;
   if (live) ws_store_g1(ws, PL_HASHX, BY_A_INF, i, aa);
-  if (rand64) jac_mul_u64(sj, sig, k); else jac_mul_u128(sj, sig, k);
+  if (mode == 2) g1_mul_glv(sj, sig, k, k + 2); else if (mode == 1) jac_mul_u64(sj, sig, k); else jac_mul_u128(sj, sig, k);
   jac_set_identity(id);
   jac_select(sj, !valid, id, sj);
   __shared__ G1JacSlot lds_s[BN_WAVE];
@@ -940,7 +941,7 @@ int bn254_batch_verify_randomized_device(bn254_ctx* c, const uint8_t* d_msgs, co
   PROF_MARK(1);
   if ((rc = launch_hash_rounds(c, s, d_msgs, d_off, n, PL_P2X, BY_P2_INF, nullptr))) return rc;
   PROF_MARK(2);
-  k_rand_scale<<<g, BN_WAVE, 0, s>>>(n, c->ws, seed, (flags & BN254_FLAG_RAND64) ? 1 : 0, gbase);
+  k_rand_scale<<<g, BN_WAVE, 0, s>>>(n, c->ws, seed, (flags & BN254_FLAG_RAND64) ? 1 : (flags & BN254_FLAG_RAND_GLV) ? 2 : 0, gbase);
   const bool two = c->rand_items_per_lane ? c->rand_items_per_lane == 2 : n >= RAND_TWO_PER_LANE_MIN_N;
   if (c->pair_lanes) {
     if ((rc = bn254_pair_miller_rand(n, n_groups, two ? 2 : 1, c->ws, gbase, s))) return rc;

@@ -230,6 +230,32 @@ def main():
     o.append("BN_CONST uint32_t C_EXP_QP1D4[8] = %s;    /* (q+1)/4, plain U256 */" % c_u256((Q + 1) // 4))
     o.append("BN_CONST uint32_t C_EXP_QM3D4[8] = %s;    /* (q-3)/4, plain U256 */" % c_u256((Q - 3) // 4))
     o.append("BN_CONST uint32_t C_EXP_QM1D2[8] = %s;    /* (q-1)/2, plain U256 */" % c_u256((Q - 1) // 2))
+    # GLV endomorphism of G1: phi(x, y) = (beta x, y) = lambda (x, y), beta^3 = 1 mod q, lambda^2 + lambda + 1 = 0 mod r
+    glv_beta = 0x59E26BCEA0D48BACD4F263F1ACDB5C4F5763473177FFFFFE
+    glv_lambda = 0xB3C4D79D41A917585BFC41088D8DAAA78B17EA66B99C90DD
+    assert pow(glv_beta, 3, Q) == 1 and glv_beta != 1 and (glv_lambda * glv_lambda + glv_lambda + 1) % R_ORDER == 0
+
+    def g1_add(P, T):
+        if P is None:
+            return T
+        if T is None:
+            return P
+        if P[0] == T[0]:
+            if (P[1] + T[1]) % Q == 0:
+                return None
+            lam = 3 * P[0] * P[0] * pow(2 * P[1], Q - 2, Q) % Q
+        else:
+            lam = (T[1] - P[1]) * pow(T[0] - P[0], Q - 2, Q) % Q
+        x3 = (lam * lam - P[0] - T[0]) % Q
+        return (x3, (lam * (P[0] - x3) - P[1]) % Q)
+    acc = None
+    for bit in bin(glv_lambda)[2:]:
+        acc = g1_add(acc, acc)
+        if bit == "1":
+            acc = g1_add(acc, (1, 2))
+    assert acc == (glv_beta % Q, 2), "lambda * G1 != (beta * x, y)"
+    o.append("BN_CONST int32_t C_GLV_BETA[BN_LIMBS] = %s;   /* phi(x, y) = (beta x, y) = lambda (x, y) on G1 */" % c_fp(glv_beta))
+    o.append("BN_CONST uint32_t C_GLV_LAMBDA[8] = %s;       /* lambda (192 bits), plain U256 */" % c_u256(glv_lambda))
     o.append("/* width-4 sliding-window schedules for the fixed exponents: {squarings, odd multiplier} steps, MSB first;")
     o.append("   the first step only selects its multiplier, a multiplier of 0 means squarings only */")
     for name, e in (("QM2", Q - 2), ("QP1D4", (Q + 1) // 4), ("QM3D4", (Q - 3) // 4), ("QM1D2", (Q - 1) // 2)):

@@ -11,6 +11,7 @@ G1_BYTES, G2_BYTES, GT_BYTES, SCALAR_BYTES = 64, 128, 384, 32
 FLAG_G2_SUBGROUP_CHECK = 1
 FLAG_REJECT_IDENTITY = 2
 FLAG_RAND64 = 0x100
+FLAG_RAND_GLV = 0x200
 OPT_SPLIT_MILLER = 1
 OPT_HASH_MAX_TRIES = 2
 OPT_RAND_ITEMS_PER_LANE = 3

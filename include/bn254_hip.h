@@ -49,6 +49,9 @@ typedef struct bn254_ctx bn254_ctx;
 #define BN254_FLAG_G2_SUBGROUP_CHECK 1u /* decode G2 inputs with the order-r check AffineG2::new performs */
 #define BN254_FLAG_REJECT_IDENTITY 2u   /* treat all-zero encodings as InvalidGroupPoint (from_uncompressed behaviour) */
 #define BN254_FLAG_RAND64 0x100u        /* bn254_batch_verify_randomized: 64-bit instead of 128-bit random scalars */
+#define BN254_FLAG_RAND_GLV 0x200u      /* ... : r_i = k1 + k2*lambda mod r with k1, k2 the two 64-bit halves of the 128 random bits
+                                           (lambda = 0xb3c4d79d41a917585bfc41088d8daaa78b17ea66b99c90dd, the eigenvalue of
+                                           (x, y) -> (beta x, y) on G1): still 2^128 distinct multipliers, 30 % cheaper to apply */
 
 #define BN254_E_BAD_ARGUMENT (-10001)
 #define BN254_E_MISALIGNED (-10002)
@@ -85,7 +88,7 @@ int bn254_batch_verify_device(bn254_ctx *ctx, const uint8_t *d_msgs, const uint6
 /* Randomised batch verification — OPT-IN, probabilistic.  No counterpart in the
  * reference, which verifies one tuple at a time (src/ecdsa.rs:49-64); same inputs and status bytes as
  * bn254_batch_verify.  Items are taken 64 at a time; with r_i = the first 16 bytes (BN254_FLAG_RAND64: 8) of
- * SHA-256(seed32 || le64(i)) read little-endian (0 -> 1), a group passes iff
+ * SHA-256(seed32 || le64(i)) read little-endian (0 -> 1; BN254_FLAG_RAND_GLV: see the flag), a group passes iff
  *     prod_i e(r_i * H(m_i), pk_i) * e(sum_i r_i * sig_i, -G2::one()) == 1      (over its items that decode and hash)
  * i.e. 64 + 1 Miller loops and ONE final exponentiation per 64 verifies.  Items of a passing group get status 0
  * (or their decode / hash error); every item of a failing group is re-verified exactly (the kernels of

@@ -840,6 +840,18 @@ API u64 bn254o_batch_verify(const u8 *msgs, const u64 *off, const u8 *sigs, cons
  *   where "valid" = decoded and hashed without error.  Items of a passing group get their decode / hash
  *   status (0 if none); items of a failing group are verified one by one exactly as bn254o_verify. */
 #define FLAG_RAND64 0x100u
+#define FLAG_RAND_GLV 0x200u
+/* eigenvalue of (x, y) -> (beta x, y) on G1 (include/bn254_hip.h: BN254_FLAG_RAND_GLV); lambda^2 + lambda + 1 = 0 mod r */
+static const u64 GLV_LAMBDA[4] = {0x8b17ea66b99c90ddULL, 0x5bfc41088d8daaa7ULL, 0xb3c4d79d41a91758ULL, 0};
+/* r_i * P for the scalar of item i; with FLAG_RAND_GLV r_i = k1 + k2*lambda, computed WITHOUT the endomorphism:
+ * k1*P + k2*(lambda*P) by plain scalar multiplications */
+static void rand_mul(g1j *out, const g1a *p, const u64 *k, u32 flags) {
+  g1j pj, t; g1j_from_affine(&pj, p);
+  if (!(flags & FLAG_RAND_GLV)) { g1j_mul(out, &pj, k); return; }
+  u64 k1[4] = {k[0], 0, 0, 0}, k2[4] = {k[1], 0, 0, 0};
+  g1j lp; g1j_mul(&lp, &pj, GLV_LAMBDA);
+  g1j_mul(out, &pj, k1); g1j_mul(&t, &lp, k2); g1j_add(out, out, &t);
+}
 static void rand_scalar(u64 *k, const u8 *seed32, u64 i, u32 flags) {
   u8 buf[40], dg[32];
   memcpy(buf, seed32, 32);
@@ -865,9 +877,9 @@ API int bn254o_batch_verify_randomized(const u8 *msgs, const u64 *off, const u8 
       status[i] = (u8)st;
       if (st != ST_OK) continue;
       u64 k[4]; rand_scalar(k, seed32, (u64)i, flags);
-      g1j hj, sj, t;
-      g1j_from_affine(&hj, &h); g1j_mul(&t, &hj, k); g1j_to_affine(&ps[np], &t); qs[np] = pk; ++np;
-      g1j_from_affine(&sj, &sig); g1j_mul(&t, &sj, k); g1j_add(&sum, &sum, &t);
+      g1j t;
+      rand_mul(&t, &h, k, flags); g1j_to_affine(&ps[np], &t); qs[np] = pk; ++np;
+      rand_mul(&t, &sig, k, flags); g1j_add(&sum, &sum, &t);
       if (np == MAX_PAIRS) { miller_loop_multi(&part, ps, qs, np); fp12_mul(&f, &f, &part); np = 0; }
     }
     g1j_to_affine(&ps[np], &sum); qs[np] = G2_GEN_NEG; ++np;

@@ -92,6 +92,7 @@ def batch_verify(msgs, sigs, pks, flags=FLAG_G2_SUBGROUP_CHECK, nthreads=1):
 
 
 FLAG_RAND64 = 0x100
+FLAG_RAND_GLV = 0x200
 
 
 def batch_verify_randomized(msgs, sigs, pks, seed32, flags=FLAG_G2_SUBGROUP_CHECK):

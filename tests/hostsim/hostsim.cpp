@@ -135,12 +135,12 @@ int hs_verify_randomized(const uint8_t* msgs, const uint64_t* off, const uint8_t
       uint32_t k[4];
       rand_scalar(k, seed, ii, (flags & 0x100u) != 0);
       G1Jac a, sj, id;
-      const bool rand64 = (flags & 0x100u) != 0;
-      if (rand64) jac_mul_u64(a, h, k); else jac_mul_u128(a, h, k);
+      const bool rand64 = (flags & 0x100u) != 0, glv = !rand64 && (flags & 0x200u) != 0;
+      if (glv) g1_mul_glv(a, h, k, k + 2); else if (rand64) jac_mul_u64(a, h, k); else jac_mul_u128(a, h, k);
       G1Affine aa;
       jac_to_affine(aa, a);
       aa.inf = aa.inf || !valid;
-      if (rand64) jac_mul_u64(sj, sig, k); else jac_mul_u128(sj, sig, k);
+      if (glv) g1_mul_glv(sj, sig, k, k + 2); else if (rand64) jac_mul_u64(sj, sig, k); else jac_mul_u128(sj, sig, k);
       jac_set_identity(id);
       jac_select(sj, !valid, id, sj);
       s_lds[t] = sj;

@@ -60,7 +60,7 @@ elif which == "randomized":
             off[i] = pos; pos += len(m)
         off[n] = pos
         st = buf(n); gr = buf(1)
-        for fl in (0, 0x100, 0x80000000):
+        for fl in (0, 0x100, 0x200, 0x80000000):
             hs.hs_verify_randomized(b"".join(msgs), off, b"".join(H(v["sig"]) for v in cases), b"".join(H(v["pk"]) for v in cases), n, fl,
                                     bytes(range(32)), st, gr)
         assert list(st.raw) == [v["status"] if "subgroup" not in v["name"] else st.raw[i] for i, v in enumerate(cases)], list(st.raw)

@@ -491,7 +491,7 @@ def test_randomized_verify_vs_oracle(eng, c):
     sigs[64 * 325:64 * 326] = c.g1_add(g(325), d)
     sigs[64 * 330:64 * 331] = c.g1_add(g(330), dn)
     from bn254_amd.engine import OPT_RAND_ITEMS_PER_LANE
-    for flags, per_lane in ((0, 1), (0x100, 1), (1, 1), (0, 2), (0x100, 2)):
+    for flags, per_lane in ((0, 1), (0x100, 1), (1, 1), (0, 2), (0x100, 2), (0x200, 1), (0x200, 2)):
         eng.set_option(OPT_RAND_ITEMS_PER_LANE, per_lane)
         try:
             got = eng.batch_verify_randomized(msgs, bytes(sigs), bytes(pks), RAND_SEED, flags=flags)

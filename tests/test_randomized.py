@@ -67,9 +67,10 @@ def test_oracle_randomized_equals_exact():
     pks[67] = pks[68]
     st, gr = c.batch_verify_randomized(msgs, b"".join(sigs), b"".join(pks), SEED, flags=0)
     assert gr == b"\x01\x00" and st == exact() and st[65] == 6 and st[66] == 9 and st[67] == 9
-    # 64-bit scalars
-    st, gr = c.batch_verify_randomized(msgs, b"".join(sigs), b"".join(pks), SEED, flags=c.FLAG_RAND64)
-    assert st == exact()
+    # 64-bit scalars, GLV scalars
+    for fl in (c.FLAG_RAND64, c.FLAG_RAND_GLV):
+        st, gr = c.batch_verify_randomized(msgs, b"".join(sigs), b"".join(pks), SEED, flags=fl)
+        assert st == exact() and gr == b"\x01\x00"
 
 
 def test_windowed_scalar_mul_device_source():
@@ -87,7 +88,7 @@ def test_hostsim_randomized_matches_oracle():
     n = 70
     msgs, sigs, pks = make_batch(n)
     sigs = list(sigs)
-    for flags in (0, c.FLAG_RAND64, 0x80000000):      # bit 31: hostsim-only knob selecting the two-items-per-lane composition
+    for flags in (0, c.FLAG_RAND64, c.FLAG_RAND_GLV, 0x80000000, 0x80000000 | c.FLAG_RAND_GLV):   # bit 31: hostsim-only knob (two items per lane)
         st, gr = hs.verify_randomized(msgs, b"".join(sigs), b"".join(pks), SEED, flags)
         assert (st, gr) == c.batch_verify_randomized(msgs, b"".join(sigs), b"".join(pks), SEED, flags=flags & 0xFFFF) == (bytes(n), b"\x01\x01")
     sigs[5] = sigs[4]
@@ -96,6 +97,18 @@ def test_hostsim_randomized_matches_oracle():
     st, gr = hs.verify_randomized(msgs, b"".join(sigs), b"".join(pks), SEED, 0)
     assert (st, gr) == c.batch_verify_randomized(msgs, b"".join(sigs), b"".join(pks), SEED, flags=0)
     assert (st, gr) == hs.verify_randomized(msgs, b"".join(sigs), b"".join(pks), SEED, 0x80000000)
+    assert (st, gr) == hs.verify_randomized(msgs, b"".join(sigs), b"".join(pks), SEED, c.FLAG_RAND_GLV)
     assert gr == b"\x00\x00" and [i for i in range(n) if st[i]] == [5, 66, 69]
     # a different seed gives the same verdicts
     assert hs.verify_randomized(msgs, b"".join(sigs), b"".join(pks), bytes(32), 0)[0] == st
+
+
+def test_glv_endomorphism_constant():
+    """lambda * P == (beta x, y): the oracle multiplies by lambda without the endomorphism, the device source uses it"""
+    lam = 0xB3C4D79D41A917585BFC41088D8DAAA78B17EA66B99C90DD
+    beta = 0x59E26BCEA0D48BACD4F263F1ACDB5C4F5763473177FFFFFE
+    assert (lam * lam + lam + 1) % m.R == 0 and pow(beta, 3, m.Q) == 1
+    for i in range(3):
+        p = c.hash_to_g1(b"glv%d" % i)[1]
+        x, y = int.from_bytes(p[:32], "big"), p[32:]
+        assert c.g1_mul(p, lam.to_bytes(32, "big")) == (beta * x % m.Q).to_bytes(32, "big") + y
