@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""Differential soak of the HIP path against the oracle (GPU box; not part of pytest).
+
+    python tests/soak_gpu.py --seconds 300 --out gpurun_out/soak.json
+
+Each round draws a batch of random size and message lengths, mutates a fraction of the signatures / keys
+(bit flips, coordinates >= q, zeros, random bytes, off-subgroup keys, wrong-message signatures), and requires
+bit-identical status bytes from every mode — exact on lane pairs, exact with one lane per verify, randomised with
+128-bit / GLV / 64-bit scalars — and from the oracle (all host cores).  The oracle is the checker only."""
+import argparse
+import hashlib
+import json
+import os
+import random
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+Q = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=120.0)
+    ap.add_argument("--out", default=None)
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+    import bn254_amd
+    from bn254_amd.engine import OPT_PAIR_LANES
+    from oracle import c_oracle as c
+    from tests.datagen import sk_bytes
+    eng = bn254_amd.Engine(0)
+    derived = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "derived_vectors.json")))
+    off_sub = bytes.fromhex(derived["g2_not_in_subgroup"])
+    rnd = random.Random(args.seed)
+    cores = len(os.sched_getaffinity(0))
+    sks = [sk_bytes(j) for j in range(64)]
+    pk_pool, _ = eng.batch_g2_mul(None, b"".join(sks), 64, reduce_scalar=True)
+    t0, rounds, items, codes = time.time(), 0, 0, {}
+    while time.time() - t0 < args.seconds:
+        n = rnd.choice([1, 63, 64, 65, 257, 1000, 2048, 4097])
+        msgs = [hashlib.sha256(b"soak%d/%d" % (rounds, i)).digest() * 5 for i in range(n)]
+        msgs = [m[:rnd.choice([0, 1, 31, 32, 55, 56, 64, 100, 119, 120, 160])] for m in msgs]
+        key = [rnd.randrange(64) for _ in range(n)]
+        sigs, st = eng.batch_sign(msgs, b"".join(sks[k] for k in key))
+        assert st == bytes(n)
+        sigs = bytearray(sigs)
+        pks = bytearray(b"".join(pk_pool[128 * k:128 * k + 128] for k in key))
+        for i in range(n):
+            kind = rnd.randrange(30)
+            s, p = memoryview(sigs)[64 * i:64 * i + 64], memoryview(pks)[128 * i:128 * i + 128]
+            if kind == 0:
+                s[rnd.randrange(64)] ^= 1 << rnd.randrange(8)
+            elif kind == 1:
+                p[rnd.randrange(128)] ^= 1 << rnd.randrange(8)
+            elif kind == 2:
+                s[:32] = (Q + rnd.randrange(1000)).to_bytes(32, "big")
+            elif kind == 3:
+                j = 32 * rnd.randrange(4)
+                p[j:j + 32] = (Q + rnd.randrange(1 << 200)).to_bytes(32, "big")
+            elif kind == 4:
+                s[:] = bytes(64)
+            elif kind == 5:
+                p[:] = bytes(128)
+            elif kind == 6:
+                s[:] = rnd.randbytes(64)
+            elif kind == 7:
+                p[:] = rnd.randbytes(128)
+            elif kind == 8:
+                p[:] = off_sub
+            elif kind == 9 and i > 0:
+                s[:] = sigs[64 * (i - 1):64 * i]              # a valid signature of another message / key
+        sigs, pks = bytes(sigs), bytes(pks)
+        seed = rnd.randbytes(32)
+        for flags in (0, 1):
+            want, _ = c.batch_verify(msgs, sigs, pks, flags=flags, nthreads=cores)
+            got = {"pair": eng.batch_verify(msgs, sigs, pks, flags=flags)}
+            eng.set_option(OPT_PAIR_LANES, 0)
+            got["single"] = eng.batch_verify(msgs, sigs, pks, flags=flags)
+            eng.set_option(OPT_PAIR_LANES, 1)
+            for name, fl in (("rand128", 0), ("rand_glv", 0x200), ("rand64", 0x100)):
+                got[name] = eng.batch_verify_randomized(msgs, sigs, pks, seed, flags=flags | fl)[0]
+            for name, g in got.items():
+                bad = [i for i in range(n) if g[i] != want[i]]
+                if bad:
+                    print("MISMATCH", name, "round", rounds, "flags", flags, "n", n, bad[:5], [(g[i], want[i]) for i in bad[:5]])
+                    sys.exit(1)
+            for b in want:
+                codes[b] = codes.get(b, 0) + 1
+        rounds += 1
+        items += n
+    res = {"rounds": rounds, "tuples": items, "comparisons": items * 2 * 5, "seconds": round(time.time() - t0, 1), "oracle_threads": cores,
+           "status_histogram": {str(k): v for k, v in sorted(codes.items())}, "mismatches": 0, "seed": args.seed,
+           "modes": ["exact on lane pairs", "exact, one lane per verify", "randomised 128-bit", "randomised GLV", "randomised 64-bit"],
+           "flags": [0, 1]}
+    print(json.dumps(res))
+    if args.out:
+        with open(args.out, "w") as f:
+            json.dump(res, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
