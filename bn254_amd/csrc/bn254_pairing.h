@@ -12,6 +12,14 @@
 #pragma once
 #include "bn254_curve.h"
 
+// Hook for kernels that keep two waves on a SIMD (bn254_pair.hip): wave priority cycling 3,2,1,0 with the step
+// count of the long loops.  The issue arbiter otherwise favours the older wave of a SIMD and the pair drifts 3 ms
+// apart; with the cycle, whichever wave falls a few steps behind is in a higher-priority part of the cycle and
+// catches up.  A no-op everywhere else.
+#ifndef BN_SET_STEP_PRIORITY
+#define BN_SET_STEP_PRIORITY(step) do { } while (0)
+#endif
+
 namespace bn254 {
 
 struct G2Proj { Fp2 x, y, z; };            // homogeneous projective twist point
@@ -107,6 +115,7 @@ BN_DEVN void miller_loop(Fp12& f, const G1Affine& pa, const G2Affine& qa, const 
   int idx = 0;
   constexpr bool BOTH = HAS_A && HAS_B;      // both pairs: one merged multiplication per step
   for (int d = 0; d < 64; ++d) {
+    BN_SET_STEP_PRIORITY(d);
     fp12_sqr(f, f);
     if constexpr (HAS_A) { dbl_step(t, l); if constexpr (!BOTH) mul_by_line(f, l, pa.x, pa.y, skip_a); }
     if constexpr (BOTH) mul_by_two_lines(f, l, pa.x, pa.y, skip_a, idx++, pb.x, pb.y, skip_b);
@@ -174,6 +183,7 @@ BN_DEVN void miller_loop_2var(Fp12& f, const G1Affine& pa, const G2Affine& qa, c
   tc.x = qc.x; tc.y = qc.y; tc.z = fp2_one();
   const Fp2 qa_yneg = fp2_norm(fp2_neg(qa.y)), qc_yneg = fp2_norm(fp2_neg(qc.y));
   for (int d = 0; d < 64; ++d) {
+    BN_SET_STEP_PRIORITY(d);
     fp12_sqr(f, f);
     dbl_step(ta, la);
     dbl_step(tc, lc);
@@ -208,6 +218,7 @@ BN_DEVN void fp12_pow_u(Fp12& r, const Fp12& a, Fp12& acc) {
   fp12_mul(odd[3], odd[2], t);
   acc = odd[C_U_W4[0] >> 1];                        // leading digit is positive
   for (int i = 1; i < BN_U_W4_LEN; ++i) {           // wave-uniform: u is a public constant
+    BN_SET_STEP_PRIORITY(i);
     fp12_cyclotomic_sqr(acc, acc);
     int d = C_U_W4[i];
     if (d > 0) fp12_mul(acc, acc, odd[d >> 1]);
