@@ -40,6 +40,14 @@ extern "C" unsigned long long bn_fp_mul_counter;
 #define BN_COUNT_MUL()
 #endif
 
+// Hook for kernels that keep two waves on a SIMD (bn254_pair.hip): wave priority cycling 3,2,1,0 with the step
+// count of the long loops.  The issue arbiter otherwise favours the older wave of a SIMD and the pair drifts 3 ms
+// apart; with the cycle, whichever wave falls a few steps behind is in a higher-priority part of the cycle and
+// catches up.  A no-op everywhere else.
+#ifndef BN_SET_STEP_PRIORITY
+#define BN_SET_STEP_PRIORITY(step) do { } while (0)
+#endif
+
 namespace bn254 {
 
 // ------------------------------------------------------------------------------------------
@@ -470,6 +478,7 @@ BN_DEVN Fp fp_pow_sched(Fp a, const unsigned char (*sched)[2], int n_steps) {
   for (int i = 1; i < 8; ++i) odd[i] = fp_mul(odd[i - 1], a2);
   Fp acc = odd[sched[0][1] >> 1];
   for (int s = 1; s < n_steps; ++s) {
+    BN_SET_STEP_PRIORITY(s);
     for (int k = 0; k < sched[s][0]; ++k) acc = fp_sqr(acc);
     if (sched[s][1]) acc = fp_mul(acc, odd[sched[s][1] >> 1]);
   }

@@ -12,13 +12,6 @@
 #pragma once
 #include "bn254_curve.h"
 
-// Hook for kernels that keep two waves on a SIMD (bn254_pair.hip): wave priority cycling 3,2,1,0 with the step
-// count of the long loops.  The issue arbiter otherwise favours the older wave of a SIMD and the pair drifts 3 ms
-// apart; with the cycle, whichever wave falls a few steps behind is in a higher-priority part of the cycle and
-// catches up.  A no-op everywhere else.
-#ifndef BN_SET_STEP_PRIORITY
-#define BN_SET_STEP_PRIORITY(step) do { } while (0)
-#endif
 
 namespace bn254 {
 
@@ -249,6 +242,7 @@ BN_DEVN void final_exponentiation(Fp12& r, const Fp12& fin, Fp12& acc) {
   fp12_conj(y5, fu2);
   fp12_frob(a, fu3, 1); fp12_mul(a, a, fu3); fp12_conj(y6, a);
   Fp12 t0, t1;
+  BN_SET_STEP_PRIORITY(2);   // the short tail: whoever is still here is behind
   fp12_cyclotomic_sqr(t0, y6); fp12_mul(t0, t0, y4); fp12_mul(t0, t0, y5);
   fp12_mul(t1, y3, y5); fp12_mul(t1, t1, t0);
   fp12_mul(t0, t0, y2);
