@@ -36,7 +36,7 @@ def main():
     cores = len(os.sched_getaffinity(0))
     sks = [sk_bytes(j) for j in range(64)]
     pk_pool, _ = eng.batch_g2_mul(None, b"".join(sks), 64, reduce_scalar=True)
-    t0, rounds, items, codes = time.time(), 0, 0, {}
+    t0, rounds, items, codes, extra = time.time(), 0, 0, {}, {}
     while time.time() - t0 < args.seconds:
         n = rnd.choice([1, 63, 64, 65, 257, 1000, 2048, 4097])
         msgs = [hashlib.sha256(b"soak%d/%d" % (rounds, i)).digest() * 5 for i in range(n)]
@@ -87,10 +87,34 @@ def main():
                     sys.exit(1)
             for b in want:
                 codes[b] = codes.get(b, 0) + 1
+        if rounds % 8 == 0:
+            # pairing API (canonical Gt bytes) and check_public_keys on lane pairs vs the oracle
+            m = 24
+            ks = [rnd.randrange(1, 1 << 250).to_bytes(32, "big") for _ in range(2 * m)]
+            g1 = (1).to_bytes(32, "big") + (2).to_bytes(32, "big")
+            ps, st1 = eng.batch_g1_mul(g1 * m, b"".join(ks[:m]), m)
+            qs, st2 = eng.batch_g2_mul(None, b"".join(ks[m:]), m)
+            assert st1 == bytes(m) and st2 == bytes(m)
+            gt, stg = eng.batch_pairing(ps, qs, m, 1)
+            for j in range(m):
+                want_gt = c.pairing(ps[64 * j:64 * j + 64], qs[128 * j:128 * j + 128])
+                if gt[384 * j:384 * j + 384] != want_gt:
+                    print("MISMATCH pairing Gt", rounds, j)
+                    sys.exit(1)
+            pk1, _ = eng.batch_g1_mul(g1 * m, b"".join(ks[m:]), m)        # matching G1 keys for the G2 keys above
+            bad_pk1 = bytearray(pk1)
+            bad_pk1[64:128] = pk1[:64]
+            got_cpk = eng.batch_check_public_keys(qs, bytes(bad_pk1), m)
+            want_cpk = bytes(c.check_public_keys(qs[128 * j:128 * j + 128], bytes(bad_pk1[64 * j:64 * j + 64]), flags=0) for j in range(m))
+            if got_cpk != want_cpk or got_cpk[1] != 9 or got_cpk[0] != 0:
+                print("MISMATCH check_public_keys", rounds, list(got_cpk), list(want_cpk))
+                sys.exit(1)
+            extra["pairings"] = extra.get("pairings", 0) + m
+            extra["check_public_keys"] = extra.get("check_public_keys", 0) + m
         rounds += 1
         items += n
     res = {"rounds": rounds, "tuples": items, "comparisons": items * 2 * 5, "seconds": round(time.time() - t0, 1), "oracle_threads": cores,
-           "status_histogram": {str(k): v for k, v in sorted(codes.items())}, "mismatches": 0, "seed": args.seed,
+           "status_histogram": {str(k): v for k, v in sorted(codes.items())}, "mismatches": 0, "seed": args.seed, "also_compared": extra,
            "modes": ["exact on lane pairs", "exact, one lane per verify", "randomised 128-bit", "randomised GLV", "randomised 64-bit"],
            "flags": [0, 1]}
     print(json.dumps(res))
