@@ -809,8 +809,14 @@ int bn254_ctx_create(int hip_device, bn254_ctx** out) {
   memset(c, 0, sizeof *c);
   c->pair_lanes = 1;
   c->device = hip_device;
-  HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  for (int i = 0; i < 5; ++i) HIP_TRY(hipEventCreate(&c->ev[i]));
+  hipError_t err = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  for (int i = 0; i < 5 && err == hipSuccess; ++i) err = hipEventCreate(&c->ev[i]);
+  if (err != hipSuccess) {
+    for (int i = 0; i < 5; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return -(int)err;
+  }
   *out = c;
   return 0;
 }
