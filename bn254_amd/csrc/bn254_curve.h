@@ -128,6 +128,42 @@ template <class F> BN_DEVN void jac_madd(Jac<F>& r, const Jac<F>& p, const Affin
   r = o;
 }
 
+// Mixed addition for running sums (aggregation): the common case without the doubling that jac_madd computes for
+// every call just to be able to select it (40 % of its cost), and a flag for the rare lanes that did hit
+// P = +-Q; the caller redoes the step with jac_madd when any lane of the wave raised it.
+template <class F> BN_DEVN void jac_madd_common(Jac<F>& r, bool& exceptional, const Jac<F>& p, const Affine<F>& q) {
+  F z1z1 = f_norm(f_sqr(p.z));
+  F u2 = f_mul(q.x, z1z1);
+  F s2 = f_mul(f_norm(f_mul(q.y, p.z)), z1z1);
+  F h = f_norm(f_sub(u2, p.x)), hh = f_norm(f_sqr(h));
+  F i = f_norm(f_dbl(f_dbl(hh))), j = f_mul(h, i);
+  F rr = f_norm(f_dbl(f_sub(s2, p.y))), v = f_mul(p.x, i);
+  Jac<F> o;
+  o.x = f_norm(f_sub(f_sub(f_sqr(rr), j), f_dbl(v)));
+  o.y = f_norm(f_sub(f_mul(rr, f_norm(f_sub(v, o.x))), f_dbl(f_mul(p.y, j))));
+  o.z = f_norm(f_sub(f_sub(f_sqr(f_add(p.z, h)), z1z1), hh));
+  const bool p_inf = f_is_zero(p.z);
+  Jac<F> qj;
+  qj.x = q.x; qj.y = q.y; f_set_one(qj.z);
+  exceptional = f_is_zero(h) && !p_inf && !q.inf;
+  jac_select(o, p_inf, qj, o);
+  jac_select(o, q.inf, p, o);
+  r = o;
+}
+#if defined(__HIPCC__)
+#define BN_WAVE_ANY(x) (__any((int)(x)) != 0)
+#else
+#define BN_WAVE_ANY(x) (x)
+#endif
+// acc += q with identical control flow across the wave
+template <class F> BN_DEV void jac_accumulate(Jac<F>& acc, const Affine<F>& q) {
+  Jac<F> t;
+  bool ex;
+  jac_madd_common(t, ex, acc, q);
+  if (BN_WAVE_ANY(ex)) jac_madd(acc, acc, q);   // some lane met P = +-Q: the complete formula for the whole wave (rare)
+  else acc = t;
+}
+
 // P + Q for operands known to satisfy P != +-Q unless one of them is the identity (add-2007-bl without
 // the doubling / cancellation overrides of jac_add, which cost a jac_dbl per call).
 template <class F> BN_DEVN void jac_add_distinct(Jac<F>& r, const Jac<F>& p, const Jac<F>& q) {

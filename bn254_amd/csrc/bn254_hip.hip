@@ -528,19 +528,6 @@ KERNEL void k_g2_decompress(const uint8_t* in, size_t n, uint8_t* out, uint8_t* 
   status[i] = st;
 }
 // ---- aggregate verify (config 3): shared pools, per-tuple signer subsets -------------------------
-// Pools are decoded once into limb-major planes of their own: word k of coordinate e of entry j at
-// pool[(e*BN_LIMBS + k) * stride + j]; status byte per entry.
-struct Pool { int32_t* planes; uint8_t* st; size_t stride; };
-__device__ __forceinline__ Fp pool_load_fp(const Pool& p, int e, size_t j) {
-  Fp r;
-#pragma unroll
-  for (int k = 0; k < BN_LIMBS; ++k) r.v[k] = p.planes[((size_t)e * BN_LIMBS + k) * p.stride + j];
-  return r;
-}
-__device__ __forceinline__ void pool_store_fp(const Pool& p, int e, size_t j, const Fp& a) {
-#pragma unroll
-  for (int k = 0; k < BN_LIMBS; ++k) p.planes[((size_t)e * BN_LIMBS + k) * p.stride + j] = a.v[k];
-}
 KERNEL_SMALL void k_pool_decode_g1(const uint8_t* pts, size_t n, uint32_t flags, Pool pool) {
   size_t i = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
   if (i >= n) return;
@@ -601,8 +588,8 @@ KERNEL void k_aggregate(const uint32_t* tuple_msg, const uint64_t* tuple_off, co
     if (valid && st == ST_OK && (s2 & 0x7f)) st = s2 & 0x7f;
     sp.inf = !valid || (s1 & 0x80);
     pp.inf = !valid || (s2 & 0x80);
-    jac_madd(acc1, acc1, sp);
-    jac_madd(acc2, acc2, pp);
+    jac_accumulate(acc1, sp);
+    jac_accumulate(acc2, pp);
   }
   G1Affine asig, h;
   G2Affine apk;
@@ -1248,7 +1235,11 @@ int bn254_batch_aggregate_verify_device(bn254_ctx* c, const uint8_t* d_msgs, con
   k_pool_decode_g1<<<grid_for(n_msgs * n_signers), BN_WAVE, 0, s>>>(d_sig_pool, n_msgs * n_signers, flags, c->pool[1]);
   if ((rc = launch_hash_rounds(c, s, d_msgs, d_msg_off, n_msgs, PL_P2X, BY_P2_INF, nullptr))) return rc;
   k_hash_to_pool<<<grid_for(n_msgs), BN_WAVE, 0, s>>>(n_msgs, c->ws, c->pool[2]);
-  k_aggregate<<<grid_for(n), BN_WAVE, 0, s>>>(d_tuple_msg, d_tuple_off, d_signer_idx, n, n_signers, c->pool[0], c->pool[1], c->pool[2], c->ws);
+  if (c->pair_lanes) {
+    if ((rc = bn254_pair_aggregate(d_tuple_msg, d_tuple_off, d_signer_idx, n, n_signers, c->pool[0], c->pool[1], c->pool[2], c->ws, s))) return rc;
+  } else {
+    k_aggregate<<<grid_for(n), BN_WAVE, 0, s>>>(d_tuple_msg, d_tuple_off, d_signer_idx, n, n_signers, c->pool[0], c->pool[1], c->pool[2], c->ws);
+  }
   if (c->pair_lanes) {
     if ((rc = bn254_pair_miller_verify(n, c->ws, nullptr, nullptr, s))) return rc;
     if ((rc = bn254_pair_final_exp(n, c->ws, 1, d_status, nullptr, nullptr, s))) return rc;

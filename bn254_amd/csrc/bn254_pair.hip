@@ -196,6 +196,84 @@ int bn254_pair_rand_tail(size_t n_groups, Ws ws, size_t gbase, hipStream_t s) {
   return 0;
 }
 
+// Aggregation for config 3 on lane pairs (see k_aggregate in bn254_hip.hip): a pair walks the signer list of its
+// tuple two entries per iteration — both public keys are added to the G2 sum in the pair layout, and each lane adds
+// the signature of "its" entry (2t + role) to its own partial G1 sum; the two partial sums are added at the end.
+KERNEL_PAIR void k_aggregate_pair(const uint32_t* tuple_msg, const uint64_t* tuple_off, const uint32_t* signer_idx, size_t n, size_t n_signers,
+                                  Pool pk_pool, Pool sig_pool, Pool h_pool, Ws ws) {
+  const unsigned role = threadIdx.x & 1u;
+  size_t i = ((size_t)blockIdx.x * BN_PAIR_WG + threadIdx.x) >> 1;
+  const bool live = i < n;                 // no early return: the wave-level votes and shuffles below need every lane
+  const size_t ii = live ? i : n - 1;
+  uint32_t m = tuple_msg[ii];
+  uint64_t lo = tuple_off[ii], hi = live ? tuple_off[ii + 1] : lo;
+  G1Jac acc1;
+  G2Jac acc2;
+  jac_set_identity(acc1);
+  jac_set_identity(acc2);
+  uint8_t st = ST_OK;
+  uint64_t longest = hi - lo;
+  for (int off = 32; off > 0; off >>= 1) {
+    uint64_t other = __shfl_xor((unsigned long long)longest, off, BN_WAVE);
+    longest = other > longest ? other : longest;
+  }
+  for (uint64_t t = 0; t < longest; t += 2) {
+    G2Affine pp[2];
+    G1Affine sp;
+    sp.x = fp_load_const(C_G1_GEN[0]); sp.y = fp_load_const(C_G1_GEN[1]); sp.inf = true;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      bool active = lo + t + e < hi;
+      uint32_t sgn = active ? signer_idx[lo + t + e] : 0u;
+      bool valid = active && sgn < n_signers;
+      if (active && !valid && st == ST_OK) st = ST_INDEX_OOB;             // IndexOutOfBounds
+      if (!valid) sgn = 0;
+      size_t sj = (size_t)m * n_signers + sgn;
+      uint8_t s1 = sig_pool.st[sj], s2 = pk_pool.st[sgn];
+      if (valid && st == ST_OK && (s1 & 0x7f)) st = s1 & 0x7f;
+      if (valid && st == ST_OK && (s2 & 0x7f)) st = s2 & 0x7f;
+      pp[e].x.c[0] = pool_load_fp(pk_pool, 0 + (int)role, sgn);
+      pp[e].y.c[0] = pool_load_fp(pk_pool, 2 + (int)role, sgn);
+      pp[e].inf = !valid || (s2 & 0x80);
+      if ((unsigned)e == role) {            // this lane's signature of the iteration
+        sp.x = pool_load_fp(sig_pool, 0, sj); sp.y = pool_load_fp(sig_pool, 1, sj);
+        sp.inf = !valid || (s1 & 0x80);
+      }
+    }
+    jac_accumulate(acc2, pp[0]);
+    jac_accumulate(acc2, pp[1]);
+    jac_accumulate(acc1, sp);
+  }
+  // G1: own partial sum + the partner's
+  G1Jac other;
+#pragma unroll
+  for (int k = 0; k < BN_LIMBS; ++k) {
+    other.x.v[k] = bn_partner_word(acc1.x.v[k]); other.y.v[k] = bn_partner_word(acc1.y.v[k]); other.z.v[k] = bn_partner_word(acc1.z.v[k]);
+  }
+  jac_add(acc1, acc1, other);
+  G1Affine asig, h;
+  G2Affine apk;
+  jac_to_affine(asig, acc1);
+  jac_to_affine(apk, acc2);
+  if (!live) return;
+  h.x = pool_load_fp(h_pool, 0, m); h.y = pool_load_fp(h_pool, 1, m); h.inf = false;
+  ws_store_fp(ws, PL_QX0 + (int)role, i, apk.x.c[0]);
+  ws_store_fp(ws, PL_QY0 + (int)role, i, apk.y.c[0]);
+  if (role == 0) {
+    ws_store_g1(ws, PL_P1X, BY_P1_INF, i, asig);
+    ws_store_g1(ws, PL_P2X, BY_P2_INF, i, h);
+    ws_byte(ws, BY_Q_INF, i) = apk.inf;
+    ws_byte(ws, BY_ST_DECODE, i) = st;
+    ws_byte(ws, BY_ST_HASH, i) = h_pool.st[m];
+  }
+}
+int bn254_pair_aggregate(const uint32_t* tuple_msg, const uint64_t* tuple_off, const uint32_t* signer_idx, size_t n, size_t n_signers, Pool pk_pool,
+                         Pool sig_pool, Pool h_pool, Ws ws, hipStream_t s) {
+  k_aggregate_pair<<<(unsigned)((2 * n + BN_PAIR_WG - 1) / BN_PAIR_WG), BN_PAIR_WG, 0, s>>>(tuple_msg, tuple_off, signer_idx, n, n_signers, pk_pool,
+                                                                                            sig_pool, h_pool, ws);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
 int bn254_pair_miller_verify(size_t n, Ws ws, const uint32_t* map, const uint32_t* count, hipStream_t s, int mode) {
   k_miller_verify_pair<<<(unsigned)((2 * n + BN_PAIR_WG - 1) / BN_PAIR_WG), BN_PAIR_WG, 0, s>>>(n, ws, map, count, mode);
   HIP_TRY(hipGetLastError());

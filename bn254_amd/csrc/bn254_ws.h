@@ -58,6 +58,19 @@ __device__ __forceinline__ void ws_load_g1(const Ws& ws, int px, int inf_plane, 
   p.x = ws_load_fp(ws, px, i); p.y = ws_load_fp(ws, px + 1, i); p.inf = ws_byte(ws, inf_plane, i) != 0;
 }
 
+// Pools are decoded once into limb-major planes of their own: word k of coordinate e of entry j at
+// pool[(e*BN_LIMBS + k) * stride + j]; status byte per entry.
+struct Pool { int32_t* planes; uint8_t* st; size_t stride; };
+__device__ __forceinline__ Fp pool_load_fp(const Pool& p, int e, size_t j) {
+  Fp r;
+#pragma unroll
+  for (int k = 0; k < BN_LIMBS; ++k) r.v[k] = p.planes[((size_t)e * BN_LIMBS + k) * p.stride + j];
+  return r;
+}
+__device__ __forceinline__ void pool_store_fp(const Pool& p, int e, size_t j, const Fp& a) {
+#pragma unroll
+  for (int k = 0; k < BN_LIMBS; ++k) p.planes[((size_t)e * BN_LIMBS + k) * p.stride + j] = a.v[k];
+}
 #define HIP_TRY(expr)                                      \
   do {                                                     \
     hipError_t e_ = (expr);                                \
@@ -74,3 +87,5 @@ __attribute__((visibility("hidden"))) int bn254_pair_final_exp(size_t n, Ws ws, 
                                                                const uint32_t* count, hipStream_t s, size_t base = 0);
 __attribute__((visibility("hidden"))) int bn254_pair_miller_rand(size_t n, size_t n_groups, int items_per_pair, Ws ws, size_t gbase, hipStream_t s);
 __attribute__((visibility("hidden"))) int bn254_pair_rand_tail(size_t n_groups, Ws ws, size_t gbase, hipStream_t s);
+__attribute__((visibility("hidden"))) int bn254_pair_aggregate(const uint32_t* tuple_msg, const uint64_t* tuple_off, const uint32_t* signer_idx, size_t n,
+                                                               size_t n_signers, Pool pk_pool, Pool sig_pool, Pool h_pool, Ws ws, hipStream_t s);

@@ -325,7 +325,7 @@ int hs_g1_msum(const uint8_t* pts, uint64_t k, uint8_t* out) {
   G1Jac acc;
   jac_set_identity(acc);
   uint8_t st = ST_OK;
-  for (uint64_t j = 0; j < k; ++j) { G1Affine p; uint8_t s = dec_g1(p, pts + 64 * j, 0); if (st == ST_OK) st = s; jac_madd(acc, acc, p); }
+  for (uint64_t j = 0; j < k; ++j) { G1Affine p; uint8_t s = dec_g1(p, pts + 64 * j, 0); if (st == ST_OK) st = s; jac_accumulate(acc, p); }
   G1Affine r;
   jac_to_affine(r, acc);
   alignas(4) uint8_t tmp[64];
@@ -337,7 +337,7 @@ int hs_g2_msum(const uint8_t* pts, uint64_t k, uint8_t* out) {
   G2Jac acc;
   jac_set_identity(acc);
   uint8_t st = ST_OK;
-  for (uint64_t j = 0; j < k; ++j) { G2Affine p; uint8_t s = dec_g2(p, pts + 128 * j, 0); if (st == ST_OK) st = s; jac_madd(acc, acc, p); }
+  for (uint64_t j = 0; j < k; ++j) { G2Affine p; uint8_t s = dec_g2(p, pts + 128 * j, 0); if (st == ST_OK) st = s; jac_accumulate(acc, p); }
   G2Affine r;
   jac_to_affine(r, acc);
   alignas(4) uint8_t tmp[128];
