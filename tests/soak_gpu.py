@@ -109,6 +109,30 @@ def main():
             if got_cpk != want_cpk or got_cpk[1] != 9 or got_cpk[0] != 0:
                 print("MISMATCH check_public_keys", rounds, list(got_cpk), list(want_cpk))
                 sys.exit(1)
+            # aggregate verification over pools (config-3 shape): random subsets, duplicates (P + P), one wrong-message row
+            M, S = 3, 12
+            amsgs = [b"soak-agg-%d-%d" % (rounds, j) for j in range(M)]
+            apk_pool = pk_pool[:128 * S]
+            asig_pool, st = eng.batch_sign([amsgs[j] for j in range(M) for _ in range(S)], b"".join(sks[:S]) * M)
+            assert st == bytes(M * S)
+            tuples = []
+            for _ in range(40):
+                k = rnd.randrange(0, 9)
+                lst = [rnd.randrange(S) for _ in range(k)]
+                if lst and rnd.randrange(4) == 0:
+                    lst.append(lst[0])                       # duplicate signer
+                tuples.append((rnd.randrange(M), lst))
+            got_a = eng.batch_aggregate_verify(amsgs, apk_pool, asig_pool, [t[0] for t in tuples], [t[1] for t in tuples])
+            for j, (mi, lst) in enumerate(tuples):
+                asig, apk = bytes(64), bytes(128)
+                for sg in lst:
+                    asig = c.g1_add(asig, asig_pool[64 * (mi * S + sg):64 * (mi * S + sg) + 64])
+                    apk = c.g2_add(apk, apk_pool[128 * sg:128 * sg + 128])
+                want_a = c.verify(amsgs[mi], asig, apk, 0)
+                if got_a[j] != want_a:
+                    print("MISMATCH aggregate", rounds, j, lst, got_a[j], want_a)
+                    sys.exit(1)
+            extra["aggregate_tuples"] = extra.get("aggregate_tuples", 0) + len(tuples)
             extra["pairings"] = extra.get("pairings", 0) + m
             extra["check_public_keys"] = extra.get("check_public_keys", 0) + m
         rounds += 1
