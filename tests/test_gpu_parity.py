@@ -582,3 +582,17 @@ def test_argument_validation_and_empty_batches(eng):
     from tests.datagen import make_verify_batch
     msgs, sigs, pks, expected = make_verify_batch(eng, 130)
     assert eng.batch_verify(msgs, sigs, pks) == expected
+
+
+def test_cpp_host_mirror_example(eng):
+    """the C++ mirror of the reference API (bn254_amd/host/bn254.hpp) runs the reference's example scenario
+    (/root/reference/examples/bn254.rs:3-34) end to end on the GPU"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    host = os.path.join(root, "bn254_amd", "host")
+    exe = os.path.join(host, "example")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", os.path.join(host, "example.cpp"), "-L" + os.path.join(root, "bn254_amd"),
+                           "-lbn254hip", "-Wl,-rpath," + os.path.join(root, "bn254_amd"), "-o", exe])
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "Successful aggregate signature verification" in p.stdout, (p.stdout, p.stderr)
