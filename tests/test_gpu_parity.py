@@ -596,3 +596,22 @@ def test_cpp_host_mirror_example(eng):
                            "-lbn254hip", "-Wl,-rpath," + os.path.join(root, "bn254_amd"), "-o", exe])
     p = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and "Successful aggregate signature verification" in p.stdout, (p.stdout, p.stderr)
+
+
+def test_api_batch_verify_randomized(eng):
+    """the Python mirror's ECDSA.batch_verify / batch_verify_randomized give the same per-item results"""
+    import bn254_amd
+    from bn254_amd import ECDSA, PrivateKey, PublicKey, Signature, Error, ErrorKind
+    sks = [PrivateKey(1000 + j) for j in range(5)]
+    pks = [PublicKey.from_private_key(k) for k in sks]
+    msgs = [b"api-rand-%d" % i for i in range(70)]
+    sigs = [ECDSA.sign(m, sks[i % 5]) for i, m in enumerate(msgs)]
+    keys = [pks[i % 5] for i in range(70)]
+    assert ECDSA.batch_verify_randomized(msgs, sigs, keys, seed=RAND_SEED) == [None] * 70
+    sigs[7] = sigs[8]
+    keys[66] = keys[67]
+    want = ECDSA.batch_verify(msgs, sigs, keys)
+    assert [i for i, r in enumerate(want) if r is not None] == [7, 66] and want[7] == Error(ErrorKind.VerificationFailed)
+    assert ECDSA.batch_verify_randomized(msgs, sigs, keys, seed=RAND_SEED) == want
+    assert ECDSA.batch_verify_randomized(msgs, sigs, keys) == want          # os.urandom seed
+    assert ECDSA.batch_verify_randomized(msgs, sigs, keys, rand64=True) == want
