@@ -470,15 +470,14 @@ KERNEL void k_g2_mul(const uint8_t* p, const uint8_t* scalars, size_t n, int red
 KERNEL void k_g1_sum(const uint8_t* pts, const uint64_t* seg, size_t n, uint8_t* out, uint8_t* status) {
   size_t i = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
   if (i >= n) return;
-  G1Jac acc, t;
+  G1Jac acc;
   jac_set_identity(acc);
   uint8_t st = ST_OK;
   for (uint64_t j = seg[i]; j < seg[i + 1]; ++j) {
     G1Affine p;
     uint8_t s = decode_g1(p, pts + 64 * j, 0);
     if (s != ST_OK) { if (st == ST_OK) st = s; continue; }
-    jac_from_affine(t, p);
-    jac_add(acc, acc, t);
+    jac_accumulate(acc, p);
   }
   G1Affine r;
   jac_to_affine(r, acc);
@@ -489,15 +488,14 @@ KERNEL void k_g1_sum(const uint8_t* pts, const uint64_t* seg, size_t n, uint8_t*
 KERNEL void k_g2_sum(const uint8_t* pts, const uint64_t* seg, size_t n, uint8_t* out, uint8_t* status) {
   size_t i = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
   if (i >= n) return;
-  G2Jac acc, t;
+  G2Jac acc;
   jac_set_identity(acc);
   uint8_t st = ST_OK;
   for (uint64_t j = seg[i]; j < seg[i + 1]; ++j) {
     G2Affine p;
     uint8_t s = decode_g2(p, pts + 128 * j, 0);
     if (s != ST_OK) { if (st == ST_OK) st = s; continue; }
-    jac_from_affine(t, p);
-    jac_add(acc, acc, t);
+    jac_accumulate(acc, p);
   }
   G2Affine r;
   jac_to_affine(r, acc);
