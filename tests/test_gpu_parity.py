@@ -418,6 +418,17 @@ def test_group_ops_vs_oracle(eng, c):
     for q in qs[1:8]:
         acc = c.g2_add(acc, q)
     assert out2[256:384] == acc
+    # the rare cases of the running sum: P + P, P + (-P), identity terms — in lanes next to ordinary sums
+    neg = lambda p: p[:32] + ((Q - int.from_bytes(p[32:], "big")) % Q).to_bytes(32, "big")    # noqa: E731
+    pts = [ps[0], ps[0], ps[1], neg(ps[1]), bytes(64), ps[2], ps[3], ps[3], ps[3]]
+    out, st = eng.batch_g1_sum(b"".join(pts), [0, 2, 4, 6, 9])
+    assert st == bytes(4)
+    assert out[:64] == c.g1_add(ps[0], ps[0]) and out[64:128] == bytes(64) and out[128:192] == ps[2]
+    assert out[192:256] == c.g1_add(c.g1_add(ps[3], ps[3]), ps[3])
+    qneg = lambda q: q[:64] + b"".join(((Q - int.from_bytes(q[64 + 32 * k:96 + 32 * k], "big")) % Q).to_bytes(32, "big") for k in range(2))  # noqa: E731
+    qpts = [qs[0], qs[0], qs[1], qneg(qs[1]), qs[2]]
+    out2, st = eng.batch_g2_sum(b"".join(qpts), [0, 2, 4, 5])
+    assert st == bytes(3) and out2[:128] == c.g2_add(qs[0], qs[0]) and out2[128:256] == bytes(128) and out2[256:384] == qs[2]
 
 
 def test_aggregate_verify_vs_oracle(eng, c):
