@@ -307,10 +307,11 @@ BN_DEVN bool g2_in_subgroup(const G2Affine& p) {
   for (int i = 0; i < BN_U_NAF_LEN; ++i) {        // wave-uniform: u is a public constant
     jac_dbl(up, up);
     int d = C_U_NAF[i];
-    if (d > 0) jac_madd(up, up, p);
-    else if (d < 0) jac_madd(up, up, pn);
+    if (d > 0) jac_accumulate(up, p);              // common-case addition; complete formula if any lane needs it
+    else if (d < 0) jac_accumulate(up, pn);        // (a crafted low-order twist point can reach P = +-Q)
   }
-  jac_madd(lhs, up, p);                            // [u+1]P
+  lhs = up;
+  jac_accumulate(lhs, p);                          // [u+1]P
   g2_psi(t, up);
   jac_add(lhs, lhs, t);                            // + psi([u]P)
   g2_psi(t, t);

@@ -747,6 +747,13 @@ static int pool_reserve(bn254_ctx* c, int which, size_t n_fp, size_t entries) {
   return 0;
 }
 
+// G2 decoding: with the subgroup test requested (one 63-bit ladder on the twist per point) it runs on lane pairs
+static int launch_decode_g2(bn254_ctx* c, hipStream_t s, const uint8_t* d_pts, size_t n, uint32_t flags, int accumulate) {
+  if (c->pair_lanes && (flags & FLAG_G2_SUBGROUP_CHECK)) return bn254_pair_decode_g2(d_pts, n, flags, c->ws, accumulate, s);
+  k_decode_g2<<<grid_for(n), BN_WAVE, 0, s>>>(d_pts, n, flags, c->ws, accumulate);
+  return 0;
+}
+
 // Enqueue the hash-to-G1 rounds for n messages; points land in planes (px, px+1), statuses in BY_ST_HASH.
 // The schedule (widths, grid sizes) is fixed on the host from the EXPECTED survivor counts
 // (p_fail = 0.5274 per try); the kernels read the actual counts from device memory and use grid-stride
@@ -866,7 +873,7 @@ int bn254_batch_verify_device(bn254_ctx* c, const uint8_t* d_msgs, const uint64_
   unsigned g = grid_for(n);
   PROF_MARK(0);
   k_decode_g1<<<g, BN_WAVE, 0, s>>>(d_sigs, n, flags, c->ws, PL_P1X, BY_P1_INF, 0);
-  k_decode_g2<<<g, BN_WAVE, 0, s>>>(d_pks, n, flags, c->ws, 1);
+  if ((rc = launch_decode_g2(c, s, d_pks, n, flags, 1))) return rc;
   PROF_MARK(1);
   if ((rc = launch_hash_rounds(c, s, d_msgs, d_off, n, PL_P2X, BY_P2_INF, nullptr))) return rc;
   PROF_MARK(2);
@@ -928,7 +935,7 @@ int bn254_batch_verify_randomized_device(bn254_ctx* c, const uint8_t* d_msgs, co
   uint8_t* d_group_st = c->ws.h_next;            // free once the hash rounds are done; n_groups <= stride
   PROF_MARK(0);
   k_decode_g1<<<g, BN_WAVE, 0, s>>>(d_sigs, n, dflags, c->ws, PL_P1X, BY_P1_INF, 0);
-  k_decode_g2<<<g, BN_WAVE, 0, s>>>(d_pks, n, dflags, c->ws, 1);
+  if ((rc = launch_decode_g2(c, s, d_pks, n, dflags, 1))) return rc;
   PROF_MARK(1);
   if ((rc = launch_hash_rounds(c, s, d_msgs, d_off, n, PL_P2X, BY_P2_INF, nullptr))) return rc;
   PROF_MARK(2);
@@ -1027,7 +1034,7 @@ static int pairing_device(bn254_ctx* c, const uint8_t* d_g1, const uint8_t* d_g2
   if (rc) return rc;
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
   k_decode_g1<<<grid_for(lanes), BN_WAVE, 0, s>>>(d_g1, lanes, flags, c->ws, PL_P1X, BY_P1_INF, 0);
-  k_decode_g2<<<grid_for(lanes), BN_WAVE, 0, s>>>(d_g2, lanes, flags, c->ws, 1);
+  if ((rc = launch_decode_g2(c, s, d_g2, lanes, flags, 1))) return rc;
   if (c->pair_lanes) {
     if ((rc = bn254_pair_miller_var(lanes, c->ws, s))) return rc;
     if ((rc = bn254_pair_final_exp_product(n, k, c->ws, d_gt, d_status, raw_only, s))) return rc;
@@ -1082,7 +1089,7 @@ int bn254_batch_check_public_keys(bn254_ctx* c, const uint8_t* pk_g2, const uint
   if ((rc = stage_reserve(c, 2, n))) return rc;
   hipStream_t s = c->stream;
   unsigned g = grid_for(n);
-  k_decode_g2<<<g, BN_WAVE, 0, s>>>(c->stage[0], n, flags, c->ws, 0);       // ecdsa.rs:82: pk_g2 first
+  if ((rc = launch_decode_g2(c, s, c->stage[0], n, flags, 0))) return rc;       // ecdsa.rs:82: pk_g2 first
   k_decode_g1<<<g, BN_WAVE, 0, s>>>(c->stage[1], n, flags, c->ws, PL_P1X, BY_P1_INF, 1);
   if (c->pair_lanes) {
     if ((rc = bn254_pair_miller_verify(n, c->ws, nullptr, nullptr, s, 1))) return rc;

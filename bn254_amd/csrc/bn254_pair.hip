@@ -55,6 +55,58 @@ __device__ __forceinline__ void ws_store_f12_own(const Ws& ws, size_t i, const F
   for (int k = 0; k < 6; ++k) ws_store_fp(ws, PL_F0 + 2 * k + (int)(threadIdx.x & 1u), i, c[k]->c[0]);
 }
 
+// Decode n uncompressed G2 points (/root/reference/src/utils.rs:107-116) on lane pairs: each lane reads, range-checks
+// and converts the two 32-byte words of its role; curve equation and (flag bit0) the subgroup test — one 63-bit
+// ladder on the twist — run in the pair layout.  Same statuses and workspace outputs as k_decode_g2.
+__device__ __forceinline__ bool load_fp_be_checked(Fp& r, const uint8_t* p, uint32_t& any) {
+  const uint32_t* w = (const uint32_t*)p;
+  U256 t;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { t.w[7 - k] = __builtin_bswap32(w[k]); any |= w[k]; }
+  bool ok = !u256_geq(t.w, C_Q);
+  r = fp_from_u256(t);
+  return ok;
+}
+KERNEL_PAIR void k_decode_g2_pair(const uint8_t* pts, size_t n, uint32_t flags, Ws ws, int accumulate) {
+  const unsigned role = threadIdx.x & 1u;
+  size_t i = ((size_t)blockIdx.x * BN_PAIR_WG + threadIdx.x) >> 1;
+  const bool live = i < n;                          // no early return: jac_accumulate votes across the wave
+  const size_t ii = live ? i : n - 1;
+  const uint8_t* b = pts + 128 * ii;
+  G2Affine q;
+  uint32_t any = 0;
+  bool ok = load_fp_be_checked(q.x.c[0], b + 32 * role, any);
+  ok = load_fp_be_checked(q.y.c[0], b + 64 + 32 * role, any) && ok;
+  any |= (uint32_t)bn_partner_word((int32_t)any);
+  ok = bn_pair_and(ok);
+  q.inf = any == 0;
+  uint8_t st = ST_OK;
+  if (q.inf) st = (flags & FLAG_REJECT_IDENTITY) ? (uint8_t)ST_INVALID_GROUP_POINT : (uint8_t)ST_OK;
+  else if (!ok) st = ST_NOT_MEMBER;
+  const bool on_curve = g2_on_curve(q);             // pair-combined; evaluated by every lane
+  if (st == ST_OK && !q.inf && !on_curve) st = ST_INVALID_GROUP_POINT;
+  G2Affine gen;
+  gen.x = fp2_load_const(C_G2_GEN[0]); gen.y = fp2_load_const(C_G2_GEN[1]); gen.inf = false;
+  if (st != ST_OK) q = gen;                          // failed lanes walk on with the generator (pairs decide together)
+  if (flags & FLAG_G2_SUBGROUP_CHECK) {              // wave-uniform
+    bool in = g2_in_subgroup(q);
+    if (st == ST_OK && !in) { st = ST_INVALID_GROUP_POINT; q = gen; }
+  }
+  if (!live) return;
+  ws_store_fp(ws, PL_QX0 + (int)role, i, q.x.c[0]);
+  ws_store_fp(ws, PL_QY0 + (int)role, i, q.y.c[0]);
+  if (role == 0) {
+    ws_byte(ws, BY_Q_INF, i) = q.inf;
+    uint8_t prev = accumulate ? ws_byte(ws, BY_ST_DECODE, i) : (uint8_t)ST_OK;
+    ws_byte(ws, BY_ST_DECODE, i) = prev != ST_OK ? prev : st;
+  }
+}
+int bn254_pair_decode_g2(const uint8_t* pts, size_t n, uint32_t flags, Ws ws, int accumulate, hipStream_t s) {
+  k_decode_g2_pair<<<(unsigned)((2 * n + BN_PAIR_WG - 1) / BN_PAIR_WG), BN_PAIR_WG, 0, s>>>(pts, n, flags, ws, accumulate);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 // f = miller(H(m), pk) * miller(sig, -G2); item = lane >> 1.  Both lanes of a pair take every branch together
 // (item-level conditions only), so the DPP exchanges always find their partner active.
 // mode 1 = check_public_keys (/root/reference/src/ecdsa.rs:80-86): miller(G1::one(), pk_g2) * miller(pk_g1, -G2) with
