@@ -367,7 +367,7 @@ def main():
             "frac_of_measured_peak": achieved / (PEAK_MAC32_MEASURED / 1e12),
             # register-resident chains of the same product routines (profiles/r01_fp_mul_chain_ceiling.jsonl):
             # 8.16e10 Fq products/s with one wave per SIMD, 1.37e11 when the multiplier pipe is saturated
-            "frac_of_occupancy1_product_ceiling": (fp_mul * n / (k_avg[dom] * 1e-3)) / 8.16e10,
+            "frac_of_occupancy1_product_ceiling": None if pair else (fp_mul * n / (k_avg[dom] * 1e-3)) / 8.16e10,   # one-lane layout only
             "frac_of_saturated_product_rate": (fp_mul * n / (k_avg[dom] * 1e-3)) / 1.37e11,
             "traffic": measured_traffic(kname),
             "multiplier_issue_frac": (fp_mul * MUL_INSTR_PER_FP_MUL * n / (k_avg[dom] * 1e-3)) / PEAK_MAC32_THEORETICAL,
