@@ -1,17 +1,18 @@
 // libbn254hip.so — HIP kernels for gfx950 (MI355X) + the C ABI declared in include/bn254_hip.h.
 //
-// Execution model: one item (verify / pairing / point operation) per wavefront lane, one
-// 64-lane wave per workgroup so the dispatcher can spread waves over all 1024 SIMDs.  A batch
-// is processed by a short chain of kernels that hand per-item state to each other through an
-// HBM workspace laid out limb-major ("planes"): word k of field element e of item i lives at
+// Execution model: a batch is processed by a short chain of kernels that hand per-item state to each other
+// through an HBM workspace laid out limb-major ("planes"): word k of field element e of item i lives at
 //   ws[(e*10 + k) * stride + i]      (10 x 27-bit limbs per field element)
-// so the 64 lanes of a wave read/write 256 contiguous bytes per limb (fully coalesced), and the
-// caller-facing byte formats (AoS, big-endian) are touched exactly once on the way in/out.
+// so a wave reads/writes contiguous bytes per limb (fully coalesced), and the caller-facing byte formats (AoS,
+// big-endian) are touched exactly once on the way in/out.  Fq-level work (decoding, hash-to-G1, G1 arithmetic)
+// runs one item per lane in this translation unit; everything built on the Fq2 tower (Miller loops, final
+// exponentiation, G2 sums and subgroup tests) runs one item per LANE PAIR in bn254_pair.hip, with the
+// one-lane-per-item kernels of this file kept behind BN254_OPT_PAIR_LANES = 0.
 //
-//   batch_verify:  k_verify_decode -> k_hash_to_g1 -> k_miller_verify -> k_final_exp
+//   batch_verify:  k_decode_g1, k_decode_g2 -> k_hash_init/round/resolve/finish -> k_miller_verify_pair -> k_final_exp_pair
 //
-// HBM traffic per verify is 225 B of input/output + 2 x ~1 KB of workspace hand-off against
-// ~24 k Montgomery products: the path is bound by VALU integer-multiply issue, not by HBM.
+// HBM traffic per verify is 225 B of input/output + 2 x ~1 KB of workspace hand-off against ~19 k Montgomery
+// products: the path is bound by VALU integer-multiply issue, not by HBM.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
