@@ -58,4 +58,34 @@ void hp_pairing(const uint8_t* g1, const uint8_t* g2, uint8_t* gt384) {
   const Fp2* c[6] = {&f.c0.c0, &f.c0.c1, &f.c0.c2, &f.c1.c0, &f.c1.c1, &f.c1.c2};
   for (int k = 0; k < 6; ++k) { fp_to_be32(gt384 + 64 * k, c[k]->c[0]); fp_to_be32(gt384 + 64 * k + 32, c[k]->c[1]); }
 }
+// two variable pairs sharing f (k_miller_rand2_pair), product of two such values (the LDS tree), final exponentiation
+void hp_pairing_product4(const uint8_t* g1x4, const uint8_t* g2x4, uint8_t* gt384) {
+  G1Affine p[4];
+  G2Affine q[4];
+  for (int j = 0; j < 4; ++j) { load_g1(p[j], g1x4 + 64 * j); load_g2(q[j], g2x4 + 128 * j); }
+  Fp12 f, g, acc;
+  miller_loop_2var(f, p[0], q[0], p[1], q[1]);
+  miller_loop_2var(g, p[2], q[2], p[3], q[3]);
+  fp12_mul(f, f, g);
+  final_exponentiation(f, f, acc);
+  const Fp2* c[6] = {&f.c0.c0, &f.c0.c1, &f.c0.c2, &f.c1.c0, &f.c1.c1, &f.c1.c2};
+  for (int k = 0; k < 6; ++k) { fp_to_be32(gt384 + 64 * k, c[k]->c[0]); fp_to_be32(gt384 + 64 * k + 32, c[k]->c[1]); }
+}
+// running G2 sum with the common-case addition (k_aggregate_pair) and the subgroup test (k_decode_g2_pair)
+int hp_g2_sum_and_subgroup(const uint8_t* pts, uint64_t k, uint8_t* out128) {
+  G2Jac acc;
+  jac_set_identity(acc);
+  int in_all = 1;
+  for (uint64_t j = 0; j < k; ++j) {
+    G2Affine q;
+    load_g2(q, pts + 128 * j);
+    if (!g2_in_subgroup(q)) in_all = 0;
+    jac_accumulate(acc, q);
+  }
+  G2Affine r;
+  jac_to_affine(r, acc);
+  if (r.inf) memset(out128, 0, 128);
+  else { fp_to_be32(out128, r.x.c[0]); fp_to_be32(out128 + 32, r.x.c[1]); fp_to_be32(out128 + 64, r.y.c[0]); fp_to_be32(out128 + 96, r.y.c[1]); }
+  return in_all;
+}
 }  // extern "C"

@@ -45,6 +45,28 @@ def test_pair_layout_verify_and_gt_match_oracle(pair_lib, derived, kats):
         assert out.raw == c.pairing(p, q)
 
 
+def test_pair_layout_multi_pair_and_g2_sums(pair_lib, derived):
+    import hashlib
+    g1, g2 = c.g1_generator(), c.g2_generator()
+    ps = [c.g1_mul(g1, hashlib.sha256(b"pp-a%d" % i).digest()) for i in range(4)]
+    qs = [c.g2_mul(g2, hashlib.sha256(b"pp-b%d" % i).digest()) for i in range(4)]
+    out = ctypes.create_string_buffer(384)
+    pair_lib.hp_pairing_product4(b"".join(ps), b"".join(qs), out)
+    assert out.raw == c.pairing(b"".join(ps), b"".join(qs), k=4)
+    # running G2 sums incl. P + P, P + (-P), identity terms; subgroup membership
+    Q = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47
+    neg = lambda q: q[:64] + b"".join(((Q - int.from_bytes(q[64 + 32 * k:96 + 32 * k], "big")) % Q).to_bytes(32, "big") for k in range(2))  # noqa: E731
+    for pts in ([qs[0], qs[1], qs[2]], [qs[0], qs[0]], [qs[1], neg(qs[1])], [bytes(128), qs[3], bytes(128)], [qs[0], qs[0], qs[0], neg(qs[0])]):
+        want = bytes(128)
+        for q in pts:
+            want = c.g2_add(want, q)
+        o = ctypes.create_string_buffer(128)
+        assert pair_lib.hp_g2_sum_and_subgroup(b"".join(pts), len(pts), o) == 1
+        assert o.raw == want
+    o = ctypes.create_string_buffer(128)
+    assert pair_lib.hp_g2_sum_and_subgroup(H(derived["g2_not_in_subgroup"]), 1, o) == 0
+
+
 DRIVER = r'''
 import ctypes, json, sys
 root = sys.argv[1]
@@ -56,6 +78,10 @@ g1 = (1).to_bytes(32, "big") + (2).to_bytes(32, "big")
 for v in d["verify_cases"]:
     if v["status"] in (0, 9):
         L.hp_verify_decoded(g1, H(v["sig"]), H(v["pk"]))      # any G1 point exercises the same operation sequence
+g2 = H(d["g2_generator"]); o = ctypes.create_string_buffer(384)
+L.hp_pairing_product4(g1 * 4, g2 * 4, o)
+o = ctypes.create_string_buffer(128)
+L.hp_g2_sum_and_subgroup(g2 + g2 + bytes(128) + g2 + H(d["g2_not_in_subgroup"]), 5, o)
 print("ok")
 '''
 
