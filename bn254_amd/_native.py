@@ -62,6 +62,8 @@ def load():
     L.bn254_ctx_set_option.argtypes = [vp, i32, i32]
     L.bn254_batch_verify.argtypes = [vp, vp, vp, vp, vp, sz, u32, vp]
     L.bn254_batch_verify_device.argtypes = [vp, vp, vp, vp, vp, sz, u32, vp, vp]
+    L.bn254_batch_verify_compressed.argtypes = [vp, vp, vp, vp, vp, sz, vp]
+    L.bn254_batch_verify_compressed_device.argtypes = [vp, vp, vp, vp, vp, sz, vp, vp]
     L.bn254_batch_verify_randomized.argtypes = [vp, vp, vp, vp, vp, sz, u32, vp, vp, vp]
     L.bn254_batch_verify_randomized_device.argtypes = [vp, vp, vp, vp, vp, sz, u32, vp, vp, vp, vp]
     L.bn254_batch_hash_to_g1.argtypes = [vp, vp, vp, sz, vp, vp, vp]
@@ -94,7 +96,7 @@ def load():
 # every symbol include/bn254_hip.h declares (checked by tests/test_abi.py without a GPU)
 EXPORTED_SYMBOLS = [
     "bn254_version", "bn254_ctx_create", "bn254_ctx_destroy", "bn254_ctx_reserve", "bn254_ctx_synchronize",
-    "bn254_batch_verify", "bn254_batch_verify_device", "bn254_batch_verify_randomized", "bn254_batch_verify_randomized_device", "bn254_batch_hash_to_g1", "bn254_batch_hash_to_g1_device",
+    "bn254_batch_verify", "bn254_batch_verify_device", "bn254_batch_verify_randomized", "bn254_batch_verify_randomized_device", "bn254_batch_verify_compressed", "bn254_batch_verify_compressed_device", "bn254_batch_hash_to_g1", "bn254_batch_hash_to_g1_device",
     "bn254_batch_pairing_check", "bn254_batch_pairing", "bn254_batch_pairing_device", "bn254_batch_check_public_keys",
     "bn254_batch_g1_add", "bn254_batch_g2_add", "bn254_batch_g1_mul", "bn254_batch_g2_mul", "bn254_batch_g1_mul_device",
     "bn254_batch_g2_mul_device", "bn254_batch_sign", "bn254_batch_sign_device", "bn254_batch_g1_sum", "bn254_batch_g2_sum",

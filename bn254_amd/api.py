@@ -262,6 +262,20 @@ class ECDSA:
 
 
     @staticmethod
+    def batch_verify_compressed(messages, signatures33, public_keys65, engine=None):
+        """batch_verify straight from the compressed wire encodings (33-byte signatures, 65-byte public keys):
+        result[i] is None, or the Error that Signature/PublicKey.from_compressed or verify would raise."""
+        n = len(messages)
+        if not (len(signatures33) == n and len(public_keys65) == n):
+            raise Error(ErrorKind.InvalidLength)
+        if any(len(s) != 33 for s in signatures33) or any(len(p) != 65 for p in public_keys65):
+            raise Error(ErrorKind.InvalidEncoding)
+        eng = engine or _eng()
+        st = eng.batch_verify_compressed([bytes(m) for m in messages], b"".join(bytes(s) for s in signatures33),
+                                         b"".join(bytes(p) for p in public_keys65))
+        return [None if s == 0 else Error(s) for s in st]
+
+    @staticmethod
     def batch_verify_randomized(messages, signatures, public_keys, seed=None, engine=None, rand64=False):
         """Same result shape as batch_verify through the randomised combined check (64 items per pairing
         product, include/bn254_hip.h: bn254_batch_verify_randomized).  Errors are always exact; a None is wrong

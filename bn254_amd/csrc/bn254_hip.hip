@@ -526,6 +526,29 @@ KERNEL void k_g2_decompress(const uint8_t* in, size_t n, uint8_t* out, uint8_t* 
   encode_g2(out + 128 * i, p);
   status[i] = st;
 }
+// the same into the workspace planes of a verify: compressed signatures (33 B) -> P1 planes, compressed public keys
+// (65 B, subgroup-checked as G2::from_compressed does) -> Q planes; status as in k_decode_g1 / k_decode_g2
+KERNEL_SMALL void k_decompress_g1_ws(const uint8_t* in, size_t n, Ws ws) {
+  size_t i = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
+  if (i >= n) return;
+  G1Affine p;
+  uint8_t st = decompress_g1(p, in + 33 * i);
+  if (st != ST_OK) g1_set_generator(p);
+  ws_store_g1(ws, PL_P1X, BY_P1_INF, i, p);
+  ws_byte(ws, BY_ST_DECODE, i) = st;
+}
+KERNEL void k_decompress_g2_ws(const uint8_t* in, size_t n, Ws ws) {
+  size_t i = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
+  if (i >= n) return;
+  G2Affine q;
+  uint8_t st = decompress_g2(q, in + 65 * i);
+  if (st != ST_OK) g2_set_generator(q);
+  bool in_sub = g2_in_subgroup(q);
+  if (st == ST_OK && !in_sub) { st = ST_NOT_MEMBER; g2_set_generator(q); }
+  ws_store_g2(ws, i, q);
+  uint8_t prev = ws_byte(ws, BY_ST_DECODE, i);
+  ws_byte(ws, BY_ST_DECODE, i) = prev != ST_OK ? prev : st;
+}
 // ---- aggregate verify (config 3): shared pools, per-tuple signer subsets -------------------------
 KERNEL_SMALL void k_pool_decode_g1(const uint8_t* pts, size_t n, uint32_t flags, Pool pool) {
   size_t i = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
@@ -858,23 +881,10 @@ int bn254_ctx_last_kernel_ms(bn254_ctx* c, float ms[4]) {
 
 #define PROF_MARK(idx) do { if (c->profiling) HIP_TRY(hipEventRecord(c->ev[idx], s)); } while (0)
 
-int bn254_batch_verify_device(bn254_ctx* c, const uint8_t* d_msgs, const uint64_t* d_off, const uint8_t* d_sigs, const uint8_t* d_pks,
-                              size_t n, uint32_t flags, uint8_t* d_status, void* stream) {
-  if (!c || (n && (!d_msgs || !d_off || !d_sigs || !d_pks || !d_status))) return BN254_E_BAD_ARGUMENT;
-  if (n == 0) return 0;
-  if (misaligned(d_sigs) || misaligned(d_pks) || ((uintptr_t)d_off & 7u)) return BN254_E_MISALIGNED;
-  HIP_TRY(hipSetDevice(c->device));
-  // default: fused 2-pair loop (shares the f^2 of every step).  Option BN254_OPT_SPLIT_MILLER runs one
-  // pairing per lane instead (two waves per verify); measured slower while the Fq12 bodies need the
-  // full 512-register budget (occupancy 1) — kept for A/B runs, see profiles/r01_c_ab_occupancy.log
-  bool split = c->split_miller && n <= BN_SPLIT_MAX_N;
-  int rc = ws_reserve(c, split ? 2 * n : n);
-  if (rc) return rc;
-  hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+// decode kernels have filled the P1 / Q planes and BY_ST_DECODE: hash, Miller loop, final exponentiation
+static int verify_after_decode(bn254_ctx* c, hipStream_t s, const uint8_t* d_msgs, const uint64_t* d_off, size_t n, uint8_t* d_status, bool split) {
+  int rc;
   unsigned g = grid_for(n);
-  PROF_MARK(0);
-  k_decode_g1<<<g, BN_WAVE, 0, s>>>(d_sigs, n, flags, c->ws, PL_P1X, BY_P1_INF, 0);
-  if ((rc = launch_decode_g2(c, s, d_pks, n, flags, 1))) return rc;
   PROF_MARK(1);
   if ((rc = launch_hash_rounds(c, s, d_msgs, d_off, n, PL_P2X, BY_P2_INF, nullptr))) return rc;
   PROF_MARK(2);
@@ -894,6 +904,58 @@ int bn254_batch_verify_device(bn254_ctx* c, const uint8_t* d_msgs, const uint64_
   PROF_MARK(4);
   if (c->profiling) c->ev_valid = 1;
   HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int bn254_batch_verify_device(bn254_ctx* c, const uint8_t* d_msgs, const uint64_t* d_off, const uint8_t* d_sigs, const uint8_t* d_pks,
+                              size_t n, uint32_t flags, uint8_t* d_status, void* stream) {
+  if (!c || (n && (!d_msgs || !d_off || !d_sigs || !d_pks || !d_status))) return BN254_E_BAD_ARGUMENT;
+  if (n == 0) return 0;
+  if (misaligned(d_sigs) || misaligned(d_pks) || ((uintptr_t)d_off & 7u)) return BN254_E_MISALIGNED;
+  HIP_TRY(hipSetDevice(c->device));
+  // default: verify on lane pairs (bn254_pair.hip).  BN254_OPT_PAIR_LANES = 0: one lane per verify, fused 2-pair
+  // loop; BN254_OPT_SPLIT_MILLER additionally runs one pairing per lane (two waves per verify) — both kept for A/B
+  // runs, see profiles/r01_c_ab_occupancy.log and DESIGN.md section 4
+  bool split = c->split_miller && n <= BN_SPLIT_MAX_N;
+  int rc = ws_reserve(c, split ? 2 * n : n);
+  if (rc) return rc;
+  hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  PROF_MARK(0);
+  k_decode_g1<<<grid_for(n), BN_WAVE, 0, s>>>(d_sigs, n, flags, c->ws, PL_P1X, BY_P1_INF, 0);
+  if ((rc = launch_decode_g2(c, s, d_pks, n, flags, 1))) return rc;
+  return verify_after_decode(c, s, d_msgs, d_off, n, d_status, split);
+}
+
+// the same from the COMPRESSED encodings callers store (serde, /root/reference/src/serde.rs:39, :54):
+// signatures 33 B (src/utils.rs:84-104), public keys 65 B (src/utils.rs:130-158, subgroup-checked on decode)
+int bn254_batch_verify_compressed_device(bn254_ctx* c, const uint8_t* d_msgs, const uint64_t* d_off, const uint8_t* d_sigs33,
+                                         const uint8_t* d_pks65, size_t n, uint8_t* d_status, void* stream) {
+  if (!c || (n && (!d_msgs || !d_off || !d_sigs33 || !d_pks65 || !d_status))) return BN254_E_BAD_ARGUMENT;
+  if (n == 0) return 0;
+  if ((uintptr_t)d_off & 7u) return BN254_E_MISALIGNED;
+  HIP_TRY(hipSetDevice(c->device));
+  int rc = ws_reserve(c, n);
+  if (rc) return rc;
+  hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  PROF_MARK(0);
+  k_decompress_g1_ws<<<grid_for(n), BN_WAVE, 0, s>>>(d_sigs33, n, c->ws);
+  k_decompress_g2_ws<<<grid_for(n), BN_WAVE, 0, s>>>(d_pks65, n, c->ws);
+  return verify_after_decode(c, s, d_msgs, d_off, n, d_status, false);
+}
+int bn254_batch_verify_compressed(bn254_ctx* c, const uint8_t* msgs, const uint64_t* off, const uint8_t* sigs33, const uint8_t* pks65, size_t n,
+                                  uint8_t* status) {
+  if (!c || (n && (!off || !sigs33 || !pks65 || !status))) return BN254_E_BAD_ARGUMENT;
+  if (n == 0) return 0;
+  HIP_TRY(hipSetDevice(c->device));
+  int rc;
+  if ((rc = stage_in(c, 0, msgs, (size_t)off[n]))) return rc;
+  if ((rc = stage_in(c, 1, off, (n + 1) * sizeof(uint64_t)))) return rc;
+  if ((rc = stage_in(c, 2, sigs33, n * 33))) return rc;
+  if ((rc = stage_in(c, 3, pks65, n * 65))) return rc;
+  if ((rc = stage_reserve(c, 4, n))) return rc;
+  if ((rc = bn254_batch_verify_compressed_device(c, c->stage[0], (const uint64_t*)c->stage[1], c->stage[2], c->stage[3], n, c->stage[4], nullptr))) return rc;
+  if ((rc = stage_out(c, 4, status, n))) return rc;
+  HIP_TRY(hipStreamSynchronize(c->stream));
   return 0;
 }
 

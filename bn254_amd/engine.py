@@ -93,6 +93,16 @@ class Engine:
         _check("bn254_batch_verify", self._lib.bn254_batch_verify(self._h, msgs, off, bytes(sigs), bytes(pks), n, flags, status))
         return status.raw[:n]
 
+    def batch_verify_compressed(self, messages, sigs33, pks65):
+        """verify from the compressed encodings (33-byte signatures, 65-byte public keys)"""
+        n = len(messages)
+        assert len(sigs33) == n * 33 and len(pks65) == n * 65
+        msgs, off = pack_messages(messages)
+        status = ctypes.create_string_buffer(max(n, 1))
+        _check("bn254_batch_verify_compressed",
+               self._lib.bn254_batch_verify_compressed(self._h, msgs, off, bytes(sigs33), bytes(pks65), n, status))
+        return status.raw[:n]
+
     def batch_verify_randomized(self, messages, sigs, pks, seed32, flags=0):
         """opt-in randomised batch verification (include/bn254_hip.h) -> (status bytes, group_ok bytes)"""
         n = len(messages)

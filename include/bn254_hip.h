@@ -85,6 +85,18 @@ int bn254_batch_verify(bn254_ctx *ctx, const uint8_t *msgs, const uint64_t *msg_
 int bn254_batch_verify_device(bn254_ctx *ctx, const uint8_t *d_msgs, const uint64_t *d_msg_off, const uint8_t *d_sigs,
                               const uint8_t *d_pks, size_t n, uint32_t flags, uint8_t *d_status, void *stream);
 
+/* bn254_batch_verify from the COMPRESSED encodings callers store (serde of the reference: src/serde.rs:39, :54):
+ * sigs n*33 B = 0x02/0x03 || x (src/utils.rs:84-104; G1::from_compressed, src/types.rs:233-237), pks n*65 B =
+ * 0x0a/0x0b || BE64(x.im*q + x.re) (src/utils.rs:130-158; G2::from_compressed, src/types.rs:91-93, which checks the
+ * order-r subgroup).  status[i] = the error the reference's from_compressed would give for the signature, else for
+ * the public key (3 InvalidEncoding, 6 NotMemberError), else what verify gives.  No alignment requirement on the
+ * 33- / 65-byte arrays. */
+int bn254_batch_verify_compressed(bn254_ctx *ctx, const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *sigs33,
+                                  const uint8_t *pks65, size_t n, uint8_t *status);
+int bn254_batch_verify_compressed_device(bn254_ctx *ctx, const uint8_t *d_msgs, const uint64_t *d_msg_off,
+                                         const uint8_t *d_sigs33, const uint8_t *d_pks65, size_t n, uint8_t *d_status,
+                                         void *stream);
+
 /* Randomised batch verification — OPT-IN, probabilistic.  No counterpart in the
  * reference, which verifies one tuple at a time (src/ecdsa.rs:49-64); same inputs and status bytes as
  * bn254_batch_verify.  Items are taken 64 at a time; with r_i = the first 16 bytes (BN254_FLAG_RAND64: 8) of

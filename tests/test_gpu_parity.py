@@ -626,3 +626,30 @@ def test_api_batch_verify_randomized(eng):
     assert ECDSA.batch_verify_randomized(msgs, sigs, keys, seed=RAND_SEED) == want
     assert ECDSA.batch_verify_randomized(msgs, sigs, keys) == want          # os.urandom seed
     assert ECDSA.batch_verify_randomized(msgs, sigs, keys, rand64=True) == want
+
+
+def test_batch_verify_from_compressed_encodings(eng, kats):
+    """bn254_batch_verify_compressed == decompress (from_compressed semantics) + verify, item by item"""
+    from bn254_amd import PublicKey, Signature
+    from tests.datagen import make_verify_batch
+    n = 300
+    msgs, sigs, pks, expected = make_verify_batch(eng, n, corrupt_every=17, pool=9)
+    sc = bytearray(b"".join(Signature(sigs[64 * i:64 * i + 64]).to_compressed() for i in range(n)))
+    pc = bytearray(b"".join(PublicKey(pks[128 * i:128 * i + 128]).to_compressed() for i in range(n)))
+    assert eng.batch_verify_compressed(msgs, bytes(sc), bytes(pc)) == expected
+    # malformed encodings: bad sign bytes, x >= q, x without a root, public key outside the subgroup / undecodable
+    sc[33 * 3] = 0x04
+    pc[65 * 5] = 0x0C
+    sc[33 * 7 + 1:33 * 8] = (Q + 5).to_bytes(32, "big")
+    sc[33 * 9 + 1:33 * 10] = (4).to_bytes(32, "big")          # 4^3 + 3 = 67 is not a square mod q
+    pc[65 * 11 + 40] ^= 0x55
+    got = eng.batch_verify_compressed(msgs, bytes(sc), bytes(pc))
+    us, s1 = eng.batch_g1_decompress(bytes(sc), n)
+    up, s2 = eng.batch_g2_decompress(bytes(pc), n)
+    base = eng.batch_verify(msgs, us, up)
+    want = bytes(s1[i] or s2[i] or base[i] for i in range(n))
+    assert got == want and got[3] == 3 and got[5] == 3 and got[7] == 6 and got[9] == 6 and got[11] in (6, 9)
+    # the reference's own compressed KAT decodes and verifies
+    v = kats["sign"][0]
+    pk = PublicKey.from_private_key(__import__("bn254_amd").PrivateKey.try_from(v["private_key"]))
+    assert eng.batch_verify_compressed([H(v["message_hex"])], H(v["signature_compressed"]), pk.to_compressed()) == b"\x00"
