@@ -118,6 +118,7 @@ def other_workloads(args, torch, eng, dev):
         # generated in chunks so that the message list stays small on the host
         n = args.batch if args.batch != BATCH else 1 << 20
         seed = hashlib.sha256(b"bench-seed").digest()
+        eng.set_option(5, 0)                                  # BN254_OPT_RAND_MIN_BATCH: time the randomised kernels at every size
         chunk = 1 << 16
         parts = [make_verify_batch(eng, min(chunk, n - lo), corrupt_every=0, tag="bn254/msgR%d" % lo) for lo in range(0, n, chunk)]
         msgs = b"".join(b"".join(p[0]) for p in parts)

@@ -380,6 +380,14 @@ KERNEL void k_rand_tail(size_t n_groups, Ws ws, size_t gbase) {
   fp12_mul(f, f, fg);
   ws_store_f12(ws, gbase + g, f);
 }
+// group verdicts for batches that were verified exactly: 1 iff no item of the group failed the pairing check
+KERNEL_SMALL void k_group_ok_from_status(size_t n_groups, size_t n, const uint8_t* status, uint8_t* group_ok_out) {
+  size_t g = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
+  if (g >= n_groups) return;
+  uint8_t ok = 1;
+  for (size_t i = g * BN_WAVE; i < (g + 1) * BN_WAVE && i < n; ++i) if (status[i] == ST_VERIFICATION_FAILED) ok = 0;
+  group_ok_out[g] = ok;
+}
 KERNEL_SMALL void k_rand_collect(size_t n, Ws ws, const uint8_t* group_st, uint8_t* status_out, uint8_t* group_ok_out) {
   size_t i = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
   if (i >= n) return;
@@ -704,6 +712,7 @@ struct bn254_ctx {
   Pool pool[3];       // aggregate verify: pk pool, sig pool, H(m) pool (grown on demand)
   size_t pool_fp[3];  // coordinates per entry: 4, 2, 2
   int pair_lanes;    // verify: Miller loop + final exponentiation on lane pairs (bn254_pair.hip); default on
+  int rand_min_batch;      // randomised verify: batches below this size run the exact kernels (default RAND_MIN_BATCH_DEFAULT)
   int rand_items_per_lane; // randomised verify: 0 = by batch size, 1 or 2 forced (A/B and tests)
   int hash_max_tries; // test knob: counters tried before HashToPointError (0 = the reference's 255)
   hipEvent_t ev[5];
@@ -824,6 +833,7 @@ int bn254_ctx_create(int hip_device, bn254_ctx** out) {
   if (!c) return BN254_E_BAD_ARGUMENT;
   memset(c, 0, sizeof *c);
   c->pair_lanes = 1;
+  c->rand_min_batch = RAND_MIN_BATCH_DEFAULT;
   c->device = hip_device;
   hipError_t err = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   for (int i = 0; i < 5 && err == hipSuccess; ++i) err = hipEventCreate(&c->ev[i]);
@@ -868,6 +878,7 @@ int bn254_ctx_set_option(bn254_ctx* c, int option, int value) {
   if (!c) return BN254_E_BAD_ARGUMENT;
   if (option == BN254_OPT_SPLIT_MILLER) { c->split_miller = value; return 0; }
   if (option == BN254_OPT_PAIR_LANES) { c->pair_lanes = value != 0; return 0; }
+  if (option == BN254_OPT_RAND_MIN_BATCH) { if (value < 0) return BN254_E_BAD_ARGUMENT; c->rand_min_batch = value; return 0; }
   if (option == BN254_OPT_RAND_ITEMS_PER_LANE) { if (value < 0 || value > 2) return BN254_E_BAD_ARGUMENT; c->rand_items_per_lane = value; return 0; }
   if (option == BN254_OPT_HASH_MAX_TRIES) { if (value < 0 || value > 255) return BN254_E_BAD_ARGUMENT; c->hash_max_tries = value; return 0; }
   return BN254_E_BAD_ARGUMENT;
@@ -986,6 +997,19 @@ int bn254_batch_verify_randomized_device(bn254_ctx* c, const uint8_t* d_msgs, co
   if (misaligned(d_sigs) || misaligned(d_pks) || ((uintptr_t)d_off & 7u)) return BN254_E_MISALIGNED;
   HIP_TRY(hipSetDevice(c->device));
   const size_t n_groups = (n + BN_WAVE - 1) / BN_WAVE;
+  if (n < (size_t)c->rand_min_batch) {
+    // too small for the combined check to pay off (its per-group tail has the latency of a whole Miller loop + final
+    // exponentiation): the exact kernels give the same statuses, faster
+    int rc0 = bn254_batch_verify_device(c, d_msgs, d_off, d_sigs, d_pks, n, flags & (BN254_FLAG_G2_SUBGROUP_CHECK | BN254_FLAG_REJECT_IDENTITY),
+                                        d_status, stream);
+    if (rc0) return rc0;
+    if (d_group_ok) {
+      hipStream_t s0 = stream ? (hipStream_t)stream : c->stream;
+      k_group_ok_from_status<<<grid_for(n_groups), BN_WAVE, 0, s0>>>(n_groups, n, d_status, d_group_ok);
+      HIP_TRY(hipGetLastError());
+    }
+    return 0;
+  }
   const size_t gbase = (n + 255) & ~(size_t)255;
   int rc = ws_reserve(c, gbase + n_groups);
   if (rc) return rc;

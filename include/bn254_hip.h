@@ -108,8 +108,8 @@ int bn254_batch_verify_compressed_device(bn254_ctx *ctx, const uint8_t *d_msgs, 
  * (2^-64) per group PROVIDED seed32 is fresh, unpredictable to whoever produced the signatures, and the public
  * keys are in the order-r subgroup (validated earlier, or pass BN254_FLAG_G2_SUBGROUP_CHECK).  group_ok (optional,
  * ceil(n/64) bytes): 1 = the group's combined check passed.  The combined check has a fixed latency of one
- * Miller loop + one final exponentiation on n/64 lanes: it pays off for n >~ 4 x the lanes of the device
- * (>~ 256 Ki items on an MI355X), see DESIGN.md.  Host variant synchronises; device variant only enqueues. */
+ * Miller loop + one final exponentiation on n/64 lanes: it pays off from ~100 k items per call on an MI355X; smaller
+ * batches are routed to the exact kernels (BN254_OPT_RAND_MIN_BATCH), see DESIGN.md.  Host variant synchronises; device variant only enqueues. */
 int bn254_batch_verify_randomized(bn254_ctx *ctx, const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *sigs,
                                   const uint8_t *pks, size_t n, uint32_t flags, const uint8_t *seed32, uint8_t *status,
                                   uint8_t *group_ok);
@@ -202,6 +202,8 @@ int bn254_ctx_set_profiling(bn254_ctx *ctx, int enabled);
  * different waves (one pairing per lane) instead of one lane sharing f^2 (default 0).  Results are
  * identical either way. */
 #define BN254_OPT_SPLIT_MILLER 1
+#define BN254_OPT_RAND_MIN_BATCH 5 /* randomised verify: batches with fewer items run the exact kernels instead (same statuses; group_ok = no item of the
+                                     group failed the pairing check).  Default 98304, the measured break-even on an MI355X; 0 = always randomised */
 #define BN254_OPT_PAIR_LANES 4 /* verify: Miller loop + final exponentiation on lane pairs, two waves per SIMD (default 1); 0 = one lane per verify */
 #define BN254_OPT_RAND_ITEMS_PER_LANE 3 /* randomised verify: items per lane in the Miller kernel; 0 = by batch size (default), 1, 2 */
 #define BN254_OPT_HASH_MAX_TRIES 2 /* test knob: counters tried before HashToPointError; 0 = 255 as in src/hash.rs:40 */

@@ -26,10 +26,11 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     args = ap.parse_args()
     import bn254_amd
-    from bn254_amd.engine import OPT_PAIR_LANES
+    from bn254_amd.engine import OPT_PAIR_LANES, OPT_RAND_MIN_BATCH
     from oracle import c_oracle as c
     from tests.datagen import sk_bytes
     eng = bn254_amd.Engine(0)
+    eng.set_option(OPT_RAND_MIN_BATCH, 0)     # always the randomised kernels
     derived = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "derived_vectors.json")))
     off_sub = bytes.fromhex(derived["g2_not_in_subgroup"])
     rnd = random.Random(args.seed)

@@ -15,7 +15,10 @@ R = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
 @pytest.fixture(scope="module")
 def eng():
     import bn254_amd
-    return bn254_amd.Engine(0)
+    from bn254_amd.engine import OPT_RAND_MIN_BATCH
+    e = bn254_amd.Engine(0)
+    e.set_option(OPT_RAND_MIN_BATCH, 0)      # the randomised-mode tests must run the randomised kernels at every size
+    return e
 
 
 @pytest.fixture(scope="module")
@@ -653,3 +656,18 @@ def test_batch_verify_from_compressed_encodings(eng, kats):
     v = kats["sign"][0]
     pk = PublicKey.from_private_key(__import__("bn254_amd").PrivateKey.try_from(v["private_key"]))
     assert eng.batch_verify_compressed([H(v["message_hex"])], H(v["signature_compressed"]), pk.to_compressed()) == b"\x00"
+
+
+def test_randomized_small_batches_route_to_exact_kernels(c):
+    """default policy: below BN254_OPT_RAND_MIN_BATCH the randomised entry point runs the exact kernels — same statuses,
+    group_ok = no item of the group failed the pairing check (what the combined check reports as well)"""
+    import bn254_amd
+    from tests.datagen import make_verify_batch
+    e = bn254_amd.Engine(0)                       # default options
+    n = 200
+    msgs, sigs, pks, expected = make_verify_batch(e, n, corrupt_every=70, pool=5)
+    sigs = bytearray(sigs)
+    sigs[64 * 130:64 * 131] = b"\xff" * 64       # undecodable: status 6, does not fail its group
+    st, gr = e.batch_verify_randomized(msgs, bytes(sigs), pks, RAND_SEED)
+    want = c.batch_verify_randomized(msgs, bytes(sigs), pks, RAND_SEED, flags=0)
+    assert (st, gr) == want and gr == bytes([1, 0, 0, 1]) and st[130] == 6
