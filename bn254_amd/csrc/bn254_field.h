@@ -568,6 +568,24 @@ BN_DEV Fp2 fp2_inv(const Fp2& a) {
   return r;
 }
 
+// i * a = (-a1, a0); the element re + im i; u512 order of utils.rs:40-45 — the three primitives besides the ring
+// operations that the layout-independent code below (fp2_sqrt, the compressed G2 codec) needs
+BN_DEV Fp2 fp2_mul_i(const Fp2& a) { Fp2 r; r.c0 = fp_neg(a.c1); r.c1 = a.c0; return r; }
+BN_DEV Fp2 fp2_make(const Fp& re, const Fp& im) { Fp2 r; r.c0 = re; r.c1 = im; return r; }
+// canonical "u512(c) = c.im * q + c.re" order == lexicographic (im, re)
+BN_DEV bool fp2_u512_greater(const Fp2& a, const Fp2& b) {
+  U256 ai = fp_to_u256(a.c1), bi = fp_to_u256(b.c1), ar = fp_to_u256(a.c0), br = fp_to_u256(b.c0);
+  bool im_eq = true;
+  for (int i = 0; i < 8; ++i) im_eq = im_eq && ai.w[i] == bi.w[i];
+  if (!im_eq) return u256_geq(ai.w, bi.w);
+  bool re_eq = true;
+  for (int i = 0; i < 8; ++i) re_eq = re_eq && ar.w[i] == br.w[i];
+  return !re_eq && u256_geq(ar.w, br.w);
+}
+
+#endif  // BN_SPLIT_FP2
+
+// ---- layout-independent Fq2 code (classic and pair layout alike) ---------------------------------------------
 // a^e in Fq2 for a fixed public exponent (plain U256 words); wave-uniform control flow
 BN_DEVN Fp2 fp2_pow_sched(Fp2 a, const unsigned char (*sched)[2], int n_steps) {   // as fp_pow_sched
   Fp2 odd[8];
@@ -594,14 +612,12 @@ BN_DEVN bool fp2_sqrt(Fp2& x, const Fp2& a_in) {
   bool alpha_is_m1 = fp2_eq(alpha, minus_one);
   Fp2 b = fp2_pow_sched(fp2_add(fp2_one(), alpha), C_SCHED_QM1D2, BN_SCHED_QM1D2_LEN);
   Fp2 xb = fp2_mul(b, x0);
-  Fp2 xi_;                       // i * x0 = (-x0.c1, x0.c0)
-  xi_.c0 = fp_norm(fp_neg(x0.c1));
-  xi_.c1 = x0.c0;
+  Fp2 xi_ = fp2_norm(fp2_mul_i(x0));
   x = fp2_select(alpha_is_m1, xi_, xb);
   return fp2_eq(fp2_sqr(x), a);
 }
 
-#endif  // BN_SPLIT_FP2
+
 
 // ------------------------------------------------------------------------------------------
 // Fq6, Fq12.  Fq12-level operations are real (non-inlined) functions on the per-lane private segment;

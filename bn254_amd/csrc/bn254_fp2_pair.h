@@ -193,4 +193,31 @@ BN_DEV Fp2 fp2_inv(const Fp2& a) {
   return r;
 }
 
+// i * a = (-a1, a0); the element re + im i (every lane holds both integers and keeps its role's); u512 order
+BN_DEV Fp2 fp2_mul_i(const Fp2& a) {
+  Fp2 r;
+  BN_FOR_ROLES(k) { const Fp ap = bn_partner(a, k); r.c[k] = fp_select(bn_role_im(k), ap, fp_neg(ap)); }
+  return r;
+}
+BN_DEV Fp2 fp2_make(const Fp& re, const Fp& im) { Fp2 r; BN_FOR_ROLES(k) r.c[k] = fp_select(bn_role_im(k), im, re); return r; }
+// canonical "u512(c) = c.im * q + c.re" order == lexicographic (im, re): each role compares its coefficient, the
+// imaginary role decides unless its coefficients are equal
+BN_DEV bool fp2_u512_greater(const Fp2& a, const Fp2& b) {
+  bool eq[BN_PAIR_ROLES], gt[BN_PAIR_ROLES];
+  BN_FOR_ROLES(k) {
+    U256 x = fp_to_u256(a.c[k]), y = fp_to_u256(b.c[k]);
+    bool e = true;
+    for (int i = 0; i < 8; ++i) e = e && x.w[i] == y.w[i];
+    eq[k] = e; gt[k] = !e && u256_geq(x.w, y.w);
+  }
+#if defined(__HIPCC__)
+  const bool im = (threadIdx.x & 1u) != 0;
+  const bool p_eq = bn_partner_word(eq[0] ? 1 : 0) != 0, p_gt = bn_partner_word(gt[0] ? 1 : 0) != 0;
+  const bool im_eq = im ? eq[0] : p_eq, im_gt = im ? gt[0] : p_gt, re_gt = im ? p_gt : gt[0];
+  return im_eq ? re_gt : im_gt;
+#else
+  return eq[1] ? gt[0] : gt[1];
+#endif
+}
+
 }  // namespace bn254

@@ -950,7 +950,8 @@ int bn254_batch_verify_compressed_device(bn254_ctx* c, const uint8_t* d_msgs, co
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
   PROF_MARK(0);
   k_decompress_g1_ws<<<grid_for(n), BN_WAVE, 0, s>>>(d_sigs33, n, c->ws);
-  k_decompress_g2_ws<<<grid_for(n), BN_WAVE, 0, s>>>(d_pks65, n, c->ws);
+  if (c->pair_lanes) { if ((rc = bn254_pair_decompress_g2(d_pks65, n, c->ws, s))) return rc; }
+  else k_decompress_g2_ws<<<grid_for(n), BN_WAVE, 0, s>>>(d_pks65, n, c->ws);
   return verify_after_decode(c, s, d_msgs, d_off, n, d_status, false);
 }
 int bn254_batch_verify_compressed(bn254_ctx* c, const uint8_t* msgs, const uint64_t* off, const uint8_t* sigs33, const uint8_t* pks65, size_t n,

@@ -103,67 +103,9 @@ BN_DEV uint8_t decompress_g1(G1Affine& pt, const uint8_t* b) {
   if (!in_range || !has_root) return ST_NOT_MEMBER;
   return ST_OK;
 }
-// U512 (16 words, little-endian) = hi * q + lo with lo < q: restoring long division by q
-BN_DEV void u512_divmod_q(U256& hi, U256& lo, bool& hi_overflow, const uint32_t* v) {
-  uint32_t rem[9];
-  for (int i = 0; i < 9; ++i) rem[i] = 0;
-  uint32_t quo[16];
-  for (int i = 0; i < 16; ++i) quo[i] = 0;
-  for (int bit = 511; bit >= 0; --bit) {
-    uint32_t carry = (v[bit >> 5] >> (bit & 31)) & 1;
-    for (int i = 0; i < 9; ++i) { uint32_t nc = rem[i] >> 31; rem[i] = (rem[i] << 1) | carry; carry = nc; }
-    uint32_t d[9], bw = 0;
-    for (int i = 0; i < 9; ++i) {
-      uint64_t x = (uint64_t)rem[i] - (i < 8 ? C_Q[i] : 0u) - bw;
-      d[i] = (uint32_t)x; bw = (uint32_t)(x >> 63);
-    }
-    if (!bw) { for (int i = 0; i < 9; ++i) rem[i] = d[i]; quo[bit >> 5] |= 1u << (bit & 31); }
-  }
-  hi_overflow = false;
-  for (int i = 8; i < 16; ++i) hi_overflow = hi_overflow || quo[i] != 0;
-  for (int i = 0; i < 8; ++i) { hi.w[i] = quo[i]; lo.w[i] = rem[i]; }
-}
-// canonical "u512(c) = c.im * q + c.re" order of utils.rs:40-45 == lexicographic (im, re)
-BN_DEV bool fp2_u512_greater(const Fp2& a, const Fp2& b) {
-  U256 ai = fp_to_u256(a.c1), bi = fp_to_u256(b.c1), ar = fp_to_u256(a.c0), br = fp_to_u256(b.c0);
-  bool im_eq = true;
-  for (int i = 0; i < 8; ++i) im_eq = im_eq && ai.w[i] == bi.w[i];
-  if (!im_eq) return u256_geq(ai.w, bi.w);
-  bool re_eq = true;
-  for (int i = 0; i < 8; ++i) re_eq = re_eq && ar.w[i] == br.w[i];
-  return !re_eq && u256_geq(ar.w, br.w);
-}
-// G2 (65 B): sign || BE64(x.im * q + x.re), sign 0x0b iff u512(y) > u512(-y), else 0x0a.
-// bn::G2::from_compressed as used at /root/reference/src/types.rs:92: bad sign or x.im >= q ->
-// InvalidEncoding(3); no root / not in the order-r subgroup -> NotMemberError(6) (the caller runs the
-// wave-uniform subgroup ladder).
-BN_DEV uint8_t decompress_g2(G2Affine& pt, const uint8_t* b) {
-  uint8_t sign = b[0];
-  uint32_t v[16];
-  for (int w = 0; w < 16; ++w) {
-    const uint8_t* p = b + 1 + 4 * (15 - w);
-    v[w] = ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3];
-  }
-  U256 hi, lo;
-  bool overflow;
-  u512_divmod_q(hi, lo, overflow, v);
-  bool enc_ok = (sign == 0x0a || sign == 0x0b) && !overflow && !u256_geq(hi.w, C_Q);
-  Fp2 x;
-  x.c0 = fp_from_u256(lo);
-  x.c1 = fp_from_u256(hi);
-  Fp2 rhs = fp2_add(fp2_mul(fp2_norm(fp2_sqr(x)), x), fp2_load_const(C_TWIST_B));
-  Fp2 y;
-  bool has_root = fp2_sqrt(y, rhs);
-  Fp2 yn = fp2_norm(fp2_neg(y));
-  bool y_gt = fp2_u512_greater(y, yn);
-  bool want_gt = sign == 0x0b;
-  pt.x = x;
-  pt.y = fp2_select(y_gt == want_gt, y, yn);
-  pt.inf = false;
-  if (!enc_ok) return ST_INVALID_ENCODING;
-  if (!has_root) return ST_NOT_MEMBER;
-  return ST_OK;
-}
+}  // namespace bn254
+#include "bn254_codec_g2.h"   // decompress_g2: written against the fp2_* interface, shared with the pair layout
+namespace bn254 {
 
 // 32-byte big-endian scalar -> plain limbs; `reduce`: bring into [0, r) like Fr::from_slice
 // (/root/reference/src/types.rs:36-38; examples/bn254.rs:7-12 loads keys > r)

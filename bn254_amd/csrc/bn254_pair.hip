@@ -23,6 +23,7 @@
   } while (0)
 #define bn254 bn254_pair   // own namespace: the Fq2 / Fq12 types differ from the other translation unit
 #include "bn254_pairing.h"
+#include "bn254_codec_g2.h"
 
 using namespace bn254;
 
@@ -100,6 +101,34 @@ KERNEL_PAIR void k_decode_g2_pair(const uint8_t* pts, size_t n, uint32_t flags, 
     uint8_t prev = accumulate ? ws_byte(ws, BY_ST_DECODE, i) : (uint8_t)ST_OK;
     ws_byte(ws, BY_ST_DECODE, i) = prev != ST_OK ? prev : st;
   }
+}
+// Compressed public keys (65 B, bn::G2::from_compressed: Fq2 square root + subgroup test) into the Q planes of a
+// verify, on lane pairs; same statuses as k_decompress_g2_ws.
+KERNEL_PAIR void k_decompress_g2_pair(const uint8_t* in, size_t n, Ws ws) {
+  const unsigned role = threadIdx.x & 1u;
+  size_t i = ((size_t)blockIdx.x * BN_PAIR_WG + threadIdx.x) >> 1;
+  const bool live = i < n;                          // no early return: the subgroup ladder votes across the wave
+  const size_t ii = live ? i : n - 1;
+  G2Affine q;
+  uint8_t st = decompress_g2(q, in + 65 * ii);
+  G2Affine gen;
+  gen.x = fp2_load_const(C_G2_GEN[0]); gen.y = fp2_load_const(C_G2_GEN[1]); gen.inf = false;
+  if (st != ST_OK) q = gen;
+  bool in_sub = g2_in_subgroup(q);
+  if (st == ST_OK && !in_sub) { st = ST_NOT_MEMBER; q = gen; }
+  if (!live) return;
+  ws_store_fp(ws, PL_QX0 + (int)role, i, q.x.c[0]);
+  ws_store_fp(ws, PL_QY0 + (int)role, i, q.y.c[0]);
+  if (role == 0) {
+    ws_byte(ws, BY_Q_INF, i) = q.inf;
+    uint8_t prev = ws_byte(ws, BY_ST_DECODE, i);
+    ws_byte(ws, BY_ST_DECODE, i) = prev != ST_OK ? prev : st;
+  }
+}
+int bn254_pair_decompress_g2(const uint8_t* in, size_t n, Ws ws, hipStream_t s) {
+  k_decompress_g2_pair<<<(unsigned)((2 * n + BN_PAIR_WG - 1) / BN_PAIR_WG), BN_PAIR_WG, 0, s>>>(in, n, ws);
+  HIP_TRY(hipGetLastError());
+  return 0;
 }
 int bn254_pair_decode_g2(const uint8_t* pts, size_t n, uint32_t flags, Ws ws, int accumulate, hipStream_t s) {
   k_decode_g2_pair<<<(unsigned)((2 * n + BN_PAIR_WG - 1) / BN_PAIR_WG), BN_PAIR_WG, 0, s>>>(pts, n, flags, ws, accumulate);

@@ -12,6 +12,7 @@
 extern "C" { unsigned long long bn_fp_mul_counter = 0; }
 
 #include "../../bn254_amd/csrc/bn254_pairing.h"
+#include "../../bn254_amd/csrc/bn254_codec_g2.h"
 
 using namespace bn254;
 
@@ -87,5 +88,14 @@ int hp_g2_sum_and_subgroup(const uint8_t* pts, uint64_t k, uint8_t* out128) {
   if (r.inf) memset(out128, 0, 128);
   else { fp_to_be32(out128, r.x.c[0]); fp_to_be32(out128 + 32, r.x.c[1]); fp_to_be32(out128 + 64, r.y.c[0]); fp_to_be32(out128 + 96, r.y.c[1]); }
   return in_all;
+}
+// G2::from_compressed through the pair layout (Fq2 square root, sign choice, subgroup test): status + 128 bytes
+int hp_g2_decompress(const uint8_t* c65, uint8_t* out128) {
+  G2Affine q;
+  uint8_t st = decompress_g2(q, c65);
+  if (st == ST_OK && !g2_in_subgroup(q)) st = ST_NOT_MEMBER;
+  memset(out128, 0, 128);
+  if (st == ST_OK) { fp_to_be32(out128, q.x.c[0]); fp_to_be32(out128 + 32, q.x.c[1]); fp_to_be32(out128 + 64, q.y.c[0]); fp_to_be32(out128 + 96, q.y.c[1]); }
+  return st;
 }
 }  // extern "C"

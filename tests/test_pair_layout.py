@@ -67,6 +67,36 @@ def test_pair_layout_multi_pair_and_g2_sums(pair_lib, derived):
     assert pair_lib.hp_g2_sum_and_subgroup(H(derived["g2_not_in_subgroup"]), 1, o) == 0
 
 
+def test_pair_layout_g2_decompress(pair_lib, kats, derived):
+    """G2::from_compressed in the pair layout against the classic-layout host build (itself pinned on the reference's
+    compressed-key vector) on random keys of both signs, and on malformed encodings"""
+    import hashlib
+    from tests import hostsim_binding as hs
+    Q = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47
+
+    def compress(p):                                   # utils.rs:130-158
+        w = [int.from_bytes(p[i:i + 32], "big") for i in range(0, 128, 32)]
+        y = w[3] * Q + w[2]
+        yn = ((-w[3]) % Q) * Q + ((-w[2]) % Q)
+        return bytes([0x0B if y > yn else 0x0A]) + (w[1] * Q + w[0]).to_bytes(64, "big")
+    cases = [H(kats["g2_compressed_roundtrip"]["hex"])]
+    g2 = c.g2_generator()
+    signs = set()
+    for i in range(8):
+        p = c.g2_mul(g2, hashlib.sha256(b"dec%d" % i).digest())
+        cases.append(compress(p))
+        signs.add(cases[-1][0])
+        out = ctypes.create_string_buffer(128)
+        assert pair_lib.hp_g2_decompress(cases[-1], out) == 0 and out.raw == p
+    assert signs == {0x0A, 0x0B}
+    bad = [b"\x0c" + cases[1][1:], cases[1][:1] + b"\xff" * 64, cases[2][:40] + bytes([cases[2][40] ^ 0x10]) + cases[2][41:], compress(H(derived["g2_not_in_subgroup"]))]
+    for enc in cases + bad:
+        out = ctypes.create_string_buffer(128)
+        st = pair_lib.hp_g2_decompress(enc, out)
+        wst, want = hs.g2_decompress(enc)
+        assert (st, out.raw if st == 0 else None) == (wst, want if wst == 0 else None), enc.hex()[:20]
+
+
 DRIVER = r'''
 import ctypes, json, sys
 root = sys.argv[1]
@@ -81,6 +111,8 @@ for v in d["verify_cases"]:
 g2 = H(d["g2_generator"]); o = ctypes.create_string_buffer(384)
 L.hp_pairing_product4(g1 * 4, g2 * 4, o)
 o = ctypes.create_string_buffer(128)
+k = json.load(open(root + "/tests/golden/reference_kats.json"))
+assert L.hp_g2_decompress(H(k["g2_compressed_roundtrip"]["hex"]), o) == 0
 L.hp_g2_sum_and_subgroup(g2 + g2 + bytes(128) + g2 + H(d["g2_not_in_subgroup"]), 5, o)
 print("ok")
 '''
