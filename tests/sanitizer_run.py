@@ -18,4 +18,21 @@ for v in k['g1_mul'][:6]:
 v=k['public_key_from_private_key'][0]; o=buf(128); hs.hs_g2_mul(None,H(v['private_key']),1,o); assert o.raw.hex()==v['uncompressed']
 o=buf(128); assert hs.hs_g2_decompress(H(k['g2_compressed_roundtrip']['hex']),o)==0
 g=H(d['g2_generator']); hs.hs_g2_msum(g+g+bytes(128)+g,4,o)
+# randomised batch verification (window ladders, GLV, wave-tree compositions) on the golden cases
+cs = d['verify_cases']; nn = len(cs); msgs = [H(v['message_hex']) for v in cs]
+off = (ctypes.c_uint64 * (nn + 1))(); pos = 0
+for i, m in enumerate(msgs):
+    off[i] = pos; pos += len(m)
+off[nn] = pos
+for fl in (0, 0x100, 0x200, 0x80000000):
+    stb = buf(nn); gr = buf(1)
+    hs.hs_verify_randomized(b"".join(msgs), off, b"".join(H(v['sig']) for v in cs), b"".join(H(v['pk']) for v in cs), nn, fl, bytes(range(32)), stb, gr)
+# the pair layout of the Fq2 tower (both lane roles emulated)
+hp = ctypes.CDLL(root + '/tests/hostsim/libhostsim_pair_san.so')
+g1 = (1).to_bytes(32, 'big') + (2).to_bytes(32, 'big')
+for v in cs[:4]:
+    if v['status'] in (0, 9): hp.hp_verify_decoded(g1, H(v['sig']), H(v['pk']))
+v = d['pairing_gt'][1]; o = buf(384); hp.hp_pairing(H(v['g1']), H(v['g2']), o); assert o.raw.hex() == v['gt']
+o = buf(128); assert hp.hp_g2_decompress(H(k['g2_compressed_roundtrip']['hex']), o) == 0
+g2b = H(d['g2_generator']); hp.hp_g2_sum_and_subgroup(g2b + g2b + bytes(128) + g2b, 4, o)
 print("sanitizer run ok:", n, "verifies + hash/pairing/group/codec flows, no ASan/UBSan report")
