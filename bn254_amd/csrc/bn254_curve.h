@@ -305,6 +305,7 @@ BN_DEVN bool g2_in_subgroup(const G2Affine& p) {
   G2Jac up, t, lhs, rhs;
   jac_from_affine(up, p);
   for (int i = 0; i < BN_U_NAF_LEN; ++i) {        // wave-uniform: u is a public constant
+    BN_SET_STEP_PRIORITY(i);
     jac_dbl(up, up);
     int d = C_U_NAF[i];
     if (d > 0) jac_accumulate(up, p);              // common-case addition; complete formula if any lane needs it

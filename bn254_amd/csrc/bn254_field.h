@@ -595,6 +595,7 @@ BN_DEVN Fp2 fp2_pow_sched(Fp2 a, const unsigned char (*sched)[2], int n_steps) {
   for (int i = 1; i < 8; ++i) odd[i] = fp2_mul(odd[i - 1], a2);
   Fp2 acc = odd[sched[0][1] >> 1];
   for (int s = 1; s < n_steps; ++s) {
+    BN_SET_STEP_PRIORITY(s);
     for (int k = 0; k < sched[s][0]; ++k) acc = fp2_norm(fp2_sqr(acc));
     if (sched[s][1]) acc = fp2_mul(acc, odd[sched[s][1] >> 1]);
   }
