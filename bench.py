@@ -113,6 +113,29 @@ def other_workloads(args, torch, eng, dev):
         assert st.raw == expected
         out.update(metric="BN254 pairings/sec (batch verify, host buffers: H2D + kernels + D2H + sync)", value=2 * n / dt, unit="pairings/s",
                    ms_per_step=1e3 * dt, batch=n)
+    elif args.workload == "verify-compressed":
+        # configs[1] tuples given as the compressed wire encodings (33-byte signatures, 65-byte public keys), device resident
+        from bn254_amd import PublicKey, Signature
+        n = args.batch
+        msgs, sigs, pks, expected = make_verify_batch(eng, n)
+        cache = {}
+
+        def pkc(b):
+            if b not in cache:
+                cache[b] = PublicKey(b).to_compressed()
+            return cache[b]
+        d_msgs = dev_bytes(b"".join(msgs))
+        d_sc = dev_bytes(b"".join(Signature(sigs[64 * i:64 * i + 64]).to_compressed() for i in range(n)))
+        d_pc = dev_bytes(b"".join(pkc(pks[128 * i:128 * i + 128]) for i in range(n)))
+        d_off = torch.arange(0, 32 * (n + 1), 32, dtype=torch.int64, device=dev)
+        d_st = torch.full((n,), 255, dtype=torch.uint8, device=dev)
+        eng.reserve(n)
+        lib, h = eng._lib, eng._h
+        dt = timed(lambda: lib.bn254_batch_verify_compressed_device(h, d_msgs.data_ptr(), d_off.data_ptr(), d_sc.data_ptr(), d_pc.data_ptr(), n,
+                                                                    d_st.data_ptr(), stream), args.steps, args.warmup)
+        assert bytes(d_st.cpu().numpy()) == expected
+        out.update(metric="BN254 pairings/sec (batch verify from compressed encodings: square roots + subgroup test on decode)", value=2 * n / dt,
+                   unit="pairings/s", ms_per_step=1e3 * dt, batch=n)
     elif args.workload == "verify-randomized":
         # opt-in randomised batch verification against the exact path on the same inputs;
         # generated in chunks so that the message list stays small on the host
@@ -221,7 +244,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pair-lanes", action="store_true", help="one lane per verify instead of lane pairs (A/B)")
     ap.add_argument("--split-miller", action="store_true", help="one pairing per lane instead of the fused 2-pair Miller loop (A/B)")
-    ap.add_argument("--workload", default="verify", choices=["verify", "verify-host", "verify-randomized", "pairing", "hash", "aggregate"],
+    ap.add_argument("--workload", default="verify", choices=["verify", "verify-host", "verify-compressed", "verify-randomized", "pairing", "hash", "aggregate"],
                     help="verify = the headline (configs[1]); the others time configs 4, 5, 3 or the host-buffer entry point "
                          "(single GPU, informational — see DESIGN.md §4b)")
     args = ap.parse_args()
