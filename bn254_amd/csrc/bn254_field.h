@@ -23,10 +23,21 @@
 #define BN_DEV __device__ __forceinline__
 #define BN_DEVN __device__ __noinline__
 #define BN_CONST __device__ __constant__ const
+// BN_DEVH: the two Fq12 routines of the Miller loop body (fp12_sqr, fp12_mul_line2).  As real functions each call
+// saves and restores the ~87 callee-saved VGPRs it needs for values that live across its product calls
+// (154 calls x 174 scratch dwords per Miller loop = 14 GB of private-segment traffic per 65 536 verifies);
+// a translation unit that defines BN_INLINE_FP12_HOT inlines them into the loop, whose own prologue then saves
+// those registers once.
+#if defined(BN_INLINE_FP12_HOT)
+#define BN_DEVH BN_DEV
+#else
+#define BN_DEVH BN_DEVN
+#endif
 #else
 #define BN_DEV static inline __attribute__((always_inline))
 #define BN_DEVN static __attribute__((noinline))
 #define BN_CONST static const
+#define BN_DEVH BN_DEVN
 #endif
 
 #include "bn254_constants.h"
@@ -683,7 +694,7 @@ BN_DEVN void fp12_mul(Fp12& r, const Fp12& a, const Fp12& b) {
   fp6_norm(r.c0, s);
   fp6_norm(r.c1, u);
 }
-BN_DEVN void fp12_sqr(Fp12& r, const Fp12& a) {
+BN_DEVH void fp12_sqr(Fp12& r, const Fp12& a) {
   Fp6 ab, s, t, u;
   fp6_mul(ab, a.c0, a.c1);
   fp6_add(s, a.c0, a.c1); fp6_norm(s, s);
@@ -724,7 +735,7 @@ BN_DEVN void fp12_mul_line(Fp12& r, const Fp12& f, const Fp2& l0, const Fp2& l1,
   fp6_norm(r.c1, u);
 }
 // f * (b0 + b1 w): b0 a full Fq6, b1 = b10 + b11 v — the shape of a product of two lines
-BN_DEVN void fp12_mul_line2(Fp12& r, const Fp12& f, const Fp6& b0, const Fp2& b10, const Fp2& b11) {
+BN_DEVH void fp12_mul_line2(Fp12& r, const Fp12& f, const Fp6& b0, const Fp2& b10, const Fp2& b11) {
   Fp6 t0, t1, s, u, bs;
   fp6_mul(t0, f.c0, b0);
   fp6_mul_01(t1, f.c1, b10, b11);

@@ -7,6 +7,9 @@
 #include <hip/hip_runtime.h>
 
 #define BN_SPLIT_FP2 1
+#ifndef BN_PAIR_CALL_FP12_HOT
+#define BN_INLINE_FP12_HOT 1       // fp12_sqr / fp12_mul_line2 inlined into the Miller loops (bn254_field.h: BN_DEVH)
+#endif
 // Measured (same box): Miller 8.8-8.95 -> 8.2-8.3 ms, final exponentiation 6.5-6.6 -> 6.4-6.45 ms per 65 536.
 #ifndef BN_PRIO_SHIFT
 #define BN_PRIO_SHIFT 1            // priority changes every 2^shift steps, cycle of 4 levels (0..3 measured: 0 and 1 best)
