@@ -82,6 +82,22 @@ def measured_traffic(kernel):
         return None
 
 
+def measured_valu_issue(kernel):
+    """VALU issue-slot utilisation of `kernel` from the same PMC summary: a 64-wide VALU instruction occupies its
+    16-lane SIMD for 4 cycles, so utilisation = SQ_INSTS_VALU (wave instructions per launch) x 4 cycles /
+    (1024 SIMDs x kernel cycles), kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs.  None if no profile is committed."""
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    try:
+        with open(path) as f:
+            k = json.load(f)["kernels"][kernel]
+        cycles = k["GRBM_GUI_ACTIVE"] / 8.0
+        return {"valu_wave_instructions_per_launch": k["SQ_INSTS_VALU"], "per_wave": k["SQ_INSTS_VALU"] / k["SQ_WAVES"],
+                "kernel_cycles": cycles, "utilisation": 4.0 * k["SQ_INSTS_VALU"] / (256 * 4 * cycles),
+                "note": "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8); source profiles/pmc_latest.json"}
+    except Exception:
+        return None
+
+
 def other_workloads(args, torch, eng, dev):
     """informational timings of configs 3-5 and of the host-buffer (PCIe-inclusive) verify; one JSON line"""
     import numpy as np
@@ -393,7 +409,9 @@ def main():
             # 8.16e10 Fq products/s with one wave per SIMD, 1.37e11 when the multiplier pipe is saturated
             "frac_of_occupancy1_product_ceiling": None if pair else (fp_mul * n / (k_avg[dom] * 1e-3)) / 8.16e10,   # one-lane layout only
             "frac_of_saturated_product_rate": (fp_mul * n / (k_avg[dom] * 1e-3)) / 1.37e11,
-            "traffic": measured_traffic(kname),
+            "traffic": (measured_traffic(kname) or {}).get("bytes_per_launch"),   # HBM bytes per launch (PMC), private-segment traffic
+            "traffic_detail": measured_traffic(kname),
+            "valu_issue": measured_valu_issue(kname),
             "multiplier_issue_frac": (fp_mul * MUL_INSTR_PER_FP_MUL * n / (k_avg[dom] * 1e-3)) / PEAK_MAC32_THEORETICAL,
             "kernel_ms": k_avg,
             "mac32_per_verify": {"miller_loop": FP_MUL_MILLER * MAC32_PER_FP_MUL, "final_exp": FP_MUL_FINAL_EXP * MAC32_PER_FP_MUL,
