@@ -104,7 +104,7 @@ BN_DEVN BN_VEC10 fp_pair_mul_impl(BN_VEC10 a, BN_VEC10 b) {
     x[i] = im ? bp : bo;          // re: a0*b0 + a1*(-b1)   im: a1*b0 + a0*b1
     y[i] = im ? bo : -bp;
   }
-  fp_dual_mul_reduce(r, ao, x, ap, y);
+  BN_MONT_DUAL_BODY(ao, x, ap, y, r);
   BN_VEC10 z;
 #pragma unroll
   for (int i = 0; i < BN_LIMBS; ++i) z[i] = r[i];
@@ -132,22 +132,19 @@ BN_DEV Fp2 fp2_mul(const Fp2& a, const Fp2& b) {   // outputs are tight
 }
 #if defined(__HIPCC__)
 // Device form of fp2_sqr, same idea: re (a0 + a1)(a0 - a1), im 2 * (a1 * a0) — one product per lane
+// A leaf: the product body is inlined (no call frame, no saved return address in scratch).
 BN_DEVN BN_VEC10 fp_pair_sqr_impl(BN_VEC10 a) {
   const bool im = (threadIdx.x & 1u) != 0;
   int32_t u[BN_LIMBS], v[BN_LIMBS];
 #pragma unroll
   for (int i = 0; i < BN_LIMBS; ++i) {
     const int32_t ao = a[i], ap = bn_partner_word(a[i]);
-    u[i] = im ? ao + ao : ao + ap;
+    u[i] = ao + (im ? ao : ap);
     v[i] = im ? ap : ao - ap;
   }
-  BN_LIMB_VEC x, y;
-#pragma unroll
-  for (int i = 0; i < BN_LIMBS; ++i) { x[i] = u[i]; y[i] = v[i]; }
-  BN_LIMB_VEC p = fp_mul_impl(x, y);
+  BN_COUNT_MUL();
   BN_VEC10 z;
-#pragma unroll
-  for (int i = 0; i < BN_LIMBS; ++i) z[i] = p[i];
+  BN_MONT_PRODUCT_BODY(u, v, z);
   return z;
 }
 #endif
