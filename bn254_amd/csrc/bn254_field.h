@@ -413,8 +413,8 @@ BN_DEVN BN_VEC20 fp2_mul_impl(BN_VEC10 a0, BN_VEC10 a1, BN_VEC10 b0, BN_VEC10 b1
   int32_t x0[BN_LIMBS], x1[BN_LIMBS], y0[BN_LIMBS], y1[BN_LIMBS], n1[BN_LIMBS], re[BN_LIMBS], im[BN_LIMBS];
 #pragma unroll
   for (int i = 0; i < BN_LIMBS; ++i) { x0[i] = a0[i]; x1[i] = a1[i]; y0[i] = b0[i]; y1[i] = b1[i]; n1[i] = -a1[i]; }
-  fp_dual_mul_reduce(re, x0, y0, n1, y1);
-  fp_dual_mul_reduce(im, x0, y1, x1, y0);
+  BN_MONT_DUAL_BODY(x0, y0, n1, y1, re);
+  BN_MONT_DUAL_BODY(x0, y1, x1, y0, im);
   BN_VEC20 r;
 #pragma unroll
   for (int i = 0; i < BN_LIMBS; ++i) { r[i] = re[i]; r[BN_LIMBS + i] = im[i]; }
@@ -688,8 +688,8 @@ BN_DEVN void fp12_mul(Fp12& r, const Fp12& a, const Fp12& b) {
   Fp6 t0, t1, s, t, u;
   fp6_mul(t0, a.c0, b.c0);
   fp6_mul(t1, a.c1, b.c1);
-  fp6_add(s, a.c0, a.c1); fp6_norm(s, s);
-  fp6_add(t, b.c0, b.c1); fp6_norm(t, t);
+  fp6_add(s, a.c0, a.c1);          // sums of two tight elements stay un-normalised: limbs < 2^28, and the products
+  fp6_add(t, b.c0, b.c1);          // of fp6_mul see at most (2^29)(2^29) per column term (bound tracker: test_bounds)
   fp6_mul(u, s, t);
   fp6_sub(u, u, t0);
   fp6_sub(u, u, t1);
@@ -701,7 +701,7 @@ BN_DEVN void fp12_mul(Fp12& r, const Fp12& a, const Fp12& b) {
 BN_DEVH void fp12_sqr(Fp12& r, const Fp12& a) {
   Fp6 ab, s, t, u;
   fp6_mul(ab, a.c0, a.c1);
-  fp6_add(s, a.c0, a.c1); fp6_norm(s, s);
+  fp6_add(s, a.c0, a.c1);
   fp6_mul_v(t, a.c1);
   fp6_add(t, t, a.c0); fp6_norm(t, t);
   fp6_mul(u, s, t);
@@ -743,8 +743,8 @@ BN_DEVH void fp12_mul_line2(Fp12& r, const Fp12& f, const Fp6& b0, const Fp2& b1
   Fp6 t0, t1, s, u, bs;
   fp6_mul(t0, f.c0, b0);
   fp6_mul_01(t1, f.c1, b10, b11);
-  fp6_add(s, f.c0, f.c1); fp6_norm(s, s);
-  bs.c0 = fp2_norm(fp2_add(b0.c0, b10)); bs.c1 = fp2_norm(fp2_add(b0.c1, b11)); bs.c2 = b0.c2;
+  fp6_add(s, f.c0, f.c1);
+  bs.c0 = fp2_add(b0.c0, b10); bs.c1 = fp2_add(b0.c1, b11); bs.c2 = b0.c2;
   fp6_mul(u, s, bs);
   fp6_sub(u, u, t0);
   fp6_sub(u, u, t1);

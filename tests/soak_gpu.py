@@ -38,6 +38,7 @@ def main():
     sks = [sk_bytes(j) for j in range(64)]
     pk_pool, _ = eng.batch_g2_mul(None, b"".join(sks), 64, reduce_scalar=True)
     t0, rounds, items, codes, extra = time.time(), 0, 0, {}, {}
+    last_note = t0
     while time.time() - t0 < args.seconds:
         n = rnd.choice([1, 63, 64, 65, 257, 1000, 2048, 4097])
         msgs = [hashlib.sha256(b"soak%d/%d" % (rounds, i)).digest() * 5 for i in range(n)]
@@ -138,6 +139,9 @@ def main():
             extra["check_public_keys"] = extra.get("check_public_keys", 0) + m
         rounds += 1
         items += n
+        if time.time() - last_note > 60:          # a progress line a minute (a silent GPU command is taken to be hung)
+            last_note = time.time()
+            print("soak: %d s, %d rounds, %d tuples, no mismatch" % (last_note - t0, rounds, items), flush=True)
     res = {"rounds": rounds, "tuples": items, "comparisons": items * 2 * 5, "seconds": round(time.time() - t0, 1), "oracle_threads": cores,
            "status_histogram": {str(k): v for k, v in sorted(codes.items())}, "mismatches": 0, "seed": args.seed, "also_compared": extra,
            "modes": ["exact on lane pairs", "exact, one lane per verify", "randomised 128-bit", "randomised GLV", "randomised 64-bit"],
