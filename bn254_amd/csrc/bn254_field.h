@@ -657,7 +657,7 @@ BN_DEV void fp6_mul(Fp6& r, const Fp6& a, const Fp6& b) {
 }
 BN_DEV void fp6_mul_fp2(Fp6& r, const Fp6& a, const Fp2& k) {
   Fp2 c0 = fp2_mul(a.c0, k), c1 = fp2_mul(a.c1, k), c2 = fp2_mul(a.c2, k);
-  r.c0 = fp2_norm(c0); r.c1 = fp2_norm(c1); r.c2 = fp2_norm(c2);
+  r.c0 = c0; r.c1 = c1; r.c2 = c2;
 }
 // a * (b0 + b1 v)
 BN_DEV void fp6_mul_01(Fp6& r, const Fp6& a, const Fp2& b0, const Fp2& b1) {
@@ -665,7 +665,7 @@ BN_DEV void fp6_mul_01(Fp6& r, const Fp6& a, const Fp2& b0, const Fp2& b1) {
   Fp2 c0 = fp2_add(fp2_mul_xi(fp2_mul(a.c2, b1)), v0);
   Fp2 c1 = fp2_sub(fp2_sub(fp2_mul(fp2_add(a.c0, a.c1), fp2_add(b0, b1)), v0), v1);
   Fp2 c2 = fp2_add(fp2_mul(a.c2, b0), v1);
-  r.c0 = fp2_norm(c0); r.c1 = fp2_norm(c1); r.c2 = fp2_norm(c2);
+  r.c0 = c0; r.c1 = c1; r.c2 = fp2_norm(c2);
 }
 BN_DEVN void fp6_inv(Fp6& r, const Fp6& a) {
   Fp2 t0 = fp2_norm(fp2_sub(fp2_sqr(a.c0), fp2_mul_xi(fp2_mul(a.c1, a.c2))));
@@ -688,8 +688,8 @@ BN_DEVN void fp12_mul(Fp12& r, const Fp12& a, const Fp12& b) {
   Fp6 t0, t1, s, t, u;
   fp6_mul(t0, a.c0, b.c0);
   fp6_mul(t1, a.c1, b.c1);
-  fp6_add(s, a.c0, a.c1);          // sums of two tight elements stay un-normalised: limbs < 2^28, and the products
-  fp6_add(t, b.c0, b.c1);          // of fp6_mul see at most (2^29)(2^29) per column term (bound tracker: test_bounds)
+  fp6_add(s, a.c0, a.c1); fp6_norm(s, s);
+  fp6_add(t, b.c0, b.c1); fp6_norm(t, t);
   fp6_mul(u, s, t);
   fp6_sub(u, u, t0);
   fp6_sub(u, u, t1);
@@ -710,7 +710,7 @@ BN_DEVH void fp12_sqr(Fp12& r, const Fp12& a) {
   fp6_sub(u, u, s);
   fp6_norm(r.c0, u);
   fp6_add(s, ab, ab);
-  fp6_norm(r.c1, s);
+  r.c1 = s;
 }
 BN_DEV void fp12_conj(Fp12& r, const Fp12& a) { r.c0 = a.c0; fp6_neg(r.c1, a.c1); fp6_norm(r.c1, r.c1); }
 BN_DEVN void fp12_inv(Fp12& r, const Fp12& a) {
@@ -729,7 +729,7 @@ BN_DEVN void fp12_mul_line(Fp12& r, const Fp12& f, const Fp2& l0, const Fp2& l1,
   Fp6 t0, t1, s, u;
   fp6_mul_fp2(t0, f.c0, l0);
   fp6_mul_01(t1, f.c1, l1, l2);
-  fp6_add(s, f.c0, f.c1); fp6_norm(s, s);
+  fp6_add(s, f.c0, f.c1); 
   fp6_mul_01(u, s, fp2_add(l0, l1), l2);
   fp6_sub(u, u, t0);
   fp6_sub(u, u, t1);

@@ -18,39 +18,43 @@ namespace bn254 {
 struct G2Proj { Fp2 x, y, z; };            // homogeneous projective twist point
 struct LineCoef { Fp2 c0, c1, c2; };
 
-// T <- 2T;  c0 = 2YZ, c1 = -3X^2, c2 = Y^2 - 3b'Z^2.   T and the line coefficients are tight.
+// T <- 2T;  c0 = 2YZ, c1 = -3X^2, c2 = Y^2 - 3b'Z^2.
+// Carry normalisations (fp2_norm) in the step functions and the line products are only where the bound tracker
+// needs them (tests/test_bounds.py, tests/test_pair_layout.py): every value here is a short signed combination of
+// fresh product outputs (limbs < 2^27), nothing accumulates from step to step, and a product tolerates operand limbs
+// up to 10*|A||B| < 2^63.  32 of 61 normalisations of the Miller loop / final exponentiation went this way (r01-l).
 BN_DEVN void dbl_step(G2Proj& t, LineCoef& l) {
-  Fp2 xy = fp2_mul(t.x, t.y), b = fp2_norm(fp2_sqr(t.y)), c = fp2_norm(fp2_sqr(t.z));
+  Fp2 xy = fp2_mul(t.x, t.y), b = fp2_sqr(t.y), c = fp2_sqr(t.z);
   Fp2 e = fp2_mul(c, fp2_load_const(C_TWIST_3B));
   Fp2 f = fp2_add(fp2_dbl(e), e);
-  Fp2 h = fp2_norm(fp2_sub(fp2_sub(fp2_sqr(fp2_add(t.y, t.z)), b), c));
+  Fp2 h = fp2_sub(fp2_sub(fp2_sqr(fp2_add(t.y, t.z)), b), c);
   Fp2 x2 = fp2_sqr(t.x);
   Fp2 e2 = fp2_norm(fp2_sqr(e));
   Fp2 e2x4 = fp2_dbl(fp2_dbl(e2));
   Fp2 e2x12 = fp2_add(fp2_dbl(e2x4), e2x4);
   G2Proj o;
-  o.x = fp2_norm(fp2_dbl(fp2_mul(xy, fp2_norm(fp2_sub(b, f)))));
-  o.y = fp2_norm(fp2_sub(fp2_sqr(fp2_norm(fp2_add(b, f))), e2x12));
-  o.z = fp2_norm(fp2_dbl(fp2_dbl(fp2_mul(b, h))));
+  o.x = fp2_dbl(fp2_mul(xy, fp2_sub(b, f)));
+  o.y = fp2_norm(fp2_sub(fp2_sqr(fp2_add(b, f)), e2x12));
+  o.z = fp2_dbl(fp2_dbl(fp2_mul(b, h)));
   l.c0 = h;
-  l.c1 = fp2_norm(fp2_neg(fp2_add(fp2_dbl(x2), x2)));
+  l.c1 = fp2_neg(fp2_add(fp2_dbl(x2), x2));
   l.c2 = fp2_norm(fp2_sub(b, e));
   t = o;
 }
 // T <- T + Q (Q affine);  c0 = mu, c1 = -theta, c2 = theta*x2 - mu*y2
 BN_DEVN void add_step(G2Proj& t, LineCoef& l, const Fp2& qx, const Fp2& qy) {
-  Fp2 theta = fp2_norm(fp2_sub(t.y, fp2_mul(qy, t.z)));
-  Fp2 mu = fp2_norm(fp2_sub(t.x, fp2_mul(qx, t.z)));
-  Fp2 c = fp2_norm(fp2_sqr(theta)), d = fp2_norm(fp2_sqr(mu)), e = fp2_mul(mu, d);
+  Fp2 theta = fp2_sub(t.y, fp2_mul(qy, t.z));
+  Fp2 mu = fp2_sub(t.x, fp2_mul(qx, t.z));
+  Fp2 c = fp2_sqr(theta), d = fp2_sqr(mu), e = fp2_mul(mu, d);
   Fp2 f = fp2_mul(t.z, c), g = fp2_mul(t.x, d);
-  Fp2 h = fp2_norm(fp2_sub(fp2_sub(fp2_add(e, f), g), g));
+  Fp2 h = fp2_sub(fp2_sub(fp2_add(e, f), g), g);
   G2Proj o;
   o.x = fp2_mul(mu, h);
-  o.y = fp2_norm(fp2_sub(fp2_mul(theta, fp2_norm(fp2_sub(g, h))), fp2_mul(e, t.y)));
+  o.y = fp2_sub(fp2_mul(theta, fp2_sub(g, h)), fp2_mul(e, t.y));
   o.z = fp2_mul(t.z, e);
   l.c0 = mu;
-  l.c1 = fp2_norm(fp2_neg(theta));
-  l.c2 = fp2_norm(fp2_sub(fp2_mul(theta, qx), fp2_mul(mu, qy)));
+  l.c1 = fp2_neg(theta);
+  l.c2 = fp2_sub(fp2_mul(theta, qx), fp2_mul(mu, qy));
   t = o;
 }
 // f <- f * line(P); a skipped pair multiplies by one
@@ -79,9 +83,9 @@ BN_DEV void mul_by_two_lines(Fp12& f, const LineCoef& l, const Fp& pax, const Fp
   Fp2 w4 = fp2_add(l1, fp2_mul(l2, m1));
   Fp6 b0;
   b0.c0 = fp2_select(skip_b, l0, fp2_norm(w0));
-  b0.c1 = fp2_select(skip_b, fp2_zero(), fp2_norm(v1));
-  b0.c2 = fp2_select(skip_b, fp2_zero(), fp2_norm(w4));
-  Fp2 b10 = fp2_select(skip_b, l1, fp2_norm(x01));
+  b0.c1 = fp2_select(skip_b, fp2_zero(), v1);
+  b0.c2 = fp2_select(skip_b, fp2_zero(), w4);
+  Fp2 b10 = fp2_select(skip_b, l1, x01);
   Fp2 b11 = fp2_select(skip_b, l2, fp2_norm(w3));
   fp12_mul_line2(f, f, b0, b10, b11);
 }
@@ -160,9 +164,9 @@ BN_DEV void mul_by_two_var_lines(Fp12& f, const LineCoef& la, const Fp& pax, con
   Fp2 x12 = fp2_sub(fp2_sub(fp2_mul(fp2_add(l1, l2), fp2_add(m1, m2)), v1), v2);
   Fp6 b0;
   b0.c0 = fp2_norm(fp2_add(v0, fp2_mul_xi(v2)));
-  b0.c1 = fp2_norm(v1);
-  b0.c2 = fp2_norm(x12);
-  fp12_mul_line2(f, f, b0, fp2_norm(x01), fp2_norm(x02));
+  b0.c1 = v1;
+  b0.c2 = x12;
+  fp12_mul_line2(f, f, b0, x01, x02);
 }
 
 // Miller loop over two pairs with variable twist points sharing f (randomised batch verification: two
