@@ -776,20 +776,28 @@ BN_DEV void fp4_sqr(Fp2& r0, Fp2& r1, const Fp2& a, const Fp2& b) {
   r0 = fp2_norm(fp2_add(a2, fp2_mul_xi_n(b2)));
 }
 // Granger-Scott squaring for the cyclotomic subgroup (after the easy part of the final exp.)
-BN_DEVN void fp12_cyclotomic_sqr(Fp12& r, const Fp12& a) {
+// The outputs 3t -+ 2a are linear in a, so across a run of squarings the value doubles each time unless the 2a term
+// uses a weakly reduced copy of a (fp_reduce_weak).  `reduce` = do that in this call; callers in a long run may skip
+// it three times out of four (values stay below ~700 q, products tolerate |a||b| < 64 * 86 000 q^2; the bound
+// tracker follows the actual sequences).  The branch is wave-uniform.
+BN_DEVN void fp12_cyclotomic_sqr(Fp12& r, const Fp12& a, bool reduce = true) {
   Fp2 t0, t1, t2, t3, t4, t5;
   fp4_sqr(t0, t1, a.c0.c0, a.c1.c1);
   fp4_sqr(t2, t3, a.c1.c0, a.c0.c2);
   fp4_sqr(t4, t5, a.c0.c1, a.c1.c2);
-  // outputs 3t -+ 2a are linear in a: use a weakly reduced copy of a for that term (see fp_reduce_weak)
+  Fp2 a00 = a.c0.c0, a11 = a.c1.c1, a10 = a.c1.c0, a02 = a.c0.c2, a01 = a.c0.c1, a12 = a.c1.c2;
+  if (reduce) {
+    a00 = fp2_reduce_weak(a00); a11 = fp2_reduce_weak(a11); a10 = fp2_reduce_weak(a10);
+    a02 = fp2_reduce_weak(a02); a01 = fp2_reduce_weak(a01); a12 = fp2_reduce_weak(a12);
+  }
   Fp12 o;
-  o.c0.c0 = fp2_norm(fp2_add(fp2_dbl(fp2_sub(t0, fp2_reduce_weak(a.c0.c0))), t0));
-  o.c1.c1 = fp2_norm(fp2_add(fp2_dbl(fp2_add(t1, fp2_reduce_weak(a.c1.c1))), t1));
+  o.c0.c0 = fp2_norm(fp2_add(fp2_dbl(fp2_sub(t0, a00)), t0));
+  o.c1.c1 = fp2_norm(fp2_add(fp2_dbl(fp2_add(t1, a11)), t1));
   t5 = fp2_norm(fp2_mul_xi(t5));
-  o.c1.c0 = fp2_norm(fp2_add(fp2_dbl(fp2_add(t5, fp2_reduce_weak(a.c1.c0))), t5));
-  o.c0.c2 = fp2_norm(fp2_add(fp2_dbl(fp2_sub(t4, fp2_reduce_weak(a.c0.c2))), t4));
-  o.c0.c1 = fp2_norm(fp2_add(fp2_dbl(fp2_sub(t2, fp2_reduce_weak(a.c0.c1))), t2));
-  o.c1.c2 = fp2_norm(fp2_add(fp2_dbl(fp2_add(t3, fp2_reduce_weak(a.c1.c2))), t3));
+  o.c1.c0 = fp2_norm(fp2_add(fp2_dbl(fp2_add(t5, a10)), t5));
+  o.c0.c2 = fp2_norm(fp2_add(fp2_dbl(fp2_sub(t4, a02)), t4));
+  o.c0.c1 = fp2_norm(fp2_add(fp2_dbl(fp2_sub(t2, a01)), t2));
+  o.c1.c2 = fp2_norm(fp2_add(fp2_dbl(fp2_add(t3, a12)), t3));
   r = o;
 }
 
