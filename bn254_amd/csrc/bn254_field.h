@@ -559,10 +559,9 @@ BN_DEV Fp2 fp2_mul(const Fp2& a, const Fp2& b) {   // lazy-reduction product; ou
   return r;
 }
 BN_DEV Fp2 fp2_sqr(const Fp2& a) {                 // 2 Fq products
-  Fp m = fp_mul(a.c0, a.c1);
   Fp2 r;
   r.c0 = fp_mul(fp_add(a.c0, a.c1), fp_sub(a.c0, a.c1));
-  r.c1 = fp_dbl(m);
+  r.c1 = fp_mul(fp_dbl(a.c0), a.c1);                // doubled before the product: the output is tight, as in the pair layout
   return r;
 }
 BN_DEV Fp2 fp2_mul_fp(const Fp2& a, const Fp& k) { Fp2 r; r.c0 = fp_mul(a.c0, k); r.c1 = fp_mul(a.c1, k); return r; }
@@ -651,7 +650,7 @@ BN_DEV void fp6_mul_v(Fp6& r, const Fp6& a) { Fp2 t = fp2_mul_xi(a.c2); r.c2 = a
 BN_DEV void fp6_mul(Fp6& r, const Fp6& a, const Fp6& b) {
   Fp2 v0 = fp2_mul(a.c0, b.c0), v1 = fp2_mul(a.c1, b.c1), v2 = fp2_mul(a.c2, b.c2);
   Fp2 c0 = fp2_add(fp2_mul_xi_n(fp2_sub(fp2_sub(fp2_mul(fp2_add(a.c1, a.c2), fp2_add(b.c1, b.c2)), v1), v2)), v0);
-  Fp2 c1 = fp2_add(fp2_sub(fp2_sub(fp2_mul(fp2_add(a.c0, a.c1), fp2_add(b.c0, b.c1)), v0), v1), fp2_mul_xi_n(v2));
+  Fp2 c1 = fp2_add(fp2_sub(fp2_sub(fp2_mul(fp2_add(a.c0, a.c1), fp2_add(b.c0, b.c1)), v0), v1), fp2_mul_xi(v2));
   Fp2 c2 = fp2_add(fp2_sub(fp2_sub(fp2_mul(fp2_add(a.c0, a.c2), fp2_add(b.c0, b.c2)), v0), v2), v1);
   r.c0 = fp2_norm(c0); r.c1 = fp2_norm(c1); r.c2 = fp2_norm(c2);
 }
@@ -773,7 +772,7 @@ BN_DEVN void fp12_frob(Fp12& r, const Fp12& a, int power) {
 BN_DEV void fp4_sqr(Fp2& r0, Fp2& r1, const Fp2& a, const Fp2& b) {
   Fp2 a2 = fp2_sqr(a), b2 = fp2_sqr(b);
   r1 = fp2_norm(fp2_sub(fp2_sub(fp2_sqr(fp2_add(a, b)), a2), b2));
-  r0 = fp2_norm(fp2_add(a2, fp2_mul_xi_n(b2)));
+  r0 = fp2_norm(fp2_add(a2, fp2_mul_xi(b2)));
 }
 // Granger-Scott squaring for the cyclotomic subgroup (after the easy part of the final exp.)
 // The outputs 3t -+ 2a are linear in a, so across a run of squarings the value doubles each time unless the 2a term

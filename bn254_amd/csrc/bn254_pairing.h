@@ -29,7 +29,7 @@ BN_DEVN void dbl_step(G2Proj& t, LineCoef& l) {
   Fp2 f = fp2_add(fp2_dbl(e), e);
   Fp2 h = fp2_sub(fp2_sub(fp2_sqr(fp2_add(t.y, t.z)), b), c);
   Fp2 x2 = fp2_sqr(t.x);
-  Fp2 e2 = fp2_norm(fp2_sqr(e));
+  Fp2 e2 = fp2_sqr(e);
   Fp2 e2x4 = fp2_dbl(fp2_dbl(e2));
   Fp2 e2x12 = fp2_add(fp2_dbl(e2x4), e2x4);
   G2Proj o;
@@ -38,7 +38,7 @@ BN_DEVN void dbl_step(G2Proj& t, LineCoef& l) {
   o.z = fp2_dbl(fp2_dbl(fp2_mul(b, h)));
   l.c0 = h;
   l.c1 = fp2_neg(fp2_add(fp2_dbl(x2), x2));
-  l.c2 = fp2_norm(fp2_sub(b, e));
+  l.c2 = fp2_sub(b, e);
   t = o;
 }
 // T <- T + Q (Q affine);  c0 = mu, c1 = -theta, c2 = theta*x2 - mu*y2
