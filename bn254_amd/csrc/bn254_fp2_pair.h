@@ -23,6 +23,11 @@ BN_DEV int bn_role_index(int) { return (int)(threadIdx.x & 1u); }
 // product in a VALU-bound kernel, but the kernels run 5 % slower with the swizzles placed by the compiler and 12 %
 // slower with all of them hoisted to the top of the product routine)
 BN_DEV int32_t bn_partner_word(int32_t v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true); }
+// the word of the pair's real-part (even) lane / imaginary-part (odd) lane, in both lanes of the pair:
+// quad_perm [0,0,2,2] and [1,1,3,3].  A broadcast needs no role select, and as the single user's DPP operand it
+// folds into that add / sub / and.
+BN_DEV int32_t bn_pair_re_word(int32_t v) { return __builtin_amdgcn_update_dpp(0, v, 0xA0, 0xF, 0xF, true); }
+BN_DEV int32_t bn_pair_im_word(int32_t v) { return __builtin_amdgcn_update_dpp(0, v, 0xF5, 0xF, 0xF, true); }
 BN_DEV Fp bn_partner(const Fp2& a, int) {
   Fp r;
 #pragma unroll
@@ -97,15 +102,16 @@ BN_DEV Fp2 fp2_select(bool c, const Fp2& a, const Fp2& b) { Fp2 r; BN_FOR_ROLES(
 // pairing, so a call passes 20 words in registers (a 40-word call spills 8 argument words to the stack) and the
 // exchange / select code exists once instead of at every call site.
 BN_DEVN BN_VEC10 fp_pair_mul_impl(BN_VEC10 a, BN_VEC10 b) {
-  const bool im = (threadIdx.x & 1u) != 0;
+  // own * b0 + partner * (+-b1):   re lane  a0*b0 + a1*(-b1)     im lane  a1*b0 + a0*b1
+  // b0 and b1 are broadcasts within the pair; the sign is a multiplication by this lane's -1 / +1
+  const int32_t sign = (int32_t)((threadIdx.x & 1u) << 1) - 1;
   int32_t ao[BN_LIMBS], ap[BN_LIMBS], x[BN_LIMBS], y[BN_LIMBS], r[BN_LIMBS];
 #pragma unroll
   for (int i = 0; i < BN_LIMBS; ++i) {
-    const int32_t bo = b[i], bp = bn_partner_word(b[i]);
     ao[i] = a[i];
     ap[i] = bn_partner_word(a[i]);
-    x[i] = im ? bp : bo;          // re: a0*b0 + a1*(-b1)   im: a1*b0 + a0*b1
-    y[i] = im ? bo : -bp;
+    x[i] = bn_pair_re_word(b[i]);
+    y[i] = (int32_t)((uint32_t)bn_pair_im_word(b[i]) * (uint32_t)sign);
   }
   BN_MONT_DUAL_BODY(ao, x, ap, y, r);
   BN_VEC10 z;
@@ -137,14 +143,39 @@ BN_DEV Fp2 fp2_mul(const Fp2& a, const Fp2& b) {   // outputs are tight
 // Device form of fp2_sqr, same idea: re (a0 + a1)(a0 - a1), im 2 * (a1 * a0) — one product per lane
 // A leaf: the product body is inlined (no call frame, no saved return address in scratch).
 BN_DEVN BN_VEC10 fp_pair_sqr_impl(BN_VEC10 a) {
-  const bool im = (threadIdx.x & 1u) != 0;
+  // re lane (a0 + a1)(a0 - a1), im lane (a1 + a1) * a0:  u = own + a1,  v = a0 - (a1 in the re lane, 0 in the im lane)
+  const int32_t re_mask = (int32_t)(threadIdx.x & 1u) - 1;
   int32_t u[BN_LIMBS], v[BN_LIMBS];
+#if defined(BN_PAIR_SQR_DPP_ASM)
+  // The three operations with their DPP operand folded in: 3 instead of 5 instructions per limb (the compiler merges
+  // the two fetches of a1 into one move with two users and then folds nothing).  No VCC.  Hazard rule (a DPP operand must
+  // not have been written by the two preceding VALU instructions, and the compiler's hazard recogniser does not look
+  // into asm): the DPP operands are the inputs a[i] only, each block opens with s_nop 1 in case the compiler copies an
+  // input right before it, and the outputs are early-clobber, so no block reads through DPP what it wrote.
+#define BN_SQR_ROLE_LIMB(U, V, A) \
+  "v_add_u32_dpp " U ", " A ", " A " quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n" \
+  "v_and_b32_dpp " V ", " A ", %15 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n" \
+  "v_sub_u32_dpp " V ", " A ", " V " quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+#define BN_SQR_ROLE_BLOCK(o) \
+  __asm__("s_nop 1\n" BN_SQR_ROLE_LIMB("%0", "%5", "%10") BN_SQR_ROLE_LIMB("%1", "%6", "%11") BN_SQR_ROLE_LIMB("%2", "%7", "%12") \
+          BN_SQR_ROLE_LIMB("%3", "%8", "%13") BN_SQR_ROLE_LIMB("%4", "%9", "%14") \
+          : "=&v"(u[o]), "=&v"(u[o + 1]), "=&v"(u[o + 2]), "=&v"(u[o + 3]), "=&v"(u[o + 4]), \
+            "=&v"(v[o]), "=&v"(v[o + 1]), "=&v"(v[o + 2]), "=&v"(v[o + 3]), "=&v"(v[o + 4]) \
+          : "v"(ai[o]), "v"(ai[o + 1]), "v"(ai[o + 2]), "v"(ai[o + 3]), "v"(ai[o + 4]), "v"(re_mask))
+  int32_t ai[BN_LIMBS];
+#pragma unroll
+  for (int i = 0; i < BN_LIMBS; ++i) ai[i] = a[i];
+  BN_SQR_ROLE_BLOCK(0);
+  BN_SQR_ROLE_BLOCK(5);
+#undef BN_SQR_ROLE_BLOCK
+#undef BN_SQR_ROLE_LIMB
+#else
 #pragma unroll
   for (int i = 0; i < BN_LIMBS; ++i) {
-    const int32_t ao = a[i], ap = bn_partner_word(a[i]);
-    u[i] = ao + (im ? ao : ap);
-    v[i] = im ? ap : ao - ap;
+    u[i] = a[i] + bn_pair_im_word(a[i]);
+    v[i] = bn_pair_re_word(a[i]) - (bn_pair_im_word(a[i]) & re_mask);
   }
+#endif
   BN_COUNT_MUL();
   BN_VEC10 z;
   BN_MONT_PRODUCT_BODY(u, v, z);

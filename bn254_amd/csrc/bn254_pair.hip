@@ -7,6 +7,9 @@
 #include <hip/hip_runtime.h>
 
 #define BN_SPLIT_FP2 1
+#ifndef BN_PAIR_NO_SQR_DPP_ASM
+#define BN_PAIR_SQR_DPP_ASM 1      // role prologue of the Fq2 squaring with folded DPP operands (bn254_fp2_pair.h)
+#endif
 #ifndef BN_PAIR_CALL_FP12_HOT
 #define BN_INLINE_FP12_HOT 1       // fp12_sqr / fp12_mul_line2 inlined into the Miller loops (bn254_field.h: BN_DEVH)
 #endif
