@@ -204,6 +204,17 @@ BN_DEV Fp2 fp2_sqr(const Fp2& a) {
 BN_DEV Fp2 fp2_mul_fp(const Fp2& a, const Fp& s) { Fp2 r; BN_FOR_ROLES(k) r.c[k] = fp_mul(a.c[k], s); return r; }
 BN_DEV Fp2 fp2_mul_xi(const Fp2& a) {              // (9 + i) * a; limb bounds grow 10x: input must be (near) tight
   Fp2 r;
+#if defined(__HIPCC__)
+  // re: 9 a0 - a1   im: 9 a1 + a0.   -p = (p ^ -1) + 1: the partner fetch folds into the XOR with this lane's mask
+  // (-1 in a real-part lane, 0 in an imaginary-part lane), the +1 / +0 rides in a three-operand add
+  const int32_t one = 1 - (int32_t)(threadIdx.x & 1u), mask = -one;
+#pragma unroll
+  for (int i = 0; i < BN_LIMBS; ++i) {
+    const int32_t own = a.c[0].v[i];
+    r.c[0].v[i] = (own << 3) + own + ((bn_partner_word(own) ^ mask) + one);
+  }
+  return r;
+#endif
   BN_FOR_ROLES(k) {
     const Fp ap = bn_partner(a, k);
     Fp a2 = fp_dbl(a.c[k]), a4 = fp_dbl(a2), a8 = fp_dbl(a4);
