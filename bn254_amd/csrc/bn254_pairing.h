@@ -71,12 +71,15 @@ BN_DEV void mul_by_line(Fp12& f, const LineCoef& l, const Fp& px, const Fp& py, 
 //   (l0 + l1 w + l2 w^3)(m0 + m1 w + w^3) =
 //     (l0 m0 + xi l2) + (l0 m1 + l1 m0) w + l1 m1 w^2 + (l0 + l2 m0) w^3 + (l1 + l2 m1) w^4
 // 5 Fq2 products for the line product and 17 for f * (5-term element), against 2 x 13.
+// `any_skip` (wave-uniform): some lane of the wave has a skipped pair; without one the selects are branched over.
 BN_DEV void mul_by_two_lines(Fp12& f, const LineCoef& l, const Fp& pax, const Fp& pay, bool skip_a, int idx, const Fp& pbx,
-                             const Fp& pby, bool skip_b) {
+                             const Fp& pby, bool skip_b, bool any_skip) {
   Fp2 l0 = fp2_mul_fp(l.c0, pay), l1 = fp2_mul_fp(l.c1, pax), l2 = l.c2;
-  l0 = fp2_select(skip_a, fp2_one(), l0);
-  l1 = fp2_select(skip_a, fp2_zero(), l1);
-  l2 = fp2_select(skip_a, fp2_zero(), l2);
+  if (any_skip) {
+    l0 = fp2_select(skip_a, fp2_one(), l0);
+    l1 = fp2_select(skip_a, fp2_zero(), l1);
+    l2 = fp2_select(skip_a, fp2_zero(), l2);
+  }
   Fp2 m0 = fp2_mul_fp(fp2_load_const(C_NEG_G2_LINES[idx][0]), pby), m1 = fp2_mul_fp(fp2_load_const(C_NEG_G2_LINES[idx][1]), pbx);
   Fp2 v0 = fp2_mul(l0, m0), v1 = fp2_mul(l1, m1);
   Fp2 x01 = fp2_sub(fp2_sub(fp2_mul(fp2_add(l0, l1), fp2_add(m0, m1)), v0), v1);
@@ -84,11 +87,15 @@ BN_DEV void mul_by_two_lines(Fp12& f, const LineCoef& l, const Fp& pax, const Fp
   Fp2 w3 = fp2_add(l0, fp2_mul(l2, m0));
   Fp2 w4 = fp2_add(l1, fp2_mul(l2, m1));
   Fp6 b0;
-  b0.c0 = fp2_select(skip_b, l0, fp2_norm(w0));
-  b0.c1 = fp2_select(skip_b, fp2_zero(), v1);
-  b0.c2 = fp2_select(skip_b, fp2_zero(), w4);
-  Fp2 b10 = fp2_select(skip_b, l1, x01);
-  Fp2 b11 = fp2_select(skip_b, l2, fp2_norm(w3));
+  b0.c0 = fp2_norm(w0); b0.c1 = v1; b0.c2 = w4;
+  Fp2 b10 = x01, b11 = fp2_norm(w3);
+  if (any_skip) {
+    b0.c0 = fp2_select(skip_b, l0, b0.c0);
+    b0.c1 = fp2_select(skip_b, fp2_zero(), b0.c1);
+    b0.c2 = fp2_select(skip_b, fp2_zero(), b0.c2);
+    b10 = fp2_select(skip_b, l1, b10);
+    b11 = fp2_select(skip_b, l2, b11);
+  }
   fp12_mul_line2(f, f, b0, b10, b11);
 }
 BN_DEV void fixed_line(LineCoef& l, int idx) {
@@ -110,6 +117,11 @@ BN_DEVN void miller_loop(Fp12& f, const G1Affine& pa, const G2Affine& qa, const 
   Fp2 qa_yneg;
   bool skip_a = !HAS_A || pa.inf || qa.inf;
   bool skip_b = !HAS_B || pb.inf;
+#if defined(__HIPCC__)
+  const bool any_skip = __builtin_amdgcn_ballot_w64(skip_a || skip_b) != 0;   // wave-uniform
+#else
+  const bool any_skip = skip_a || skip_b;
+#endif
   if constexpr (HAS_A) { t.x = qa.x; t.y = qa.y; t.z = fp2_one(); qa_yneg = fp2_norm(fp2_neg(qa.y)); }
   int idx = 0;
   constexpr bool BOTH = HAS_A && HAS_B;      // both pairs: one merged multiplication per step
@@ -117,7 +129,7 @@ BN_DEVN void miller_loop(Fp12& f, const G1Affine& pa, const G2Affine& qa, const 
     BN_SET_STEP_PRIORITY(d);
     fp12_sqr(f, f);
     if constexpr (HAS_A) { dbl_step(t, l); if constexpr (!BOTH) mul_by_line(f, l, pa.x, pa.y, skip_a); }
-    if constexpr (BOTH) mul_by_two_lines(f, l, pa.x, pa.y, skip_a, idx++, pb.x, pb.y, skip_b);
+    if constexpr (BOTH) mul_by_two_lines(f, l, pa.x, pa.y, skip_a, idx++, pb.x, pb.y, skip_b, any_skip);
     else if constexpr (HAS_B) { fixed_line(l, idx++); mul_by_line(f, l, pb.x, pb.y, skip_b); }
     int digit = C_ATE_NAF[d];
     if (digit != 0) {   // wave-uniform
@@ -126,7 +138,7 @@ BN_DEVN void miller_loop(Fp12& f, const G1Affine& pa, const G2Affine& qa, const 
         add_step(t, l, qa.x, qy);
         if constexpr (!BOTH) mul_by_line(f, l, pa.x, pa.y, skip_a);
       }
-      if constexpr (BOTH) mul_by_two_lines(f, l, pa.x, pa.y, skip_a, idx++, pb.x, pb.y, skip_b);
+      if constexpr (BOTH) mul_by_two_lines(f, l, pa.x, pa.y, skip_a, idx++, pb.x, pb.y, skip_b, any_skip);
       else if constexpr (HAS_B) { fixed_line(l, idx++); mul_by_line(f, l, pb.x, pb.y, skip_b); }
     }
   }
@@ -137,14 +149,14 @@ BN_DEVN void miller_loop(Fp12& f, const G1Affine& pa, const G2Affine& qa, const 
     add_step(t, l, q1x, q1y);
     if constexpr (!BOTH) mul_by_line(f, l, pa.x, pa.y, skip_a);
   }
-  if constexpr (BOTH) mul_by_two_lines(f, l, pa.x, pa.y, skip_a, idx++, pb.x, pb.y, skip_b);
+  if constexpr (BOTH) mul_by_two_lines(f, l, pa.x, pa.y, skip_a, idx++, pb.x, pb.y, skip_b, any_skip);
   else if constexpr (HAS_B) { fixed_line(l, idx++); mul_by_line(f, l, pb.x, pb.y, skip_b); }
   if constexpr (HAS_A) {
     Fp2 q2x = fp2_mul(qa.x, fp2_load_const(C_TW_FROB_X2));
     add_step(t, l, q2x, qa.y);
     if constexpr (!BOTH) mul_by_line(f, l, pa.x, pa.y, skip_a);
   }
-  if constexpr (BOTH) mul_by_two_lines(f, l, pa.x, pa.y, skip_a, idx++, pb.x, pb.y, skip_b);
+  if constexpr (BOTH) mul_by_two_lines(f, l, pa.x, pa.y, skip_a, idx++, pb.x, pb.y, skip_b, any_skip);
   else if constexpr (HAS_B) { fixed_line(l, idx++); mul_by_line(f, l, pb.x, pb.y, skip_b); }
 }
 
