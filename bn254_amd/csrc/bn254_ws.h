@@ -4,7 +4,7 @@
 
 #define BN_WAVE 64
 #define BN_SPLIT_MAX_N ((size_t)98304)   // <= 1.5 waves per SIMD with one lane per verify
-#define RAND_MIN_BATCH_DEFAULT 98304               // randomised verify pays off from about here
+#define RAND_MIN_BATCH_DEFAULT 131072              // randomised verify pays off from about here
 #define RAND_TWO_PER_LANE_MIN_N ((size_t)131072)   // randomised verify: two items per lane once that still fills 1024 SIMDs
 // Register budget: amdgpu_waves_per_eu(W, W) on the kernels is propagated to every device function
 // they call (AMDGPU attributor), capping VGPR+AGPR at 512/W so that W waves fit on each SIMD.

@@ -203,7 +203,7 @@ int bn254_ctx_set_profiling(bn254_ctx *ctx, int enabled);
  * identical either way. */
 #define BN254_OPT_SPLIT_MILLER 1
 #define BN254_OPT_RAND_MIN_BATCH 5 /* randomised verify: batches with fewer items run the exact kernels instead (same statuses; group_ok = no item of the
-                                     group failed the pairing check).  Default 98304, the measured break-even on an MI355X; 0 = always randomised */
+                                     group failed the pairing check).  Default 131072, the measured break-even on an MI355X; 0 = always randomised */
 #define BN254_OPT_PAIR_LANES 4 /* verify: Miller loop + final exponentiation on lane pairs, two waves per SIMD (default 1); 0 = one lane per verify */
 #define BN254_OPT_RAND_ITEMS_PER_LANE 3 /* randomised verify: items per lane in the Miller kernel; 0 = by batch size (default), 1, 2 */
 #define BN254_OPT_HASH_MAX_TRIES 2 /* test knob: counters tried before HashToPointError; 0 = 255 as in src/hash.rs:40 */
