@@ -229,7 +229,7 @@ BN_DEVN void fp12_pow_u(Fp12& r, const Fp12& a, Fp12& acc) {
   fp12_mul(odd[3], odd[2], t);
   acc = odd[C_U_W4[0] >> 1];                        // leading digit is positive
   for (int i = 1; i < BN_U_W4_LEN; ++i) {           // wave-uniform: u is a public constant
-    BN_SET_STEP_PRIORITY(i);
+    BN_SET_STEP_PRIORITY(i >> 1);                    // half the rate of the Miller loop's cycle (measured: -1.3 % here)
     fp12_cyclotomic_sqr(acc, acc, (i & 1) == 1);   // weak reduction of the linear term every other squaring
     int d = C_U_W4[i];
     if (d > 0) fp12_mul(acc, acc, odd[d >> 1]);
