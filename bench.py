@@ -7,9 +7,15 @@ tuples per GPU (BASELINE.json configs[1]), inputs already resident in HBM, throu
 -> final exponentiation -> status byte.  One verify = 2 pairings (two Miller loops, one final
 exponentiation), so pairings/s = 2 x verifies/s.
 
-Multi-GPU: one process per GPU (torchrun), each rank verifies its own 65 536-tuple shard
-(weak scaling, no data-path collective) and the per-item status bytes are all-gathered over
-RCCL/xGMI inside every timed step (the "final boolean gather" of the north star).
+Multi-GPU: one process per GPU, each rank works on its own shard (weak scaling, no data-path
+collective) and the per-item status bytes are all-gathered over RCCL/xGMI inside every timed step
+(the "final boolean gather" of the north star).  `--workload pairing` is BASELINE configs[3]
+(independent pairings with canonical Gt output, 512 Ki per GPU): besides the status gather, the additive
+64-bit checksum over all Gt words is all-reduced (8 bytes) in every step.
+
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself
+(torch.distributed.run, rendezvous on 127.0.0.1) from a parent that never touches the GPU, relays rank 0's
+JSON line and exits non-zero if any rank failed.  Under an external torchrun it is a rank.
 
 Prints ONE JSON line on rank 0 (see README/DESIGN.md for the roofline + cpu_baseline objects).
 """
@@ -17,6 +23,8 @@ import argparse
 import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,23 +33,29 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 BATCH = 65536                      # tuples per GPU per step (configs[1])
-CORRUPT_EVERY = 64                 # every 64th signature is wrong -> expected status 9 there
+PAIRING_BATCH = 1 << 19            # pairings per GPU per step (configs[3]: 4 Mi over 8 GPUs)
+CORRUPT_EVERY = 64                 # one signature in 64 is wrong -> expected status 9 there
 # Algorithmic work per verify, counted by instrumenting the device arithmetic source compiled for
 # the host (tests/test_workcount.py keeps these in sync): Montgomery products per kernel stage.
 FP_MUL_DECODE = 19
 FP_MUL_HASH_FILTER = 4             # per tested counter: x -> Montgomery, x^3 + 3, back to an integer for the Jacobi symbol
 FP_MUL_HASH_FINISH = 311           # once per message: the square-root exponentiation of the winning counter + checks
 FP_MUL_MILLER = 11138
-FP_MUL_FINAL_EXP = 7449           # width-4 window exponentiations by u; incl. 12 canonicalisations for the == 1 test
+FP_MUL_FINAL_EXP = 7449            # width-4 window exponentiations by u; incl. 12 canonicalisations for the == 1 test
+FP_MUL_MILLER_SINGLE = 8419        # one variable pair (configs[3] pairing workload), same instrumentation
 MAC32_PER_FP_MUL = 136             # ALGORITHMIC unit: an 8x32-bit Montgomery product = 2*8*8 + 8 MAC32.
-MUL_INSTR_PER_FP_MUL = 210         # what the kernels actually issue per product with 10x27-bit limbs: 200 v_mad_*64 + 10 v_mul_lo
+# What the pair-layout kernels actually issue per lane (tests/test_workcount.py: hp_lane_counts): multiply-add
+# instructions per dual product / single product / square of the device's limb representation.
+LIMBS = 10
+MADS_DUAL, MADS_SINGLE = 3 * LIMBS * LIMBS, 2 * LIMBS * LIMBS
+MUL_LO_PER_PRODUCT = LIMBS
 # VALU roofline: v_mad_u64_u32 issues once per 4 cycles per SIMD (half the 2-cycle full rate):
-# 256 CU x 4 SIMD x 64 lanes x 2.4 GHz / 4 = 39.3 T MAC32/s.  The committed microbenchmark
-# (profiles/r01_valu_rates_microbench.jsonl) sustains 29.9 T/s of that.
+# 256 CU x 4 SIMD x 64 lanes x 2.4 GHz / 4 = 39.3 T MAC32/s.  The rate the multiplier actually sustains is measured
+# in this process (bn254_probe_issue_rate) and reported next to it.
 PEAK_MAC32_THEORETICAL = 256 * 4 * 64 * 2.4e9 / 4
-PEAK_MAC32_MEASURED = 2.99e13
 HBM_PEAK_GBPS = 8000.0
 BYTES_PER_VERIFY_IO = 32 + 8 + 64 + 128 + 1   # message + offset + sig + pk + status
+BYTES_PER_PAIRING_IO = 64 + 128 + 384 + 1     # G1 + G2 in, Gt + status out
 
 
 def D(tag, i):
@@ -67,42 +81,70 @@ def effective_cores():
     return n
 
 
+def _pmc(kernel):
+    """the committed rocprofv3 PMC summary of this same command for `kernel` (profiles/pmc_latest.json, produced by
+    tests/pmc_profile.sh + tests/pmc_to_json.py; separate --pmc passes), or None"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
+            return json.load(f)["kernels"][kernel]
+    except Exception:
+        return None
+
+
 def measured_traffic(kernel):
-    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC summary of this same command
-    (profiles/pmc_latest.json, produced by tests/pmc_profile.sh + tests/pmc_to_json.py): FETCH_SIZE and
-    WRITE_SIZE are KiB counts collected in separate passes; on gfx950 FETCH_SIZE under-counts wide coalesced
-    reads by 2x (MI355X_MICROARCH.md §HBM), so reads are doubled.  None if no profile is committed."""
-    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
-    try:
-        with open(path) as f:
-            k = json.load(f)["kernels"][kernel]
-        return {"bytes_per_launch": 2.0 * 1024.0 * k["FETCH_SIZE"] + 1024.0 * k["WRITE_SIZE"], "fetch_kib_raw": k["FETCH_SIZE"],
-                "write_kib_raw": k["WRITE_SIZE"], "batch": k.get("batch"), "source": "profiles/pmc_latest.json"}
-    except Exception:
+    """HBM-side bytes per launch of `kernel`: FETCH_SIZE and WRITE_SIZE are KiB counts.  On gfx950 FETCH_SIZE
+    under-counts wide coalesced reads by 2x (MI355X_MICROARCH.md §HBM); whether that holds for the dword scratch
+    reloads that make up this traffic is unproven, so both readings are reported and `traffic` is the corrected one."""
+    k = _pmc(kernel)
+    if not k or "FETCH_SIZE" not in k:
         return None
+    return {"bytes_per_launch": 2.0 * 1024.0 * k["FETCH_SIZE"] + 1024.0 * k["WRITE_SIZE"],
+            "bytes_per_launch_uncorrected": 1024.0 * k["FETCH_SIZE"] + 1024.0 * k["WRITE_SIZE"],
+            "fetch_kib_raw": k["FETCH_SIZE"], "write_kib_raw": k["WRITE_SIZE"], "batch": k.get("batch"), "source": "profiles/pmc_latest.json"}
 
 
-def measured_valu_issue(kernel):
-    """VALU issue-slot utilisation of `kernel` from the same PMC summary: a 64-wide VALU instruction occupies its
-    16-lane SIMD for 4 cycles, so utilisation = SQ_INSTS_VALU (wave instructions per launch) x 4 cycles /
-    (1024 SIMDs x kernel cycles), kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs.  None if no profile is committed."""
-    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
-    try:
-        with open(path) as f:
-            k = json.load(f)["kernels"][kernel]
-        cycles = k["GRBM_GUI_ACTIVE"] / 8.0
-        return {"valu_wave_instructions_per_launch": k["SQ_INSTS_VALU"], "per_wave": k["SQ_INSTS_VALU"] / k["SQ_WAVES"],
-                "kernel_cycles": cycles, "utilisation": 4.0 * k["SQ_INSTS_VALU"] / (256 * 4 * cycles),
-                "note": "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8); source profiles/pmc_latest.json"}
-    except Exception:
+def measured_valu_issue(kernel, lane_products, probe):
+    """Cost-weighted VALU issue utilisation of `kernel` from the PMC summary and this run's issue-rate probe:
+    SQ_INSTS_VALU wave instructions split into the multiplier class (v_mad_*64 + v_mul_lo: counted exactly from the
+    per-lane product counts of the host instrumentation x the instructions per product) and everything else, each
+    priced at the cycles per wave instruction the probe measured for its class on this device at two waves per SIMD;
+    utilisation = priced cycles / (SIMDs x kernel cycles), kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs."""
+    k = _pmc(kernel)
+    if not k or "SQ_INSTS_VALU" not in k or not probe:
         return None
+    cycles = k["GRBM_GUI_ACTIVE"] / 8.0
+    per_wave = k["SQ_INSTS_VALU"] / k["SQ_WAVES"]
+    n_mul = lane_products["dual"] * (MADS_DUAL + MUL_LO_PER_PRODUCT) + lane_products["single"] * (MADS_SINGLE + MUL_LO_PER_PRODUCT)
+    n_other = max(per_wave - n_mul, 0.0)
+    # the probe's rates are wall-clock; convert to cycles of THIS kernel's clock (kernel cycles / kernel seconds)
+    c_mul, c_other = probe["cycles_per_wave_inst_mad"], probe["cycles_per_wave_inst_add"]
+    priced = (n_mul * c_mul + n_other * c_other) * k["SQ_WAVES"]
+    return {"valu_wave_instructions_per_launch": k["SQ_INSTS_VALU"], "per_wave": per_wave, "multiplier_class_per_wave": n_mul,
+            "other_per_wave": n_other, "cycles_per_wave_inst": {"multiplier_class": c_mul, "other": c_other},
+            "kernel_cycles": cycles, "utilisation": priced / (probe["n_simd"] * cycles),
+            "utilisation_flat_4_cycles": 4.0 * k["SQ_INSTS_VALU"] / (probe["n_simd"] * cycles),
+            "note": "cost-weighted: (N_mul x c_mul + N_other x c_other) / (SIMDs x GRBM_GUI_ACTIVE / 8); c_* from bn254_probe_issue_rate "
+                    "in this process at 2.4 GHz nominal; source profiles/pmc_latest.json"}
 
 
-def other_workloads(args, torch, eng, dev):
-    """informational timings of configs 3-5 and of the host-buffer (PCIe-inclusive) verify; one JSON line"""
-    import numpy as np
-    from tests.datagen import KEY_POOL, make_verify_batch, sk_bytes
-    stream = torch.cuda.current_stream().cuda_stream
+def issue_probe(eng):
+    """multiplier and plain-VALU issue rates of this device, measured now (two waves per SIMD like the pair kernels)"""
+    mad, simds = eng.probe_issue_rate(0, 2)
+    add, _ = eng.probe_issue_rate(1, 2)
+    mul_lo, _ = eng.probe_issue_rate(2, 2)
+    mad8, _ = eng.probe_issue_rate(0, 8)
+    return {"n_simd": simds, "waves_per_simd": 2, "mad_u64_u32_wave_inst_per_s": mad, "add_u32_wave_inst_per_s": add,
+            "mul_lo_u32_wave_inst_per_s": mul_lo, "mad_u64_u32_wave_inst_per_s_8_waves": mad8,
+            "peak_mac32_measured": 64.0 * max(mad, mad8),
+            "cycles_per_wave_inst_mad": simds * 2.4e9 / mad, "cycles_per_wave_inst_add": simds * 2.4e9 / add,
+            "cycles_per_wave_inst_mul_lo": simds * 2.4e9 / mul_lo}
+
+
+def other_workloads(args, torch, eng, dev, stream):
+    """informational timings of configs 2 (aggregate) and 4 (hash) and of the host-buffer (PCIe-inclusive) verify;
+    one JSON line, single GPU"""
+    from tests.datagen import make_verify_batch, sk_bytes
+    sh = stream.cuda_stream
 
     def timed(fn, steps, warmup):
         for _ in range(warmup):
@@ -119,7 +161,7 @@ def other_workloads(args, torch, eng, dev):
 
     out = {"workload": args.workload, "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "data": "synthetic"}
     if args.workload == "verify-host":
-        n = args.batch
+        n = args.batch or BATCH
         msgs, sigs, pks, expected = make_verify_batch(eng, n)
         assert eng.batch_verify(msgs, sigs, pks) == expected
         packed = bn254_pack(msgs)
@@ -132,7 +174,7 @@ def other_workloads(args, torch, eng, dev):
     elif args.workload == "verify-compressed":
         # configs[1] tuples given as the compressed wire encodings (33-byte signatures, 65-byte public keys), device resident
         from bn254_amd import PublicKey, Signature
-        n = args.batch
+        n = args.batch or BATCH
         msgs, sigs, pks, expected = make_verify_batch(eng, n)
         cache = {}
 
@@ -148,14 +190,14 @@ def other_workloads(args, torch, eng, dev):
         eng.reserve(n)
         lib, h = eng._lib, eng._h
         dt = timed(lambda: lib.bn254_batch_verify_compressed_device(h, d_msgs.data_ptr(), d_off.data_ptr(), d_sc.data_ptr(), d_pc.data_ptr(), n,
-                                                                    d_st.data_ptr(), stream), args.steps, args.warmup)
+                                                                    d_st.data_ptr(), sh), args.steps, args.warmup)
         assert bytes(d_st.cpu().numpy()) == expected
         out.update(metric="BN254 pairings/sec (batch verify from compressed encodings: square roots + subgroup test on decode)", value=2 * n / dt,
                    unit="pairings/s", ms_per_step=1e3 * dt, batch=n)
     elif args.workload == "verify-randomized":
         # opt-in randomised batch verification against the exact path on the same inputs;
         # generated in chunks so that the message list stays small on the host
-        n = args.batch if args.batch != BATCH else 1 << 20
+        n = args.batch or (1 << 20)
         seed = hashlib.sha256(b"bench-seed").digest()
         eng.set_option(5, 0)                                  # BN254_OPT_RAND_MIN_BATCH: time the randomised kernels at every size
         chunk = 1 << 16
@@ -169,42 +211,26 @@ def other_workloads(args, torch, eng, dev):
         ptrs = (d_msgs.data_ptr(), d_off.data_ptr(), d_sigs.data_ptr(), d_pks.data_ptr(), n)
         res = {}
         for name, flags in (("rand128", 0), ("rand128_glv", 0x200), ("rand64", 0x100)):
-            dt = timed(lambda: eng.batch_verify_randomized_device(*ptrs, seed, d_st.data_ptr(), d_gr.data_ptr(), flags=flags, stream=stream),
+            dt = timed(lambda: eng.batch_verify_randomized_device(*ptrs, seed, d_st.data_ptr(), d_gr.data_ptr(), flags=flags, stream=sh),
                        args.steps, args.warmup)
             assert int(d_st.max()) == 0 and int(d_gr.min()) == 1
             res[name] = {"verifies_per_s": n / dt, "ms_per_step": 1e3 * dt}
-        dt = timed(lambda: eng.batch_verify_device(*ptrs, d_st.data_ptr(), flags=0, stream=stream), args.steps, args.warmup)
+        dt = timed(lambda: eng.batch_verify_device(*ptrs, d_st.data_ptr(), flags=0, stream=sh), args.steps, args.warmup)
         assert int(d_st.max()) == 0
         res["exact"] = {"verifies_per_s": n / dt, "ms_per_step": 1e3 * dt}
         # worst case: one corrupted item in every group of 64 -> every group fails and is re-verified exactly
         sig_view = d_sigs.view(n, 64)
         saved = sig_view[63::64].clone()
         sig_view[63::64] = sig_view[62::64]
-        dt = timed(lambda: eng.batch_verify_randomized_device(*ptrs, seed, d_st.data_ptr(), d_gr.data_ptr(), stream=stream), args.steps, args.warmup)
+        dt = timed(lambda: eng.batch_verify_randomized_device(*ptrs, seed, d_st.data_ptr(), d_gr.data_ptr(), stream=sh), args.steps, args.warmup)
         assert int(d_gr.max()) == 0 and int((d_st != 0).sum()) == n // 64 and int(d_st.view(-1)[63::64].min()) == 9
         sig_view[63::64] = saved
         res["rand128_every_group_fails"] = {"verifies_per_s": n / dt, "ms_per_step": 1e3 * dt}
         out.update(metric="BN254 verifies/sec, randomised batch verification (groups of 64) vs exact, all-valid batch", unit="verifies/s",
                    value=res["rand128"]["verifies_per_s"], ms_per_step=res["rand128"]["ms_per_step"], batch=n, modes=res,
                    speedup_vs_exact=res["rand128"]["verifies_per_s"] / res["exact"]["verifies_per_s"])
-    elif args.workload == "pairing":
-        n = args.batch if args.batch != BATCH else 1 << 19          # config 4: 4 Mi pairings over 8 GPUs
-        pool = 512
-        sc = [hashlib.sha256(b"cfg4-%d" % j).digest() for j in range(2 * pool)]
-        g1 = (1).to_bytes(32, "big") + (2).to_bytes(32, "big")
-        P, _ = eng.batch_g1_mul(g1 * pool, b"".join(sc[:pool]), pool, reduce_scalar=True)
-        Qs, _ = eng.batch_g2_mul(None, b"".join(sc[pool:]), pool, reduce_scalar=True)
-        i = np.arange(n)
-        d_g1 = torch.from_numpy(np.frombuffer(P, dtype=np.uint8).reshape(pool, 64)[(i * 7 + 3) % pool].reshape(-1).copy()).to(dev)
-        d_g2 = torch.from_numpy(np.frombuffer(Qs, dtype=np.uint8).reshape(pool, 128)[(i * 13 + 5) % pool].reshape(-1).copy()).to(dev)
-        d_gt = torch.empty(n * 384, dtype=torch.uint8, device=dev)
-        d_st = torch.empty(n, dtype=torch.uint8, device=dev)
-        eng.reserve(n)
-        dt = timed(lambda: eng.batch_pairing_device(d_g1.data_ptr(), d_g2.data_ptr(), n, 1, d_gt.data_ptr(), d_st.data_ptr(), stream=stream),
-                   args.steps, args.warmup)
-        out.update(metric="BN254 pairings/sec (independent pairings, canonical Gt out)", value=n / dt, unit="pairings/s", ms_per_step=1e3 * dt, batch=n)
     elif args.workload == "hash":
-        n = args.batch if args.batch != BATCH else 1 << 24          # config 5: 16 Mi messages
+        n = args.batch or (1 << 24)                                 # config 4: 16 Mi messages
         g = torch.Generator(device=dev)
         g.manual_seed(5)
         d_msgs = torch.randint(0, 256, (n * 32,), dtype=torch.uint8, device=dev, generator=g)
@@ -212,12 +238,12 @@ def other_workloads(args, torch, eng, dev):
         d_pts = torch.empty(n * 64, dtype=torch.uint8, device=dev)
         d_st = torch.empty(n, dtype=torch.uint8, device=dev)
         eng.reserve(n)
-        dt = timed(lambda: eng.batch_hash_to_g1_device(d_msgs.data_ptr(), d_off.data_ptr(), n, d_pts.data_ptr(), d_st.data_ptr(), None, stream=stream),
+        dt = timed(lambda: eng.batch_hash_to_g1_device(d_msgs.data_ptr(), d_off.data_ptr(), n, d_pts.data_ptr(), d_st.data_ptr(), None, stream=sh),
                    args.steps, args.warmup)
         assert int(d_st.max()) == 0
         out.update(metric="hash_to_try_and_increment messages/sec", value=n / dt, unit="messages/s", ms_per_step=1e3 * dt, batch=n)
     else:
-        n = args.batch if args.batch != BATCH else 1 << 20          # config 3: 1 Mi tuples, 1024 signers
+        n = args.batch or (1 << 20)                                 # config 2: 1 Mi tuples, 1024 signers
         M = S = 1024
         sks = [sk_bytes(j) for j in range(S)]
         msgs = [D("bn254/msg3", m) for m in range(M)]
@@ -239,7 +265,7 @@ def other_workloads(args, torch, eng, dev):
         d_st = torch.empty(n, dtype=torch.uint8, device=dev)
         dt = timed(lambda: eng.batch_aggregate_verify_device(d_msgs.data_ptr(), d_moff.data_ptr(), M, d_pk.data_ptr(), S, d_sig.data_ptr(),
                                                              tuple_msg.data_ptr(), tuple_off.data_ptr(), signer_idx.data_ptr(), n, d_st.data_ptr(),
-                                                             stream=stream), args.steps, args.warmup)
+                                                             stream=sh), args.steps, args.warmup)
         assert int(d_st.max()) == 0
         out.update(metric="aggregate verifies/sec (1024 signers, ~512 per tuple, pools decoded per step)", value=n / dt, unit="verifies/s",
                    ms_per_step=1e3 * dt, batch=n, mean_signers_per_tuple=float(signer_idx.numel()) / n)
@@ -251,56 +277,137 @@ def bn254_pack(msgs):
     return pack_messages(msgs)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=BATCH, help="tuples per GPU per step")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-pair-lanes", action="store_true", help="one lane per verify instead of lane pairs (A/B)")
-    ap.add_argument("--split-miller", action="store_true", help="one pairing per lane instead of the fused 2-pair Miller loop (A/B)")
-    ap.add_argument("--workload", default="verify", choices=["verify", "verify-host", "verify-compressed", "verify-randomized", "pairing", "hash", "aggregate"],
-                    help="verify = the headline (configs[1]); the others time configs 4, 5, 3 or the host-buffer entry point "
-                         "(single GPU, informational — see DESIGN.md §4b)")
-    args = ap.parse_args()
+# ------------------------------------------------------------------------------------------------------------
+# launcher: `bench.py --gpus N` without an external torchrun
+# ------------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
 
-    import torch
-    import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    # test knobs (not used by the driver): run several ranks on ONE GPU over gloo to exercise the rank logic
-    backend = os.environ.get("BN254_BENCH_BACKEND", "nccl")
-    if os.environ.get("BN254_BENCH_SINGLE_DEVICE") == "1":
-        local_rank = 0
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend=backend)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device (bn254_amd has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+def launch_ranks(args, argv):
+    """Parent of an N-rank run.  Makes no GPU call and imports no torch: it starts
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N … bench.py <argv>` as a CHILD process (never an
+    exec), relays the single JSON line of rank 0 and returns non-zero if any rank failed or no line was printed."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["MASTER_ADDR"] = "127.0.0.1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus, "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    for ln in proc.stdout.splitlines():
+        if ln not in lines:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0:
+        print("bench.py: a rank failed (torchrun exit code %d)" % proc.returncode, file=sys.stderr)
+        return proc.returncode
+    if len(lines) != 1:
+        print("bench.py: expected one JSON line from rank 0, got %d" % len(lines), file=sys.stderr)
+        return 1
+    print(lines[0])
+    return 0
 
+
+class Rank:
+    """what a rank knows: its place in the job, its device, the stream everything runs on"""
+
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if args.gpus > 1 and self.world != args.gpus:
+            raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, self.world))
+        # test knobs (not used by the driver): several ranks on ONE GPU over gloo exercise the rank logic on a 1-GPU box
+        self.backend = os.environ.get("BN254_BENCH_BACKEND", "nccl")
+        if os.environ.get("BN254_BENCH_SINGLE_DEVICE") == "1":
+            self.local_rank = 0
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a HIP device (bn254_amd has no CPU fallback)")
+        torch.cuda.set_device(self.local_rank)
+        self.dev = torch.device("cuda", self.local_rank)
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            if self.backend == "nccl":
+                dist.init_process_group(backend="nccl", device_id=self.dev)
+            else:
+                dist.init_process_group(backend=self.backend)
+            assert dist.get_world_size() == self.world
+        # ONE explicit stream carries the kernels of the library (its handle is passed to every *_device call), the
+        # torch ops that prepare the inputs, and the RCCL collectives (torch orders a collective after the current
+        # stream) — no reliance on the null stream or on the context's private non-blocking stream.
+        self.stream = torch.cuda.Stream(device=self.dev)
+
+    def gather(self, local_status, out):
+        """the one collective of a verify step: all-gather of the status bytes (RCCL over xGMI)"""
+        from bn254_amd.sharding import gather_status
+        if self.backend == "nccl":
+            gather_status(local_status, out=out)
+        else:                                                       # gloo test mode: staged through the host
+            out.copy_(gather_status(local_status.cpu()))
+
+    def allreduce_checksum(self, local_sum):
+        from bn254_amd.sharding import allreduce_checksum
+        return allreduce_checksum(local_sum if self.backend == "nccl" else local_sum.cpu())
+
+    def time_steps(self, step, steps, warmup, after_warmup=None, per_step=None):
+        """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks"""
+        torch, dist = self.torch, self.dist
+        with torch.cuda.stream(self.stream):
+            for k in range(warmup):
+                step(k)
+            torch.cuda.synchronize()
+            if after_warmup:
+                after_warmup()
+            if self.world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(steps):
+                step(warmup + k)
+                if per_step:
+                    per_step()
+            if self.world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            elapsed = time.perf_counter() - t0
+        if self.world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed
+
+    def finish(self):
+        if self.world > 1:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def corrupt_phase(rank, step):
+    """which residue (mod CORRUPT_EVERY) of a shard carries the wrong signature: depends on the rank AND on the
+    step parity, so a gather that returned another rank's or a stale step's statuses is caught"""
+    return (CORRUPT_EVERY - 1 - rank - (CORRUPT_EVERY // 2) * (step & 1)) % CORRUPT_EVERY
+
+
+def run_verify(args, R):
+    torch = R.torch
     import bn254_amd
-    from bn254_amd.sharding import gather_status
     from tests.datagen import KEY_POOL, sk_bytes
-
-    eng = bn254_amd.Engine(local_rank)
-    if args.workload != "verify":
-        return other_workloads(args, torch, eng, dev)
-    n = args.batch
+    eng = bn254_amd.Engine(R.local_rank)
+    n = args.batch or BATCH
     eng.reserve(2 * n)
     if args.split_miller:
         eng.set_option(1, 1)
     if args.no_pair_lanes:
         eng.set_option(4, 0)
-
+    rank, world, dev = R.rank, R.world, R.dev
 
     # ---- synthetic inputs, generated on the GPU by the product's own sign / keygen kernels -------
     base = rank * n                                          # each rank owns a distinct shard
@@ -309,63 +416,73 @@ def main():
     sks = [sk_bytes(j) for j in range(pool)]
     pk_pool, st = eng.batch_g2_mul(None, b"".join(sks), pool, reduce_scalar=True)
     assert st == bytes(pool)
-    sigs, st = eng.batch_sign(msgs, b"".join(sks[(base + i) % pool] for i in range(n)))
+    good, st = eng.batch_sign(msgs, b"".join(sks[(base + i) % pool] for i in range(n)))
     assert st == bytes(n)
-    sigs = bytearray(sigs)
-    expected = bytearray(n)
-    good = bytes(sigs)
-    for i in range(CORRUPT_EVERY - 1, n, CORRUPT_EVERY):
-        sigs[64 * i:64 * i + 64] = good[64 * (i - 1):64 * i]
-        expected[i] = 9
     pks = b"".join(pk_pool[128 * ((base + i) % pool):128 * ((base + i) % pool) + 128] for i in range(n))
 
-    def to_dev(b, dtype=torch.uint8):
-        return torch.frombuffer(bytearray(b), dtype=dtype).to(dev)
+    def corrupted(phase):
+        """signatures with every item at residue `phase` replaced by its neighbour's (valid point, wrong message)"""
+        sigs = bytearray(good)
+        for i in range(phase, n, CORRUPT_EVERY):
+            j = i - 1 if i else i + 1
+            sigs[64 * i:64 * i + 64] = good[64 * j:64 * j + 64]
+        return bytes(sigs)
 
-    d_msgs = to_dev(b"".join(msgs))
-    d_off = torch.arange(0, 32 * (n + 1), 32, dtype=torch.int64, device=dev)
-    d_sigs = to_dev(bytes(sigs))
-    d_pks = to_dev(pks)
-    d_status = torch.zeros(n, dtype=torch.uint8, device=dev)
-    d_all = torch.zeros(n * world, dtype=torch.uint8, device=dev) if world > 1 else None
-    stream = torch.cuda.current_stream().cuda_stream
+    def expected_for(r, step, length=n):
+        e = bytearray(length)
+        for i in range(corrupt_phase(r, step), length, CORRUPT_EVERY):
+            e[i] = 9
+        return bytes(e)
 
-    def step():
-        eng.batch_verify_device(d_msgs.data_ptr(), d_off.data_ptr(), d_sigs.data_ptr(), d_pks.data_ptr(), n, d_status.data_ptr(),
-                                flags=0, stream=stream)
+    with torch.cuda.stream(R.stream):
+        def to_dev(b):
+            return torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+        d_msgs = to_dev(b"".join(msgs))
+        d_off = torch.arange(0, 32 * (n + 1), 32, dtype=torch.int64, device=dev)
+        sig_sets = [corrupted(corrupt_phase(rank, 0)), corrupted(corrupt_phase(rank, 1))]
+        d_sigs = [to_dev(sig_sets[0]), to_dev(sig_sets[1])]
+        d_pks = to_dev(pks)
+        d_status = torch.zeros(n, dtype=torch.uint8, device=dev)
+        d_all = torch.zeros(n * world, dtype=torch.uint8, device=dev) if world > 1 else None
+    sh = R.stream.cuda_stream
+    assert sh != 0
+
+    def step(k):
+        eng.batch_verify_device(d_msgs.data_ptr(), d_off.data_ptr(), d_sigs[k & 1].data_ptr(), d_pks.data_ptr(), n, d_status.data_ptr(),
+                                flags=0, stream=sh)
         if world > 1:
-            if backend == "nccl":
-                gather_status(d_status, out=d_all)           # RCCL all-gather over xGMI: the only collective
-            else:
-                d_all.copy_(gather_status(d_status.cpu()))   # gloo test mode: staged through the host
+            R.gather(d_status, d_all)                        # the only collective
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    # parity gate before any timing is accepted: device statuses == expected pattern
-    got = bytes(d_status.cpu().numpy())
-    assert got == bytes(expected), "GPU status bytes differ from the expected pattern"
+    checks = {"steps_checked": 0, "mismatches": 0}
+
+    def check(step_index):
+        """device statuses (own shard, and every shard of the gathered vector) == the pattern of that step"""
+        torch.cuda.synchronize()
+        got = bytes(d_status.cpu().numpy())
+        bad = int(got != expected_for(rank, step_index))
+        if world > 1:
+            allst = bytes(d_all.cpu().numpy())
+            for r in range(world):
+                bad += int(allst[r * n:(r + 1) * n] != expected_for(r, step_index))
+        checks["steps_checked"] += 1
+        checks["mismatches"] += bad
+        return bad == 0
 
     eng.set_profiling(True)
     kernel_ms = {"decode": 0.0, "hash_to_g1": 0.0, "miller_loop": 0.0, "final_exp": 0.0}
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        ms = eng.last_kernel_ms()                            # HIP events on the launch stream
-        for k in kernel_ms:
-            kernel_ms[k] += ms[k]
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        assert bytes(d_all[rank * n:(rank + 1) * n].cpu().numpy()) == bytes(expected)
+
+    def after_warmup():
+        # parity gate before any timing is accepted
+        assert args.warmup == 0 or check(args.warmup - 1), "GPU status bytes differ from the expected pattern"
+
+    def per_step():
+        ms = eng.last_kernel_ms()                            # HIP events on the launch stream (synchronises it)
+        for key in kernel_ms:
+            kernel_ms[key] += ms[key]
+
+    elapsed = R.time_steps(step, args.steps, args.warmup, after_warmup, per_step)
+    ok_last = check(args.warmup + args.steps - 1)            # the LAST step's pattern (differs from the one before)
+    assert ok_last, "GPU status bytes of the last timed step differ from the expected pattern"
 
     verifies = n * world * args.steps
     verifies_per_s = verifies / elapsed
@@ -383,8 +500,10 @@ def main():
         "dtype": "u32",
         "data": "synthetic",
         "config": {"workload": "configs[1]: batch of 65536 independent e(H(m),pk)*e(sig,-G2)==1 verifies per GPU "
-                               "(32-byte messages, 1/64 corrupted), 2 pairings per verify",
-                   "batch_per_gpu": n, "verifies_per_s": verifies_per_s, "bit_exact_vs_expected": True},
+                               "(32-byte messages, 1/64 corrupted, pattern alternates per step and differs per rank), 2 pairings per verify",
+                   "batch_per_gpu": n, "verifies_per_s": verifies_per_s,
+                   "bit_exact_vs_expected": checks["mismatches"] == 0, "status_vectors_checked": checks["steps_checked"] * (1 + (world if world > 1 else 0)),
+                   "collective": "all_gather_into_tensor(status bytes) per step over %s" % R.backend if world > 1 else None},
     }
 
     if rank == 0:
@@ -397,22 +516,21 @@ def main():
         mac_per_launch = fp_mul * MAC32_PER_FP_MUL * n
         achieved = mac_per_launch / (k_avg[dom] * 1e-3) / 1e12
         io_bytes = BYTES_PER_VERIFY_IO * n
+        probe = issue_probe(eng) if world == 1 else None
+        lane_products = lane_product_counts().get(kname)
+        traffic = measured_traffic(kname)
         result["roofline"] = {
             "bound": "valu",                       # integer multiply issue (v_mad_u64_u32); not HBM, not MFMA
             "kernel": kname,
             "layout": "one verify per lane pair (Fq2 coefficients in adjacent lanes), two waves per SIMD" if pair else "one verify per lane",
             "achieved": achieved, "peak": PEAK_MAC32_THEORETICAL / 1e12, "unit": "TMAC32/s",
             "frac": achieved / (PEAK_MAC32_THEORETICAL / 1e12),
-            "peak_measured_microbench": PEAK_MAC32_MEASURED / 1e12,
-            "frac_of_measured_peak": achieved / (PEAK_MAC32_MEASURED / 1e12),
-            # register-resident chains of the same product routines (profiles/r01_fp_mul_chain_ceiling.jsonl):
-            # 8.16e10 Fq products/s with one wave per SIMD, 1.37e11 when the multiplier pipe is saturated
-            "frac_of_occupancy1_product_ceiling": None if pair else (fp_mul * n / (k_avg[dom] * 1e-3)) / 8.16e10,   # one-lane layout only
-            "frac_of_saturated_product_rate": (fp_mul * n / (k_avg[dom] * 1e-3)) / 1.37e11,
-            "traffic": (measured_traffic(kname) or {}).get("bytes_per_launch"),   # HBM bytes per launch (PMC), private-segment traffic
-            "traffic_detail": measured_traffic(kname),
-            "valu_issue": measured_valu_issue(kname),
-            "multiplier_issue_frac": (fp_mul * MUL_INSTR_PER_FP_MUL * n / (k_avg[dom] * 1e-3)) / PEAK_MAC32_THEORETICAL,
+            "peak_measured_in_this_run": probe["peak_mac32_measured"] / 1e12 if probe else None,
+            "frac_of_measured_peak": achieved / (probe["peak_mac32_measured"] / 1e12) if probe else None,
+            "issue_probe": probe,
+            "traffic": (traffic or {}).get("bytes_per_launch"),   # HBM bytes per launch (PMC), private-segment traffic
+            "traffic_detail": traffic,
+            "valu_issue": measured_valu_issue(kname, lane_products, probe) if lane_products else None,
             "kernel_ms": k_avg,
             "mac32_per_verify": {"miller_loop": FP_MUL_MILLER * MAC32_PER_FP_MUL, "final_exp": FP_MUL_FINAL_EXP * MAC32_PER_FP_MUL,
                                  "hash_to_g1_mean": (FP_MUL_HASH_FILTER * 2.12 + FP_MUL_HASH_FINISH) * MAC32_PER_FP_MUL, "decode": FP_MUL_DECODE * MAC32_PER_FP_MUL},
@@ -423,23 +541,162 @@ def main():
             from oracle import c_oracle
             cores = effective_cores()
             sample = min(n, 8192)                            # ~11 CPU-seconds of work in total (1.4 ms per verify)
+            last = args.warmup + args.steps - 1
             t1 = time.perf_counter()
-            st_cpu, _ = c_oracle.batch_verify(msgs[:sample], bytes(sigs[:64 * sample]), pks[:128 * sample], flags=0, nthreads=cores)
+            st_cpu, _ = c_oracle.batch_verify(msgs[:sample], sig_sets[last & 1][:64 * sample], pks[:128 * sample], flags=0, nthreads=cores)
             dt_all = time.perf_counter() - t1
-            assert st_cpu == bytes(expected[:sample]), "oracle disagrees with the expected pattern"
+            assert st_cpu == expected_for(0, last, sample), "oracle disagrees with the expected pattern"
             one = min(sample, 256)
             t1 = time.perf_counter()
-            c_oracle.batch_verify(msgs[:one], bytes(sigs[:64 * one]), pks[:128 * one], flags=0, nthreads=1)
+            c_oracle.batch_verify(msgs[:one], sig_sets[last & 1][:64 * one], pks[:128 * one], flags=0, nthreads=1)
             dt_one = time.perf_counter() - t1
             result["cpu_baseline"] = {
                 "value": 2.0 * sample / dt_all, "unit": "pairings/s", "cores": cores, "kind": "port",
                 "sample": "first %d tuples of the same batch, oracle/bn254_oracle.c (C restatement of the reference path, "
-                          "4x64-bit Montgomery limbs, pthreads, gcc -O2)" % sample,
+                          "4x64-bit Montgomery limbs, pthreads, gcc -O2); statuses equal the GPU's" % sample,
                 "single_thread_value": 2.0 * one / dt_one,
             }
         print(json.dumps(result))
-    if world > 1:
-        dist.destroy_process_group()
+    R.finish()
+
+
+def lane_product_counts():
+    """per-lane product counts of the pair kernels (dual-accumulated products / single products incl. squares) from
+    the host instrumentation, committed by tests/test_workcount.py as profiles/lane_product_counts.json"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "lane_product_counts.json")) as f:
+            return json.load(f)
+    except Exception:
+        return {}
+
+
+def pairing_indices(np, base, n, pool):
+    """(P index, Q index) of global item g = base + i: period pool^2, so shards of different ranks differ"""
+    g = np.arange(base, base + n, dtype=np.int64)
+    return (g * 7 + 3) % pool, (g * 13 + 5 + (g // pool) * 29) % pool
+
+
+def run_pairing(args, R):
+    """BASELINE configs[3]: independent pairings e(P_i, Q_i) -> canonical Gt (384 B, stays in HBM) + status byte
+    (Gt != 1), sharded over the ranks; per step: kernels, 64-bit additive Gt checksum, status all-gather, checksum
+    all-reduce.  Unit = one Miller loop + one final exponentiation."""
+    import numpy as np
+    torch = R.torch
+    import bn254_amd
+    from bn254_amd.sharding import gt_checksum
+    eng = bn254_amd.Engine(R.local_rank)
+    n = args.batch or PAIRING_BATCH
+    pool = min(4096, max(2, n))
+    rank, world, dev = R.rank, R.world, R.dev
+    sc = [hashlib.sha256(b"cfg4-%d" % j).digest() for j in range(2 * pool)]
+    g1 = (1).to_bytes(32, "big") + (2).to_bytes(32, "big")
+    P, st1 = eng.batch_g1_mul(g1 * pool, b"".join(sc[:pool]), pool, reduce_scalar=True)
+    Qs, st2 = eng.batch_g2_mul(None, b"".join(sc[pool:]), pool, reduce_scalar=True)
+    assert st1 == bytes(pool) and st2 == bytes(pool)
+    Pn = np.frombuffer(P, dtype=np.uint8).reshape(pool, 64)
+    Qn = np.frombuffer(Qs, dtype=np.uint8).reshape(pool, 128)
+    pi, qi = pairing_indices(np, rank * n, n, pool)
+    with torch.cuda.stream(R.stream):
+        d_g1 = torch.from_numpy(Pn[pi].reshape(-1).copy()).to(dev)
+        d_g2 = torch.from_numpy(Qn[qi].reshape(-1).copy()).to(dev)
+        d_gt = torch.empty(n * 384, dtype=torch.uint8, device=dev)
+        d_st = torch.zeros(n, dtype=torch.uint8, device=dev)
+        d_all = torch.zeros(n * world, dtype=torch.uint8, device=dev) if world > 1 else None
+    eng.reserve(n)
+    sh = R.stream.cuda_stream
+    state = {"sum": None, "sums": set()}
+
+    def step(k):
+        eng.batch_pairing_device(d_g1.data_ptr(), d_g2.data_ptr(), n, 1, d_gt.data_ptr(), d_st.data_ptr(), stream=sh)
+        local = gt_checksum(d_gt)
+        if world > 1:
+            R.gather(d_st, d_all)
+        state["sum"] = R.allreduce_checksum(local)           # 8-byte all-reduce (a host read: ends the step)
+        state["sums"].add(state["sum"])
+
+    def after_warmup():
+        torch.cuda.synchronize()
+        assert int(d_st.min()) == 9 and int(d_st.max()) == 9, "a pairing of two non-identity points came out as one"
+        if world > 1:
+            assert int(d_all.min()) == 9 and int(d_all.max()) == 9
+
+    elapsed = R.time_steps(step, args.steps, args.warmup, after_warmup)
+    torch.cuda.synchronize()
+    # size-independent properties on the full shard: items with equal (P, Q) have equal Gt bytes; the checksum is
+    # the same in every step (same inputs); statuses all "not one"
+    gt = d_gt.view(n, 384)
+    key = torch.from_numpy(pi * pool + qi).to(dev)
+    order = torch.argsort(key)
+    same = key[order][1:] == key[order][:-1]
+    dup_ok = bool((gt[order][1:][same] == gt[order][:-1][same]).all()) if bool(same.any()) else True
+    assert dup_ok, "items with identical inputs produced different Gt bytes"
+    assert len(state["sums"]) == 1, "Gt checksum changed between steps"
+    assert int(d_st.min()) == 9 and int(d_st.max()) == 9
+    total = n * world * args.steps
+    result = {
+        "metric": "BN254 pairings/sec (independent pairings, canonical Gt out)",
+        "value": total / elapsed, "unit": "pairings/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
+        "data": "synthetic",
+        "config": {"workload": "configs[3]: independent pairings e(P_i,Q_i) sharded over the GPUs, %d per GPU (pool of %d P x %d Q combined by "
+                               "index), 1 Miller loop + 1 final exponentiation each, Gt stays in HBM" % (n, pool, pool),
+                   "batch_per_gpu": n, "gt_checksum_u64": "%016x" % state["sum"], "duplicate_inputs_equal_gt": dup_ok,
+                   "collective": ("all_gather_into_tensor(status bytes) + all_reduce(sum, 8-byte Gt checksum) per step over %s" % R.backend) if world > 1 else None},
+    }
+    if rank == 0:
+        ms = 1e3 * elapsed / args.steps
+        fp_mul = FP_MUL_MILLER_SINGLE + FP_MUL_FINAL_EXP
+        achieved = fp_mul * MAC32_PER_FP_MUL * n / (ms * 1e-3) / 1e12
+        result["roofline"] = {"bound": "valu", "kernel": "k_miller_var_pair + k_final_exp_pair (whole step)", "achieved": achieved,
+                              "peak": PEAK_MAC32_THEORETICAL / 1e12, "unit": "TMAC32/s", "frac": achieved / (PEAK_MAC32_THEORETICAL / 1e12), "traffic": None,
+                              "hbm": {"algorithmic_bytes_per_step": BYTES_PER_PAIRING_IO * n, "achieved_GBps": BYTES_PER_PAIRING_IO * n / (ms * 1e-3) / 1e9,
+                                      "peak_GBps": HBM_PEAK_GBPS}}
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import c_oracle
+            cores = effective_cores()
+            sample = min(n, 8192)
+            t1 = time.perf_counter()
+            gt_cpu, st_cpu = c_oracle.batch_pairing(Pn[pi[:sample]].tobytes(), Qn[qi[:sample]].tobytes(), sample, 1, nthreads=cores)
+            dt = time.perf_counter() - t1
+            same_bytes = gt_cpu == gt[:sample].cpu().numpy().tobytes() and st_cpu == bytes([9]) * sample
+            assert same_bytes, "oracle Gt bytes differ from the GPU's"
+            result["cpu_baseline"] = {"value": sample / dt, "unit": "pairings/s", "cores": cores, "kind": "port",
+                                      "sample": "first %d pairings of the shard, oracle/bn254_oracle.c; canonical Gt bytes equal the GPU's" % sample}
+        print(json.dumps(result))
+    R.finish()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=0, help="items per GPU per step (default: the size BASELINE.json names for the workload)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pair-lanes", action="store_true", help="one lane per verify instead of lane pairs (A/B)")
+    ap.add_argument("--split-miller", action="store_true", help="one pairing per lane instead of the fused 2-pair Miller loop (A/B)")
+    ap.add_argument("--workload", default="verify", choices=["verify", "pairing", "verify-host", "verify-compressed", "verify-randomized", "hash", "aggregate"],
+                    help="verify = the headline (configs[1]) and pairing = configs[3]: both run on N ranks; the others time configs 2, 4 or "
+                         "other entry points on one GPU (informational — see DESIGN.md §4b)")
+    args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        if args.workload not in ("verify", "pairing"):
+            raise SystemExit("--workload %s is a single-GPU measurement" % args.workload)
+        sys.exit(launch_ranks(args, sys.argv[1:]))
+
+    R = Rank(args)
+    if args.workload == "verify":
+        return run_verify(args, R)
+    if args.workload == "pairing":
+        return run_pairing(args, R)
+    if R.world != 1:
+        raise SystemExit("--workload %s is a single-GPU measurement" % args.workload)
+    import bn254_amd
+    eng = bn254_amd.Engine(R.local_rank)
+    with R.torch.cuda.stream(R.stream):
+        other_workloads(args, R.torch, eng, R.dev, R.stream)
 
 
 if __name__ == "__main__":

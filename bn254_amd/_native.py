@@ -12,7 +12,7 @@ _CSRC = os.path.join(_PKG, "csrc")
 LIB_PATH = os.environ.get("BN254_LIB", os.path.join(_PKG, "libbn254hip.so"))   # BN254_LIB: A/B-test another build
 _SOURCES = ["bn254_hip.hip", "bn254_pair.hip", "bn254_ws.h", "bn254_fp2_pair.h", "bn254_codec_g2.h", "bn254_field.h", "bn254_curve.h", "bn254_pairing.h", "bn254_hash.h", "bn254_io.h", "gen_constants.py"]
 
-HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC"]
+HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-Wl,--no-undefined"]   # a missing translation unit fails at link time
 
 
 def _stale():
@@ -89,6 +89,8 @@ def load():
     L.bn254_debug_fp_op.argtypes = [vp, i32, vp, vp, sz, vp, vp]
     L.bn254_debug_fp12_op.argtypes = [vp, i32, vp, vp, sz, vp]
     L.bn254_debug_miller_loop.argtypes = [vp, vp, vp, sz, vp]
+    L.bn254_debug_hash_candidate.argtypes = [vp, vp, sz, vp, vp]
+    L.bn254_probe_issue_rate.argtypes = [vp, i32, i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(i32)]
     _lib = L
     return L
 
@@ -100,5 +102,5 @@ EXPORTED_SYMBOLS = [
     "bn254_batch_pairing_check", "bn254_batch_pairing", "bn254_batch_pairing_device", "bn254_batch_check_public_keys",
     "bn254_batch_g1_add", "bn254_batch_g2_add", "bn254_batch_g1_mul", "bn254_batch_g2_mul", "bn254_batch_g1_mul_device",
     "bn254_batch_g2_mul_device", "bn254_batch_sign", "bn254_batch_sign_device", "bn254_batch_g1_sum", "bn254_batch_g2_sum",
-    "bn254_batch_aggregate_verify", "bn254_batch_aggregate_verify_device", "bn254_batch_g1_decompress", "bn254_batch_g2_decompress", "bn254_debug_fp_op", "bn254_debug_fp12_op", "bn254_debug_miller_loop", "bn254_ctx_set_profiling", "bn254_ctx_last_kernel_ms", "bn254_ctx_set_option",
+    "bn254_batch_aggregate_verify", "bn254_batch_aggregate_verify_device", "bn254_batch_g1_decompress", "bn254_batch_g2_decompress", "bn254_debug_fp_op", "bn254_debug_fp12_op", "bn254_debug_miller_loop", "bn254_debug_hash_candidate", "bn254_probe_issue_rate", "bn254_ctx_set_profiling", "bn254_ctx_last_kernel_ms", "bn254_ctx_set_option",
 ]

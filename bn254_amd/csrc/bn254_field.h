@@ -46,9 +46,12 @@
 // the algorithmic-work figure behind bench.py's roofline (1 product = 136 MAC32)
 #if defined(BN_COUNT_FP_MUL) && !defined(__HIPCC__)
 extern "C" unsigned long long bn_fp_mul_counter;
+extern "C" unsigned long long bn_fp_dual_counter;   // of those, dual-accumulated products (pair layout: x0*y0 + x1*y1, one reduction)
 #define BN_COUNT_MUL() (++bn_fp_mul_counter)
+#define BN_COUNT_DUAL() (++bn_fp_dual_counter)
 #else
 #define BN_COUNT_MUL()
+#define BN_COUNT_DUAL()
 #endif
 
 // Hook for kernels that keep two waves on a SIMD (bn254_pair.hip): wave priority cycling 3,2,1,0 with the step

@@ -62,6 +62,7 @@ static inline void bn_trk_dual(Fp& r, const Fp& x0, const Fp& y0, const Fp& x1, 
 BN_DEVN BN_VEC10 fp_dual_impl(BN_VEC10 x0, BN_VEC10 y0, BN_VEC10 x1, BN_VEC10 y1) {
   BN_COUNT_MUL();   // a lane pair spends 2 x 1.5 = the 3 algorithmic products of a Karatsuba Fq2 multiplication;
                     // counted per lane as 1 (host emulation: 2 per Fq2 product)
+  BN_COUNT_DUAL();
   int32_t a[BN_LIMBS], b[BN_LIMBS], c[BN_LIMBS], d[BN_LIMBS], r[BN_LIMBS];
 #pragma unroll
   for (int i = 0; i < BN_LIMBS; ++i) { a[i] = x0[i]; b[i] = y0[i]; c[i] = x1[i]; d[i] = y1[i]; }

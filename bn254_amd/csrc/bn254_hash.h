@@ -129,17 +129,10 @@ BN_DEVN bool u256_is_square_mod_q(const U256& a_in) {
   return (t & 1u) == 0;
 }
 
-// The candidate x of counter `ctr` (hash.rs:40-54): SHA-256(msg || ctr) read big-endian, rejected if >= 5q,
-// reduced by mod_u256's strict rule; false = this counter yields no x.
-BN_DEV bool hash_candidate(U256& x, const HashState& s, const uint8_t* msg, uint64_t len, uint32_t ctr) {
-  uint32_t h[8], blk[16];
-  for (int i = 0; i < 8; ++i) h[i] = s.mid[i];
-  for (uint64_t b = s.first_block; b < s.n_blocks; ++b) {        // hash.rs:41-42  SHA256(msg || ctr)
-    load_block(blk, msg, len, ctr, b, s.padded_len);
-    sha256_compress(h, blk);
-  }
-#pragma unroll
-  for (int i = 0; i < 8; ++i) x.w[i] = h[7 - i];                 // hash.rs:44: digest read big-endian
+// The range rules applied to a digest value x (hash.rs:49-54): rejected if >= 5q, reduced by mod_u256's strict rule;
+// false = this value yields no x.  (Separate from the SHA-256 so that tests can feed chosen values: no preimage of
+// k*q exists — bn254_debug_hash_candidate.)
+BN_DEV bool hash_reduce_candidate(U256& x) {
   if (u256_geq(x.w, C_QMULT[4])) return false;                   // hash.rs:49-51: h >= 5q -> next ctr
   // utils.rs:27-37 mod_u256: while x > q { x -= q } (strict), i.e. x mod q except exact multiples
   // k*q (k >= 1), which stop at q and are then rejected by Fq::from_slice
@@ -158,6 +151,18 @@ BN_DEV bool hash_candidate(U256& x, const HashState& s, const uint8_t* msg, uint
   for (int i = 0; i < 8; ++i) any |= x.w[i];
   return !(was_reduced && any == 0);
 }
+// The candidate x of counter `ctr` (hash.rs:40-54): SHA-256(msg || ctr) read big-endian, then the range rules
+BN_DEV bool hash_candidate(U256& x, const HashState& s, const uint8_t* msg, uint64_t len, uint32_t ctr) {
+  uint32_t h[8], blk[16];
+  for (int i = 0; i < 8; ++i) h[i] = s.mid[i];
+  for (uint64_t b = s.first_block; b < s.n_blocks; ++b) {        // hash.rs:41-42  SHA256(msg || ctr)
+    load_block(blk, msg, len, ctr, b, s.padded_len);
+    sha256_compress(h, blk);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) x.w[i] = h[7 - i];                 // hash.rs:44: digest read big-endian
+  return hash_reduce_candidate(x);
+}
 // x^3 + 3 for a candidate (utils.rs:56-63 arbitrary_string_to_g1 -> G1::from_compressed(0x02 || x))
 BN_DEV void hash_curve_rhs(Fp& xm, Fp& rhs, const U256& x) {
   xm = fp_from_u256(x);
@@ -171,10 +176,8 @@ BN_DEV bool hash_try_filter(const HashState& s, const uint8_t* msg, uint64_t len
   hash_curve_rhs(xm, rhs, x);
   return u256_is_square_mod_q(fp_to_u256(rhs));
 }
-// One try of /root/reference/src/hash.rs:40-59 for counter `ctr`; true iff it yields a point (the even root).
-BN_DEV bool hash_try(G1Affine& out, const HashState& s, const uint8_t* msg, uint64_t len, uint32_t ctr) {
-  U256 x;
-  if (!hash_candidate(x, s, msg, len, ctr)) return false;
+// A reduced candidate x -> the point with the even root (utils.rs:56-63), false if x^3 + 3 is no square
+BN_DEV bool hash_point_from_candidate(G1Affine& out, const U256& x) {
   Fp xm, rhs, y;
   hash_curve_rhs(xm, rhs, x);
   if (!fp_sqrt(y, rhs)) return false;
@@ -182,6 +185,12 @@ BN_DEV bool hash_try(G1Affine& out, const HashState& s, const uint8_t* msg, uint
   if (yp.w[0] & 1) y = fp_norm(fp_neg(y));
   out.x = xm; out.y = y; out.inf = false;
   return true;
+}
+// One try of /root/reference/src/hash.rs:40-59 for counter `ctr`; true iff it yields a point (the even root).
+BN_DEV bool hash_try(G1Affine& out, const HashState& s, const uint8_t* msg, uint64_t len, uint32_t ctr) {
+  U256 x;
+  if (!hash_candidate(x, s, msg, len, ctr)) return false;
+  return hash_point_from_candidate(out, x);
 }
 
 // Scalar of item i for the randomised batch verification (include/bn254_hip.h:

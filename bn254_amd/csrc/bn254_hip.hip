@@ -584,7 +584,7 @@ KERNEL void k_pool_decode_g2(const uint8_t* pts, size_t n, uint32_t flags, Pool 
 // tuple i: agg_sig = sum_s sig_pool[msg_i * S + s], agg_pk = sum_s pk_pool[s] over its signer list
 // (Add for Signature / PublicKey, types.rs:264-270, :126-132); results + H(msg_i) go to the verify planes.
 // A wave walks its lanes' lists in lockstep until the longest is exhausted.
-KERNEL void k_aggregate(const uint32_t* tuple_msg, const uint64_t* tuple_off, const uint32_t* signer_idx, size_t n, size_t n_signers,
+KERNEL void k_aggregate(const uint32_t* tuple_msg, const uint64_t* tuple_off, const uint32_t* signer_idx, size_t n, size_t n_signers, size_t n_msgs,
                         Pool pk_pool, Pool sig_pool, Pool h_pool, Ws ws) {
   size_t i = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
   if (i >= n) return;
@@ -595,6 +595,10 @@ KERNEL void k_aggregate(const uint32_t* tuple_msg, const uint64_t* tuple_off, co
   jac_set_identity(acc1);
   jac_set_identity(acc2);
   uint8_t st = ST_OK;
+  // indices come from caller memory: a message index out of range is IndexOutOfBounds like a signer index, and a
+  // decreasing offset pair is an empty list — never an out-of-range pool read
+  if (m >= n_msgs) { st = ST_INDEX_OOB; m = 0; }
+  if (hi < lo) { if (st == ST_OK) st = ST_INDEX_OOB; hi = lo; }
   uint64_t longest = hi - lo;
   for (int off = 32; off > 0; off >>= 1) {
     uint64_t other = __shfl_xor((unsigned long long)longest, off, BN_WAVE);
@@ -672,6 +676,30 @@ KERNEL_SMALL void k_debug_fp_op(int op, const uint8_t* a, const uint8_t* b, size
   fp_to_be(out + 32 * i, r);
   status[i] = st;
 }
+// The try loop's treatment of ONE chosen digest value (32 B big-endian): range rules + mod_u256, the Jacobi filter of
+// k_hash_round and the square root of k_hash_finish.  status 0 = yields the point written to out, 1 = next counter;
+// bit 7 set = filter and square root disagree (never expected).
+KERNEL_SMALL void k_debug_hash_candidate(const uint8_t* h, size_t n, uint8_t* out, uint8_t* status) {
+  size_t i = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
+  if (i >= n) return;
+  U256 x;
+  const uint32_t* w = (const uint32_t*)(h + 32 * i);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) x.w[7 - k] = __builtin_bswap32(w[k]);
+  bool cand = hash_reduce_candidate(x);
+  bool filt = false, ok = false;
+  G1Affine p;
+  g1_set_generator(p);
+  if (cand) {
+    Fp xm, rhs;
+    hash_curve_rhs(xm, rhs, x);
+    filt = u256_is_square_mod_q(fp_to_u256(rhs));
+    ok = hash_point_from_candidate(p, x);
+  }
+  if (!ok) p.inf = true;
+  encode_g1(out + 64 * i, p);
+  status[i] = (uint8_t)((ok ? 0 : 1) | (filt != ok ? 0x80 : 0));
+}
 __device__ __forceinline__ void decode_fp12(Fp12& f, const uint8_t* b) {
   uint32_t any = 0;
   Fp2* c[6] = {&f.c0.c0, &f.c0.c1, &f.c0.c2, &f.c1.c0, &f.c1.c1, &f.c1.c2};
@@ -695,6 +723,40 @@ KERNEL void k_debug_fp12_op(int op, const uint8_t* a, const uint8_t* b, size_t n
     default: { Fp12 acc; final_exponentiation(r, x, acc); } break;
   }
   encode_fp12(out + 384 * i, r);
+}
+
+// ---- in-process issue-rate probe (bench.py's roofline calibration) --------------------------------------------
+// 16 independent chains of one instruction, 4096 trips, on every SIMD of the device with `waves_per_simd` waves each
+// (256-thread workgroups = one wave per SIMD of a CU, like the pair kernels).  op 0: v_mad_u64_u32, 1: v_add_u32,
+// 2: v_mul_lo_u32.  The standalone sweep over more instructions is bn254_amd/csrc/microbench/valu_rates.hip.
+#define PROBE_ITERS 4096
+#define PROBE_CHAINS 16
+template <int OP>
+__global__ void __launch_bounds__(256) k_issue_probe(uint32_t* out, uint32_t seed) {
+  uint32_t a = seed + threadIdx.x * 2654435761u, b = seed ^ (threadIdx.x * 40503u + 977u);
+  uint64_t acc[PROBE_CHAINS];
+#pragma unroll
+  for (int j = 0; j < PROBE_CHAINS; ++j) acc[j] = a + j;
+  for (int i = 0; i < PROBE_ITERS; ++i) {
+#pragma unroll
+    for (int j = 0; j < PROBE_CHAINS; ++j) {
+      if (OP == 0) {
+        asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[j]) : "v"(a), "v"(b) : "vcc");
+      } else if (OP == 1) {
+        uint32_t lo = (uint32_t)acc[j];
+        asm volatile("v_add_u32 %0, %0, %1" : "+v"(lo) : "v"(a));
+        acc[j] = lo;
+      } else {
+        uint32_t lo = (uint32_t)acc[j];
+        asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(lo) : "v"(b));
+        acc[j] = lo;
+      }
+    }
+  }
+  uint64_t sum = 0;
+#pragma unroll
+  for (int j = 0; j < PROBE_CHAINS; ++j) sum += acc[j];
+  out[(size_t)blockIdx.x * 256 + threadIdx.x] = (uint32_t)sum ^ (uint32_t)(sum >> 32);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -764,6 +826,13 @@ static int stage_out(bn254_ctx* c, int slot, void* host, size_t bytes) {
   return 0;
 }
 static bool misaligned(const void* p) { return ((uintptr_t)p & 3u) != 0; }
+// host-pointer entry points: an offsets array (n + 1 entries) must be non-decreasing — a kernel computes lengths as
+// off[i+1] - off[i], and a wrapped length walks far outside the staged buffer.  O(n) on memory the host already has.
+// (The *_device variants cannot look: there it is a documented precondition, include/bn254_hip.h.)
+static bool offsets_ok(const uint64_t* off, size_t n) {
+  for (size_t i = 0; i < n; ++i) if (off[i] > off[i + 1]) return false;
+  return true;
+}
 static int pool_reserve(bn254_ctx* c, int which, size_t n_fp, size_t entries) {
   Pool& p = c->pool[which];
   if (entries <= p.stride && c->pool_fp[which] == n_fp) return 0;
@@ -960,6 +1029,7 @@ int bn254_batch_verify_compressed(bn254_ctx* c, const uint8_t* msgs, const uint6
   if (n == 0) return 0;
   HIP_TRY(hipSetDevice(c->device));
   int rc;
+  if (!offsets_ok(off, n)) return BN254_E_BAD_ARGUMENT;
   if ((rc = stage_in(c, 0, msgs, (size_t)off[n]))) return rc;
   if ((rc = stage_in(c, 1, off, (n + 1) * sizeof(uint64_t)))) return rc;
   if ((rc = stage_in(c, 2, sigs33, n * 33))) return rc;
@@ -976,6 +1046,7 @@ int bn254_batch_verify(bn254_ctx* c, const uint8_t* msgs, const uint64_t* off, c
   if (!c || (n && (!off || !sigs || !pks || !status))) return BN254_E_BAD_ARGUMENT;
   if (n == 0) return 0;
   HIP_TRY(hipSetDevice(c->device));
+  if (!offsets_ok(off, n)) return BN254_E_BAD_ARGUMENT;
   size_t msg_bytes = (size_t)off[n];
   int rc;
   if ((rc = stage_in(c, 0, msgs, msg_bytes))) return rc;
@@ -1061,6 +1132,7 @@ int bn254_batch_verify_randomized(bn254_ctx* c, const uint8_t* msgs, const uint6
   if (!c || !seed32 || (n && (!off || !sigs || !pks || !status))) return BN254_E_BAD_ARGUMENT;
   if (n == 0) return 0;
   HIP_TRY(hipSetDevice(c->device));
+  if (!offsets_ok(off, n)) return BN254_E_BAD_ARGUMENT;
   size_t msg_bytes = (size_t)off[n], n_groups = (n + BN_WAVE - 1) / BN_WAVE;
   int rc;
   if ((rc = stage_in(c, 0, msgs, msg_bytes))) return rc;
@@ -1097,6 +1169,7 @@ int bn254_batch_hash_to_g1(bn254_ctx* c, const uint8_t* msgs, const uint64_t* of
   if (n == 0) return 0;
   HIP_TRY(hipSetDevice(c->device));
   int rc;
+  if (!offsets_ok(off, n)) return BN254_E_BAD_ARGUMENT;
   if ((rc = stage_in(c, 0, msgs, (size_t)off[n]))) return rc;
   if ((rc = stage_in(c, 1, off, (n + 1) * sizeof(uint64_t)))) return rc;
   if ((rc = stage_reserve(c, 2, n * 64))) return rc;
@@ -1274,6 +1347,7 @@ int bn254_batch_sign(bn254_ctx* c, const uint8_t* msgs, const uint64_t* off, con
   if (n == 0) return 0;
   HIP_TRY(hipSetDevice(c->device));
   int rc;
+  if (!offsets_ok(off, n)) return BN254_E_BAD_ARGUMENT;
   if ((rc = stage_in(c, 0, msgs, (size_t)off[n]))) return rc;
   if ((rc = stage_in(c, 1, off, (n + 1) * sizeof(uint64_t)))) return rc;
   if ((rc = stage_in(c, 2, sks, n * 32))) return rc;
@@ -1291,6 +1365,7 @@ static int sum_host(bn254_ctx* c, int g2, const uint8_t* pts, const uint64_t* se
   if (n == 0) return 0;
   HIP_TRY(hipSetDevice(c->device));
   size_t sz = g2 ? 128 : 64;
+  if (!offsets_ok(seg, n)) return BN254_E_BAD_ARGUMENT;
   size_t total = (size_t)seg[n];
   int rc;
   if ((rc = stage_in(c, 0, pts, total * sz))) return rc;
@@ -1329,9 +1404,9 @@ int bn254_batch_aggregate_verify_device(bn254_ctx* c, const uint8_t* d_msgs, con
   if ((rc = launch_hash_rounds(c, s, d_msgs, d_msg_off, n_msgs, PL_P2X, BY_P2_INF, nullptr))) return rc;
   k_hash_to_pool<<<grid_for(n_msgs), BN_WAVE, 0, s>>>(n_msgs, c->ws, c->pool[2]);
   if (c->pair_lanes) {
-    if ((rc = bn254_pair_aggregate(d_tuple_msg, d_tuple_off, d_signer_idx, n, n_signers, c->pool[0], c->pool[1], c->pool[2], c->ws, s))) return rc;
+    if ((rc = bn254_pair_aggregate(d_tuple_msg, d_tuple_off, d_signer_idx, n, n_signers, n_msgs, c->pool[0], c->pool[1], c->pool[2], c->ws, s))) return rc;
   } else {
-    k_aggregate<<<grid_for(n), BN_WAVE, 0, s>>>(d_tuple_msg, d_tuple_off, d_signer_idx, n, n_signers, c->pool[0], c->pool[1], c->pool[2], c->ws);
+    k_aggregate<<<grid_for(n), BN_WAVE, 0, s>>>(d_tuple_msg, d_tuple_off, d_signer_idx, n, n_signers, n_msgs, c->pool[0], c->pool[1], c->pool[2], c->ws);
   }
   if (c->pair_lanes) {
     if ((rc = bn254_pair_miller_verify(n, c->ws, nullptr, nullptr, s))) return rc;
@@ -1348,7 +1423,7 @@ int bn254_batch_aggregate_verify(bn254_ctx* c, const uint8_t* msgs, const uint64
                                  uint32_t flags, uint8_t* status) {
   if (!c || !n_msgs || !n_signers || (n && (!msg_off || !pk_pool || !sig_pool || !tuple_msg || !tuple_off || !signer_idx || !status))) return BN254_E_BAD_ARGUMENT;
   if (n == 0) return 0;
-  for (size_t i = 0; i < n; ++i) if (tuple_msg[i] >= n_msgs) return BN254_E_BAD_ARGUMENT;
+  if (!offsets_ok(tuple_off, n) || !offsets_ok(msg_off, n_msgs)) return BN254_E_BAD_ARGUMENT;
   HIP_TRY(hipSetDevice(c->device));
   int rc;
   if ((rc = stage_in(c, 0, msgs, (size_t)msg_off[n_msgs]))) return rc;
@@ -1387,6 +1462,38 @@ static int decompress_host(bn254_ctx* c, int g2, const uint8_t* in, size_t n, ui
 int bn254_batch_g1_decompress(bn254_ctx* c, const uint8_t* in, size_t n, uint8_t* out, uint8_t* status) { return decompress_host(c, 0, in, n, out, status); }
 int bn254_batch_g2_decompress(bn254_ctx* c, const uint8_t* in, size_t n, uint8_t* out, uint8_t* status) { return decompress_host(c, 1, in, n, out, status); }
 
+// issue-rate probe: wave-instructions per second of `op` with `waves_per_simd` waves on every SIMD, timed with HIP events
+int bn254_probe_issue_rate(bn254_ctx* c, int op, int waves_per_simd, double* wave_inst_per_s, int* n_simd) {
+  if (!c || !wave_inst_per_s || op < 0 || op > 2 || waves_per_simd < 1 || waves_per_simd > 8) return BN254_E_BAD_ARGUMENT;
+  HIP_TRY(hipSetDevice(c->device));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, c->device));
+  const int n_cu = prop.multiProcessorCount, blocks = n_cu * waves_per_simd;
+  int rc;
+  if ((rc = stage_reserve(c, 0, sizeof(uint32_t) * 256 * (size_t)blocks))) return rc;
+  uint32_t* out = (uint32_t*)c->stage[0];
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  float best = 0;
+  for (int rep = 0; rep < 3; ++rep) {       // first repetition warms up; keep the fastest
+    HIP_TRY(hipEventRecord(e0, c->stream));
+    if (op == 0) k_issue_probe<0><<<blocks, 256, 0, c->stream>>>(out, 12345u);
+    else if (op == 1) k_issue_probe<1><<<blocks, 256, 0, c->stream>>>(out, 12345u);
+    else k_issue_probe<2><<<blocks, 256, 0, c->stream>>>(out, 12345u);
+    HIP_TRY(hipEventRecord(e1, c->stream));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    if (rep > 0 && (best == 0 || ms < best)) best = ms;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *wave_inst_per_s = (double)PROBE_ITERS * PROBE_CHAINS * 4.0 * blocks / (best * 1e-3);
+  if (n_simd) *n_simd = n_cu * 4;
+  return 0;
+}
+
 // ---- test hooks --------------------------------------------------------------------------
 int bn254_debug_fp_op(bn254_ctx* c, int op, const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out, uint8_t* status) {
   if (!c || (n && (!a || !out || !status))) return BN254_E_BAD_ARGUMENT;
@@ -1400,6 +1507,21 @@ int bn254_debug_fp_op(bn254_ctx* c, int op, const uint8_t* a, const uint8_t* b, 
   k_debug_fp_op<<<grid_for(n), BN_WAVE, 0, c->stream>>>(op, c->stage[0], b ? c->stage[1] : nullptr, n, c->stage[2], c->stage[3]);
   HIP_TRY(hipGetLastError());
   if ((rc = stage_out(c, 2, out, n * 32))) return rc;
+  if ((rc = stage_out(c, 3, status, n))) return rc;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+int bn254_debug_hash_candidate(bn254_ctx* c, const uint8_t* h, size_t n, uint8_t* out, uint8_t* status) {
+  if (!c || (n && (!h || !out || !status))) return BN254_E_BAD_ARGUMENT;
+  if (n == 0) return 0;
+  HIP_TRY(hipSetDevice(c->device));
+  int rc;
+  if ((rc = stage_in(c, 0, h, n * 32))) return rc;
+  if ((rc = stage_reserve(c, 2, n * 64))) return rc;
+  if ((rc = stage_reserve(c, 3, n))) return rc;
+  k_debug_hash_candidate<<<grid_for(n), BN_WAVE, 0, c->stream>>>(c->stage[0], n, c->stage[2], c->stage[3]);
+  HIP_TRY(hipGetLastError());
+  if ((rc = stage_out(c, 2, out, n * 64))) return rc;
   if ((rc = stage_out(c, 3, status, n))) return rc;
   HIP_TRY(hipStreamSynchronize(c->stream));
   return 0;

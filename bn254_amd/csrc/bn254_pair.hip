@@ -287,7 +287,7 @@ int bn254_pair_rand_tail(size_t n_groups, Ws ws, size_t gbase, hipStream_t s) {
 // tuple two entries per iteration — both public keys are added to the G2 sum in the pair layout, and each lane adds
 // the signature of "its" entry (2t + role) to its own partial G1 sum; the two partial sums are added at the end.
 KERNEL_PAIR void k_aggregate_pair(const uint32_t* tuple_msg, const uint64_t* tuple_off, const uint32_t* signer_idx, size_t n, size_t n_signers,
-                                  Pool pk_pool, Pool sig_pool, Pool h_pool, Ws ws) {
+                                  size_t n_msgs, Pool pk_pool, Pool sig_pool, Pool h_pool, Ws ws) {
   const unsigned role = threadIdx.x & 1u;
   size_t i = ((size_t)blockIdx.x * BN_PAIR_WG + threadIdx.x) >> 1;
   const bool live = i < n;                 // no early return: the wave-level votes and shuffles below need every lane
@@ -299,6 +299,9 @@ KERNEL_PAIR void k_aggregate_pair(const uint32_t* tuple_msg, const uint64_t* tup
   jac_set_identity(acc1);
   jac_set_identity(acc2);
   uint8_t st = ST_OK;
+  // as in k_aggregate: an out-of-range message index is IndexOutOfBounds, a decreasing offset pair an empty list
+  if (m >= n_msgs) { st = ST_INDEX_OOB; m = 0; }
+  if (hi < lo) { if (st == ST_OK) st = ST_INDEX_OOB; hi = lo; }
   uint64_t longest = hi - lo;
   for (int off = 32; off > 0; off >>= 1) {
     uint64_t other = __shfl_xor((unsigned long long)longest, off, BN_WAVE);
@@ -354,10 +357,10 @@ KERNEL_PAIR void k_aggregate_pair(const uint32_t* tuple_msg, const uint64_t* tup
     ws_byte(ws, BY_ST_HASH, i) = h_pool.st[m];
   }
 }
-int bn254_pair_aggregate(const uint32_t* tuple_msg, const uint64_t* tuple_off, const uint32_t* signer_idx, size_t n, size_t n_signers, Pool pk_pool,
-                         Pool sig_pool, Pool h_pool, Ws ws, hipStream_t s) {
-  k_aggregate_pair<<<(unsigned)((2 * n + BN_PAIR_WG - 1) / BN_PAIR_WG), BN_PAIR_WG, 0, s>>>(tuple_msg, tuple_off, signer_idx, n, n_signers, pk_pool,
-                                                                                            sig_pool, h_pool, ws);
+int bn254_pair_aggregate(const uint32_t* tuple_msg, const uint64_t* tuple_off, const uint32_t* signer_idx, size_t n, size_t n_signers, size_t n_msgs,
+                         Pool pk_pool, Pool sig_pool, Pool h_pool, Ws ws, hipStream_t s) {
+  k_aggregate_pair<<<(unsigned)((2 * n + BN_PAIR_WG - 1) / BN_PAIR_WG), BN_PAIR_WG, 0, s>>>(tuple_msg, tuple_off, signer_idx, n, n_signers, n_msgs,
+                                                                                            pk_pool, sig_pool, h_pool, ws);
   HIP_TRY(hipGetLastError());
   return 0;
 }

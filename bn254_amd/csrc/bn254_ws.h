@@ -89,6 +89,6 @@ __attribute__((visibility("hidden"))) int bn254_pair_final_exp(size_t n, Ws ws, 
 __attribute__((visibility("hidden"))) int bn254_pair_miller_rand(size_t n, size_t n_groups, int items_per_pair, Ws ws, size_t gbase, hipStream_t s);
 __attribute__((visibility("hidden"))) int bn254_pair_rand_tail(size_t n_groups, Ws ws, size_t gbase, hipStream_t s);
 __attribute__((visibility("hidden"))) int bn254_pair_aggregate(const uint32_t* tuple_msg, const uint64_t* tuple_off, const uint32_t* signer_idx, size_t n,
-                                                               size_t n_signers, Pool pk_pool, Pool sig_pool, Pool h_pool, Ws ws, hipStream_t s);
+                                                               size_t n_signers, size_t n_msgs, Pool pk_pool, Pool sig_pool, Pool h_pool, Ws ws, hipStream_t s);
 __attribute__((visibility("hidden"))) int bn254_pair_decode_g2(const uint8_t* pts, size_t n, uint32_t flags, Ws ws, int accumulate, hipStream_t s);
 __attribute__((visibility("hidden"))) int bn254_pair_decompress_g2(const uint8_t* in, size_t n, Ws ws, hipStream_t s);

@@ -80,6 +80,12 @@ class Engine:
     def set_option(self, option, value):
         _check("bn254_ctx_set_option", self._lib.bn254_ctx_set_option(self._h, option, value))
 
+    def probe_issue_rate(self, op, waves_per_simd=2):
+        """(wave-instructions per second, SIMD count) of op 0 v_mad_u64_u32 / 1 v_add_u32 / 2 v_mul_lo_u32"""
+        rate, simds = ctypes.c_double(0), ctypes.c_int(0)
+        _check("bn254_probe_issue_rate", self._lib.bn254_probe_issue_rate(self._h, op, waves_per_simd, ctypes.byref(rate), ctypes.byref(simds)))
+        return rate.value, simds.value
+
     def last_kernel_ms(self):
         ms = (ctypes.c_float * 4)()
         _check("bn254_ctx_last_kernel_ms", self._lib.bn254_ctx_last_kernel_ms(self._h, ms))
@@ -239,6 +245,12 @@ class Engine:
         out = ctypes.create_string_buffer(max(n, 1) * GT_BYTES)
         _check("bn254_debug_miller_loop", self._lib.bn254_debug_miller_loop(self._h, bytes(g1s), bytes(g2s), n, out))
         return out.raw[:n * GT_BYTES]
+
+    def debug_hash_candidate(self, h, n):
+        out = ctypes.create_string_buffer(max(n, 1) * G1_BYTES)
+        status = ctypes.create_string_buffer(max(n, 1))
+        _check("bn254_debug_hash_candidate", self._lib.bn254_debug_hash_candidate(self._h, bytes(h), n, out, status))
+        return out.raw[:n * G1_BYTES], status.raw[:n]
 
     # ---- device-pointer entry points (inputs resident in HBM; enqueue only) ---------------
     def batch_verify_device(self, d_msgs, d_off, d_sigs, d_pks, n, d_status, flags=0, stream=None):

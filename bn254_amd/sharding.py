@@ -1,5 +1,6 @@
-"""Multi-GPU sharding of a verify batch: one process per GPU, contiguous shards, and ONE collective —
-an all-gather of the per-item status bytes (RCCL over xGMI when the backend is "nccl").
+"""Multi-GPU sharding of a verify / pairing batch: one process per GPU, contiguous shards, and ONE collective —
+an all-gather of the per-item status bytes (RCCL over xGMI when the backend is "nccl"); for the pairing workload
+(BASELINE config 4) additionally an 8-byte all-reduce of the additive 64-bit checksum over all Gt words.
 
 Every tuple is independent (/root/reference/src/ecdsa.rs:49-64 shares no state), so there is no
 data-path exchange; constant tables are replicated per device.
@@ -37,3 +38,22 @@ def failure_count(status):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
     return int(c.item())
+
+
+def gt_checksum(gt_bytes):
+    """additive checksum over all little-endian 64-bit words of a uint8 tensor of canonical Gt bytes, mod 2^64
+    (returned as a 1-element int64 tensor on the tensor's device; int64 addition wraps like uint64 addition)"""
+    import torch
+
+    assert gt_bytes.dtype == torch.uint8 and gt_bytes.numel() % 8 == 0
+    return gt_bytes.view(torch.int64).sum().reshape(1)
+
+
+def allreduce_checksum(local_sum):
+    """sum of the per-rank checksums mod 2^64 (8-byte all-reduce); returns a Python int in [0, 2^64)"""
+    import torch.distributed as dist
+
+    t = local_sum.clone()
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(t.item()) & 0xFFFFFFFFFFFFFFFF

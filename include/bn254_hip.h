@@ -32,7 +32,14 @@
  * HIP kernels on the context's device and fails if that is impossible.
  *
  * *_device variants take DEVICE pointers (4-byte aligned, resident in HBM), enqueue on `stream`
- * (a hipStream_t passed as void*; NULL = the context's own stream) and do not synchronise.
+ * (a hipStream_t passed as void*) and do not synchronise.  stream = NULL means the context's OWN stream, which is
+ * created non-blocking: it has NO implicit ordering with the legacy null stream or any other stream, so a caller
+ * that fills the inputs or reads the outputs on another stream must pass that stream (or order the two with events /
+ * bn254_ctx_synchronize).  A context carries ONE call in flight: its workspace in HBM is shared by all its calls,
+ * so a second *_device call may be enqueued only on the same stream as the first (stream order then keeps them
+ * apart) — for concurrent calls on several streams create one context per stream.
+ * Offsets arrays (n + 1 entries) must be non-decreasing: the host-pointer entry points check it and return
+ * BN254_E_BAD_ARGUMENT, for the *_device variants it is a precondition (the arrays live in device memory).
  */
 #ifndef BN254_HIP_H
 #define BN254_HIP_H
@@ -167,8 +174,9 @@ int bn254_batch_g2_sum(bn254_ctx *ctx, const uint8_t *points, const uint64_t *se
  * listed signers' signatures on that message, sum of their public keys) — aggregation is plain point
  * addition (src/types.rs:126-132, :264-270) and only meaningful for one common message (src/lib.rs:34-38).
  * sig_pool[(m * n_signers + s) * 64]: signature of signer s on message m; pk_pool[s * 128].
- * An out-of-range signer index gives status 2 (IndexOutOfBounds); an undecodable pool entry gives its
- * decode status to every tuple that uses it. */
+ * An out-of-range signer index or message index (tuple_msg[i] >= n_msgs) gives status 2 (IndexOutOfBounds), as does
+ * a decreasing tuple_off pair in the _device variant; an undecodable pool entry gives its decode status to every
+ * tuple that uses it.  d_signer_idx must hold at least d_tuple_off[n] entries. */
 int bn254_batch_aggregate_verify(bn254_ctx *ctx, const uint8_t *msgs, const uint64_t *msg_off /* n_msgs+1 */, size_t n_msgs,
                                  const uint8_t *pk_pool /* n_signers*128 */, size_t n_signers, const uint8_t *sig_pool /* n_msgs*n_signers*64 */,
                                  const uint32_t *tuple_msg /* n */, const uint64_t *tuple_off /* n+1 */, const uint32_t *signer_idx, size_t n,
@@ -191,9 +199,18 @@ int bn254_batch_g2_decompress(bn254_ctx *ctx, const uint8_t *in /* n*65 */, size
  *            8 final exponentiation                                                    [384 B] */
 int bn254_debug_fp_op(bn254_ctx *ctx, int op, const uint8_t *a, const uint8_t *b, size_t n, uint8_t *out, uint8_t *status);
 int bn254_debug_fp12_op(bn254_ctx *ctx, int op, const uint8_t *a, const uint8_t *b, size_t n, uint8_t *out);
+/* what ONE pass of the try loop of hash_to_try_and_increment does with a chosen 256-bit digest value h (32 B
+ * big-endian each) instead of SHA-256(msg || ctr): the h >= 5q rule (src/hash.rs:49-51), mod_u256's strict '>'
+ * (src/utils.rs:27-37) and G1::from_compressed(0x02 || x) (src/utils.rs:56-63).  status 0: out = the point; 1: the
+ * loop would move to the next counter (out = zeros).  Exists because h = k*q has no known preimage. */
+int bn254_debug_hash_candidate(bn254_ctx *ctx, const uint8_t *h /* n*32 */, size_t n, uint8_t *out /* n*64 */, uint8_t *status);
 /* un-exponentiated Miller-loop value of each single pair (debugging aid) */
 int bn254_debug_miller_loop(bn254_ctx *ctx, const uint8_t *g1, const uint8_t *g2, size_t n, uint8_t *f /* n*384 */);
 
+/* calibration probe for the roofline figures of bench.py: sustained wave-instructions per second of one VALU
+ * instruction (op 0 v_mad_u64_u32, 1 v_add_u32, 2 v_mul_lo_u32; 16 independent chains) with waves_per_simd (1..8)
+ * waves on every SIMD of the device; n_simd (optional) = SIMD count.  Synchronises the context's stream. */
+int bn254_probe_issue_rate(bn254_ctx *ctx, int op, int waves_per_simd, double *wave_inst_per_s, int *n_simd);
 /* timing of the most recent batch_verify*(…) on this context, from HIP events recorded on the
  * launch stream around each kernel: ms[0] decode, ms[1] hash-to-G1, ms[2] Miller loop,
  * ms[3] final exponentiation.  Synchronises the stream.  Requires bn254_ctx_set_profiling(ctx, 1). */

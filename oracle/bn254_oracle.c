@@ -703,22 +703,28 @@ static void sha256_msg_plus_byte(u8 *digest, const u8 *msg, size_t len, u8 last)
 /* ------------------------------------------------------------------------------------------ */
 static const u64 FIVE_Q[4] = {0x2ca2bc723a70f263ULL, 0xf58714d70a38f4c2ULL, 0x99915c908786b9d3ULL, 0xf1f5883e65f820d0ULL}; /* hash.rs:11-14 */
 
+/* One candidate of the try loop from its 256-bit digest value h (hash.rs:44-59): range rule, mod_u256, decompression
+ * with the 0x02 prefix.  1 = yields a point, 0 = the loop moves on to the next counter. */
+static int hash_candidate_point(g1a *out, u64 *h) {
+  if (u256_geq(h, FIVE_Q)) return 0;                                /* :49-51 */
+  /* mod_u256, utils.rs:27-37: while reduced > modulus { reduced -= modulus } (strict) */
+  while (u256_geq(h, FP_Q.l) && memcmp(h, FP_Q.l, 32) != 0) u256_sub(h, h, FP_Q.l);
+  /* arbitrary_string_to_g1 -> G1::from_compressed(0x02 || x): x < q else NotMember */
+  if (u256_geq(h, FP_Q.l)) return 0;                                /* h == q: rejected */
+  fp x, y, rhs; fp_from_u256(&x, h);
+  fp_sqr(&rhs, &x); fp_mul(&rhs, &rhs, &x); fp_add(&rhs, &rhs, &FP_B);
+  if (!fp_sqrt(&y, &rhs)) return 0;
+  u64 yi[4]; fp_to_u256(yi, &y);
+  if (yi[0] & 1) fp_neg(&y, &y);                                    /* 0x02 prefix: even y */
+  out->x = x; out->y = y; out->inf = 0;
+  return 1;
+}
 static int hash_to_g1(g1a *out, const u8 *msg, size_t len, int *tries) {
   u8 dg[32];
   for (int ctr = 0; ctr < 255; ++ctr) {                             /* hash.rs:40 */
     sha256_msg_plus_byte(dg, msg, len, (u8)ctr);                    /* :41-42 */
     u64 h[4]; be32_to_u256(h, dg);                                  /* :44 */
-    if (u256_geq(h, FIVE_Q)) continue;                              /* :49-51 */
-    /* mod_u256, utils.rs:27-37: while reduced > modulus { reduced -= modulus } (strict) */
-    while (u256_geq(h, FP_Q.l) && memcmp(h, FP_Q.l, 32) != 0) u256_sub(h, h, FP_Q.l);
-    /* arbitrary_string_to_g1 -> G1::from_compressed(0x02 || x): x < q else NotMember */
-    if (u256_geq(h, FP_Q.l)) continue;                              /* h == q: rejected */
-    fp x, y, rhs; fp_from_u256(&x, h);
-    fp_sqr(&rhs, &x); fp_mul(&rhs, &rhs, &x); fp_add(&rhs, &rhs, &FP_B);
-    if (!fp_sqrt(&y, &rhs)) continue;
-    u64 yi[4]; fp_to_u256(yi, &y);
-    if (yi[0] & 1) fp_neg(&y, &y);                                  /* 0x02 prefix: even y */
-    out->x = x; out->y = y; out->inf = 0;
+    if (!hash_candidate_point(out, h)) continue;
     if (tries) *tries = ctr + 1;
     return ST_OK;
   }
@@ -918,6 +924,108 @@ API int bn254o_pairing(const u8 *g1s, const u8 *g2s, size_t k, u32 flags, u8 *gt
   }
   fp12 gt; pairing_product(&gt, ps, qs, (int)k); encode_fp12(gt384, &gt);
   return ST_OK;
+}
+/* n independent pairing products of k pairs each (BASELINE config 4 checker), sharded over nthreads:
+ * gt[i] = canonical bytes, status[i] = decode error, else 0 if the product is one, else 9 */
+typedef struct { const u8 *g1s, *g2s; size_t k, lo, hi; u32 flags; u8 *gt, *status; } pairing_job;
+static void *pairing_worker(void *arg) {
+  pairing_job *j = (pairing_job *)arg;
+  for (size_t i = j->lo; i < j->hi; ++i) {
+    g1a ps[MAX_PAIRS]; g2a qs[MAX_PAIRS]; int st = ST_OK;
+    for (size_t e = 0; e < j->k && st == ST_OK; ++e) {
+      if ((st = decode_g1(&ps[e], j->g1s + 64 * (i * j->k + e), j->flags)) != ST_OK) break;
+      st = decode_g2(&qs[e], j->g2s + 128 * (i * j->k + e), j->flags);
+    }
+    if (st != ST_OK) { if (j->gt) memset(j->gt + 384 * i, 0, 384); j->status[i] = (u8)st; continue; }
+    fp12 gt; pairing_product(&gt, ps, qs, (int)j->k);
+    if (j->gt) encode_fp12(j->gt + 384 * i, &gt);
+    j->status[i] = fp12_eq(&gt, &FP12_ONE) ? ST_OK : ST_VERIFICATION_FAILED;
+  }
+  return NULL;
+}
+API int bn254o_batch_pairing(const u8 *g1s, const u8 *g2s, size_t n, size_t k, u32 flags, u8 *gt, u8 *status, int nthreads) {
+  ensure_init();
+  if (k > MAX_PAIRS) return ST_INVALID_LENGTH;
+  if (nthreads < 1) nthreads = 1;
+  if (nthreads > 256) nthreads = 256;
+  pthread_t th[256]; pairing_job jobs[256];
+  size_t per = (n + nthreads - 1) / nthreads;
+  int used = 0;
+  for (int t = 0; t < nthreads; ++t) {
+    size_t lo = per * t, hi = lo + per > n ? n : lo + per;
+    if (lo >= hi) break;
+    jobs[t] = (pairing_job){g1s, g2s, k, lo, hi, flags, gt, status};
+    if (nthreads == 1) pairing_worker(&jobs[t]); else pthread_create(&th[t], NULL, pairing_worker, &jobs[t]);
+    ++used;
+  }
+  if (nthreads != 1) for (int t = 0; t < used; ++t) pthread_join(th[t], NULL);
+  return ST_OK;
+}
+/* Aggregate verification over shared pools (BASELINE config 2; restates include/bn254_hip.h:bn254_batch_aggregate_verify):
+ * tuple i = message tuple_msg[i] + signer list signer_idx[tuple_off[i] .. tuple_off[i+1]); the aggregate signature /
+ * public key are the sums of the listed pool entries (Add for Signature / PublicKey, types.rs:264-270, :126-132), then
+ * ECDSA::verify (ecdsa.rs:49-64).  An out-of-range index gives 2 (IndexOutOfBounds); an undecodable pool entry gives its
+ * decode status; the first problem in list order wins, signature before public key. */
+typedef struct {
+  const u8 *msgs; const u64 *msg_off; size_t n_msgs; const u8 *pk_pool; size_t n_signers; const u8 *sig_pool;
+  const u32 *tuple_msg; const u64 *tuple_off; const u32 *signer_idx; size_t lo, hi; u32 flags; u8 *status;
+} agg_job;
+static void *agg_worker(void *arg) {
+  agg_job *j = (agg_job *)arg;
+  for (size_t i = j->lo; i < j->hi; ++i) {
+    int st = ST_OK;
+    u32 m = j->tuple_msg[i];
+    if (m >= j->n_msgs) { j->status[i] = ST_INDEX_OOB; continue; }
+    g1j s1; g2j s2;
+    g1j_from_affine(&s1, &(g1a){.inf = 1});
+    g2j_from_affine(&s2, &(g2a){.inf = 1});
+    for (u64 t = j->tuple_off[i]; t < j->tuple_off[i + 1] && st == ST_OK; ++t) {
+      u32 sg = j->signer_idx[t];
+      if (sg >= j->n_signers) { st = ST_INDEX_OOB; break; }
+      g1a sa; g2a pa;
+      if ((st = decode_g1(&sa, j->sig_pool + 64 * ((size_t)m * j->n_signers + sg), j->flags)) != ST_OK) break;
+      if ((st = decode_g2(&pa, j->pk_pool + 128 * (size_t)sg, j->flags)) != ST_OK) break;
+      g1j tj; g2j uj;
+      g1j_from_affine(&tj, &sa); g1j_add(&s1, &s1, &tj);
+      g2j_from_affine(&uj, &pa); g2j_add(&s2, &s2, &uj);
+    }
+    if (st != ST_OK) { j->status[i] = (u8)st; continue; }
+    g1a ps[2]; g2a qs[2];
+    g1j_to_affine(&ps[1], &s1); g2j_to_affine(&qs[0], &s2);
+    if ((st = hash_to_g1(&ps[0], j->msgs + j->msg_off[m], (size_t)(j->msg_off[m + 1] - j->msg_off[m]), NULL)) != ST_OK) { j->status[i] = (u8)st; continue; }
+    qs[1] = G2_GEN_NEG;
+    fp12 gt; pairing_product(&gt, ps, qs, 2);
+    j->status[i] = fp12_eq(&gt, &FP12_ONE) ? ST_OK : ST_VERIFICATION_FAILED;
+  }
+  return NULL;
+}
+API int bn254o_batch_aggregate_verify(const u8 *msgs, const u64 *msg_off, size_t n_msgs, const u8 *pk_pool, size_t n_signers, const u8 *sig_pool,
+                                      const u32 *tuple_msg, const u64 *tuple_off, const u32 *signer_idx, size_t n, u32 flags, u8 *status, int nthreads) {
+  ensure_init();
+  if (nthreads < 1) nthreads = 1;
+  if (nthreads > 256) nthreads = 256;
+  pthread_t th[256]; agg_job jobs[256];
+  size_t per = (n + nthreads - 1) / nthreads;
+  int used = 0;
+  for (int t = 0; t < nthreads; ++t) {
+    size_t lo = per * t, hi = lo + per > n ? n : lo + per;
+    if (lo >= hi) break;
+    jobs[t] = (agg_job){msgs, msg_off, n_msgs, pk_pool, n_signers, sig_pool, tuple_msg, tuple_off, signer_idx, lo, hi, flags, status};
+    if (nthreads == 1) agg_worker(&jobs[t]); else pthread_create(&th[t], NULL, agg_worker, &jobs[t]);
+    ++used;
+  }
+  if (nthreads != 1) for (int t = 0; t < used; ++t) pthread_join(th[t], NULL);
+  return ST_OK;
+}
+/* the try loop's treatment of ONE digest value h (32 B big-endian): 1 + point if it yields one, else 0
+ * (hash.rs:44-59 incl. mod_u256 of utils.rs:27-37; no SHA-256 preimage of h = k*q exists, hence this hook) */
+API int bn254o_hash_candidate(const u8 *h32, u8 *out64) {
+  ensure_init();
+  u64 h[4]; be32_to_u256(h, h32);
+  g1a p;
+  if (!hash_candidate_point(&p, h)) { memset(out64, 0, 64); return 0; }
+  encode_g1(out64, &p);
+  return 1;
 }
 /* un-exponentiated Miller-loop value (for kernel-by-kernel debugging of the HIP path) */
 API int bn254o_miller_loop(const u8 *g1s, const u8 *g2s, size_t k, u8 *f384) {

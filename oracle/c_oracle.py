@@ -40,6 +40,11 @@ def lib():
         L.bn254o_pairing_check.argtypes = [u8p, u8p, ctypes.c_size_t, ctypes.c_uint32]
         L.bn254o_pairing.argtypes = [u8p, u8p, ctypes.c_size_t, ctypes.c_uint32, u8p]
         L.bn254o_miller_loop.argtypes = [u8p, u8p, ctypes.c_size_t, u8p]
+        L.bn254o_batch_pairing.argtypes = [u8p, u8p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_uint32, u8p, u8p, ctypes.c_int]
+        L.bn254o_hash_candidate.argtypes = [u8p, u8p]
+        u32p = ctypes.POINTER(ctypes.c_uint32)
+        L.bn254o_batch_aggregate_verify.argtypes = [u8p, u64p, ctypes.c_size_t, u8p, ctypes.c_size_t, u8p, u32p, u64p, u32p, ctypes.c_size_t,
+                                                    ctypes.c_uint32, u8p, ctypes.c_int]
         for name in ("bn254o_g1_add", "bn254o_g1_mul", "bn254o_g2_add", "bn254o_g2_mul"):
             getattr(L, name).argtypes = [u8p, u8p, u8p]
         L.bn254o_g1_validate.argtypes = [u8p, ctypes.c_uint32]
@@ -121,6 +126,46 @@ def pairing(g1s, g2s, k=1, flags=0):
     if st:
         raise OracleError(st)
     return out.raw
+
+
+def batch_pairing(g1s, g2s, n, k=1, flags=0, nthreads=1, want_gt=True):
+    """n independent products of k pairings -> (canonical Gt bytes n*384 or None, status bytes)"""
+    assert len(g1s) == n * k * 64 and len(g2s) == n * k * 128
+    gt = _buf(max(n, 1) * 384) if want_gt else None
+    status = _buf(max(n, 1))
+    st = lib().bn254o_batch_pairing(bytes(g1s), bytes(g2s), n, k, flags, gt, status, nthreads)
+    if st:
+        raise OracleError(st)
+    return (gt.raw[:n * 384] if want_gt else None), status.raw[:n]
+
+
+def batch_aggregate_verify(messages, pk_pool, sig_pool, tuple_msg, tuple_off, signer_idx, flags=0, nthreads=1):
+    """aggregate verification over shared pools (config 2); tuple_off has n+1 entries into signer_idx -> status bytes"""
+    n, n_msgs = len(tuple_msg), len(messages)
+    n_signers = len(pk_pool) // 128
+    assert len(sig_pool) == n_msgs * n_signers * 64 and len(tuple_off) == n + 1
+    moff = (ctypes.c_uint64 * (n_msgs + 1))()
+    pos = 0
+    for i, m in enumerate(messages):
+        moff[i] = pos
+        pos += len(m)
+    moff[n_msgs] = pos
+    import numpy as np
+    tm = np.ascontiguousarray(np.asarray(tuple_msg, dtype=np.uint32).reshape(-1))
+    to = np.ascontiguousarray(np.asarray(tuple_off, dtype=np.uint64).reshape(-1))
+    si = np.ascontiguousarray(np.concatenate([np.asarray(signer_idx, dtype=np.uint32).reshape(-1), np.zeros(1, dtype=np.uint32)]))
+    u32p, u64p = ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint64)
+    status = _buf(max(n, 1))
+    lib().bn254o_batch_aggregate_verify(b"".join(messages), moff, n_msgs, bytes(pk_pool), n_signers, bytes(sig_pool), tm.ctypes.data_as(u32p),
+                                        to.ctypes.data_as(u64p), si.ctypes.data_as(u32p), n, flags, status, nthreads)
+    return status.raw[:n]
+
+
+def hash_candidate(h32):
+    """what one pass of the try loop does with the digest value h: (1, point64) or (0, zeros)"""
+    out = _buf(64)
+    ok = lib().bn254o_hash_candidate(bytes(h32), out)
+    return ok, out.raw
 
 
 def miller_loop(g1s, g2s, k=1):

@@ -10,7 +10,7 @@
 #include <cstring>
 
 #define BN_COUNT_FP_MUL 1
-extern "C" { unsigned long long bn_fp_mul_counter = 0; }
+extern "C" { unsigned long long bn_fp_mul_counter = 0; unsigned long long bn_fp_dual_counter = 0; }
 
 #include "../../bn254_amd/csrc/bn254_hash.h"
 #include "../../bn254_amd/csrc/bn254_io.h"

@@ -9,7 +9,7 @@
 
 #define BN_SPLIT_FP2 1
 #define BN_COUNT_FP_MUL 1
-extern "C" { unsigned long long bn_fp_mul_counter = 0; }
+extern "C" { unsigned long long bn_fp_mul_counter = 0; unsigned long long bn_fp_dual_counter = 0; }
 
 #include "../../bn254_amd/csrc/bn254_pairing.h"
 #include "../../bn254_amd/csrc/bn254_codec_g2.h"
@@ -47,6 +47,26 @@ int hp_verify_decoded(const uint8_t* h64, const uint8_t* sig64, const uint8_t* p
   miller_loop<true, true>(f, h, pk, sig);
   final_exponentiation(f, f, acc);
   return fp12_is_one(f) ? 0 : 9;
+}
+// Products per LANE of the pair kernels for one verify / one pairing (both roles run here in sequence, so totals / 2):
+// out = {miller_verify dual, single, final_exp dual, single, miller_var dual, single}.  "single" includes squares.
+// bench.py prices the multiplier-class instructions of a kernel with these (profiles/lane_product_counts.json).
+void hp_lane_counts(const uint8_t* h64, const uint8_t* sig64, const uint8_t* pk128, unsigned long long* out6) {
+  G1Affine h, sig;
+  G2Affine pk;
+  load_g1(h, h64); load_g1(sig, sig64); load_g2(pk, pk128);
+  Fp12 f, g, acc;
+  unsigned long long m0 = bn_fp_mul_counter, d0 = bn_fp_dual_counter;
+  miller_loop<true, true>(f, h, pk, sig);
+  out6[0] = (bn_fp_dual_counter - d0) / 2; out6[1] = ((bn_fp_mul_counter - m0) - (bn_fp_dual_counter - d0)) / 2;
+  m0 = bn_fp_mul_counter; d0 = bn_fp_dual_counter;
+  final_exponentiation(g, f, acc);
+  bool one = fp12_is_one(g);
+  (void)one;
+  out6[2] = (bn_fp_dual_counter - d0) / 2; out6[3] = ((bn_fp_mul_counter - m0) - (bn_fp_dual_counter - d0)) / 2;
+  m0 = bn_fp_mul_counter; d0 = bn_fp_dual_counter;
+  miller_loop<true, false>(f, h, pk, h);
+  out6[4] = (bn_fp_dual_counter - d0) / 2; out6[5] = ((bn_fp_mul_counter - m0) - (bn_fp_dual_counter - d0)) / 2;
 }
 // canonical Gt of one pairing through the pair layout
 void hp_pairing(const uint8_t* g1, const uint8_t* g2, uint8_t* gt384) {

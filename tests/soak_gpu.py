@@ -19,12 +19,30 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 Q = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47
 
 
+class SoakMismatch(AssertionError):
+    pass
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120.0)
     ap.add_argument("--out", default=None)
     ap.add_argument("--seed", type=int, default=1)
     args = ap.parse_args()
+    try:
+        res = soak(args)
+    except SoakMismatch as e:
+        print(e)
+        sys.exit(1)
+    print(json.dumps(res))
+    if args.out:
+        with open(args.out, "w") as f:
+            json.dump(res, f, indent=1)
+
+
+def soak(args):
+    """run the differential for args.seconds with args.seed; returns the summary, raises SoakMismatch on a difference
+    (tests/test_gpu_fullsize.py runs a slice of it in the driver-run suite)"""
     import bn254_amd
     from bn254_amd.engine import OPT_PAIR_LANES, OPT_RAND_MIN_BATCH
     from oracle import c_oracle as c
@@ -85,8 +103,7 @@ def main():
             for name, g in got.items():
                 bad = [i for i in range(n) if g[i] != want[i]]
                 if bad:
-                    print("MISMATCH", name, "round", rounds, "flags", flags, "n", n, bad[:5], [(g[i], want[i]) for i in bad[:5]])
-                    sys.exit(1)
+                    raise SoakMismatch("MISMATCH %s round %d flags %d n %d %r %r" % (name, rounds, flags, n, bad[:5], [(g[i], want[i]) for i in bad[:5]]))
             for b in want:
                 codes[b] = codes.get(b, 0) + 1
         if rounds % 8 == 0:
@@ -101,16 +118,14 @@ def main():
             for j in range(m):
                 want_gt = c.pairing(ps[64 * j:64 * j + 64], qs[128 * j:128 * j + 128])
                 if gt[384 * j:384 * j + 384] != want_gt:
-                    print("MISMATCH pairing Gt", rounds, j)
-                    sys.exit(1)
+                    raise SoakMismatch("MISMATCH pairing Gt round %d item %d" % (rounds, j))
             pk1, _ = eng.batch_g1_mul(g1 * m, b"".join(ks[m:]), m)        # matching G1 keys for the G2 keys above
             bad_pk1 = bytearray(pk1)
             bad_pk1[64:128] = pk1[:64]
             got_cpk = eng.batch_check_public_keys(qs, bytes(bad_pk1), m)
             want_cpk = bytes(c.check_public_keys(qs[128 * j:128 * j + 128], bytes(bad_pk1[64 * j:64 * j + 64]), flags=0) for j in range(m))
             if got_cpk != want_cpk or got_cpk[1] != 9 or got_cpk[0] != 0:
-                print("MISMATCH check_public_keys", rounds, list(got_cpk), list(want_cpk))
-                sys.exit(1)
+                raise SoakMismatch("MISMATCH check_public_keys round %d %r %r" % (rounds, list(got_cpk), list(want_cpk)))
             # aggregate verification over pools (config-3 shape): random subsets, duplicates (P + P), one wrong-message row
             M, S = 3, 12
             amsgs = [b"soak-agg-%d-%d" % (rounds, j) for j in range(M)]
@@ -132,8 +147,7 @@ def main():
                     apk = c.g2_add(apk, apk_pool[128 * sg:128 * sg + 128])
                 want_a = c.verify(amsgs[mi], asig, apk, 0)
                 if got_a[j] != want_a:
-                    print("MISMATCH aggregate", rounds, j, lst, got_a[j], want_a)
-                    sys.exit(1)
+                    raise SoakMismatch("MISMATCH aggregate round %d tuple %d %r %d %d" % (rounds, j, lst, got_a[j], want_a))
             extra["aggregate_tuples"] = extra.get("aggregate_tuples", 0) + len(tuples)
             extra["pairings"] = extra.get("pairings", 0) + m
             extra["check_public_keys"] = extra.get("check_public_keys", 0) + m
@@ -146,10 +160,7 @@ def main():
            "status_histogram": {str(k): v for k, v in sorted(codes.items())}, "mismatches": 0, "seed": args.seed, "also_compared": extra,
            "modes": ["exact on lane pairs", "exact, one lane per verify", "randomised 128-bit", "randomised GLV", "randomised 64-bit"],
            "flags": [0, 1]}
-    print(json.dumps(res))
-    if args.out:
-        with open(args.out, "w") as f:
-            json.dump(res, f, indent=1)
+    return res
 
 
 if __name__ == "__main__":

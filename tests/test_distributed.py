@@ -1,8 +1,14 @@
-"""The N>1 path on CPU: world_size-2 gloo processes shard a batch, produce their status shards and
-all-gather them exactly as bench.py does over RCCL.  (The verify itself needs a GPU; here each rank's
-statuses come from the oracle on its own shard, which is what the gather must reassemble.)"""
+"""The N>1 path.
+CPU (gloo, world size 2): the shard / gather / checksum functions bench.py's ranks use, with each rank's statuses
+coming from the oracle on its own shard, and the launcher of `bench.py --gpus N` (the parent starts the ranks, relays
+one JSON line, fails loudly when a rank fails — here every rank fails for want of a HIP device).
+GPU (-m gpu): the exact command line `bench.py --gpus 2` for both sharded workloads, two ranks sharing the one GPU of
+the box over gloo (BN254_BENCH_BACKEND / BN254_BENCH_SINGLE_DEVICE are test knobs), checked against the oracle."""
+import hashlib
+import json
 import os
 import socket
+import subprocess
 import sys
 
 import pytest
@@ -10,7 +16,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from bn254_amd.sharding import failure_count, gather_status, shard_range
+from bn254_amd.sharding import allreduce_checksum, failure_count, gather_status, gt_checksum, shard_range
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -54,8 +60,11 @@ def _worker(rank, world, port, q):
     local[: hi - lo] = torch.tensor(list(st), dtype=torch.uint8)
     allst = gather_status(local, n_total=n)
     fails = failure_count(local[: hi - lo])
+    # the 8-byte checksum all-reduce of the pairing workload: each rank sums the words of "its" bytes, wrapping mod 2^64
+    blob = torch.frombuffer(bytearray(hashlib.sha256(b"gt-%d" % rank).digest() * 12), dtype=torch.uint8)   # 384 B
+    total = allreduce_checksum(gt_checksum(blob) + torch.tensor([0x7FFFFFFFFFFFFF00 + rank], dtype=torch.int64))   # forces a wrap-around
     if rank == 0:
-        q.put((bytes(allst.tolist()), fails))
+        q.put((bytes(allst.tolist()), fails, total))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -68,10 +77,97 @@ def test_two_rank_gather_gloo(derived):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got, fails = q.get(timeout=240)
+    got, fails, total = q.get(timeout=120)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
     want = bytes(v["status"] for v in derived["verify_cases"])
     assert got == want
     assert fails == sum(1 for s in want if s)
+    ref = 0
+    for r in range(2):
+        b = hashlib.sha256(b"gt-%d" % r).digest() * 12
+        ref += sum(int.from_bytes(b[i:i + 8], "little") for i in range(0, 384, 8)) + 0x7FFFFFFFFFFFFF00 + r
+    assert total == ref % (1 << 64)
+
+
+def _run_bench(extra, env_extra, timeout):
+    env = dict(os.environ)
+    env.update(env_extra)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                          timeout=timeout)
+
+
+@pytest.mark.timeout(600)
+def test_bench_launcher_starts_ranks_and_fails_loudly_without_gpu():
+    """`bench.py --gpus 2` with no WORLD_SIZE starts two ranks itself; on this GPU-less host each rank stops with
+    "needs a HIP device" (no CPU fallback), and the parent relays the failure: non-zero exit, no JSON line."""
+    if torch.cuda.is_available():
+        pytest.skip("a HIP device is present: covered by the gpu tests below")
+    env = {"BN254_BENCH_BACKEND": "gloo", "BN254_BENCH_SINGLE_DEVICE": "1"}
+    env_clean = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "128"],
+                       env={**env_clean, **env}, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=540)
+    assert p.returncode != 0
+    assert '"metric"' not in p.stdout
+    assert "needs a HIP device" in p.stderr
+    # a mismatch between --gpus and an external launcher's world size is refused before any GPU call
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env={**env_clean, "WORLD_SIZE": "2", "RANK": "0"},
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode != 0 and "WORLD_SIZE=2" in p.stderr
+
+
+def _two_rank_env():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(BN254_BENCH_BACKEND="gloo", BN254_BENCH_SINGLE_DEVICE="1")
+    return env
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_bench_gpus2_verify_command_line():
+    """the driver-shaped command for configs[1], two ranks: n_gpus 2, every gathered status vector checked"""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "4096"],
+                       env=_two_rank_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=840)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 3 and r["warmup"] == 1 and r["scaling"] == "weak" and r["unit"] == "pairings/s"
+    assert r["config"]["bit_exact_vs_expected"] is True and r["config"]["batch_per_gpu"] == 4096
+    assert r["config"]["status_vectors_checked"] == 2 * 3                    # 2 checks x (own shard + 2 gathered shards)
+    assert abs(r["value"] - 2 * 2 * 4096 * 3 / (r["ms_per_step"] * 3e-3)) / r["value"] < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_bench_gpus2_pairing_command_line_checksum_vs_oracle():
+    """configs[3] on two ranks: status gather, and the all-reduced 64-bit Gt checksum equals the oracle's over BOTH shards"""
+    import numpy as np
+    from oracle import c_oracle as c
+    n = 1024
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "pairing", "--steps", "2", "--warmup", "1",
+                        "--batch", str(n)], env=_two_rank_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=840)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["config"]["batch_per_gpu"] == n and r["config"]["duplicate_inputs_equal_gt"] is True
+    # rebuild both shards' inputs with the oracle alone and sum the Gt words
+    spec = __import__("importlib.util").util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = __import__("importlib.util").util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    pool = min(4096, n)
+    sc = [hashlib.sha256(b"cfg4-%d" % j).digest() for j in range(2 * pool)]
+    R = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+    red = lambda k: (int.from_bytes(k, "big") % R).to_bytes(32, "big")   # noqa: E731
+    g1, g2 = c.g1_generator(), c.g2_generator()
+    P = [c.g1_mul(g1, red(k)) for k in sc[:pool]]
+    Qs = [c.g2_mul(g2, red(k)) for k in sc[pool:]]
+    total = 0
+    for rank in range(2):
+        pi, qi = bench.pairing_indices(np, rank * n, n, pool)
+        gt, st = c.batch_pairing(b"".join(P[i] for i in pi), b"".join(Qs[i] for i in qi), n, 1, nthreads=8)
+        assert st == bytes([9]) * n
+        total += int(np.frombuffer(gt, dtype="<u8").sum(dtype=np.uint64))
+    assert "%016x" % (total % (1 << 64)) == r["config"]["gt_checksum_u64"]

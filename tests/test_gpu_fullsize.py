@@ -1,6 +1,8 @@
-"""BASELINE.json configs 3, 4 and 5 at their full per-GPU sizes, checked through size-independent
-properties (plus oracle parity on subsamples).  Inputs live in HBM (torch tensors) and go through the
-*_device entry points of the C ABI.  Run on the MI355X box: -m gpu."""
+"""BASELINE.json configs 1 - 4 (0-based: verify, aggregate verify, pairings, hash) at their full per-GPU sizes, each
+with an ORACLE comparison at that size — all 65 536 verify statuses; 2 048 aggregate tuples of the 1 Mi run at
+1 024 signers; 4 096 Gt values + their additive checksum of the 512 Ki pairings; 2 001 hashes of the 16 Mi — plus
+size-independent properties over the whole batch, and a 45-second slice of the randomised differential soak.  Inputs
+live in HBM (torch tensors) and go through the *_device entry points of the C ABI.  Run on the MI355X box: -m gpu."""
 import hashlib
 
 import pytest
@@ -22,6 +24,64 @@ def env():
 def _dev(torch, dev, data, dtype=None):
     t = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(dev)
     return t if dtype is None else t.view(dtype)
+
+
+def _cores():
+    import os
+    return max(1, len(os.sched_getaffinity(0)))
+
+
+def test_config1_all_65536_statuses_vs_oracle(env):
+    """configs[1] at its own size: every one of the 65 536 status bytes equals the oracle's, on a batch that mixes valid
+    tuples, wrong-message signatures, undecodable points, coordinates >= q, identities and off-curve keys"""
+    import random
+    torch, eng, c, dev = env
+    from tests.datagen import make_verify_batch
+    n = 65536
+    msgs, sigs, pks, _ = make_verify_batch(eng, n)
+    sigs, pks = bytearray(sigs), bytearray(pks)
+    rnd = random.Random(65536)
+    for i in rnd.sample(range(n), 2048):
+        kind = rnd.randrange(8)
+        if kind == 0:
+            sigs[64 * i + rnd.randrange(64)] ^= 1 << rnd.randrange(8)
+        elif kind == 1:
+            pks[128 * i + rnd.randrange(128)] ^= 1 << rnd.randrange(8)
+        elif kind == 2:
+            sigs[64 * i:64 * i + 32] = (Q + rnd.randrange(1000)).to_bytes(32, "big")
+        elif kind == 3:
+            j = 128 * i + 32 * rnd.randrange(4)
+            pks[j:j + 32] = (Q + rnd.randrange(1 << 200)).to_bytes(32, "big")
+        elif kind == 4:
+            sigs[64 * i:64 * i + 64] = bytes(64)
+        elif kind == 5:
+            pks[128 * i:128 * i + 128] = bytes(128)
+        elif kind == 6:
+            pks[128 * i:128 * i + 128] = pks[128 * (i ^ 1):128 * (i ^ 1) + 128]      # a valid key of another signer
+        else:
+            sigs[64 * i:64 * i + 64] = rnd.randbytes(64)
+    sigs, pks = bytes(sigs), bytes(pks)
+    d_msgs, d_sigs, d_pks = _dev(torch, dev, b"".join(msgs)), _dev(torch, dev, sigs), _dev(torch, dev, pks)
+    d_off = torch.arange(0, 32 * (n + 1), 32, dtype=torch.int64, device=dev)
+    d_st = torch.full((n,), 255, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        eng.batch_verify_device(d_msgs.data_ptr(), d_off.data_ptr(), d_sigs.data_ptr(), d_pks.data_ptr(), n, d_st.data_ptr(), flags=0,
+                                stream=stream.cuda_stream)
+    stream.synchronize()
+    got = bytes(d_st.cpu().numpy())
+    want, _ = c.batch_verify(msgs, sigs, pks, flags=0, nthreads=_cores())
+    assert got == want
+    hist = {b: got.count(b) for b in set(got)}
+    assert hist.get(0, 0) > 60000 and hist.get(9, 0) > 1000 and len(hist) >= 4, hist
+
+
+def test_soak_slice_45s(env):
+    """a slice of tests/soak_gpu.py (random sizes, lengths, mutations; 5 modes x 2 flag settings vs the oracle)"""
+    from types import SimpleNamespace
+    from tests import soak_gpu
+    res = soak_gpu.soak(SimpleNamespace(seconds=45.0, seed=20261003))
+    assert res["mismatches"] == 0 and res["tuples"] > 1000 and len(res["status_histogram"]) >= 4, res
 
 
 def test_config5_hash_16m(env):
@@ -89,6 +149,14 @@ def test_config4_pairings_512k(env):
     gt = d_gt.view(n, 384)
     for k in list(range(16)) + [n - 1, n // 2 + 17]:
         assert gt[k].cpu().numpy().tobytes() == c.pairing(Pn[pi[k]].tobytes(), Qn[qi[k]].tobytes())
+    # 4 096 Gt values spread over the shard vs the oracle, byte for byte, and the additive 64-bit checksum over them
+    # (the quantity bench.py all-reduces) computed on the device bytes and on the oracle's
+    from bn254_amd.sharding import gt_checksum
+    sel = np.unique(np.concatenate([np.arange(0, n, n // 3072)[:3072], np.random.default_rng(4).integers(0, n, 1024)]))[:4096]
+    want_gt, want_st = c.batch_pairing(Pn[pi[sel]].tobytes(), Qn[qi[sel]].tobytes(), len(sel), 1, nthreads=_cores())
+    got_sel = gt[torch.from_numpy(sel).to(dev)].contiguous()
+    assert got_sel.cpu().numpy().tobytes() == want_gt and want_st == bytes([9]) * len(sel)
+    assert int(gt_checksum(got_sel.view(-1)).item()) & (2**64 - 1) == int(np.frombuffer(want_gt, dtype="<u8").sum(dtype=np.uint64))
     # items with the same (P,Q) indices produce identical bytes: period lcm(512,512) = 512
     assert bool((gt[:1024] == gt[512 * 100:512 * 100 + 1024]).all())
 
@@ -106,6 +174,13 @@ def test_config3_aggregate_1m(env):
     assert st == bytes(S)
     sig_pool, st = eng.batch_sign([msgs[m] for m in range(M) for _ in range(S)], b"".join(sks) * M)
     assert st == bytes(M * S)
+    # poison a few pool entries (signer s's signature on message m replaced by signer s+1's): every tuple of message m
+    # that lists s must fail, everything else verifies — so the 1 Mi run has a non-trivial expected status vector
+    sig_pool = bytearray(sig_pool)
+    poisoned = [(37 * k % M, 91 * k % (S - 1)) for k in range(1, 9)]
+    for m, sg in poisoned:
+        sig_pool[64 * (m * S + sg):64 * (m * S + sg) + 64] = sig_pool[64 * (m * S + sg + 1):64 * (m * S + sg + 1) + 64]
+    sig_pool = bytes(sig_pool)
     g = torch.Generator(device=dev)
     g.manual_seed(3)
     tuple_msg = torch.randint(0, M, (n,), dtype=torch.int32, device=dev, generator=g)
@@ -131,7 +206,30 @@ def test_config3_aggregate_1m(env):
     eng.batch_aggregate_verify_device(d_msgs.data_ptr(), d_moff.data_ptr(), M, d_pk.data_ptr(), S, d_sig.data_ptr(), tuple_msg.data_ptr(),
                                       tuple_off.data_ptr(), signer_idx.data_ptr(), n, d_st.data_ptr(), stream=stream)
     torch.cuda.synchronize()
-    assert int(d_st.max()) == 0
+    # expected statuses from the construction: 9 iff the tuple's message is poisoned at a signer the tuple lists
+    tm = tuple_msg.cpu().numpy()
+    st_all = d_st.cpu().numpy()
+    off_h = tuple_off.cpu().numpy()
+    idx_h = signer_idx.cpu().numpy()
+    import numpy as np
+    bad_of = {}
+    for m, sg in poisoned:
+        bad_of.setdefault(m, []).append(sg)
+    expect = np.zeros(n, dtype=np.uint8)
+    for i in np.nonzero(np.isin(tm, list(bad_of)))[0]:
+        lst = idx_h[off_h[i]:off_h[i + 1]]
+        if np.isin(bad_of[int(tm[i])], lst).any():
+            expect[i] = 9
+    assert 1000 < int(expect.sum()) // 9 < 20000
+    assert (st_all == expect).all()
+    # ORACLE at this size (1 024 signers): 2 048 tuples of this very run — 1 024 random ones and 1 024 of the failing ones —
+    # re-derived from the pools with the oracle's own point additions and verify
+    rng = np.random.default_rng(3)
+    sel = np.concatenate([rng.integers(0, n, 1024), rng.choice(np.nonzero(expect)[0], 1024, replace=False)])
+    lists = [idx_h[off_h[i]:off_h[i + 1]] for i in sel]
+    t_off = np.concatenate([[0], np.cumsum([len(x) for x in lists])])
+    want = c.batch_aggregate_verify(msgs, pk_pool, sig_pool, tm[sel], t_off, np.concatenate(lists), flags=0, nthreads=_cores())
+    assert bytes(st_all[sel]) == want and want.count(9) >= 1024 and want.count(0) >= 900
     # signatures of message m presented for message m+1: every tuple must fail
     d_sig_shift = torch.roll(d_sig.view(M, S * 64), 1, dims=0).contiguous().view(-1)
     k = 1 << 14

@@ -144,6 +144,29 @@ def test_hash_to_point_error_path(eng, derived):
             assert st_sign[i] == 1 and sigs[64 * i:64 * i + 64] == bytes(64)     # ecdsa.rs:28 propagates the error
 
 
+def test_hash_candidate_range_rules_vs_oracle(eng, c):
+    """the branch no SHA-256 preimage reaches: digest values h = k*q stop at q under mod_u256's
+    strict '>' (/root/reference/src/utils.rs:27-37) and are rejected, h >= 5q is skipped (src/hash.rs:49-51).  Chosen
+    values of h go through the device's range / reduction / Jacobi filter / square-root code via the debug hook and are
+    compared with the oracle's treatment of the same values: q, 2q, 3q, 4q, 5q-1, 5q, neighbours, edges, random."""
+    rnd = random.Random(7)
+    hs = [0, 1, 2, Q - 1, Q, Q + 1, 2 * Q - 1, 2 * Q, 2 * Q + 1, 3 * Q - 1, 3 * Q, 3 * Q + 1, 4 * Q - 1, 4 * Q, 4 * Q + 1, 5 * Q - 2, 5 * Q - 1, 5 * Q,
+          5 * Q + 1, 2**256 - 1, 2**255, Q + 2, 2 * Q + 2, 3 * Q + 2, 4 * Q + 2]
+    hs += [rnd.randrange(2**256) for _ in range(400)] + [k * Q + rnd.randrange(1, 50) for k in range(5) for _ in range(20)]
+    blob = b"".join(h.to_bytes(32, "big") for h in hs)
+    pts, st = eng.debug_hash_candidate(blob, len(hs))
+    n_point = 0
+    for i, h in enumerate(hs):
+        ok, want = c.hash_candidate(h.to_bytes(32, "big"))
+        assert st[i] == (0 if ok else 1), (hex(h), st[i])          # bit 7 (filter vs square root disagree) never set
+        assert pts[64 * i:64 * i + 64] == want, hex(h)
+        n_point += ok
+    for k in range(1, 6):
+        assert st[hs.index(k * Q)] == 1                              # exact multiples of q never yield a point
+    assert st[hs.index(5 * Q - 1)] in (0, 1) and st[hs.index(5 * Q + 1)] == 1 and st[hs.index(2**256 - 1)] == 1
+    assert 150 < n_point < 400
+
+
 def test_hash_large_batch_statistics(eng, c):
     """200 000 messages: every round shape (speculative and one-try rounds) is exercised; spot-check
     against the oracle and check the try-count distribution (mean 2.116 = 1/0.4726)."""
@@ -592,10 +615,53 @@ def test_argument_validation_and_empty_batches(eng):
     assert L.bn254_batch_verify_device(h, p, off, p, None, 2, 0, p + 2048, None) == -10001
     assert L.bn254_ctx_set_option(h, 3, 7) == -10001 and L.bn254_ctx_set_option(h, 2, 300) == -10001
     assert L.bn254_ctx_set_option(h, 99, 0) == -10001
+    # host entry points refuse a decreasing offsets array (a wrapped length would walk outside the staged buffer)
+    bad_off = (ctypes.c_uint64 * 4)(0, 40, 8, 48)
+    assert L.bn254_batch_verify(h, bytes(64), bad_off, bytes(192), bytes(384), 3, 0, st) == -10001
+    pts = ctypes.create_string_buffer(192)
+    assert L.bn254_batch_hash_to_g1(h, bytes(64), bad_off, 3, pts, st, None) == -10001
+    assert L.bn254_batch_g1_sum(h, bytes(64 * 48), bad_off, 3, pts, st) == -10001
     # the context is still usable afterwards
     from tests.datagen import make_verify_batch
     msgs, sigs, pks, expected = make_verify_batch(eng, 130)
     assert eng.batch_verify(msgs, sigs, pks) == expected
+
+
+def test_aggregate_verify_index_validation_device_and_host(eng, c):
+    """indices from caller memory: a message index >= n_msgs or a signer index >= n_signers is IndexOutOfBounds (status 2)
+    and a decreasing tuple_off pair in the _device variant is status 2 as well — never an out-of-range pool read; both
+    kernels (lane pairs / one lane per tuple) and the oracle's restatement agree"""
+    import torch
+    from bn254_amd.engine import OPT_PAIR_LANES
+    from tests.datagen import sk_bytes
+    dev = torch.device("cuda", 0)
+    M, S = 2, 5
+    msgs = [b"idx-msg-%d" % m for m in range(M)]
+    sks = [sk_bytes(300 + s) for s in range(S)]
+    pk_pool, _ = eng.batch_g2_mul(None, b"".join(sks), S, reduce_scalar=True)
+    sig_pool, _ = eng.batch_sign([msgs[m] for m in range(M) for _ in range(S)], b"".join(sks * M))
+    tuple_msg = [0, 1, 2, 0xFFFFFFFF, 1, 0, 1]
+    lists = [[0, 1], [2, 3, 4], [0], [1], [S], [4, 0, 3], []]
+    want = c.batch_aggregate_verify(msgs, pk_pool, sig_pool, tuple_msg, [0, 2, 5, 6, 7, 8, 11, 11], sum(lists, []))
+    assert list(want) == [0, 0, 2, 2, 2, 0, 0]
+    for pair in (1, 0):
+        eng.set_option(OPT_PAIR_LANES, pair)
+        assert eng.batch_aggregate_verify(msgs, pk_pool, sig_pool, tuple_msg, lists) == want
+        # _device entry with a decreasing offset pair (tuple 1: [5, 2)) -> status 2 for that tuple, others unaffected
+        t = lambda data, dt: torch.tensor(data, dtype=dt, device=dev)   # noqa: E731
+        d_msgs = torch.frombuffer(bytearray(b"".join(msgs)), dtype=torch.uint8).to(dev)
+        d_moff = t([0, len(msgs[0]), len(msgs[0]) + len(msgs[1])], torch.int64)
+        d_pk = torch.frombuffer(bytearray(pk_pool), dtype=torch.uint8).to(dev)
+        d_sig = torch.frombuffer(bytearray(sig_pool), dtype=torch.uint8).to(dev)
+        d_tm, d_to, d_si = t([0, 1, 1], torch.int32), t([0, 5, 2, 4], torch.int64), t([0, 1, 2, 3, 4, 0], torch.int32)
+        d_st = torch.full((3,), 255, dtype=torch.uint8, device=dev)
+        stream = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(stream):
+            eng.batch_aggregate_verify_device(d_msgs.data_ptr(), d_moff.data_ptr(), M, d_pk.data_ptr(), S, d_sig.data_ptr(), d_tm.data_ptr(),
+                                              d_to.data_ptr(), d_si.data_ptr(), 3, d_st.data_ptr(), stream=stream.cuda_stream)
+        stream.synchronize()
+        assert d_st.cpu().tolist() == [0, 2, 0]
+    eng.set_option(OPT_PAIR_LANES, 1)
 
 
 def test_cpp_host_mirror_example(eng):

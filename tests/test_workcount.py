@@ -31,6 +31,33 @@ def test_stage_counts_match_bench_constants(derived):
         assert out[1] == b.FP_MUL_HASH_FILTER * tries + b.FP_MUL_HASH_FINISH, (out[1], tries)
 
 
+def test_lane_product_counts_for_bench(derived):
+    """per-lane product counts of the pair kernels (dual-accumulated / single) — what bench.py prices the multiplier
+    instructions with; committed as profiles/lane_product_counts.json and re-derived here"""
+    import json
+    import subprocess
+    from oracle import c_oracle as c
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "hostsim"), "libhostsim_pair.so"])
+    L = ctypes.CDLL(os.path.join(ROOT, "tests", "hostsim", "libhostsim_pair.so"))
+    L.hp_lane_counts.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_ulonglong)]
+    seen = set()
+    for v in [v for v in derived["verify_cases"] if v["status"] in (0, 9)][:4]:
+        st, h, _ = c.hash_to_g1(bytes.fromhex(v["message_hex"]))
+        out = (ctypes.c_ulonglong * 6)()
+        L.hp_lane_counts(h, bytes.fromhex(v["sig"]), bytes.fromhex(v["pk"]), out)
+        seen.add(tuple(out))
+    assert len(seen) == 1                                   # data-independent control flow
+    o = seen.pop()
+    counts = {"k_miller_verify_pair": {"dual": o[0], "single": o[1]}, "k_final_exp_pair": {"dual": o[2], "single": o[3]},
+              "k_miller_var_pair": {"dual": o[4], "single": o[5]}}
+    path = os.path.join(ROOT, "profiles", "lane_product_counts.json")
+    if os.environ.get("BN254_WRITE_COUNTS") == "1" or not os.path.exists(path):
+        with open(path, "w") as f:
+            json.dump(counts, f, indent=1, sort_keys=True)
+    assert json.load(open(path)) == counts
+    assert _bench().lane_product_counts() == counts
+
+
 def test_host_example_compiles():
     """the C++ host mirror (bn254_amd/host/bn254.hpp) compiles and links against the C ABI"""
     import subprocess
