@@ -42,10 +42,10 @@ BN_DEV uint8_t decompress_g2(G2Affine& pt, const uint8_t* b) {
   u512_divmod_q(hi, lo, overflow, v);
   bool enc_ok = (sign == 0x0a || sign == 0x0b) && !overflow && !u256_geq(hi.w, C_Q);
   Fp2 x = fp2_make(fp_from_u256(lo), fp_from_u256(hi));
-  Fp2 rhs = fp2_add(fp2_mul(fp2_norm(fp2_sqr(x)), x), fp2_load_const(C_TWIST_B));
+  Fp2 rhs = fp2_add(fp2_mul(fp2_sqr(x), x), fp2_load_const(C_TWIST_B));
   Fp2 y;
   bool has_root = fp2_sqrt(y, rhs);
-  Fp2 yn = fp2_norm(fp2_neg(y));
+  Fp2 yn = fp2_neg(y);
   bool y_gt = fp2_u512_greater(y, yn);
   bool want_gt = sign == 0x0b;
   pt.x = x;

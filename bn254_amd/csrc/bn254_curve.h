@@ -30,6 +30,8 @@ BN_DEV Fp f_inv(const Fp& a) { return fp_inv(a); }
 BN_DEV void f_set_one(Fp& a) { a = fp_one(); }
 BN_DEV void f_set_zero(Fp& a) { a = fp_zero(); }
 BN_DEV Fp f_norm(const Fp& a) { return fp_norm(a); }
+BN_DEV Fp f_mul8(const Fp& a) { return fp_mul8_spread(a); }
+BN_DEV Fp f_reduce(const Fp& a) { return fp_reduce_weak(a); }
 
 BN_DEV Fp2 f_add(const Fp2& a, const Fp2& b) { return fp2_add(a, b); }
 BN_DEV Fp2 f_sub(const Fp2& a, const Fp2& b) { return fp2_sub(a, b); }
@@ -44,6 +46,8 @@ BN_DEV Fp2 f_inv(const Fp2& a) { return fp2_inv(a); }
 BN_DEV void f_set_one(Fp2& a) { a = fp2_one(); }
 BN_DEV void f_set_zero(Fp2& a) { a = fp2_zero(); }
 BN_DEV Fp2 f_norm(const Fp2& a) { return fp2_norm(a); }
+BN_DEV Fp2 f_mul8(const Fp2& a) { return fp2_mul8(a); }
+BN_DEV Fp2 f_reduce(const Fp2& a) { return fp2_reduce_weak(a); }
 
 template <class F> struct Affine { F x, y; bool inf; };
 template <class F> struct Jac { F x, y, z; };   // z == 0 <=> identity
@@ -63,30 +67,31 @@ template <class F> BN_DEV void jac_select(Jac<F>& r, bool c, const Jac<F>& a, co
 }
 
 // dbl-2009-l (a = 0); the identity (z = 0) maps to z = 0 without a branch.
-// Coordinates in and out are tight (normalised limbs); f_norm marks where lazy sums are carried.
+// Coordinates in and out are tight (carried limbs).  Products and squares give tight results; f_norm stands where a
+// lazy sum meets a product whose 64-bit columns it would overflow (an Fq2 square takes a tight operand, an Fq2
+// product limb magnitudes with A * B <= 6 units of 2^28 — bn254_field.h; tests/test_bounds.py proves every flow).
 template <class F> BN_DEVN void jac_dbl(Jac<F>& r, const Jac<F>& p) {
-  F a = f_norm(f_sqr(p.x)), b = f_norm(f_sqr(p.y)), c = f_norm(f_sqr(b));
-  F d = f_norm(f_dbl(f_sub(f_sub(f_sqr(f_add(p.x, b)), a), c)));
+  F a = f_sqr(p.x), b = f_sqr(p.y), c = f_sqr(b);
+  F d = f_norm(f_dbl(f_sub(f_sub(f_sqr(f_norm(f_add(p.x, b))), a), c)));
   F e = f_norm(f_add(f_dbl(a), a)), f = f_sqr(e);
-  F x3 = f_norm(f_sub(f, f_dbl(d)));
-  F z3 = f_norm(f_dbl(f_mul(p.y, p.z)));
-  F c8 = f_dbl(f_dbl(f_dbl(c)));
-  F y3 = f_norm(f_sub(f_mul(e, f_norm(f_sub(d, x3))), c8));
+  F x3 = f_reduce(f_sub(f, f_dbl(d)));                                // f_reduce: carry + weak reduction — with R / q = 169 the
+  F z3 = f_norm(f_dbl(f_mul(p.y, p.z)));                              // coordinates of a long chain of group operations would
+  F y3 = f_reduce(f_sub(f_mul(e, f_norm(f_sub(d, x3))), f_mul8(c)));  // otherwise grow; 8 C through the limb-crossing shift
   r.x = x3; r.y = y3; r.z = z3;
 }
 
 // add-2007-bl with every exceptional case resolved by selects (lanes never diverge):
 // P = O -> Q, Q = O -> P, P = Q -> 2P, P = -Q -> O
 template <class F> BN_DEVN void jac_add(Jac<F>& r, const Jac<F>& p, const Jac<F>& q) {
-  F z1z1 = f_norm(f_sqr(p.z)), z2z2 = f_norm(f_sqr(q.z));
+  F z1z1 = f_sqr(p.z), z2z2 = f_sqr(q.z);
   F u1 = f_mul(p.x, z2z2), u2 = f_mul(q.x, z1z1);
-  F s1 = f_mul(f_norm(f_mul(p.y, q.z)), z2z2), s2 = f_mul(f_norm(f_mul(q.y, p.z)), z1z1);
-  F h = f_norm(f_sub(u2, u1)), i = f_norm(f_sqr(f_dbl(h))), j = f_mul(h, i);
+  F s1 = f_mul(f_mul(p.y, q.z), z2z2), s2 = f_mul(f_mul(q.y, p.z), z1z1);
+  F h = f_norm(f_sub(u2, u1)), i = f_norm(f_dbl(f_dbl(f_sqr(h)))), j = f_mul(h, i);
   F rr = f_norm(f_dbl(f_sub(s2, s1))), v = f_mul(u1, i);
   Jac<F> o;
-  o.x = f_norm(f_sub(f_sub(f_sqr(rr), j), f_dbl(v)));
-  o.y = f_norm(f_sub(f_mul(rr, f_norm(f_sub(v, o.x))), f_dbl(f_mul(s1, j))));
-  o.z = f_mul(f_norm(f_sub(f_sub(f_sqr(f_add(p.z, q.z)), z1z1), z2z2)), h);
+  o.x = f_reduce(f_sub(f_sub(f_sqr(rr), j), f_dbl(v)));
+  o.y = f_reduce(f_sub(f_mul(rr, f_norm(f_sub(v, o.x))), f_dbl(f_mul(s1, j))));
+  o.z = f_mul(f_norm(f_sub(f_sub(f_sqr(f_norm(f_add(p.z, q.z))), z1z1), z2z2)), h);
   bool p_inf = f_is_zero(p.z), q_inf = f_is_zero(q.z);
   bool same_x = f_is_zero(h), same_y = f_is_zero(rr);
   Jac<F> d;
@@ -105,16 +110,16 @@ template <class F> BN_DEVN void jac_add(Jac<F>& r, const Jac<F>& p, const Jac<F>
 // operation of signature / public-key aggregation (/root/reference/src/types.rs:126-132, :264-270).
 // Exceptional cases by selects, as in jac_add: P = O -> Q, P = Q -> 2Q, P = -Q -> O; q_inf skips.
 template <class F> BN_DEVN void jac_madd(Jac<F>& r, const Jac<F>& p, const Affine<F>& q) {
-  F z1z1 = f_norm(f_sqr(p.z));
+  F z1z1 = f_sqr(p.z);
   F u2 = f_mul(q.x, z1z1);
-  F s2 = f_mul(f_norm(f_mul(q.y, p.z)), z1z1);
-  F h = f_norm(f_sub(u2, p.x)), hh = f_norm(f_sqr(h));
+  F s2 = f_mul(f_mul(q.y, p.z), z1z1);
+  F h = f_norm(f_sub(u2, p.x)), hh = f_sqr(h);
   F i = f_norm(f_dbl(f_dbl(hh))), j = f_mul(h, i);
   F rr = f_norm(f_dbl(f_sub(s2, p.y))), v = f_mul(p.x, i);
   Jac<F> o;
-  o.x = f_norm(f_sub(f_sub(f_sqr(rr), j), f_dbl(v)));
-  o.y = f_norm(f_sub(f_mul(rr, f_norm(f_sub(v, o.x))), f_dbl(f_mul(p.y, j))));
-  o.z = f_norm(f_sub(f_sub(f_sqr(f_add(p.z, h)), z1z1), hh));
+  o.x = f_reduce(f_sub(f_sub(f_sqr(rr), j), f_dbl(v)));
+  o.y = f_reduce(f_sub(f_mul(rr, f_norm(f_sub(v, o.x))), f_dbl(f_mul(p.y, j))));
+  o.z = f_norm(f_sub(f_sub(f_sqr(f_norm(f_add(p.z, h))), z1z1), hh));
   bool p_inf = f_is_zero(p.z);
   bool same_x = f_is_zero(h), same_y = f_is_zero(rr);
   Jac<F> qj, d, id;
@@ -132,16 +137,16 @@ template <class F> BN_DEVN void jac_madd(Jac<F>& r, const Jac<F>& p, const Affin
 // every call just to be able to select it (40 % of its cost), and a flag for the rare lanes that did hit
 // P = +-Q; the caller redoes the step with jac_madd when any lane of the wave raised it.
 template <class F> BN_DEVN void jac_madd_common(Jac<F>& r, bool& exceptional, const Jac<F>& p, const Affine<F>& q) {
-  F z1z1 = f_norm(f_sqr(p.z));
+  F z1z1 = f_sqr(p.z);
   F u2 = f_mul(q.x, z1z1);
-  F s2 = f_mul(f_norm(f_mul(q.y, p.z)), z1z1);
-  F h = f_norm(f_sub(u2, p.x)), hh = f_norm(f_sqr(h));
+  F s2 = f_mul(f_mul(q.y, p.z), z1z1);
+  F h = f_norm(f_sub(u2, p.x)), hh = f_sqr(h);
   F i = f_norm(f_dbl(f_dbl(hh))), j = f_mul(h, i);
   F rr = f_norm(f_dbl(f_sub(s2, p.y))), v = f_mul(p.x, i);
   Jac<F> o;
-  o.x = f_norm(f_sub(f_sub(f_sqr(rr), j), f_dbl(v)));
-  o.y = f_norm(f_sub(f_mul(rr, f_norm(f_sub(v, o.x))), f_dbl(f_mul(p.y, j))));
-  o.z = f_norm(f_sub(f_sub(f_sqr(f_add(p.z, h)), z1z1), hh));
+  o.x = f_reduce(f_sub(f_sub(f_sqr(rr), j), f_dbl(v)));
+  o.y = f_reduce(f_sub(f_mul(rr, f_norm(f_sub(v, o.x))), f_dbl(f_mul(p.y, j))));
+  o.z = f_norm(f_sub(f_sub(f_sqr(f_norm(f_add(p.z, h))), z1z1), hh));
   const bool p_inf = f_is_zero(p.z);
   Jac<F> qj;
   qj.x = q.x; qj.y = q.y; f_set_one(qj.z);
@@ -167,15 +172,15 @@ template <class F> BN_DEV void jac_accumulate(Jac<F>& acc, const Affine<F>& q) {
 // P + Q for operands known to satisfy P != +-Q unless one of them is the identity (add-2007-bl without
 // the doubling / cancellation overrides of jac_add, which cost a jac_dbl per call).
 template <class F> BN_DEVN void jac_add_distinct(Jac<F>& r, const Jac<F>& p, const Jac<F>& q) {
-  F z1z1 = f_norm(f_sqr(p.z)), z2z2 = f_norm(f_sqr(q.z));
+  F z1z1 = f_sqr(p.z), z2z2 = f_sqr(q.z);
   F u1 = f_mul(p.x, z2z2), u2 = f_mul(q.x, z1z1);
-  F s1 = f_mul(f_norm(f_mul(p.y, q.z)), z2z2), s2 = f_mul(f_norm(f_mul(q.y, p.z)), z1z1);
-  F h = f_norm(f_sub(u2, u1)), i = f_norm(f_sqr(f_dbl(h))), j = f_mul(h, i);
+  F s1 = f_mul(f_mul(p.y, q.z), z2z2), s2 = f_mul(f_mul(q.y, p.z), z1z1);
+  F h = f_norm(f_sub(u2, u1)), i = f_norm(f_dbl(f_dbl(f_sqr(h)))), j = f_mul(h, i);
   F rr = f_norm(f_dbl(f_sub(s2, s1))), v = f_mul(u1, i);
   Jac<F> o;
-  o.x = f_norm(f_sub(f_sub(f_sqr(rr), j), f_dbl(v)));
-  o.y = f_norm(f_sub(f_mul(rr, f_norm(f_sub(v, o.x))), f_dbl(f_mul(s1, j))));
-  o.z = f_mul(f_norm(f_sub(f_sub(f_sqr(f_add(p.z, q.z)), z1z1), z2z2)), h);
+  o.x = f_reduce(f_sub(f_sub(f_sqr(rr), j), f_dbl(v)));
+  o.y = f_reduce(f_sub(f_mul(rr, f_norm(f_sub(v, o.x))), f_dbl(f_mul(s1, j))));
+  o.z = f_mul(f_norm(f_sub(f_sub(f_sqr(f_norm(f_add(p.z, q.z))), z1z1), z2z2)), h);
   bool p_inf = f_is_zero(p.z), q_inf = f_is_zero(q.z);
   jac_select(o, q_inf, p, o);
   jac_select(o, p_inf, q, o);
@@ -214,7 +219,7 @@ template <int WORDS, bool COMPLETE, class F> BN_DEVN void jac_mul_window(Jac<F>&
     int d = digit[j], m = d < 0 ? -d : d;
     jac_set_identity(t);
     for (int e = 0; e < 8; ++e) jac_select(t, m == e + 1, tab[e], t);
-    t.y = f_select(d < 0, f_norm(f_neg(t.y)), t.y);
+    t.y = f_select(d < 0, f_neg(t.y), t.y);
     if constexpr (COMPLETE) jac_add(acc, acc, t); else jac_add_distinct(acc, acc, t);
   }
   r = acc;
@@ -252,13 +257,13 @@ BN_DEVN void g1_mul_glv(G1Jac& r, const G1Affine& p, const uint32_t* k1, const u
     int d = d1[j], m = d < 0 ? -d : d;
     jac_set_identity(t);
     for (int e = 0; e < 8; ++e) jac_select(t, m == e + 1, tab[e], t);
-    t.y = fp_select(d < 0, fp_norm(fp_neg(t.y)), t.y);
+    t.y = fp_select(d < 0, fp_neg(t.y), t.y);
     jac_add_distinct(acc, acc, t);
     d = d2[j]; m = d < 0 ? -d : d;
     jac_set_identity(t);
     for (int e = 0; e < 8; ++e) jac_select(t, m == e + 1, tab[e], t);
     t.x = fp_mul(t.x, beta);                                   // phi: x -> beta x (the identity keeps z = 0)
-    t.y = fp_select(d < 0, fp_norm(fp_neg(t.y)), t.y);
+    t.y = fp_select(d < 0, fp_neg(t.y), t.y);
     jac_add_distinct(acc, acc, t);
   }
   r = acc;
@@ -266,9 +271,9 @@ BN_DEVN void g1_mul_glv(G1Jac& r, const G1Affine& p, const uint32_t* k1, const u
 
 template <class F> BN_DEVN void jac_to_affine(Affine<F>& r, const Jac<F>& p) {
   bool inf = f_is_zero(p.z);
-  F zi = f_norm(f_inv(p.z)), zi2 = f_norm(f_sqr(zi));
+  F zi = f_norm(f_inv(p.z)), zi2 = f_sqr(zi);
   r.x = f_mul(p.x, zi2);
-  r.y = f_mul(p.y, f_norm(f_mul(zi2, zi)));
+  r.y = f_mul(p.y, f_mul(zi2, zi));
   r.inf = inf;
   if (inf) { f_set_zero(r.x); f_set_zero(r.y); }
 }
@@ -283,12 +288,12 @@ BN_DEV bool g2_on_curve(const G2Affine& p) {   // y^2 = x^3 + 3/xi
 BN_DEV void g2_psi(G2Jac& r, const G2Jac& p) {
   r.x = fp2_mul(fp2_conj(p.x), fp2_load_const(C_TW_FROB_X1));
   r.y = fp2_mul(fp2_conj(p.y), fp2_load_const(C_TW_FROB_Y1));
-  r.z = fp2_norm(fp2_conj(p.z));
+  r.z = fp2_conj(p.z);
 }
 // equality of two Jacobian points (cross-multiplied; identity only equals identity)
 BN_DEV bool g2_jac_equal(const G2Jac& a, const G2Jac& b) {
   bool ai = fp2_is_zero(a.z), bi = fp2_is_zero(b.z);
-  Fp2 za2 = fp2_norm(fp2_sqr(a.z)), zb2 = fp2_norm(fp2_sqr(b.z));
+  Fp2 za2 = fp2_sqr(a.z), zb2 = fp2_sqr(b.z);
   bool ex = fp2_eq(fp2_mul(a.x, zb2), fp2_mul(b.x, za2));
   bool ey = fp2_eq(fp2_mul(a.y, fp2_mul(zb2, b.z)), fp2_mul(b.y, fp2_mul(za2, a.z)));
   return (ai && bi) || (!ai && !bi && ex && ey);
@@ -301,7 +306,7 @@ BN_DEV bool g2_jac_equal(const G2Jac& a, const G2Jac& b) {
 // random twist points in and out of the subgroup; the CPU suite also runs this implementation on them.
 BN_DEVN bool g2_in_subgroup(const G2Affine& p) {
   G2Affine pn = p;
-  pn.y = fp2_norm(fp2_neg(p.y));
+  pn.y = fp2_neg(p.y);
   G2Jac up, t, lhs, rhs;
   jac_from_affine(up, p);
   for (int i = 0; i < BN_U_NAF_LEN; ++i) {        // wave-uniform: u is a public constant

@@ -1,10 +1,11 @@
 // BN254 base field Fq and the tower Fq2 / Fq6 / Fq12 for gfx950 lanes.
 //
-// One field element per lane: 10 signed limbs of 27 bits in VGPRs, Montgomery form (R = 2^270).
-// The hot primitive is a product-scanning Montgomery product built from v_mad_i64_i32 /
-// v_mad_u64_u32 (measured on MI355X: ~5 cycles per wave64 instruction per SIMD — the same issue
-// cost as v_mul_lo/hi_u32, v_add_co/v_addc or v_fma_f64, so what matters is the instruction COUNT:
-// unsaturated limbs let a 64-bit column accumulator absorb every carry; no MFMA — integer work).
+// One field element per lane: 9 signed BALANCED limbs of 29 bits in VGPRs, Montgomery form (R = 2^261).
+// The hot primitive is a product-scanning Montgomery product built from v_mad_i64_i32 (measured on
+// MI355X: ~4.3-5.3 cycles per wave64 instruction per SIMD, twice a plain 32-bit VALU operation, the same
+// as v_mul_lo/hi_u32 or v_fma_f64 — the multiply-add COUNT is what a product costs: unsaturated limbs let
+// a 64-bit column accumulator absorb every carry, and 9 limbs need 81 + 81 multiply-adds where 10 limbs of
+// 27 bits needed 100 + 100; no MFMA — integer carry-chain work).
 //
 // Tower: Fq2 = Fq[i]/(i^2+1), Fq6 = Fq2[v]/(v^3 - xi), Fq12 = Fq6[w]/(w^2 - v), xi = 9+i
 // (SURVEY.md Appendix A.1).  This replaces, for the hot path only, the arithmetic the
@@ -33,11 +34,23 @@
 #else
 #define BN_DEVH BN_DEVN
 #endif
+// BN_DEVF: the two Fq12 routines of the loop of fp12_pow_u (fp12_cyclotomic_sqr, fp12_mul), 254 of the 270 Fq12-level
+// calls of a final exponentiation.  A real function that keeps values alive across its product calls uses the
+// callee-saved VGPRs (fp12_mul: all 112 of them) and saves / restores every one it touches on EACH call although its
+// caller holds nothing in them: 224 scratch dwords per fp12_mul call.  A translation unit that defines
+// BN_INLINE_FE_HOT gets *_hot variants inlined into that loop (one call site each), whose enclosing function then
+// saves the registers once; everywhere else the ordinary functions are called.
+#if defined(BN_INLINE_FE_HOT)
+#define BN_DEVF BN_DEV
+#else
+#define BN_DEVF BN_DEVN
+#endif
 #else
 #define BN_DEV static inline __attribute__((always_inline))
 #define BN_DEVN static __attribute__((noinline))
 #define BN_CONST static const
 #define BN_DEVH BN_DEVN
+#define BN_DEVF BN_DEVN
 #endif
 
 #include "bn254_constants.h"
@@ -67,21 +80,28 @@ namespace bn254 {
 // ------------------------------------------------------------------------------------------
 // Fq: unsaturated signed limbs.
 //
-// An element is 10 int32 limbs of nominally 27 bits, value = sum v[i] * 2^(27 i), Montgomery form
-// with R = 2^270.  Limbs are SIGNED and may temporarily exceed 27 bits:
-//   * add / sub / neg / dbl are 10 plain v_add/v_sub (no carry chain, no modular correction);
-//   * mul is a product-scanning Montgomery product: each of the 19 columns accumulates its
-//     a_i*b_j and m_i*q_j terms in one 64-bit register with v_mad_i64_i32 / v_mad_u64_u32 — no
-//     carry handling at all — followed by one shift per column (~280 instructions instead of
-//     ~575 for saturated 8x32-bit CIOS);
-//   * norm() propagates carries so that limbs 0..8 are back in [0, 2^27) (the top limb absorbs);
-//   * canon() produces the unique representative in [0, q) (only for comparisons and output).
+// An element is 9 int32 limbs of nominally 29 bits, value = sum v[i] * 2^(29 i), Montgomery form
+// with R = 2^261.  Limbs are SIGNED and BALANCED: a "tight" element has limbs 0..7 in [-2^28, 2^28)
+// and the top limb absorbs the rest.  Balanced digits are what makes 29 bits fit: a product of two
+// tight limbs is < 2^56, so a 64-bit column holds 9 (a*b) + 9 (m*q) terms with room for operands that
+// are lazy sums of a few tight values — with digits in [0, 2^29) a column of a dual product would
+// overflow as soon as one operand is a sum of two.
+//   * add / sub / neg / dbl are 9 plain v_add/v_sub (no carry chain, no modular correction);
+//   * mul is a product-scanning Montgomery product: each of the 17 columns accumulates its
+//     a_i*b_j and m_i*q_j terms in one 64-bit register with v_mad_i64_i32 — no carry handling at
+//     all; m_k and the output digits are the sign-extended low 29 bits of the column (v_bfe_i32),
+//     q itself is held in balanced digits, and the balanced m makes the result SYMMETRIC:
+//     |value| <= |a||b| / R + q/2;
+//   * norm() propagates carries so that limbs 0..7 are back in [-2^28, 2^28) (the top limb absorbs);
+//   * norm_floor() / canon() produce digits in [0, 2^29) / the unique representative in [0, q) (only for
+//     comparisons and output).
 // Safety conditions (machine-checked by the bound-tracking host build, tests/test_bounds.py):
-//   mul(a,b): 10 * max|a_i| * max|b_j| + 10 * 2^54 + 2^37 < 2^63   and   |a||b| < q*R/2^6
+//   mul(a,b): 9 * max|a_i| * max|b_j| + 9 * 2^56 + 2^37 < 2^63   and   |a||b| / (qR) small enough for the top limb
 //   every limb always fits int32.
-// mul outputs are "tight": limbs 0..8 in [0, 2^27), |value| < q * (1 + |a||b|/(qR)).
+// R / q = 169: a product shrinks values much less than the 86 000 of the earlier 10 x 27-bit layout (R = 2^270), so
+// the formulas keep operands within a few q (the tracker follows the actual sequences) and the one place where an
+// output is linear in an input (cyclotomic squaring) reduces that term weakly (fp_reduce_weak).
 // ------------------------------------------------------------------------------------------
-#define BN_QL_ARRAY {BN_QL0, BN_QL1, BN_QL2, BN_QL3, BN_QL4, BN_QL5, BN_QL6, BN_QL7, BN_QL8, BN_QL9}
 
 #if defined(BN_TRACK_BOUNDS) && !defined(__HIPCC__)
 // Host-only interval bookkeeping: [lo,hi] bounds every limb, [vlo,vhi] bounds value/q.  The
@@ -93,10 +113,13 @@ namespace bn254 {
 #include <cstdlib>
 #include <execinfo.h>
 namespace bn254 {
-struct FpBounds { double lo, hi, top, vlo, vhi; };   // limbs 0..8 in [lo,hi], |limb 9| <= top, value/q in [vlo,vhi]
+struct FpBounds { double lo, hi, top, vlo, vhi; };   // limbs 0..7 in [lo,hi], |limb 8| <= top, value/q in [vlo,vhi]
 #define BN_BOUNDS_MEMBER FpBounds bd;
-#define BN_T 134217728.0 /* 2^27 */
+#define BN_T ((double)BN_HALF) /* 2^28: magnitude of a balanced digit */
+extern "C" int bn_bound_soft;     // 1: record the violation in bn_bound_failed and go on (tests/norm_site_search.py)
+extern "C" int bn_bound_failed;
 static inline void bn_bound_fail(const char* what, double x) {
+  if (bn_bound_soft) { bn_bound_failed = 1; return; }
   fprintf(stderr, "BOUND VIOLATION: %s (%g)\n", what, x);
   void* bt[24];
   int n = backtrace(bt, 24);
@@ -127,10 +150,15 @@ struct U256 { uint32_t w[8]; };   // plain 256-bit integer
 #if defined(BN_TRACK_BOUNDS) && !defined(__HIPCC__)
 static inline double bn_absmax(const Fp& a) { return std::fmax(std::fmax(std::fabs(a.bd.lo), std::fabs(a.bd.hi)), a.bd.top); }
 static inline double bn_vabs(const Fp& a) { return std::fmax(std::fabs(a.bd.vlo), std::fabs(a.bd.vhi)); }
-// "tight": limbs 0..8 in [0, 2^27); the top limb is then exactly floor(value / 2^243), |top| <= |value/q| * 1549 + 1
+// "tight": limbs 0..7 in [-2^28, 2^28); the top limb is then round(value / 2^232), |top| <= |value/q| * (q / 2^232) + 1
 static inline void bn_set_tight(Fp& r, double vlo, double vhi) {
-  r.bd.lo = 0; r.bd.hi = BN_T; r.bd.vlo = vlo; r.bd.vhi = vhi;
-  r.bd.top = std::fmax(std::fabs(vlo), std::fabs(vhi)) * 1549.0 + 2.0;
+  r.bd.lo = -BN_T; r.bd.hi = BN_T; r.bd.vlo = vlo; r.bd.vhi = vhi;
+  r.bd.top = std::fmax(std::fabs(vlo), std::fabs(vhi)) * BN_TOP_PER_Q + 2.0;
+}
+// "floor-tight": limbs 0..7 in [0, 2^29) (fp_norm_floor, fp_from_u256_plain)
+static inline void bn_set_floor_tight(Fp& r, double vlo, double vhi) {
+  bn_set_tight(r, vlo, vhi);
+  r.bd.lo = 0; r.bd.hi = 2.0 * BN_T;
 }
 static inline void bn_chk_i32(const Fp& r) { if (bn_absmax(r) >= 2147483648.0) bn_bound_fail("limb exceeds int32", bn_absmax(r)); }
 #define BN_TRK(stmt) do { stmt; } while (0)
@@ -193,8 +221,48 @@ BN_DEV Fp fp_neg(const Fp& a) {
   return r;
 }
 BN_DEV Fp fp_dbl(const Fp& a) { return fp_add(a, a); }
-// carry propagation: limbs 0..8 -> [0, 2^27), the top limb absorbs; the value is unchanged
+// 8 * a WITHOUT growing the limbs eight-fold (8 x 2^28 would leave int32): the shift crosses the limb boundary with
+// a BALANCED split  a_i = h_i * 2^26 + l_i,  l_i in [-2^25, 2^25):
+//   limb i = 8 * l_i + h_{i-1}      (top limb: 8 * a_top + h_{top-1}; it is small)
+// so the result's limbs stay within +-(2^28 + 2^6) for any int32 input.  This is what lets xi = 9 + i be applied
+// to a tight (or slightly lazy) element without a carry pass: 9 a -+ b has limbs <= 2^28 + |a_i| + |b_i| (fp2_mul_xi).
+#define BN_SPREAD 26
+BN_DEV int32_t bn_spread_lo(int32_t a) { return (int32_t)((uint32_t)a << (32 - BN_SPREAD)) >> (32 - BN_SPREAD); }   // v_bfe_i32
+BN_DEV int32_t bn_spread_hi(int32_t a) { return (int32_t)((uint32_t)a + (1u << (BN_SPREAD - 1))) >> BN_SPREAD; }
+BN_DEV Fp fp_mul8_spread(const Fp& a) {
+  Fp r;
+  int32_t h = 0;
+#pragma unroll
+  for (int i = 0; i < BN_LIMBS - 1; ++i) {
+    r.v[i] = bn_spread_lo(a.v[i]) * 8 + h;
+    h = bn_spread_hi(a.v[i]);
+  }
+  r.v[BN_LIMBS - 1] = a.v[BN_LIMBS - 1] * 8 + h;
+  BN_TRK(double am_ = std::fmax(std::fabs(a.bd.lo), std::fabs(a.bd.hi));
+         if (am_ + 33554432.0 + 64.0 >= 2147483648.0 || 8.0 * a.bd.top + 64.0 >= 2147483648.0) bn_bound_fail("mul8_spread input", am_);
+         r.bd = FpBounds({-BN_T - am_ / 67108864.0 - 1.0, BN_T + am_ / 67108864.0 + 1.0, 8.0 * a.bd.top + am_ / 67108864.0 + 1.0,
+                          8.0 * a.bd.vlo, 8.0 * a.bd.vhi}));
+  return r;
+}
+// the sign-extended low BN_W bits of x: the balanced digit of x, one v_bfe_i32
+BN_DEV int32_t bn_digit(uint32_t x) { return (int32_t)(x << (32 - BN_W)) >> (32 - BN_W); }
+// carry propagation: limbs 0..7 -> [-2^28, 2^28), the top limb absorbs; the value is unchanged
 BN_DEV Fp fp_norm(const Fp& a) {
+  Fp r;
+  int32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < BN_LIMBS - 1; ++i) {
+    int32_t x = a.v[i] + c;
+    r.v[i] = bn_digit((uint32_t)x);
+    c = (int32_t)((uint32_t)x + (uint32_t)BN_HALF) >> BN_W;       // (x - digit) / 2^W
+  }
+  r.v[BN_LIMBS - 1] = a.v[BN_LIMBS - 1] + c;
+  BN_TRK(if (bn_absmax(a) + BN_T + 64 >= 2147483648.0) bn_bound_fail("norm input", bn_absmax(a)); bn_set_tight(r, a.bd.vlo, a.bd.vhi));
+  return r;
+}
+// carry propagation to digits in [0, 2^29) (floor): the top limb is then floor(value / 2^232), so its sign is the
+// sign of the value — what fp_canon / fp_to_u256 need; not used on the arithmetic paths
+BN_DEV Fp fp_norm_floor(const Fp& a) {
   Fp r;
   int32_t c = 0;
 #pragma unroll
@@ -204,36 +272,38 @@ BN_DEV Fp fp_norm(const Fp& a) {
     c = x >> BN_W;
   }
   r.v[BN_LIMBS - 1] = a.v[BN_LIMBS - 1] + c;
-  BN_TRK(if (bn_absmax(a) + 64 >= 2147483648.0) bn_bound_fail("norm input", bn_absmax(a)); bn_set_tight(r, a.bd.vlo, a.bd.vhi));
+  BN_TRK(if (bn_absmax(a) + 64 >= 2147483648.0) bn_bound_fail("norm_floor input", bn_absmax(a)); bn_set_floor_tight(r, a.bd.vlo, a.bd.vhi));
   return r;
 }
 
-// Weak modular reduction of a tight element: subtract k*q with k ~ value/q estimated from the top
-// limb (k = floor(top * 21 / 2^15), 21/2^15 = 0.9924 * 2^243/q).  The residue is unchanged and the
-// value drops to within [-0.0076|V| - 0.01, 0.0076|V| + 1.02] * q.  Used where an output is LINEAR in
-// an input (cyclotomic squaring) so that values cannot build up across iterations.
+// Weak modular reduction (with carry propagation; the input may be lazy): subtract k*q with k = round(value / q)
+// estimated from the top limb: k = mulhi(top + (q/2^232)/2, round(2^32 / (q/2^232))) (one v_mul_hi_i32; the multiplier
+// is 0.99985 of the exact ratio; lazy lower limbs shift the estimate by < 10^-5).  The residue is unchanged, the limbs
+// come out tight and the value within +-(0.51 + 0.0003 |V|) * q.  Used on the outputs of the Fq12-level operations:
+// with R / q = 169 the products alone do not keep the values of a long chain bounded.
 BN_DEV Fp fp_reduce_weak(const Fp& a) {
   const int32_t q[BN_LIMBS] = BN_QL_ARRAY;
-  int32_t k = (a.v[BN_LIMBS - 1] * 21) >> 15;
+  int32_t k = (int32_t)(((int64_t)(a.v[BN_LIMBS - 1] + BN_WEAK_HALF) * BN_WEAK_KMUL) >> 32);
   int32_t carry = 0;
   Fp r;
 #pragma unroll
   for (int i = 0; i < BN_LIMBS; ++i) {
-    int64_t acc = (int64_t)(a.v[i] + carry) - (int64_t)k * q[i];
+    int64_t acc = (int64_t)a.v[i] + carry - (int64_t)k * q[i];
     if (i < BN_LIMBS - 1) {
-      r.v[i] = (int32_t)((uint32_t)acc & BN_MASK);
-      carry = (int32_t)(acc >> BN_W);
+      r.v[i] = bn_digit((uint32_t)acc);
+      carry = (int32_t)((acc + BN_HALF) >> BN_W);
     } else {
       r.v[i] = (int32_t)acc;
     }
   }
-  BN_TRK(if (a.bd.lo < 0 || a.bd.hi > BN_T || a.bd.top * 21.0 >= 2147483648.0) bn_bound_fail("reduce_weak needs a tight input", a.bd.hi);
-         double va_ = bn_vabs(a); bn_set_tight(r, -0.0076 * va_ - 0.01, 0.0076 * va_ + 1.02));
+  BN_TRK(if (bn_absmax(a) + 4194304.0 >= 2147483648.0) bn_bound_fail("reduce_weak input limbs", bn_absmax(a));
+         double va_ = bn_vabs(a); if (va_ > 600.0) bn_bound_fail("reduce_weak input value", va_);
+         bn_set_tight(r, -0.0003 * va_ - 0.51, 0.0003 * va_ + 0.51));
   return r;
 }
 
 // Montgomery product a*b*R^-1 (mod q), product scanning.  Columns are accumulated in a signed
-// 64-bit register; m_k = (column * -q^-1) mod 2^27 makes each column divisible by 2^27.
+// 64-bit register; m_k = the balanced digit of (column * -q^-1) makes each column divisible by 2^29.
 #if defined(__HIPCC__)
 typedef int32_t bn_i32x16 __attribute__((vector_size(64)));   // 10 limbs travel in VGPRs across the call
 #define BN_LIMB_VEC bn_i32x16
@@ -242,9 +312,12 @@ struct bn_limbvec { int32_t e[16]; int32_t& operator[](int i) { return e[i]; } c
 #define BN_LIMB_VEC bn_limbvec
 #endif
 
-// acc >>= 27 (arithmetic): one v_ashrrev_i64 — measured at the issue cost of a 32-bit VALU op on gfx950
+// acc >>= 29 (arithmetic): one v_ashrrev_i64 — measured at the issue cost of a 32-bit VALU op on gfx950
 // (profiles/r01_issue_mix_microbench.jsonl), cheaper than an alignbit + ashr pair
 #define BN_COLUMN_SHIFT(acc) do { (acc) >>= BN_W; } while (0)
+// an output column: digit = balanced low 29 bits (v_bfe_i32), carry = (acc - digit) / 2^29 = (acc + 2^28) >> 29
+// (one 64-bit add of a constant + the shift)
+#define BN_COLUMN_OUT(acc, digit) do { (digit) = bn_digit((uint32_t)(acc)); (acc) = ((acc) + (int64_t)BN_HALF) >> BN_W; } while (0)
 
 // acc += x * y: one v_mad_i64_i32 per limb product, left to the compiler.  Measured and rejected: spelling the
 // instruction out with the (unused) carry-out alternating between two SGPR pairs.  In a synthetic stream that
@@ -273,12 +346,12 @@ struct bn_limbvec { int32_t e[16]; int32_t& operator[](int i) { return e[i]; } c
         BN_MAC(acc_, m_[i_], q_[j_]);                                                    \
       }                                                                                  \
       if (k_ < BN_LIMBS) {                                                               \
-        m_[k_] = (int32_t)(((uint32_t)acc_ * BN_N0) & BN_MASK);                          \
+        m_[k_] = bn_digit((uint32_t)acc_ * BN_N0);                                       \
         BN_MAC(acc_, m_[k_], q_[0]);                                                     \
+        BN_COLUMN_SHIFT(acc_);                                                           \
       } else {                                                                           \
-        (r)[k_ - BN_LIMBS] = (int32_t)((uint32_t)acc_ & BN_MASK);                        \
+        BN_COLUMN_OUT(acc_, (r)[k_ - BN_LIMBS]);                                         \
       }                                                                                  \
-      BN_COLUMN_SHIFT(acc_);                                                             \
     }                                                                                    \
     (r)[BN_LIMBS - 1] = (int32_t)acc_;                                                   \
   } while (0)
@@ -288,7 +361,7 @@ BN_DEVN BN_LIMB_VEC fp_mul_impl(BN_LIMB_VEC a, BN_LIMB_VEC b) {
   BN_MONT_PRODUCT_BODY(a, b, r);
   return r;
 }
-// a^2: 55 limb products instead of 100 (cross terms through the doubled operand)
+// a^2: 45 limb products instead of 81 (cross terms through the doubled operand)
 BN_DEVN BN_LIMB_VEC fp_sqr_impl(BN_LIMB_VEC a) {
   BN_COUNT_MUL();
   const int32_t q[BN_LIMBS] = BN_QL_ARRAY;
@@ -314,28 +387,31 @@ BN_DEVN BN_LIMB_VEC fp_sqr_impl(BN_LIMB_VEC a) {
       BN_MAC(acc, m[i], q[j]);
     }
     if (k < BN_LIMBS) {
-      m[k] = (int32_t)(((uint32_t)acc * BN_N0) & BN_MASK);
+      m[k] = bn_digit((uint32_t)acc * BN_N0);
       BN_MAC(acc, m[k], q[0]);
+      BN_COLUMN_SHIFT(acc);
     } else {
-      r[k - BN_LIMBS] = (int32_t)((uint32_t)acc & BN_MASK);
+      BN_COLUMN_OUT(acc, r[k - BN_LIMBS]);
     }
-    BN_COLUMN_SHIFT(acc);
   }
   r[BN_LIMBS - 1] = (int32_t)acc;
   return r;
 }
 
 #if defined(BN_TRACK_BOUNDS) && !defined(__HIPCC__)
+// the m*q part of a column (9 balanced x balanced digit products) plus the carry from the column below
+#define BN_COL_EXTRA ((double)BN_LIMBS * BN_T * BN_T + 137438953472.0 /* 2^37 */)
+#define BN_VALUE_CAP 64.0   /* |value| / q allowed for a product output: its top limb stays below 2^28 */
 static inline void bn_trk_mul(Fp& r, const Fp& a, const Fp& b) {
   double A = bn_absmax(a), B = bn_absmax(b);
-  double col = 10.0 * A * B + 10.0 * 18014398509481984.0 /* 2^54 */ + 137438953472.0 /* 2^37 */;
-  if (col >= 9223372036854775808.0) bn_bound_fail("mul column overflow: 10*A*B", col);
-  double vv = bn_vabs(a) * bn_vabs(b) / 86000.0;   // |a||b| / (q R) in units of q  (q/R = 2^-16.4 < 1/86000)
-  if (vv > 64.0) { fprintf(stderr, "  |a| < %g q, |b| < %g q, limbs %g %g\n", bn_vabs(a), bn_vabs(b), A / BN_T, B / BN_T); bn_bound_fail("mul value bound |a||b|/(qR)", vv); }
-  // value = (ab + mq)/R with 0 <= m < R
-  double plo = std::fmin(std::fmin(a.bd.vlo * b.bd.vlo, a.bd.vlo * b.bd.vhi), std::fmin(a.bd.vhi * b.bd.vlo, a.bd.vhi * b.bd.vhi)) / 86000.0;
-  double phi = std::fmax(std::fmax(a.bd.vlo * b.bd.vlo, a.bd.vlo * b.bd.vhi), std::fmax(a.bd.vhi * b.bd.vlo, a.bd.vhi * b.bd.vhi)) / 86000.0;
-  bn_set_tight(r, std::fmin(plo, 0.0), 1.0 + std::fmax(phi, 0.0));
+  double col = (double)BN_LIMBS * A * B + BN_COL_EXTRA;
+  if (col >= 9223372036854775808.0) { if (!bn_bound_soft) fprintf(stderr, "  limbs %g x %g (units of 2^28)\n", A / BN_T, B / BN_T); bn_bound_fail("mul column overflow: 9*A*B", col); }
+  double vv = bn_vabs(a) * bn_vabs(b) / BN_R_OVER_Q;   // |a||b| / (q R) in units of q
+  if (vv > BN_VALUE_CAP) { if (!bn_bound_soft) fprintf(stderr, "  |a| < %g q, |b| < %g q, limbs %g %g\n", bn_vabs(a), bn_vabs(b), A / BN_T, B / BN_T); bn_bound_fail("mul value bound |a||b|/(qR)", vv); }
+  // value = (ab + mq)/R with |m| <= R/2 (balanced digits)
+  double plo = std::fmin(std::fmin(a.bd.vlo * b.bd.vlo, a.bd.vlo * b.bd.vhi), std::fmin(a.bd.vhi * b.bd.vlo, a.bd.vhi * b.bd.vhi)) / BN_R_OVER_Q;
+  double phi = std::fmax(std::fmax(a.bd.vlo * b.bd.vlo, a.bd.vlo * b.bd.vhi), std::fmax(a.bd.vhi * b.bd.vlo, a.bd.vhi * b.bd.vhi)) / BN_R_OVER_Q;
+  bn_set_tight(r, plo - 0.501, phi + 0.501);
 }
 #endif
 
@@ -364,17 +440,17 @@ BN_DEV Fp fp_sqr(const Fp& a) {
 
 // ---- lazy-reduction Fq2 product -------------------------------------------------------------------
 // (a0 + a1 i)(b0 + b1 i): both limb products of each output coefficient are accumulated into the same
-// 64-bit columns (re: a0*b0 + (-a1)*b1, im: a0*b1 + a1*b0) and reduced ONCE — 600 multiplies like a
+// 64-bit columns (re: a0*b0 + (-a1)*b1, im: a0*b1 + a1*b0) and reduced ONCE — 6 x 81 multiply-adds like a
 // 3-product Karatsuba, but no Karatsuba additions, no separate carry normalisation (outputs are tight)
-// and one call instead of three.  Column bound: 10*(A0*B0 + A1*B1) + 10*2^54 + 2^37 < 2^63.
+// and one call instead of three.  Column bound: 9*(A0*B0 + A1*B1) + 9*2^56 + 2^37 < 2^63.
 #if defined(__HIPCC__)
-typedef int32_t bn_i32x10 __attribute__((ext_vector_type(10)));
-typedef int32_t bn_i32x20 __attribute__((ext_vector_type(20)));
+typedef int32_t bn_i32x10 __attribute__((ext_vector_type(BN_LIMBS)));        // "VEC10": one element's limbs (the name predates 9 limbs)
+typedef int32_t bn_i32x20 __attribute__((ext_vector_type(2 * BN_LIMBS)));
 #define BN_VEC10 bn_i32x10
 #define BN_VEC20 bn_i32x20
 #else
-struct bn_vec10 { int32_t e[10]; int32_t& operator[](int i) { return e[i]; } const int32_t& operator[](int i) const { return e[i]; } };
-struct bn_vec20 { int32_t e[20]; int32_t& operator[](int i) { return e[i]; } const int32_t& operator[](int i) const { return e[i]; } };
+struct bn_vec10 { int32_t e[BN_LIMBS]; int32_t& operator[](int i) { return e[i]; } const int32_t& operator[](int i) const { return e[i]; } };
+struct bn_vec20 { int32_t e[2 * BN_LIMBS]; int32_t& operator[](int i) { return e[i]; } const int32_t& operator[](int i) const { return e[i]; } };
 #define BN_VEC10 bn_vec10
 #define BN_VEC20 bn_vec20
 #endif
@@ -398,12 +474,12 @@ struct bn_vec20 { int32_t e[20]; int32_t& operator[](int i) { return e[i]; } con
         BN_MAC(acc_, m_[i_], q_[j_]);                                                    \
       }                                                                                  \
       if (k_ < BN_LIMBS) {                                                               \
-        m_[k_] = (int32_t)(((uint32_t)acc_ * BN_N0) & BN_MASK);                          \
+        m_[k_] = bn_digit((uint32_t)acc_ * BN_N0);                                       \
         BN_MAC(acc_, m_[k_], q_[0]);                                                     \
+        BN_COLUMN_SHIFT(acc_);                                                           \
       } else {                                                                           \
-        (r)[k_ - BN_LIMBS] = (int32_t)((uint32_t)acc_ & BN_MASK);                        \
+        BN_COLUMN_OUT(acc_, (r)[k_ - BN_LIMBS]);                                         \
       }                                                                                  \
-      BN_COLUMN_SHIFT(acc_);                                                             \
     }                                                                                    \
     (r)[BN_LIMBS - 1] = (int32_t)acc_;                                                   \
   } while (0)
@@ -429,13 +505,13 @@ BN_DEVN BN_VEC20 fp2_mul_impl(BN_VEC10 a0, BN_VEC10 a1, BN_VEC10 b0, BN_VEC10 b1
 // One product by the Montgomery one brings |value| into (-eps q, (1+eps) q); then at most one
 // correction by q either way.
 BN_DEVN Fp fp_canon(Fp a) {
-  Fp t = fp_mul(a, fp_one());
+  Fp t = fp_norm_floor(fp_mul(a, fp_one()));         // |value| < 0.51 q + |a| / 169; floor digits: sign(top) = sign(value)
   Fp ql = fp_load_const(C_QL);
-  Fp up = fp_norm(fp_add(t, ql));
+  Fp up = fp_norm_floor(fp_add(t, ql));
   t = fp_select(t.v[BN_LIMBS - 1] < 0, up, t);
-  Fp dn = fp_norm(fp_sub(t, ql));
+  Fp dn = fp_norm_floor(fp_sub(t, ql));
   t = fp_select(dn.v[BN_LIMBS - 1] >= 0, dn, t);
-  BN_TRK(bn_set_tight(t, 0, 1));
+  BN_TRK(if (bn_vabs(a) > 80.0) bn_bound_fail("canon input value", bn_vabs(a)); bn_set_floor_tight(t, 0, 1));
   return t;
 }
 BN_DEV bool fp_limbs_all_zero(const Fp& a) {
@@ -457,7 +533,7 @@ BN_DEV Fp fp_from_u256_plain(const U256& x) {
     if (s + BN_W > 32 && w + 1 < 8) v |= x.w[w + 1] << (32 - s);
     r.v[i] = (int32_t)(v & BN_MASK);
   }
-  BN_TRK(bn_set_tight(r, 0, 5.3));   // any 256-bit integer is < 5.3 q
+  BN_TRK(bn_set_floor_tight(r, 0, 5.3));   // any 256-bit integer is < 5.3 q
   return r;
 }
 // integer x (any U256) -> Montgomery form of x mod q
@@ -468,12 +544,13 @@ BN_DEVN U256 fp_to_u256(Fp a) {
   one.v[0] = 1;
   BN_TRK(bn_set_tight(one, 0, 1));
   // a * 1 / R is the plain residue; canonicalise it with the same +-q correction as fp_canon
-  Fp t = fp_mul(a, one);
+  Fp t = fp_norm_floor(fp_mul(a, one));
   Fp ql = fp_load_const(C_QL);
-  Fp up = fp_norm(fp_add(t, ql));
+  Fp up = fp_norm_floor(fp_add(t, ql));
   t = fp_select(t.v[BN_LIMBS - 1] < 0, up, t);
-  Fp dn = fp_norm(fp_sub(t, ql));
+  Fp dn = fp_norm_floor(fp_sub(t, ql));
   t = fp_select(dn.v[BN_LIMBS - 1] >= 0, dn, t);
+  BN_TRK(if (bn_vabs(a) > 80.0) bn_bound_fail("to_u256 input value", bn_vabs(a)));
   U256 r;
 #pragma unroll
   for (int w = 0; w < 8; ++w) r.w[w] = 0;
@@ -534,20 +611,20 @@ BN_DEV Fp2 fp2_select(bool c, const Fp2& a, const Fp2& b) { Fp2 r; r.c0 = fp_sel
 #if defined(BN_TRACK_BOUNDS) && !defined(__HIPCC__)
 static inline void bn_trk_fp2mul(Fp2& r, const Fp2& a, const Fp2& b) {
   double A0 = bn_absmax(a.c0), A1 = bn_absmax(a.c1), B0 = bn_absmax(b.c0), B1 = bn_absmax(b.c1);
-  double extra = 10.0 * 18014398509481984.0 + 137438953472.0;
-  double col_re = 10.0 * (A0 * B0 + A1 * B1) + extra, col_im = 10.0 * (A0 * B1 + A1 * B0) + extra;
+  double extra = BN_COL_EXTRA;
+  double col_re = (double)BN_LIMBS * (A0 * B0 + A1 * B1) + extra, col_im = (double)BN_LIMBS * (A0 * B1 + A1 * B0) + extra;
   if (col_re >= 9223372036854775808.0 || col_im >= 9223372036854775808.0) bn_bound_fail("fp2_mul column overflow", std::fmax(col_re, col_im));
   auto prod = [](const Fp& x, const Fp& y, double& lo, double& hi) {
     double c[4] = {x.bd.vlo * y.bd.vlo, x.bd.vlo * y.bd.vhi, x.bd.vhi * y.bd.vlo, x.bd.vhi * y.bd.vhi};
-    lo = std::fmin(std::fmin(c[0], c[1]), std::fmin(c[2], c[3])) / 86000.0;
-    hi = std::fmax(std::fmax(c[0], c[1]), std::fmax(c[2], c[3])) / 86000.0;
+    lo = std::fmin(std::fmin(c[0], c[1]), std::fmin(c[2], c[3])) / BN_R_OVER_Q;
+    hi = std::fmax(std::fmax(c[0], c[1]), std::fmax(c[2], c[3])) / BN_R_OVER_Q;
   };
   double l00, h00, l11, h11, l01, h01, l10, h10;
   prod(a.c0, b.c0, l00, h00); prod(a.c1, b.c1, l11, h11); prod(a.c0, b.c1, l01, h01); prod(a.c1, b.c0, l10, h10);
   double re_lo = l00 - h11, re_hi = h00 - l11, im_lo = l01 + l10, im_hi = h01 + h10;
-  if (std::fmax(std::fmax(std::fabs(re_lo), std::fabs(re_hi)), std::fmax(std::fabs(im_lo), std::fabs(im_hi))) > 64.0) bn_bound_fail("fp2_mul value bound", re_hi);
-  bn_set_tight(r.c0, re_lo, re_hi + 1.0);
-  bn_set_tight(r.c1, im_lo, im_hi + 1.0);
+  if (std::fmax(std::fmax(std::fabs(re_lo), std::fabs(re_hi)), std::fmax(std::fabs(im_lo), std::fabs(im_hi))) > BN_VALUE_CAP) bn_bound_fail("fp2_mul value bound", re_hi);
+  bn_set_tight(r.c0, re_lo - 0.501, re_hi + 0.501);
+  bn_set_tight(r.c1, im_lo - 0.501, im_hi + 0.501);
 }
 #endif
 BN_DEV Fp2 fp2_mul(const Fp2& a, const Fp2& b) {   // lazy-reduction product; outputs are tight
@@ -568,15 +645,15 @@ BN_DEV Fp2 fp2_sqr(const Fp2& a) {                 // 2 Fq products
   return r;
 }
 BN_DEV Fp2 fp2_mul_fp(const Fp2& a, const Fp& k) { Fp2 r; r.c0 = fp_mul(a.c0, k); r.c1 = fp_mul(a.c1, k); return r; }
-BN_DEV Fp2 fp2_mul_xi(const Fp2& a) {              // (9 + i) * a; limb bounds grow 10x: input must be (near) tight
-  Fp a2 = fp_dbl(a.c0), a4 = fp_dbl(a2), a8 = fp_dbl(a4);
-  Fp b2 = fp_dbl(a.c1), b4 = fp_dbl(b2), b8 = fp_dbl(b4);
+BN_DEV Fp2 fp2_mul_xi(const Fp2& a) {              // (9 + i) * a through fp_mul8_spread: limbs <= 2^28 + |a0_i| + |a1_i|
+  Fp a8 = fp_mul8_spread(a.c0), b8 = fp_mul8_spread(a.c1);
   Fp2 r;
   r.c0 = fp_sub(fp_add(a8, a.c0), a.c1);
   r.c1 = fp_add(fp_add(b8, a.c1), a.c0);
   return r;
 }
 BN_DEV Fp2 fp2_mul_xi_n(const Fp2& a) { return fp2_mul_xi(fp2_norm(a)); }
+BN_DEV Fp2 fp2_mul8(const Fp2& a) { Fp2 r; r.c0 = fp_mul8_spread(a.c0); r.c1 = fp_mul8_spread(a.c1); return r; }
 BN_DEV Fp2 fp2_inv(const Fp2& a) {
   Fp n = fp_inv(fp_add(fp_sqr(a.c0), fp_sqr(a.c1)));
   Fp2 r;
@@ -608,12 +685,12 @@ BN_DEVN Fp2 fp2_pow_sched(Fp2 a, const unsigned char (*sched)[2], int n_steps) {
   Fp2 odd[8];
   a = fp2_norm(a);
   odd[0] = a;
-  Fp2 a2 = fp2_norm(fp2_sqr(a));
+  Fp2 a2 = fp2_sqr(a);
   for (int i = 1; i < 8; ++i) odd[i] = fp2_mul(odd[i - 1], a2);
   Fp2 acc = odd[sched[0][1] >> 1];
   for (int s = 1; s < n_steps; ++s) {
     BN_SET_STEP_PRIORITY(s);
-    for (int k = 0; k < sched[s][0]; ++k) acc = fp2_norm(fp2_sqr(acc));
+    for (int k = 0; k < sched[s][0]; ++k) acc = fp2_sqr(acc);
     if (sched[s][1]) acc = fp2_mul(acc, odd[sched[s][1] >> 1]);
   }
   return acc;
@@ -624,7 +701,7 @@ BN_DEVN Fp2 fp2_pow_sched(Fp2 a, const unsigned char (*sched)[2], int n_steps) {
 BN_DEVN bool fp2_sqrt(Fp2& x, const Fp2& a_in) {
   Fp2 a = fp2_norm(a_in);
   Fp2 a1 = fp2_pow_sched(a, C_SCHED_QM3D4, BN_SCHED_QM3D4_LEN);
-  Fp2 alpha = fp2_mul(fp2_norm(fp2_sqr(a1)), a);
+  Fp2 alpha = fp2_mul(fp2_sqr(a1), a);
   Fp2 x0 = fp2_mul(a1, a);
   Fp2 minus_one = fp2_norm(fp2_neg(fp2_one()));
   bool alpha_is_m1 = fp2_eq(alpha, minus_one);
@@ -642,39 +719,64 @@ BN_DEVN bool fp2_sqrt(Fp2& x, const Fp2& a_in) {
 // the Fq6 layer is inlined into them so that all intermediates of one Fq12 operation live in VGPRs and
 // each operand crosses memory once (rocprofv3 showed the earlier call-per-Fq6-product structure moving
 // ~1.5 MB of private-segment traffic per verify: HBM-bound instead of VALU-bound).
-// Contract: inputs with |limb| <= 2^27 ("tight"), outputs tight again (norm at the end).
+//
+// Limb / value management with R = 2^261 (bn254_field.h header): a product column holds ~13 units of (2^28)^2, so
+//   fp2_mul(a, b) needs A * B <= 6 (A, B = limb magnitudes in units of 2^28), fp2_sqr(a) needs A <= 1.8,
+// and a product only shrinks values by R / q = 169 while xi = 9 + i and the Karatsuba subtractions expand them
+// ~30-fold per Fq6 level.  Contract of the Fq12-level operations: inputs tight and of small value (|V| < ~1 q),
+// outputs the same — every output coefficient passes through a SITE that carries (fp2_norm) or carries and weakly
+// reduces (fp2_reduce_weak) it.  Which sites are needed at all, and in which mode, is decided by a search under the
+// bound tracker (tests/norm_site_search.py) and recorded in bn254_norm_sites.h; the source states the safe default.
 // ------------------------------------------------------------------------------------------
+}  // namespace bn254
+#include "bn254_norm_sites.h"                  // constexpr int bn_site_override(int id): -1 or the mode found by the search
+namespace bn254 {
+#if defined(BN_TRACK_BOUNDS) && !defined(__HIPCC__)
+extern "C" signed char bn_site_mode[1024];     // starts as bn_site_override(id); the search rewrites entries at run time
+extern "C" unsigned int bn_site_hits[1024];    // how often a flow passed through each site (the search's cost weights)
+extern "C" signed char bn_site_dflt[1024];     // the default mode the source states for the site
+#define BN_SITE_MODE(id, dflt) (++bn_site_hits[id], bn_site_dflt[id] = (dflt), bn_site_mode[id] < 0 ? (dflt) : (int)bn_site_mode[id])
+#else
+#define BN_SITE_MODE(id, dflt) (bn_site_override(id) < 0 ? (dflt) : bn_site_override(id))
+#endif
+BN_DEV Fp2 fp2_site(const Fp2& x, int mode) { return mode == 2 ? fp2_reduce_weak(x) : mode == 1 ? fp2_norm(x) : x; }
+#define NS(id, x) fp2_site((x), BN_SITE_MODE(id, 1))   /* default: carry */
+#define NR(id, x) fp2_site((x), BN_SITE_MODE(id, 2))   /* default: carry + weak reduction */
+
 BN_DEV void fp6_add(Fp6& r, const Fp6& a, const Fp6& b) { r.c0 = fp2_add(a.c0, b.c0); r.c1 = fp2_add(a.c1, b.c1); r.c2 = fp2_add(a.c2, b.c2); }
 BN_DEV void fp6_sub(Fp6& r, const Fp6& a, const Fp6& b) { r.c0 = fp2_sub(a.c0, b.c0); r.c1 = fp2_sub(a.c1, b.c1); r.c2 = fp2_sub(a.c2, b.c2); }
 BN_DEV void fp6_neg(Fp6& r, const Fp6& a) { r.c0 = fp2_neg(a.c0); r.c1 = fp2_neg(a.c1); r.c2 = fp2_neg(a.c2); }
 BN_DEV void fp6_norm(Fp6& r, const Fp6& a) { r.c0 = fp2_norm(a.c0); r.c1 = fp2_norm(a.c1); r.c2 = fp2_norm(a.c2); }
-BN_DEV void fp6_mul_v(Fp6& r, const Fp6& a) { Fp2 t = fp2_mul_xi(a.c2); r.c2 = a.c1; r.c1 = a.c0; r.c0 = t; }   // a.c2 tight
+BN_DEV void fp6_mul_v(Fp6& r, const Fp6& a) { Fp2 t = fp2_mul_xi(a.c2); r.c2 = a.c1; r.c1 = a.c0; r.c0 = t; }
+template <int S> BN_DEV void fp6_site_n(Fp6& r, const Fp6& a) { r.c0 = NS(S, a.c0); r.c1 = NS(S + 1, a.c1); r.c2 = NS(S + 2, a.c2); }
+template <int S> BN_DEV void fp6_site_r(Fp6& r, const Fp6& a) { r.c0 = NR(S, a.c0); r.c1 = NR(S + 1, a.c1); r.c2 = NR(S + 2, a.c2); }
 
-BN_DEV void fp6_mul(Fp6& r, const Fp6& a, const Fp6& b) {
+// a * b, Karatsuba: 6 Fq2 products.  Sites S .. S+3.
+template <int S> BN_DEV void fp6_mul(Fp6& r, const Fp6& a, const Fp6& b) {
   Fp2 v0 = fp2_mul(a.c0, b.c0), v1 = fp2_mul(a.c1, b.c1), v2 = fp2_mul(a.c2, b.c2);
-  Fp2 c0 = fp2_add(fp2_mul_xi_n(fp2_sub(fp2_sub(fp2_mul(fp2_add(a.c1, a.c2), fp2_add(b.c1, b.c2)), v1), v2)), v0);
+  Fp2 c0 = fp2_add(fp2_mul_xi(NS(S, fp2_sub(fp2_sub(fp2_mul(fp2_add(a.c1, a.c2), fp2_add(b.c1, b.c2)), v1), v2))), v0);
   Fp2 c1 = fp2_add(fp2_sub(fp2_sub(fp2_mul(fp2_add(a.c0, a.c1), fp2_add(b.c0, b.c1)), v0), v1), fp2_mul_xi(v2));
   Fp2 c2 = fp2_add(fp2_sub(fp2_sub(fp2_mul(fp2_add(a.c0, a.c2), fp2_add(b.c0, b.c2)), v0), v2), v1);
-  r.c0 = fp2_norm(c0); r.c1 = fp2_norm(c1); r.c2 = fp2_norm(c2);
+  r.c0 = NS(S + 1, c0); r.c1 = NS(S + 2, c1); r.c2 = NS(S + 3, c2);
 }
 BN_DEV void fp6_mul_fp2(Fp6& r, const Fp6& a, const Fp2& k) {
   Fp2 c0 = fp2_mul(a.c0, k), c1 = fp2_mul(a.c1, k), c2 = fp2_mul(a.c2, k);
   r.c0 = c0; r.c1 = c1; r.c2 = c2;
 }
-// a * (b0 + b1 v)
-BN_DEV void fp6_mul_01(Fp6& r, const Fp6& a, const Fp2& b0, const Fp2& b1) {
+// a * (b0 + b1 v): 5 Fq2 products.  Sites S .. S+2.
+template <int S> BN_DEV void fp6_mul_01(Fp6& r, const Fp6& a, const Fp2& b0, const Fp2& b1) {
   Fp2 v0 = fp2_mul(a.c0, b0), v1 = fp2_mul(a.c1, b1);
   Fp2 c0 = fp2_add(fp2_mul_xi(fp2_mul(a.c2, b1)), v0);
   Fp2 c1 = fp2_sub(fp2_sub(fp2_mul(fp2_add(a.c0, a.c1), fp2_add(b0, b1)), v0), v1);
   Fp2 c2 = fp2_add(fp2_mul(a.c2, b0), v1);
-  r.c0 = c0; r.c1 = c1; r.c2 = fp2_norm(c2);
+  r.c0 = NS(S, c0); r.c1 = NS(S + 1, c1); r.c2 = NS(S + 2, c2);
 }
-BN_DEVN void fp6_inv(Fp6& r, const Fp6& a) {
-  Fp2 t0 = fp2_norm(fp2_sub(fp2_sqr(a.c0), fp2_mul_xi(fp2_mul(a.c1, a.c2))));
-  Fp2 t1 = fp2_norm(fp2_sub(fp2_mul_xi_n(fp2_sqr(a.c2)), fp2_mul(a.c0, a.c1)));
-  Fp2 t2 = fp2_norm(fp2_sub(fp2_sqr(a.c1), fp2_mul(a.c0, a.c2)));
-  Fp2 d = fp2_add(fp2_mul_xi_n(fp2_add(fp2_mul(a.c2, t1), fp2_mul(a.c1, t2))), fp2_mul(a.c0, t0));
-  d = fp2_norm(fp2_inv(fp2_norm(d)));
+BN_DEVN void fp6_inv(Fp6& r, const Fp6& a) {      // sites 10 .. 15
+  Fp2 t0 = NS(10, fp2_sub(fp2_sqr(a.c0), fp2_mul_xi(fp2_mul(a.c1, a.c2))));
+  Fp2 t1 = NS(11, fp2_sub(fp2_mul_xi(fp2_sqr(a.c2)), fp2_mul(a.c0, a.c1)));
+  Fp2 t2 = NS(12, fp2_sub(fp2_sqr(a.c1), fp2_mul(a.c0, a.c2)));
+  Fp2 d = fp2_add(fp2_mul_xi(NS(13, fp2_add(fp2_mul(a.c2, t1), fp2_mul(a.c1, t2)))), fp2_mul(a.c0, t0));
+  d = NS(15, fp2_inv(NR(14, d)));
   r.c0 = fp2_mul(t0, d); r.c1 = fp2_mul(t1, d); r.c2 = fp2_mul(t2, d);
 }
 
@@ -686,74 +788,82 @@ BN_DEV bool fp12_is_one(const Fp12& a) {
   return fp2_eq(a.c0.c0, fp2_one()) && fp2_is_zero(a.c0.c1) && fp2_is_zero(a.c0.c2) && fp2_is_zero(a.c1.c0) &&
          fp2_is_zero(a.c1.c1) && fp2_is_zero(a.c1.c2);
 }
-BN_DEVN void fp12_mul(Fp12& r, const Fp12& a, const Fp12& b) {
-  Fp6 t0, t1, s, t, u;
-  fp6_mul(t0, a.c0, b.c0);
-  fp6_mul(t1, a.c1, b.c1);
-  fp6_add(s, a.c0, a.c1); fp6_norm(s, s);
-  fp6_add(t, b.c0, b.c1); fp6_norm(t, t);
-  fp6_mul(u, s, t);
-  fp6_sub(u, u, t0);
-  fp6_sub(u, u, t1);
-  fp6_mul_v(s, t1);
-  fp6_add(s, t0, s);
-  fp6_norm(r.c0, s);
-  fp6_norm(r.c1, u);
+BN_DEV void fp12_mul_body(Fp12& r, const Fp12& a, const Fp12& b) {  // sites 20 .. 49
+  // Order chosen for register pressure (values that live across the product calls must sit in the ~110 callee-saved
+  // VGPRs): the Karatsuba product of the sums first, while nothing else is alive, then one Fq6 product at a time.
+  // t0 = a0 b0 is parked in r.c0 (memory) while a1 b1 is computed: r may be a or b themselves (acc = acc * x), and by
+  // then a.c0 / b.c0 have had their last use.
+  Fp6 s, t, u;
+  fp6_add(s, a.c0, a.c1); fp6_site_n<28>(s, s);
+  fp6_add(t, b.c0, b.c1); fp6_site_n<31>(t, t);
+  fp6_mul<34>(u, s, t);
+  fp6_mul<20>(s, a.c0, b.c0);                      // t0
+  fp6_sub(u, u, s);
+  r.c0 = s;
+  fp6_mul<24>(t, a.c1, b.c1);                      // t1
+  fp6_sub(u, u, t);
+  fp6_site_r<41>(r.c1, u);
+  fp6_mul_v(s, t);
+  fp6_add(s, r.c0, s);
+  fp6_site_r<38>(r.c0, s);
 }
-BN_DEVH void fp12_sqr(Fp12& r, const Fp12& a) {
+BN_DEVN void fp12_mul(Fp12& r, const Fp12& a, const Fp12& b) { fp12_mul_body(r, a, b); }
+BN_DEVF void fp12_mul_hot(Fp12& r, const Fp12& a, const Fp12& b) { fp12_mul_body(r, a, b); }     // the loop of fp12_pow_u
+BN_DEVH void fp12_sqr(Fp12& r, const Fp12& a) {                       // sites 50 .. 79
   Fp6 ab, s, t, u;
-  fp6_mul(ab, a.c0, a.c1);
-  fp6_add(s, a.c0, a.c1);
+  fp6_mul<50>(ab, a.c0, a.c1);
+  fp6_add(s, a.c0, a.c1); fp6_site_n<54>(s, s);
   fp6_mul_v(t, a.c1);
-  fp6_add(t, t, a.c0); fp6_norm(t, t);
-  fp6_mul(u, s, t);
+  fp6_add(t, t, a.c0); fp6_site_n<57>(t, t);
+  fp6_mul<60>(u, s, t);
   fp6_sub(u, u, ab);
   fp6_mul_v(s, ab);
   fp6_sub(u, u, s);
-  fp6_norm(r.c0, u);
+  fp6_site_r<64>(r.c0, u);
   fp6_add(s, ab, ab);
-  r.c1 = s;
+  fp6_site_r<67>(r.c1, s);
 }
-BN_DEV void fp12_conj(Fp12& r, const Fp12& a) { r.c0 = a.c0; fp6_neg(r.c1, a.c1); fp6_norm(r.c1, r.c1); }
-BN_DEVN void fp12_inv(Fp12& r, const Fp12& a) {
+// the negated half keeps balanced digits balanced: no carry needed
+BN_DEV void fp12_conj(Fp12& r, const Fp12& a) { r.c0 = a.c0; fp6_neg(r.c1, a.c1); }
+BN_DEVN void fp12_inv(Fp12& r, const Fp12& a) {                       // sites 80 .. 109
   Fp6 t0, t1, d;
-  fp6_mul(t0, a.c0, a.c0);
-  fp6_mul(t1, a.c1, a.c1);
+  fp6_mul<80>(t0, a.c0, a.c0);
+  fp6_mul<84>(t1, a.c1, a.c1);
   fp6_mul_v(t1, t1);
-  fp6_sub(d, t0, t1); fp6_norm(d, d);
+  fp6_sub(d, t0, t1); fp6_site_r<88>(d, d);
   fp6_inv(d, d);
-  fp6_mul(t0, a.c1, d);
-  fp6_mul(r.c0, a.c0, d);
-  fp6_neg(t0, t0); fp6_norm(r.c1, t0);
+  fp6_mul<91>(t0, a.c1, d);
+  fp6_mul<95>(r.c0, a.c0, d);
+  fp6_neg(r.c1, t0);
 }
-// f * (l0 + (l1 + l2 v) w): the sparse shape of a D-twist line (l0 at w^0, l1 at w^1, l2 at w^3)
-BN_DEVN void fp12_mul_line(Fp12& r, const Fp12& f, const Fp2& l0, const Fp2& l1, const Fp2& l2) {
+// f * (l0 + (l1 + l2 v) w): the sparse shape of a D-twist line (l0 at w^0, l1 at w^1, l2 at w^3); l0, l1, l2 tight
+BN_DEVN void fp12_mul_line(Fp12& r, const Fp12& f, const Fp2& l0, const Fp2& l1, const Fp2& l2) {   // sites 110 .. 139
   Fp6 t0, t1, s, u;
   fp6_mul_fp2(t0, f.c0, l0);
-  fp6_mul_01(t1, f.c1, l1, l2);
-  fp6_add(s, f.c0, f.c1); 
-  fp6_mul_01(u, s, fp2_add(l0, l1), l2);
+  fp6_mul_01<110>(t1, f.c1, l1, l2);
+  fp6_add(s, f.c0, f.c1); fp6_site_n<113>(s, s);
+  fp6_mul_01<116>(u, s, NS(119, fp2_add(l0, l1)), l2);
   fp6_sub(u, u, t0);
   fp6_sub(u, u, t1);
   fp6_mul_v(s, t1);
   fp6_add(s, t0, s);
-  fp6_norm(r.c0, s);
-  fp6_norm(r.c1, u);
+  fp6_site_r<120>(r.c0, s);
+  fp6_site_r<123>(r.c1, u);
 }
-// f * (b0 + b1 w): b0 a full Fq6, b1 = b10 + b11 v — the shape of a product of two lines
-BN_DEVH void fp12_mul_line2(Fp12& r, const Fp12& f, const Fp6& b0, const Fp2& b10, const Fp2& b11) {
+// f * (b0 + b1 w): b0 a full Fq6, b1 = b10 + b11 v — the shape of a product of two lines; the b's tight
+BN_DEVH void fp12_mul_line2(Fp12& r, const Fp12& f, const Fp6& b0, const Fp2& b10, const Fp2& b11) {   // sites 140 .. 169
   Fp6 t0, t1, s, u, bs;
-  fp6_mul(t0, f.c0, b0);
-  fp6_mul_01(t1, f.c1, b10, b11);
-  fp6_add(s, f.c0, f.c1);
-  bs.c0 = fp2_add(b0.c0, b10); bs.c1 = fp2_add(b0.c1, b11); bs.c2 = b0.c2;
-  fp6_mul(u, s, bs);
+  fp6_mul<140>(t0, f.c0, b0);
+  fp6_mul_01<144>(t1, f.c1, b10, b11);
+  fp6_add(s, f.c0, f.c1); fp6_site_n<147>(s, s);
+  bs.c0 = NS(150, fp2_add(b0.c0, b10)); bs.c1 = NS(151, fp2_add(b0.c1, b11)); bs.c2 = b0.c2;
+  fp6_mul<152>(u, s, bs);
   fp6_sub(u, u, t0);
   fp6_sub(u, u, t1);
   fp6_mul_v(s, t1);
   fp6_add(s, t0, s);
-  fp6_norm(r.c0, s);
-  fp6_norm(r.c1, u);
+  fp6_site_r<156>(r.c0, s);
+  fp6_site_r<159>(r.c1, u);
 }
 // coefficient k of w^k in the polynomial basis: c[2i] = c0.c_i, c[2i+1] = c1.c_i
 BN_DEV Fp2& fp12_coef(Fp12& a, int k) {
@@ -771,36 +881,31 @@ BN_DEVN void fp12_frob(Fp12& r, const Fp12& a, int power) {
   }
   r = t;
 }
-// (a + b s)^2 in Fq4 = Fq2[s]/(s^2 - xi): r0 = a^2 + xi b^2, r1 = 2ab
-BN_DEV void fp4_sqr(Fp2& r0, Fp2& r1, const Fp2& a, const Fp2& b) {
+// (a + b s)^2 in Fq4 = Fq2[s]/(s^2 - xi): r0 = a^2 + xi b^2, r1 = 2ab; a, b tight.  Sites S .. S+2.
+template <int S> BN_DEV void fp4_sqr(Fp2& r0, Fp2& r1, const Fp2& a, const Fp2& b) {
   Fp2 a2 = fp2_sqr(a), b2 = fp2_sqr(b);
-  r1 = fp2_norm(fp2_sub(fp2_sub(fp2_sqr(fp2_add(a, b)), a2), b2));
-  r0 = fp2_norm(fp2_add(a2, fp2_mul_xi(b2)));
+  r1 = NS(S + 1, fp2_sub(fp2_sub(fp2_sqr(NS(S, fp2_add(a, b))), a2), b2));
+  r0 = NS(S + 2, fp2_add(a2, fp2_mul_xi(b2)));
 }
-// Granger-Scott squaring for the cyclotomic subgroup (after the easy part of the final exp.)
-// The outputs 3t -+ 2a are linear in a, so across a run of squarings the value doubles each time unless the 2a term
-// uses a weakly reduced copy of a (fp_reduce_weak).  `reduce` = do that in this call; callers in a long run may skip
-// it three times out of four (values stay below ~700 q, products tolerate |a||b| < 64 * 86 000 q^2; the bound
-// tracker follows the actual sequences).  The branch is wave-uniform.
-BN_DEVN void fp12_cyclotomic_sqr(Fp12& r, const Fp12& a, bool reduce = true) {
+// Granger-Scott squaring for the cyclotomic subgroup (after the easy part of the final exp.).
+// The outputs 3t -+ 2a are linear in a and xi-fold in the squares, so every output is weakly reduced (site default):
+// across a run of squarings the values stay below ~0.6 q.
+BN_DEV void fp12_cyclotomic_sqr_body(Fp12& r, const Fp12& a) {       // sites 170 .. 189
   Fp2 t0, t1, t2, t3, t4, t5;
-  fp4_sqr(t0, t1, a.c0.c0, a.c1.c1);
-  fp4_sqr(t2, t3, a.c1.c0, a.c0.c2);
-  fp4_sqr(t4, t5, a.c0.c1, a.c1.c2);
-  Fp2 a00 = a.c0.c0, a11 = a.c1.c1, a10 = a.c1.c0, a02 = a.c0.c2, a01 = a.c0.c1, a12 = a.c1.c2;
-  if (reduce) {
-    a00 = fp2_reduce_weak(a00); a11 = fp2_reduce_weak(a11); a10 = fp2_reduce_weak(a10);
-    a02 = fp2_reduce_weak(a02); a01 = fp2_reduce_weak(a01); a12 = fp2_reduce_weak(a12);
-  }
+  fp4_sqr<170>(t0, t1, a.c0.c0, a.c1.c1);
+  fp4_sqr<173>(t2, t3, a.c1.c0, a.c0.c2);
+  fp4_sqr<176>(t4, t5, a.c0.c1, a.c1.c2);
   Fp12 o;
-  o.c0.c0 = fp2_norm(fp2_add(fp2_dbl(fp2_sub(t0, a00)), t0));
-  o.c1.c1 = fp2_norm(fp2_add(fp2_dbl(fp2_add(t1, a11)), t1));
-  t5 = fp2_norm(fp2_mul_xi(t5));
-  o.c1.c0 = fp2_norm(fp2_add(fp2_dbl(fp2_add(t5, a10)), t5));
-  o.c0.c2 = fp2_norm(fp2_add(fp2_dbl(fp2_sub(t4, a02)), t4));
-  o.c0.c1 = fp2_norm(fp2_add(fp2_dbl(fp2_sub(t2, a01)), t2));
-  o.c1.c2 = fp2_norm(fp2_add(fp2_dbl(fp2_add(t3, a12)), t3));
+  o.c0.c0 = NR(180, fp2_add(fp2_dbl(fp2_sub(t0, a.c0.c0)), t0));
+  o.c1.c1 = NR(181, fp2_add(fp2_dbl(fp2_add(t1, a.c1.c1)), t1));
+  t5 = NS(179, fp2_mul_xi(t5));
+  o.c1.c0 = NR(182, fp2_add(fp2_dbl(fp2_add(t5, a.c1.c0)), t5));
+  o.c0.c2 = NR(183, fp2_add(fp2_dbl(fp2_sub(t4, a.c0.c2)), t4));
+  o.c0.c1 = NR(184, fp2_add(fp2_dbl(fp2_sub(t2, a.c0.c1)), t2));
+  o.c1.c2 = NR(185, fp2_add(fp2_dbl(fp2_add(t3, a.c1.c2)), t3));
   r = o;
 }
+BN_DEVN void fp12_cyclotomic_sqr(Fp12& r, const Fp12& a) { fp12_cyclotomic_sqr_body(r, a); }
+BN_DEVF void fp12_cyclotomic_sqr_hot(Fp12& r, const Fp12& a) { fp12_cyclotomic_sqr_body(r, a); }  // the loop of fp12_pow_u
 
 }  // namespace bn254

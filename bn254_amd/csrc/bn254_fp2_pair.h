@@ -46,17 +46,23 @@ BN_DEV bool bn_pair_and(bool x) { return x; }
 // r = Montgomery-reduce(x0*y0 + x1*y1): the per-lane half of an Fq2 product
 #if defined(BN_TRACK_BOUNDS) && !defined(__HIPCC__)
 static inline void bn_trk_dual(Fp& r, const Fp& x0, const Fp& y0, const Fp& x1, const Fp& y1) {
-  double col = 10.0 * (bn_absmax(x0) * bn_absmax(y0) + bn_absmax(x1) * bn_absmax(y1)) + 10.0 * 18014398509481984.0 + 137438953472.0;
-  if (col >= 9223372036854775808.0) bn_bound_fail("pair product column overflow", col);
+  double col = (double)BN_LIMBS * (bn_absmax(x0) * bn_absmax(y0) + bn_absmax(x1) * bn_absmax(y1)) + BN_COL_EXTRA;
+  if (col >= 9223372036854775808.0) {
+    if (!bn_bound_soft) fprintf(stderr, "  limbs %g x %g + %g x %g (units of 2^28)\n", bn_absmax(x0) / BN_T, bn_absmax(y0) / BN_T, bn_absmax(x1) / BN_T, bn_absmax(y1) / BN_T);
+    bn_bound_fail("pair product column overflow", col);
+  }
   auto prod = [](const Fp& x, const Fp& y, double& lo, double& hi) {
     double c[4] = {x.bd.vlo * y.bd.vlo, x.bd.vlo * y.bd.vhi, x.bd.vhi * y.bd.vlo, x.bd.vhi * y.bd.vhi};
-    lo = std::fmin(std::fmin(c[0], c[1]), std::fmin(c[2], c[3])) / 86000.0;
-    hi = std::fmax(std::fmax(c[0], c[1]), std::fmax(c[2], c[3])) / 86000.0;
+    lo = std::fmin(std::fmin(c[0], c[1]), std::fmin(c[2], c[3])) / BN_R_OVER_Q;
+    hi = std::fmax(std::fmax(c[0], c[1]), std::fmax(c[2], c[3])) / BN_R_OVER_Q;
   };
   double l0, h0, l1, h1;
   prod(x0, y0, l0, h0); prod(x1, y1, l1, h1);
-  if (std::fmax(std::fabs(l0 + l1), std::fabs(h0 + h1)) > 64.0) bn_bound_fail("pair product value bound", h0 + h1);
-  bn_set_tight(r, l0 + l1 - 1.0, h0 + h1 + 1.0);
+  if (std::fmax(std::fabs(l0 + l1), std::fabs(h0 + h1)) > BN_VALUE_CAP) {
+    if (!bn_bound_soft) fprintf(stderr, "  values %g x %g + %g x %g q\n", bn_vabs(x0), bn_vabs(y0), bn_vabs(x1), bn_vabs(y1));
+    bn_bound_fail("pair product value bound", h0 + h1);
+  }
+  bn_set_tight(r, l0 + l1 - 0.501, h0 + h1 + 0.501);
 }
 #endif
 BN_DEVN BN_VEC10 fp_dual_impl(BN_VEC10 x0, BN_VEC10 y0, BN_VEC10 x1, BN_VEC10 y1) {
@@ -104,15 +110,17 @@ BN_DEV Fp2 fp2_select(bool c, const Fp2& a, const Fp2& b) { Fp2 r; BN_FOR_ROLES(
 // exchange / select code exists once instead of at every call site.
 BN_DEVN BN_VEC10 fp_pair_mul_impl(BN_VEC10 a, BN_VEC10 b) {
   // own * b0 + partner * (+-b1):   re lane  a0*b0 + a1*(-b1)     im lane  a1*b0 + a0*b1
-  // b0 and b1 are broadcasts within the pair; the sign is a multiplication by this lane's -1 / +1
-  const int32_t sign = (int32_t)((threadIdx.x & 1u) << 1) - 1;
+  // b0 and b1 are broadcasts within the pair
+  // -b1 in the real-part lanes: (p ^ -1) + 1, the fetch folded into the XOR (v_xor_b32_dpp) and the +1 / +0 a plain add —
+  // two 32-bit VALU operations where a multiplication by the lane's -1 / +1 cost a v_mul_lo_u32 (issue cost of a multiply-add)
+  const int32_t one = 1 - (int32_t)(threadIdx.x & 1u), mask = -one;
   int32_t ao[BN_LIMBS], ap[BN_LIMBS], x[BN_LIMBS], y[BN_LIMBS], r[BN_LIMBS];
 #pragma unroll
   for (int i = 0; i < BN_LIMBS; ++i) {
     ao[i] = a[i];
     ap[i] = bn_partner_word(a[i]);
     x[i] = bn_pair_re_word(b[i]);
-    y[i] = (int32_t)((uint32_t)bn_pair_im_word(b[i]) * (uint32_t)sign);
+    y[i] = (bn_pair_im_word(b[i]) ^ mask) + one;
   }
   BN_MONT_DUAL_BODY(ao, x, ap, y, r);
   BN_VEC10 z;
@@ -151,23 +159,22 @@ BN_DEVN BN_VEC10 fp_pair_sqr_impl(BN_VEC10 a) {
   // The three operations with their DPP operand folded in: 3 instead of 5 instructions per limb (the compiler merges
   // the two fetches of a1 into one move with two users and then folds nothing).  No VCC.  Hazard rule (a DPP operand must
   // not have been written by the two preceding VALU instructions, and the compiler's hazard recogniser does not look
-  // into asm): the DPP operands are the inputs a[i] only, each block opens with s_nop 1 in case the compiler copies an
-  // input right before it, and the outputs are early-clobber, so no block reads through DPP what it wrote.
+  // into asm): the DPP operands are the inputs a[i] only, each block (three limbs) opens with s_nop 1 in case the
+  // compiler copies an input right before it, and the outputs are early-clobber, so no block reads through DPP what it wrote.
 #define BN_SQR_ROLE_LIMB(U, V, A) \
   "v_add_u32_dpp " U ", " A ", " A " quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n" \
-  "v_and_b32_dpp " V ", " A ", %15 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n" \
+  "v_and_b32_dpp " V ", " A ", %9 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n" \
   "v_sub_u32_dpp " V ", " A ", " V " quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
 #define BN_SQR_ROLE_BLOCK(o) \
-  __asm__("s_nop 1\n" BN_SQR_ROLE_LIMB("%0", "%5", "%10") BN_SQR_ROLE_LIMB("%1", "%6", "%11") BN_SQR_ROLE_LIMB("%2", "%7", "%12") \
-          BN_SQR_ROLE_LIMB("%3", "%8", "%13") BN_SQR_ROLE_LIMB("%4", "%9", "%14") \
-          : "=&v"(u[o]), "=&v"(u[o + 1]), "=&v"(u[o + 2]), "=&v"(u[o + 3]), "=&v"(u[o + 4]), \
-            "=&v"(v[o]), "=&v"(v[o + 1]), "=&v"(v[o + 2]), "=&v"(v[o + 3]), "=&v"(v[o + 4]) \
-          : "v"(ai[o]), "v"(ai[o + 1]), "v"(ai[o + 2]), "v"(ai[o + 3]), "v"(ai[o + 4]), "v"(re_mask))
+  __asm__("s_nop 1\n" BN_SQR_ROLE_LIMB("%0", "%3", "%6") BN_SQR_ROLE_LIMB("%1", "%4", "%7") BN_SQR_ROLE_LIMB("%2", "%5", "%8") \
+          : "=&v"(u[o]), "=&v"(u[o + 1]), "=&v"(u[o + 2]), "=&v"(v[o]), "=&v"(v[o + 1]), "=&v"(v[o + 2]) \
+          : "v"(ai[o]), "v"(ai[o + 1]), "v"(ai[o + 2]), "v"(re_mask))
+  static_assert(BN_LIMBS % 3 == 0, "the asm role prologue works on blocks of three limbs");
   int32_t ai[BN_LIMBS];
 #pragma unroll
   for (int i = 0; i < BN_LIMBS; ++i) ai[i] = a[i];
-  BN_SQR_ROLE_BLOCK(0);
-  BN_SQR_ROLE_BLOCK(5);
+#pragma unroll
+  for (int o = 0; o < BN_LIMBS; o += 3) BN_SQR_ROLE_BLOCK(o);
 #undef BN_SQR_ROLE_BLOCK
 #undef BN_SQR_ROLE_LIMB
 #else
@@ -203,28 +210,38 @@ BN_DEV Fp2 fp2_sqr(const Fp2& a) {
   return r;
 }
 BN_DEV Fp2 fp2_mul_fp(const Fp2& a, const Fp& s) { Fp2 r; BN_FOR_ROLES(k) r.c[k] = fp_mul(a.c[k], s); return r; }
-BN_DEV Fp2 fp2_mul_xi(const Fp2& a) {              // (9 + i) * a; limb bounds grow 10x: input must be (near) tight
+BN_DEV Fp2 fp2_mul_xi(const Fp2& a) {              // (9 + i) * a; 8 * own by fp_mul8_spread: limbs <= 2^28 + |own_i| + |partner_i|
   Fp2 r;
 #if defined(__HIPCC__)
   // re: 9 a0 - a1   im: 9 a1 + a0.   -p = (p ^ -1) + 1: the partner fetch folds into the XOR with this lane's mask
-  // (-1 in a real-part lane, 0 in an imaginary-part lane), the +1 / +0 rides in a three-operand add
+  // (-1 in a real-part lane, 0 in an imaginary-part lane).  8 * own crosses the limb boundary (fp_mul8_spread: own =
+  // h * 2^26 + l, 8 l stays in limb i, h moves up) so that no limb grows eight-fold; the +1 of the negation rides in
+  // the rounding constant of h:  h' = (own + 2^25 + one * 2^26) >> 26 = h + one.       6 instructions per limb.
   const int32_t one = 1 - (int32_t)(threadIdx.x & 1u), mask = -one;
+  const uint32_t hround = (1u << (BN_SPREAD - 1)) + ((uint32_t)one << BN_SPREAD);
+  int32_t h = one;
 #pragma unroll
   for (int i = 0; i < BN_LIMBS; ++i) {
     const int32_t own = a.c[0].v[i];
-    r.c[0].v[i] = (own << 3) + own + ((bn_partner_word(own) ^ mask) + one);
+    const int32_t t = (bn_partner_word(own) ^ mask) + own + h;        // own -+ partner, + what limb i-1 carried up
+    if (i < BN_LIMBS - 1) {
+      r.c[0].v[i] = bn_spread_lo(own) * 8 + t;
+      h = (int32_t)((uint32_t)own + hround) >> BN_SPREAD;
+    } else {
+      r.c[0].v[i] = own * 8 + t;
+    }
   }
   return r;
 #endif
   BN_FOR_ROLES(k) {
     const Fp ap = bn_partner(a, k);
-    Fp a2 = fp_dbl(a.c[k]), a4 = fp_dbl(a2), a8 = fp_dbl(a4);
     // re: 9 a0 - a1   im: 9 a1 + a0
-    r.c[k] = fp_add(fp_add(a8, a.c[k]), fp_select(bn_role_im(k), ap, fp_neg(ap)));
+    r.c[k] = fp_add(fp_add(fp_mul8_spread(a.c[k]), a.c[k]), fp_select(bn_role_im(k), ap, fp_neg(ap)));
   }
   return r;
 }
 BN_DEV Fp2 fp2_mul_xi_n(const Fp2& a) { return fp2_mul_xi(fp2_norm(a)); }
+BN_DEV Fp2 fp2_mul8(const Fp2& a) { Fp2 r; BN_FOR_ROLES(k) r.c[k] = fp_mul8_spread(a.c[k]); return r; }
 BN_DEV Fp2 fp2_inv(const Fp2& a) {
   Fp2 t, r;
   BN_FOR_ROLES(k) t.c[k] = fp_sqr(a.c[k]);

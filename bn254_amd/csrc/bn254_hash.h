@@ -182,7 +182,7 @@ BN_DEV bool hash_point_from_candidate(G1Affine& out, const U256& x) {
   hash_curve_rhs(xm, rhs, x);
   if (!fp_sqrt(y, rhs)) return false;
   U256 yp = fp_to_u256(y);
-  if (yp.w[0] & 1) y = fp_norm(fp_neg(y));
+  if (yp.w[0] & 1) y = fp_neg(y);
   out.x = xm; out.y = y; out.inf = false;
   return true;
 }

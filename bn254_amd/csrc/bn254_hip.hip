@@ -2,7 +2,7 @@
 //
 // Execution model: a batch is processed by a short chain of kernels that hand per-item state to each other
 // through an HBM workspace laid out limb-major ("planes"): word k of field element e of item i lives at
-//   ws[(e*10 + k) * stride + i]      (10 x 27-bit limbs per field element)
+//   ws[(e*9 + k) * stride + i]       (9 x 29-bit balanced limbs per field element)
 // so a wave reads/writes contiguous bytes per limb (fully coalesced), and the caller-facing byte formats (AoS,
 // big-endian) are touched exactly once on the way in/out.  Fq-level work (decoding, hash-to-G1, G1 arithmetic)
 // runs one item per lane in this translation unit; everything built on the Fq2 tower (Miller loops, final
@@ -54,12 +54,12 @@ __device__ __forceinline__ void ws_load_g2(const Ws& ws, size_t i, G2Affine& q) 
 __device__ __forceinline__ void g1_set_generator(G1Affine& p) { p.x = fp_load_const(C_G1_GEN[0]); p.y = fp_load_const(C_G1_GEN[1]); p.inf = false; }
 __device__ __forceinline__ void g2_set_generator(G2Affine& q) { q.x = fp2_load_const(C_G2_GEN[0]); q.y = fp2_load_const(C_G2_GEN[1]); q.inf = false; }
 
-// The Miller accumulator f (12 field elements = 480 B per lane) is the hottest per-lane state: every
+// The Miller accumulator f (12 field elements = 432 B per lane) is the hottest per-lane state: every
 // Fq12 squaring / line multiplication reads and rewrites it.  It is staged in LDS, one padded slot per
-// lane (121 words: an odd word stride keeps the 64 lanes of a wave on distinct banks), so those
-// accesses never leave the CU.  31 KB per 64-lane workgroup -> 5 workgroups per 160 KB CU.
+// lane (109 words: an odd word stride keeps the 64 lanes of a wave on distinct banks), so those
+// accesses never leave the CU.  28 KB per 64-lane workgroup -> 5 workgroups per 160 KB CU.
 struct Fp12Slot { Fp12 v; int32_t pad; };
-static_assert(sizeof(Fp12Slot) == 484, "LDS slot must be 121 words");
+static_assert(sizeof(Fp12Slot) == (12 * BN_LIMBS + 1) * 4 && ((12 * BN_LIMBS + 1) & 1), "LDS slot: 12 x 9 limbs + 1 pad word (odd stride)");
 
 // ------------------------------------------------------------------------------------------
 // kernels
@@ -889,7 +889,7 @@ static int launch_hash_rounds(bn254_ctx* c, hipStream_t s, const uint8_t* d_msgs
 
 extern "C" {
 
-const char* bn254_version(void) { return "bn254-mi355x 0.3 (gfx950; 10x27-bit signed Montgomery limbs; verify on lane pairs)"; }
+const char* bn254_version(void) { return "bn254-mi355x 0.4 (gfx950; 9x29-bit balanced Montgomery limbs; verify on lane pairs)"; }
 
 int bn254_ctx_create(int hip_device, bn254_ctx** out) {
   if (!out) return BN254_E_BAD_ARGUMENT;

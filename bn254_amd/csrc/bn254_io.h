@@ -97,7 +97,7 @@ BN_DEV uint8_t decompress_g1(G1Affine& pt, const uint8_t* b) {
   bool has_root = fp_sqrt(y, rhs);
   U256 yp = fp_to_u256(y);
   bool odd = yp.w[0] & 1;
-  if (odd != (sign == 3)) y = fp_norm(fp_neg(y));
+  if (odd != (sign == 3)) y = fp_neg(y);
   pt.x = x; pt.y = y; pt.inf = false;
   if (!ok_sign) return ST_INVALID_ENCODING;
   if (!in_range || !has_root) return ST_NOT_MEMBER;

@@ -2,7 +2,7 @@
 // carried by a LANE PAIR (bn254_fp2_pair.h): lane 2i holds the real parts and lane 2i+1 the imaginary parts of
 // every Fq2 value of item i.  Same tower / pairing source as bn254_hip.hip (bn254_field.h, bn254_pairing.h),
 // compiled against the pair implementation of the fp2_* interface.  Per lane: half the multiplications, half the
-// registers (<= 256, two waves per SIMD), half the LDS (an accumulator slot is 61 words).
+// registers (<= 256, two waves per SIMD), half the LDS (an accumulator slot is 55 words).
 // Replaces, for ECDSA::verify (/root/reference/src/ecdsa.rs:49-64), k_miller_verify + k_final_exp.
 #include <hip/hip_runtime.h>
 
@@ -12,6 +12,9 @@
 #endif
 #ifndef BN_PAIR_CALL_FP12_HOT
 #define BN_INLINE_FP12_HOT 1       // fp12_sqr / fp12_mul_line2 inlined into the Miller loops (bn254_field.h: BN_DEVH)
+#endif
+#ifndef BN_PAIR_CALL_FE_HOT
+#define BN_INLINE_FE_HOT 1         // fp12_cyclotomic_sqr / fp12_mul inlined into the loop of fp12_pow_u (bn254_field.h: BN_DEVF)
 #endif
 // Measured (same box): Miller 8.8-8.95 -> 8.2-8.3 ms, final exponentiation 6.5-6.6 -> 6.4-6.45 ms per 65 536.
 #ifndef BN_PRIO_SHIFT
@@ -44,7 +47,7 @@ using namespace bn254;
 #define KERNEL_PAIR __global__ __launch_bounds__(BN_PAIR_WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
 struct Fp12PairSlot { Fp12 v; int32_t pad; };
-static_assert(sizeof(Fp12PairSlot) == 61 * 4, "LDS slot must be 61 words (odd stride: conflict-free)");
+static_assert(sizeof(Fp12PairSlot) == (6 * BN_LIMBS + 1) * 4 && ((6 * BN_LIMBS + 1) & 1), "LDS slot: 6 x 9 limbs + 1 pad word (odd stride: conflict-free)");
 
 __device__ __forceinline__ Fp2 ws_load_fp2_own(const Ws& ws, int plane_re, size_t i) {
   Fp2 r;

@@ -19,40 +19,38 @@ struct G2Proj { Fp2 x, y, z; };            // homogeneous projective twist point
 struct LineCoef { Fp2 c0, c1, c2; };
 
 // T <- 2T;  c0 = 2YZ, c1 = -3X^2, c2 = Y^2 - 3b'Z^2.
-// Carry normalisations (fp2_norm) in the step functions and the line products are only where the bound tracker
-// needs them (tests/test_bounds.py, tests/test_pair_layout.py): every value here is a short signed combination of
-// fresh product outputs (limbs < 2^27), nothing accumulates from step to step, and a product tolerates operand limbs
-// up to 10*|A||B| < 2^63.  35 of 61 normalisations of the Miller loop / final exponentiation went this way (r01-m/n);
-// two more that the tracker allows (the operand sums of fp12_mul) stay: without them that routine needs 147 instead of
-// 31 callee-saved registers and the final exponentiation is 6 % slower.
-BN_DEVN void dbl_step(G2Proj& t, LineCoef& l) {
+// Contract of the step functions: T tight on entry and on exit; the line coefficients come out lazy (up to 3 units)
+// and are made tight by the line products below.  Carry sites (NS) mark every place a lazy value meets a product
+// whose column budget (fp2_mul: A * B <= 6, fp2_sqr: A <= 1.8 units of 2^28, bn254_field.h) it might exceed; the
+// search under the bound tracker (tests/norm_site_search.py -> bn254_norm_sites.h) keeps the ones that are needed.
+// The values of T stay small by themselves (every coordinate is a short combination of fresh products).
+BN_DEVN void dbl_step(G2Proj& t, LineCoef& l) {                       // sites 200 .. 209
   Fp2 xy = fp2_mul(t.x, t.y), b = fp2_sqr(t.y), c = fp2_sqr(t.z);
   Fp2 e = fp2_mul(c, fp2_load_const(C_TWIST_3B));
   Fp2 f = fp2_add(fp2_dbl(e), e);
-  Fp2 h = fp2_sub(fp2_sub(fp2_sqr(fp2_add(t.y, t.z)), b), c);
+  Fp2 h = fp2_sub(fp2_sub(fp2_sqr(NS(200, fp2_add(t.y, t.z))), b), c);
   Fp2 x2 = fp2_sqr(t.x);
-  Fp2 e2 = fp2_sqr(e);
-  Fp2 e2x4 = fp2_dbl(fp2_dbl(e2));
+  Fp2 e2x4 = NS(201, fp2_dbl(fp2_dbl(fp2_sqr(e))));                 // 12 e^2 = 3 * carry(4 e^2): 12-fold limbs would leave int32
   Fp2 e2x12 = fp2_add(fp2_dbl(e2x4), e2x4);
   G2Proj o;
-  o.x = fp2_dbl(fp2_mul(xy, fp2_sub(b, f)));
-  o.y = fp2_norm(fp2_sub(fp2_sqr(fp2_add(b, f)), e2x12));
-  o.z = fp2_dbl(fp2_dbl(fp2_mul(b, h)));
+  o.x = NS(203, fp2_mul(fp2_dbl(xy), NS(202, fp2_sub(b, f))));
+  o.y = NS(205, fp2_sub(fp2_sqr(NS(204, fp2_add(b, f))), e2x12));
+  o.z = NS(206, fp2_dbl(fp2_dbl(fp2_mul(b, h))));
   l.c0 = h;
   l.c1 = fp2_neg(fp2_add(fp2_dbl(x2), x2));
   l.c2 = fp2_sub(b, e);
   t = o;
 }
-// T <- T + Q (Q affine);  c0 = mu, c1 = -theta, c2 = theta*x2 - mu*y2
-BN_DEVN void add_step(G2Proj& t, LineCoef& l, const Fp2& qx, const Fp2& qy) {
-  Fp2 theta = fp2_sub(t.y, fp2_mul(qy, t.z));
-  Fp2 mu = fp2_sub(t.x, fp2_mul(qx, t.z));
+// T <- T + Q (Q affine, tight);  c0 = mu, c1 = -theta, c2 = theta*x2 - mu*y2
+BN_DEVN void add_step(G2Proj& t, LineCoef& l, const Fp2& qx, const Fp2& qy) {   // sites 210 .. 219
+  Fp2 theta = NS(210, fp2_sub(t.y, fp2_mul(qy, t.z)));
+  Fp2 mu = NS(211, fp2_sub(t.x, fp2_mul(qx, t.z)));
   Fp2 c = fp2_sqr(theta), d = fp2_sqr(mu), e = fp2_mul(mu, d);
   Fp2 f = fp2_mul(t.z, c), g = fp2_mul(t.x, d);
-  Fp2 h = fp2_sub(fp2_sub(fp2_add(e, f), g), g);
+  Fp2 h = NS(212, fp2_sub(fp2_sub(fp2_add(e, f), g), g));
   G2Proj o;
   o.x = fp2_mul(mu, h);
-  o.y = fp2_sub(fp2_mul(theta, fp2_sub(g, h)), fp2_mul(e, t.y));
+  o.y = NS(214, fp2_sub(fp2_mul(theta, NS(213, fp2_sub(g, h))), fp2_mul(e, t.y)));
   o.z = fp2_mul(t.z, e);
   l.c0 = mu;
   l.c1 = fp2_neg(theta);
@@ -60,8 +58,8 @@ BN_DEVN void add_step(G2Proj& t, LineCoef& l, const Fp2& qx, const Fp2& qy) {
   t = o;
 }
 // f <- f * line(P); a skipped pair multiplies by one
-BN_DEV void mul_by_line(Fp12& f, const LineCoef& l, const Fp& px, const Fp& py, bool skip) {
-  Fp2 l0 = fp2_mul_fp(l.c0, py), l1 = fp2_mul_fp(l.c1, px), l2 = l.c2;
+BN_DEV void mul_by_line(Fp12& f, const LineCoef& l, const Fp& px, const Fp& py, bool skip) {   // sites 220 .. 222
+  Fp2 l0 = fp2_mul_fp(l.c0, py), l1 = fp2_mul_fp(l.c1, px), l2 = NS(220, l.c2);
   l0 = fp2_select(skip, fp2_one(), l0);
   l1 = fp2_select(skip, fp2_zero(), l1);
   l2 = fp2_select(skip, fp2_zero(), l2);
@@ -73,8 +71,8 @@ BN_DEV void mul_by_line(Fp12& f, const LineCoef& l, const Fp& px, const Fp& py, 
 // 5 Fq2 products for the line product and 17 for f * (5-term element), against 2 x 13.
 // `any_skip` (wave-uniform): some lane of the wave has a skipped pair; without one the selects are branched over.
 BN_DEV void mul_by_two_lines(Fp12& f, const LineCoef& l, const Fp& pax, const Fp& pay, bool skip_a, int idx, const Fp& pbx,
-                             const Fp& pby, bool skip_b, bool any_skip) {
-  Fp2 l0 = fp2_mul_fp(l.c0, pay), l1 = fp2_mul_fp(l.c1, pax), l2 = l.c2;
+                             const Fp& pby, bool skip_b, bool any_skip) {   // sites 223 .. 229
+  Fp2 l0 = fp2_mul_fp(l.c0, pay), l1 = fp2_mul_fp(l.c1, pax), l2 = NS(223, l.c2);
   if (any_skip) {
     l0 = fp2_select(skip_a, fp2_one(), l0);
     l1 = fp2_select(skip_a, fp2_zero(), l1);
@@ -87,8 +85,8 @@ BN_DEV void mul_by_two_lines(Fp12& f, const LineCoef& l, const Fp& pax, const Fp
   Fp2 w3 = fp2_add(l0, fp2_mul(l2, m0));
   Fp2 w4 = fp2_add(l1, fp2_mul(l2, m1));
   Fp6 b0;
-  b0.c0 = fp2_norm(w0); b0.c1 = v1; b0.c2 = w4;
-  Fp2 b10 = x01, b11 = fp2_norm(w3);
+  b0.c0 = NS(224, w0); b0.c1 = v1; b0.c2 = NS(225, w4);
+  Fp2 b10 = NS(226, x01), b11 = NS(227, w3);
   if (any_skip) {
     b0.c0 = fp2_select(skip_b, l0, b0.c0);
     b0.c1 = fp2_select(skip_b, fp2_zero(), b0.c1);
@@ -122,7 +120,7 @@ BN_DEVN void miller_loop(Fp12& f, const G1Affine& pa, const G2Affine& qa, const 
 #else
   const bool any_skip = skip_a || skip_b;
 #endif
-  if constexpr (HAS_A) { t.x = qa.x; t.y = qa.y; t.z = fp2_one(); qa_yneg = fp2_norm(fp2_neg(qa.y)); }
+  if constexpr (HAS_A) { t.x = qa.x; t.y = qa.y; t.z = fp2_one(); qa_yneg = fp2_neg(qa.y); }
   int idx = 0;
   constexpr bool BOTH = HAS_A && HAS_B;      // both pairs: one merged multiplication per step
   for (int d = 0; d < 64; ++d) {
@@ -163,12 +161,12 @@ BN_DEVN void miller_loop(Fp12& f, const G1Affine& pa, const G2Affine& qa, const 
 // f <- f * lineA(pa) * lineC(pc) for two variable lines: 6 Fq2 products for the line product (Karatsuba over
 // the three coefficients) + 17 for f * (5-term element), against 2 x 13 one line at a time.
 BN_DEV void mul_by_two_var_lines(Fp12& f, const LineCoef& la, const Fp& pax, const Fp& pay, bool skip_a, const LineCoef& lc, const Fp& pcx,
-                                 const Fp& pcy, bool skip_c) {
-  Fp2 l0 = fp2_mul_fp(la.c0, pay), l1 = fp2_mul_fp(la.c1, pax), l2 = la.c2;
+                                 const Fp& pcy, bool skip_c) {       // sites 230 .. 239
+  Fp2 l0 = fp2_mul_fp(la.c0, pay), l1 = fp2_mul_fp(la.c1, pax), l2 = NS(230, la.c2);
   l0 = fp2_select(skip_a, fp2_one(), l0);
   l1 = fp2_select(skip_a, fp2_zero(), l1);
   l2 = fp2_select(skip_a, fp2_zero(), l2);
-  Fp2 m0 = fp2_mul_fp(lc.c0, pcy), m1 = fp2_mul_fp(lc.c1, pcx), m2 = lc.c2;
+  Fp2 m0 = fp2_mul_fp(lc.c0, pcy), m1 = fp2_mul_fp(lc.c1, pcx), m2 = NS(231, lc.c2);
   m0 = fp2_select(skip_c, fp2_one(), m0);
   m1 = fp2_select(skip_c, fp2_zero(), m1);
   m2 = fp2_select(skip_c, fp2_zero(), m2);
@@ -177,10 +175,10 @@ BN_DEV void mul_by_two_var_lines(Fp12& f, const LineCoef& la, const Fp& pax, con
   Fp2 x02 = fp2_sub(fp2_sub(fp2_mul(fp2_add(l0, l2), fp2_add(m0, m2)), v0), v2);
   Fp2 x12 = fp2_sub(fp2_sub(fp2_mul(fp2_add(l1, l2), fp2_add(m1, m2)), v1), v2);
   Fp6 b0;
-  b0.c0 = fp2_norm(fp2_add(v0, fp2_mul_xi(v2)));
+  b0.c0 = NS(232, fp2_add(v0, fp2_mul_xi(v2)));
   b0.c1 = v1;
-  b0.c2 = x12;
-  fp12_mul_line2(f, f, b0, x01, x02);
+  b0.c2 = NS(233, x12);
+  fp12_mul_line2(f, f, b0, NS(234, x01), NS(235, x02));
 }
 
 // Miller loop over two pairs with variable twist points sharing f (randomised batch verification: two
@@ -192,7 +190,7 @@ BN_DEVN void miller_loop_2var(Fp12& f, const G1Affine& pa, const G2Affine& qa, c
   const bool skip_a = pa.inf || qa.inf, skip_c = pc.inf || qc.inf;
   ta.x = qa.x; ta.y = qa.y; ta.z = fp2_one();
   tc.x = qc.x; tc.y = qc.y; tc.z = fp2_one();
-  const Fp2 qa_yneg = fp2_norm(fp2_neg(qa.y)), qc_yneg = fp2_norm(fp2_neg(qc.y));
+  const Fp2 qa_yneg = fp2_neg(qa.y), qc_yneg = fp2_neg(qc.y);
   for (int d = 0; d < 64; ++d) {
     BN_SET_STEP_PRIORITY(d);
     fp12_sqr(f, f);
@@ -230,10 +228,13 @@ BN_DEVN void fp12_pow_u(Fp12& r, const Fp12& a, Fp12& acc) {
   acc = odd[C_U_W4[0] >> 1];                        // leading digit is positive
   for (int i = 1; i < BN_U_W4_LEN; ++i) {           // wave-uniform: u is a public constant
     BN_SET_STEP_PRIORITY(i >> 1);                    // half the rate of the Miller loop's cycle (measured: -1.3 % here)
-    fp12_cyclotomic_sqr(acc, acc, (i & 1) == 1);   // weak reduction of the linear term every other squaring
-    int d = C_U_W4[i];
-    if (d > 0) fp12_mul(acc, acc, odd[d >> 1]);
-    else if (d < 0) { fp12_conj(t, odd[(-d) >> 1]); fp12_mul(acc, acc, t); }
+    fp12_cyclotomic_sqr_hot(acc, acc);
+    const int d = C_U_W4[i];
+    if (d != 0) {                                    // ONE multiplication site: the inlined body exists once
+      const Fp12* m = &odd[(d < 0 ? -d : d) >> 1];
+      if (d < 0) { fp12_conj(t, *m); m = &t; }
+      fp12_mul_hot(acc, acc, *m);
+    }
   }
   r = acc;
 }

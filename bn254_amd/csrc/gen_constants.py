@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Generate bn254_constants.h: every numeric table the HIP kernels need.  Field elements are
-10 little-endian limbs of 27 bits (stored in int32) in Montgomery form with R = 2^270; plain
-256-bit integers (moduli multiples, exponents, group order) stay 8 x 32-bit words.
+9 little-endian BALANCED limbs of 29 bits (digits in [-2^28, 2^28), the top limb absorbs; stored in
+int32) in Montgomery form with R = 2^261; plain 256-bit integers (moduli multiples, exponents, group
+order) stay 8 x 32-bit words.
 
 Self-contained (plain Python integers; imports nothing from oracle/): derived from the curve
 definition in SURVEY.md Appendix A.1 only — u, the polynomials q(u), r(u), xi = 9+i, the
@@ -19,8 +20,8 @@ import os
 U = 4965661367192848881
 Q = 36 * U**4 + 36 * U**3 + 24 * U**2 + 6 * U + 1
 R_ORDER = 36 * U**4 + 36 * U**3 + 18 * U**2 + 6 * U + 1
-LIMB_BITS = 27
-N_LIMBS = 10
+LIMB_BITS = 29
+N_LIMBS = 9
 MONT_R = 1 << (LIMB_BITS * N_LIMBS)
 XI = (9, 1)
 G2X = (10857046999023057135944570762232829481370756359578518086990519993285655852781,
@@ -149,7 +150,22 @@ def words32(x):
     return [(x >> (32 * i)) & 0xFFFFFFFF for i in range(8)]
 
 
-def limbs27(x):
+def limbs_balanced(x):
+    """digits d_i in [-2^(W-1), 2^(W-1)) for i < N-1, the top limb takes the rest: x = sum d_i 2^(W i)"""
+    out = []
+    for _ in range(N_LIMBS - 1):
+        d = x & ((1 << LIMB_BITS) - 1)
+        if d >= 1 << (LIMB_BITS - 1):
+            d -= 1 << LIMB_BITS
+        out.append(d)
+        x = (x - d) >> LIMB_BITS
+    out.append(x)
+    assert abs(x) < 1 << 31
+    return out
+
+
+def limbs_floor(x):
+    """plain non-negative digits in [0, 2^W)"""
     return [(x >> (LIMB_BITS * i)) & ((1 << LIMB_BITS) - 1) for i in range(N_LIMBS)]
 
 
@@ -163,8 +179,8 @@ def c_u256(x):
 
 
 def c_fp(x, m=True):
-    """field element as 10 x 27-bit limbs (Montgomery form unless m=False)"""
-    return "{" + ", ".join("0x%07x" % w for w in limbs27(mont(x) if m else x)) + "}"
+    """field element as balanced limbs (Montgomery form unless m=False)"""
+    return "{" + ", ".join("%d" % w for w in limbs_balanced(mont(x) if m else x)) + "}"
 
 
 def c_fp2(a):
@@ -208,16 +224,24 @@ def main():
 
     o = []
     o.append("// GENERATED by bn254_amd/csrc/gen_constants.py — do not edit.")
-    o.append("// BN254 constants.  Field elements: 10 x 27-bit limbs (int32), Montgomery form, R = 2^270.")
+    o.append("// BN254 constants.  Field elements: %d balanced limbs of %d bits (int32), Montgomery form, R = 2^%d." % (N_LIMBS, LIMB_BITS, N_LIMBS * LIMB_BITS))
     o.append("// Plain integers (U256): 8 x 32-bit words, little-endian.")
     o.append("#pragma once")
     o.append("")
     o.append("#define BN_LIMBS %d" % N_LIMBS)
     o.append("#define BN_W %d" % LIMB_BITS)
     o.append("#define BN_MASK 0x%xu" % ((1 << LIMB_BITS) - 1))
-    for i, w in enumerate(limbs27(Q)):
-        o.append("#define BN_QL%d 0x%07x" % (i, w))
-    o.append("#define BN_N0 0x%07xu   /* -q^-1 mod 2^27 */" % ((-pow(Q, -1, 1 << LIMB_BITS)) % (1 << LIMB_BITS)))
+    o.append("#define BN_HALF 0x%x   /* 2^(W-1): digits are in [-BN_HALF, BN_HALF) */" % (1 << (LIMB_BITS - 1)))
+    for i, w in enumerate(limbs_balanced(Q)):
+        o.append("#define BN_QL%d (%d)" % (i, w))
+    o.append("#define BN_QL_ARRAY {%s}" % ", ".join("BN_QL%d" % i for i in range(N_LIMBS)))
+    o.append("#define BN_N0 0x%07xu   /* -q^-1 mod 2^%d */" % ((-pow(Q, -1, 1 << LIMB_BITS)) % (1 << LIMB_BITS), LIMB_BITS))
+    top_unit = Q / float(1 << (LIMB_BITS * (N_LIMBS - 1)))           # q in units of the top limb
+    o.append("#define BN_TOP_PER_Q %.1f   /* q / 2^%d: the top limb of a tight element of value v*q is ~ v * this */" % (top_unit, LIMB_BITS * (N_LIMBS - 1)))
+    o.append("#define BN_R_OVER_Q %.3f   /* R / q: a Montgomery product shrinks |a||b| (in units of q^2) by this */" % (MONT_R / float(Q)))
+    kmul = round((1 << 32) / top_unit)
+    o.append("#define BN_WEAK_KMUL %d   /* round(2^32 / (q / 2^%d)): k = mulhi(top + BN_WEAK_HALF, KMUL) ~ round(value / q) */" % (kmul, LIMB_BITS * (N_LIMBS - 1)))
+    o.append("#define BN_WEAK_HALF %d" % int(top_unit / 2))
     o.append("#define BN_U_LO 0x%08xu" % (U & 0xFFFFFFFF))
     o.append("#define BN_U_HI 0x%08xu" % (U >> 32))
     o.append("#define BN_N_FIXED_LINES %d" % len(lines))
@@ -263,19 +287,19 @@ def main():
         o.append("#define BN_SCHED_%s_LEN %d" % (name, len(ops)))
         o.append("BN_CONST unsigned char C_SCHED_%s[BN_SCHED_%s_LEN][2] = {%s};  /* %d squarings, %d multiplications */" %
                  (name, name, ", ".join("{%d, %d}" % op for op in ops), sum(op[0] for op in ops), sum(1 for op in ops[1:] if op[1])))
-    o.append("BN_CONST int32_t C_QL[10] = %s;           /* q as 27-bit limbs (plain) */" % c_fp(Q, False))
-    o.append("BN_CONST int32_t C_R2[10] = %s;           /* R^2 mod q, plain limbs: to_mont(x) = mul(x, R2) */" % c_fp(MONT_R * MONT_R % Q, False))
-    o.append("BN_CONST int32_t C_ONE[10] = %s;          /* 1 (Montgomery) */" % c_fp(1))
-    o.append("BN_CONST int32_t C_THREE[10] = %s;        /* curve b = 3 */" % c_fp(3))
-    o.append("BN_CONST int32_t C_TWIST_B[2][10] = %s;   /* 3/xi */" % c_fp2(TWIST_B))
-    o.append("BN_CONST int32_t C_TWIST_3B[2][10] = %s;  /* 9/xi */" % c_fp2(TWIST_3B))
+    o.append("BN_CONST int32_t C_QL[BN_LIMBS] = %s;           /* q as balanced limbs (plain) */" % c_fp(Q, False))
+    o.append("BN_CONST int32_t C_R2[BN_LIMBS] = %s;           /* R^2 mod q, plain limbs: to_mont(x) = mul(x, R2) */" % c_fp(MONT_R * MONT_R % Q, False))
+    o.append("BN_CONST int32_t C_ONE[BN_LIMBS] = %s;          /* 1 (Montgomery) */" % c_fp(1))
+    o.append("BN_CONST int32_t C_THREE[BN_LIMBS] = %s;        /* curve b = 3 */" % c_fp(3))
+    o.append("BN_CONST int32_t C_TWIST_B[2][BN_LIMBS] = %s;   /* 3/xi */" % c_fp2(TWIST_B))
+    o.append("BN_CONST int32_t C_TWIST_3B[2][BN_LIMBS] = %s;  /* 9/xi */" % c_fp2(TWIST_3B))
     for j in (1, 2, 3):
-        o.append("BN_CONST int32_t C_FROB%d[6][2][10] = {%s};  /* xi^(k(q^%d-1)/6), k=0..5 */" % (j, ", ".join(c_fp2(t) for t in frob[j]), j))
-    o.append("BN_CONST int32_t C_TW_FROB_X1[2][10] = %s;" % c_fp2(g_x1))
-    o.append("BN_CONST int32_t C_TW_FROB_Y1[2][10] = %s;" % c_fp2(g_y1))
-    o.append("BN_CONST int32_t C_TW_FROB_X2[2][10] = %s;" % c_fp2(g_x2))
-    o.append("BN_CONST int32_t C_G1_GEN[2][10] = {%s, %s};" % (c_fp(1), c_fp(2)))
-    o.append("BN_CONST int32_t C_G2_GEN[2][2][10] = {%s, %s};" % (c_fp2(G2X), c_fp2(G2Y)))
+        o.append("BN_CONST int32_t C_FROB%d[6][2][BN_LIMBS] = {%s};  /* xi^(k(q^%d-1)/6), k=0..5 */" % (j, ", ".join(c_fp2(t) for t in frob[j]), j))
+    o.append("BN_CONST int32_t C_TW_FROB_X1[2][BN_LIMBS] = %s;" % c_fp2(g_x1))
+    o.append("BN_CONST int32_t C_TW_FROB_Y1[2][BN_LIMBS] = %s;" % c_fp2(g_y1))
+    o.append("BN_CONST int32_t C_TW_FROB_X2[2][BN_LIMBS] = %s;" % c_fp2(g_x2))
+    o.append("BN_CONST int32_t C_G1_GEN[2][BN_LIMBS] = {%s, %s};" % (c_fp(1), c_fp(2)))
+    o.append("BN_CONST int32_t C_G2_GEN[2][2][BN_LIMBS] = {%s, %s};" % (c_fp2(G2X), c_fp2(G2Y)))
     o.append("BN_CONST signed char C_ATE_NAF[64] = {%s};  /* digits of 6u+2 after the leading 1, MSB first */" % ", ".join(str(d) for d in naf))
     unaf = naf_plain(U)
     o.append("#define BN_U_NAF_LEN %d" % len(unaf))
@@ -298,7 +322,7 @@ def main():
     o.append("BN_CONST signed char C_U_W4[BN_U_W4_LEN] = {%s};  /* width-4 signed window digits of u (odd, |d| <= 7), MSB first, %d non-zero */" %
              (", ".join(str(d) for d in w4), sum(1 for d in w4 if d)))
     o.append("/* line coefficients (c0 -> *yP, c1 -> *xP, c2 == 1) for Q = -G2::one(), in order of use */")
-    o.append("BN_CONST int32_t C_NEG_G2_LINES[BN_N_FIXED_LINES][3][2][10] = {")
+    o.append("BN_CONST int32_t C_NEG_G2_LINES[BN_N_FIXED_LINES][3][2][BN_LIMBS] = {")
     for ln in lines:
         o.append("  {%s, %s, %s}," % (c_fp2(ln[0]), c_fp2(ln[1]), c_fp2(ln[2])))
     o.append("};")

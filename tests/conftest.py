@@ -4,6 +4,14 @@ import sys
 
 import pytest
 
+# torch first: its bundled HIP runtime and the system one libbn254hip.so links share a SONAME, and the process must
+# end up with ONE runtime — the copy loaded first.  A test that imported torch only after the library had initialised
+# the device found "No HIP GPUs are available" (two runtimes in one process).
+try:
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover - CPU-only environments without torch still run the oracle tests
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -10,6 +10,11 @@
 #define BN_SPLIT_FP2 1
 #define BN_COUNT_FP_MUL 1
 extern "C" { unsigned long long bn_fp_mul_counter = 0; unsigned long long bn_fp_dual_counter = 0; }
+#if defined(BN_TRACK_BOUNDS)
+#include "../../bn254_amd/csrc/bn254_norm_sites.h"
+extern "C" { signed char bn_site_mode[1024]; unsigned int bn_site_hits[1024]; signed char bn_site_dflt[1024]; int bn_bound_soft = 0; int bn_bound_failed = 0; }
+static struct BnSiteInit { BnSiteInit() { for (int i = 0; i < 1024; ++i) bn_site_mode[i] = (signed char)bn_site_override(i); } } bn_site_init_;
+#endif
 
 #include "../../bn254_amd/csrc/bn254_pairing.h"
 #include "../../bn254_amd/csrc/bn254_codec_g2.h"
