@@ -45,12 +45,29 @@
 #else
 #define BN_DEVF BN_DEVN
 #endif
+// BN_DEVM: the Miller loops as real functions (default) or inlined into their kernels (BN_INLINE_MILLER; measured and
+// rejected: Miller launch 5.8 -> 8.3 ms per 65 536 — the kernel-level register allocation spills the twist point and the
+// affine inputs around every step).  The accumulator f lives in LDS either way; BN_ASSUME_LDS tells the compiler so inside
+// the function, which turns the flat_load / flat_store through the generic reference (flat aperture path, both vmcnt
+// and lgkmcnt held) into ds_read / ds_write.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BN_NO_ASSUME_LDS)
+#define BN_ASSUME_LDS(ptr) __builtin_assume(__builtin_amdgcn_is_shared((const void*)(ptr)))
+#else
+#define BN_ASSUME_LDS(ptr) do { } while (0)        /* host pass of hipcc */
+#endif
+#if defined(BN_INLINE_MILLER)
+#define BN_DEVM BN_DEV
+#else
+#define BN_DEVM BN_DEVN
+#endif
 #else
 #define BN_DEV static inline __attribute__((always_inline))
 #define BN_DEVN static __attribute__((noinline))
 #define BN_CONST static const
 #define BN_DEVH BN_DEVN
 #define BN_DEVF BN_DEVN
+#define BN_DEVM BN_DEVN
+#define BN_ASSUME_LDS(ptr) do { } while (0)
 #endif
 
 #include "bn254_constants.h"

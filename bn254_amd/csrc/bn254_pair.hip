@@ -13,6 +13,7 @@
 #ifndef BN_PAIR_CALL_FP12_HOT
 #define BN_INLINE_FP12_HOT 1       // fp12_sqr / fp12_mul_line2 inlined into the Miller loops (bn254_field.h: BN_DEVH)
 #endif
+// (BN_INLINE_MILLER — the Miller loops inlined into their kernels — is an A/B knob only: measured 8.3 instead of 5.8 ms)
 #ifndef BN_PAIR_CALL_FE_HOT
 #define BN_INLINE_FE_HOT 1         // fp12_cyclotomic_sqr / fp12_mul inlined into the loop of fp12_pow_u (bn254_field.h: BN_DEVF)
 #endif
@@ -163,7 +164,7 @@ KERNEL_PAIR void k_miller_verify_pair(size_t n, Ws ws, const uint32_t* map, cons
   pk.inf = ws_byte(ws, BY_Q_INF, i) != 0;
   __shared__ Fp12PairSlot lds_f[BN_PAIR_WG];
   Fp12& f = lds_f[threadIdx.x].v;
-  miller_loop<true, true>(f, h, pk, sig);
+  miller_loop<true, true, true>(f, h, pk, sig);
   ws_store_f12_own(ws, i, f);
 }
 // generic single pair per lane pair: f = miller(P1, Q)   (bn254_batch_pairing*)
@@ -178,7 +179,7 @@ KERNEL_PAIR void k_miller_var_pair(size_t n, Ws ws) {
   q.inf = ws_byte(ws, BY_Q_INF, i) != 0;
   __shared__ Fp12PairSlot lds_f[BN_PAIR_WG];
   Fp12& f = lds_f[threadIdx.x].v;
-  miller_loop<true, false>(f, p, q, p);
+  miller_loop<true, false, true>(f, p, q, p);
   ws_store_f12_own(ws, i, f);
 }
 // 32 big-endian bytes of the canonical value (4-byte aligned destination)
@@ -208,7 +209,7 @@ KERNEL_PAIR void k_final_exp_pair(size_t n, size_t k, size_t item_stride, size_t
   }
   if (st == ST_OK && use_hash) st = ws_byte(ws, BY_ST_HASH, i);
   __shared__ Fp12PairSlot lds_acc[BN_PAIR_WG];
-  if (!raw_only) final_exponentiation(f, f, lds_acc[threadIdx.x].v);
+  if (!raw_only) final_exponentiation<true>(f, f, lds_acc[threadIdx.x].v);
   const unsigned role = threadIdx.x & 1u;
   if (gt_out) {
     const Fp2* c[6] = {&f.c0.c0, &f.c0.c1, &f.c0.c2, &f.c1.c0, &f.c1.c1, &f.c1.c2};
@@ -244,9 +245,9 @@ __device__ __forceinline__ void miller_rand_pair_body(size_t n, size_t n_groups,
     ws_load_g1(ws, PL_HASHX, BY_A_INF, j1, a1);
     if (i1 >= n) a1.inf = true;
     pk1.x = ws_load_fp2_own(ws, PL_QX0, j1); pk1.y = ws_load_fp2_own(ws, PL_QY0, j1); pk1.inf = ws_byte(ws, BY_Q_INF, j1) != 0;
-    miller_loop_2var(f, a0, pk0, a1, pk1);
+    miller_loop_2var<true>(f, a0, pk0, a1, pk1);
   } else {
-    miller_loop<true, false>(f, a0, pk0, a0);
+    miller_loop<true, false, true>(f, a0, pk0, a0);
   }
   __syncthreads();
   for (unsigned stride = PAIRS_PER_GROUP / 2; stride >= 1; stride >>= 1) {
@@ -270,7 +271,7 @@ KERNEL_PAIR void k_rand_tail_pair(size_t n_groups, Ws ws, size_t gbase) {
   ws_load_f12_own(ws, gbase + g, fg);
   __shared__ Fp12PairSlot lds_f[BN_PAIR_WG];
   Fp12& f = lds_f[threadIdx.x].v;
-  miller_loop<false, true>(f, unused_g1, unused_g2, s);
+  miller_loop<false, true, true>(f, unused_g1, unused_g2, s);
   fp12_mul(f, f, fg);
   ws_store_f12_own(ws, gbase + g, f);
 }

@@ -107,8 +107,10 @@ BN_DEV void fixed_line(LineCoef& l, int idx) {
 //   pair B: (pb, -G2::one()) through the constant line table (enabled by HAS_B; skipped if skip_b)
 // "skipped" = the pair has an identity member and contributes 1; the
 // lane still walks the loop with dummy coordinates so the wave stays convergent.
-template <bool HAS_A, bool HAS_B>
-BN_DEVN void miller_loop(Fp12& f, const G1Affine& pa, const G2Affine& qa, const G1Affine& pb) {
+// F_LDS: the caller's f is a __shared__ object (every kernel of bn254_pair.hip) -> LDS instructions for it
+template <bool HAS_A, bool HAS_B, bool F_LDS = false>
+BN_DEVM void miller_loop(Fp12& f, const G1Affine& pa, const G2Affine& qa, const G1Affine& pb) {
+  if constexpr (F_LDS) BN_ASSUME_LDS(&f);
   fp12_set_one(f);
   G2Proj t;
   LineCoef l;
@@ -183,7 +185,9 @@ BN_DEV void mul_by_two_var_lines(Fp12& f, const LineCoef& la, const Fp& pax, con
 
 // Miller loop over two pairs with variable twist points sharing f (randomised batch verification: two
 // items per lane).  A pair with an identity member contributes 1.
-BN_DEVN void miller_loop_2var(Fp12& f, const G1Affine& pa, const G2Affine& qa, const G1Affine& pc, const G2Affine& qc) {
+template <bool F_LDS = false>
+BN_DEVM void miller_loop_2var(Fp12& f, const G1Affine& pa, const G2Affine& qa, const G1Affine& pc, const G2Affine& qc) {
+  if constexpr (F_LDS) BN_ASSUME_LDS(&f);
   fp12_set_one(f);
   G2Proj ta, tc;
   LineCoef la, lc;
@@ -218,7 +222,9 @@ BN_DEVN void miller_loop_2var(Fp12& f, const G1Affine& pa, const G2Affine& qa, c
 // and 16 multiplications (3 for the table, 13 for the 14 non-zero digits) instead of the 28 of plain
 // square-and-multiply.  `acc` is caller-provided working storage (the kernels pass an LDS slot: the
 // accumulator is read and rewritten by every squaring).
+template <bool ACC_LDS = false>
 BN_DEVN void fp12_pow_u(Fp12& r, const Fp12& a, Fp12& acc) {
+  if constexpr (ACC_LDS) BN_ASSUME_LDS(&acc);
   Fp12 odd[4], t;
   fp12_cyclotomic_sqr(t, a);
   odd[0] = a;
@@ -242,6 +248,7 @@ BN_DEVN void fp12_pow_u(Fp12& r, const Fp12& a, Fp12& acc) {
 // f^((q^12-1)/r): easy part (q^6-1)(q^2+1), then the exact hard part (q^4-q^2+1)/r =
 // q^3 + (6u^2+1) q^2 + (-36u^3-18u^2-12u+1) q + (-36u^3-30u^2-18u-2) by the vectorial
 // addition chain y0 * y1^2 * y2^6 * y3^12 * y4^18 * y5^30 * y6^36.
+template <bool ACC_LDS = false>
 BN_DEVN void final_exponentiation(Fp12& r, const Fp12& fin, Fp12& acc) {
   Fp12 f, t, a, b;
   fp12_inv(t, fin);
@@ -250,9 +257,9 @@ BN_DEVN void final_exponentiation(Fp12& r, const Fp12& fin, Fp12& acc) {
   fp12_frob(t, f, 2);
   fp12_mul(f, t, f);
   Fp12 fu, fu2, fu3, y0, y1, y2, y3, y4, y5, y6;
-  fp12_pow_u(fu, f, acc);
-  fp12_pow_u(fu2, fu, acc);
-  fp12_pow_u(fu3, fu2, acc);
+  fp12_pow_u<ACC_LDS>(fu, f, acc);
+  fp12_pow_u<ACC_LDS>(fu2, fu, acc);
+  fp12_pow_u<ACC_LDS>(fu3, fu2, acc);
   fp12_frob(a, f, 1); fp12_frob(b, f, 2); fp12_mul(y0, a, b); fp12_frob(a, f, 3); fp12_mul(y0, y0, a);
   fp12_conj(y1, f);
   fp12_frob(y2, fu2, 2);
