@@ -41,12 +41,12 @@ FP_MUL_DECODE = 19
 FP_MUL_HASH_FILTER = 4             # per tested counter: x -> Montgomery, x^3 + 3, back to an integer for the Jacobi symbol
 FP_MUL_HASH_FINISH = 311           # once per message: the square-root exponentiation of the winning counter + checks
 FP_MUL_MILLER = 11138
-FP_MUL_FINAL_EXP = 7449            # width-4 window exponentiations by u; incl. 12 canonicalisations for the == 1 test
+FP_MUL_FINAL_EXP = 6909            # exponentiations by u over the digit set {1, 15, 19} (13 multiplications each); incl. 12 canonicalisations for the == 1 test
 FP_MUL_MILLER_SINGLE = 8419        # one variable pair (configs[3] pairing workload), same instrumentation
 MAC32_PER_FP_MUL = 136             # ALGORITHMIC unit: an 8x32-bit Montgomery product = 2*8*8 + 8 MAC32.
 # What the pair-layout kernels actually issue per lane (tests/test_workcount.py: hp_lane_counts): multiply-add
 # instructions per dual product / single product / square of the device's limb representation.
-LIMBS = 10
+LIMBS = 9
 MADS_DUAL, MADS_SINGLE = 3 * LIMBS * LIMBS, 2 * LIMBS * LIMBS
 MUL_LO_PER_PRODUCT = LIMBS
 # VALU roofline: v_mad_u64_u32 issues once per 4 cycles per SIMD (half the 2-cycle full rate):

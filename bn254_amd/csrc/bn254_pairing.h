@@ -217,27 +217,32 @@ BN_DEVM void miller_loop_2var(Fp12& f, const G1Affine& pa, const G2Affine& qa, c
   mul_by_two_var_lines(f, la, pa.x, pa.y, skip_a, lc, pc.x, pc.y, skip_c);
 }
 
-// a^u for a in the cyclotomic subgroup (u = 4965661367192848881, 63 bits): width-4 signed sliding
-// window over the odd powers a, a^3, a^5, a^7 (a^-1 is the conjugate there): 63 cyclotomic squarings
-// and 16 multiplications (3 for the table, 13 for the 14 non-zero digits) instead of the 28 of plain
-// square-and-multiply.  `acc` is caller-provided working storage (the kernels pass an LDS slot: the
-// accumulator is read and rewritten by every squaring).
+// a^u for a in the cyclotomic subgroup (u = 4965661367192848881, 63 bits; a^-1 is the conjugate there): signed digits
+// from the set {1, 15, 19} (bn254_constants.h, found by a search over small digit sets): the table costs 4 cyclotomic
+// squarings and 2 multiplications (a^16, a^15 = a^16 / a, a^19 = a^15 * a^4), the 12 non-zero digits 11 more —
+// 13 multiplications where width-4 signed windows took 16 and plain square-and-multiply 28.
+// `acc` is caller-provided working storage (the kernels pass an LDS slot: the accumulator is read and rewritten by every
+// squaring).
 template <bool ACC_LDS = false>
 BN_DEVN void fp12_pow_u(Fp12& r, const Fp12& a, Fp12& acc) {
   if constexpr (ACC_LDS) BN_ASSUME_LDS(&acc);
-  Fp12 odd[4], t;
+  Fp12 tab[3], t, a4;                               // a, a^15, a^19
+  tab[0] = a;
   fp12_cyclotomic_sqr(t, a);
-  odd[0] = a;
-  fp12_mul(odd[1], a, t);
-  fp12_mul(odd[2], odd[1], t);
-  fp12_mul(odd[3], odd[2], t);
-  acc = odd[C_U_W4[0] >> 1];                        // leading digit is positive
+  fp12_cyclotomic_sqr(a4, t);
+  fp12_cyclotomic_sqr(t, a4);
+  fp12_cyclotomic_sqr(t, t);                        // a^16
+  fp12_conj(tab[1], a);
+  fp12_mul(tab[1], t, tab[1]);                      // a^15
+  fp12_mul(tab[2], tab[1], a4);                     // a^19
+  acc = tab[C_U_W4[0] == 1 ? 0 : C_U_W4[0] == 15 ? 1 : 2];   // leading digit is positive
   for (int i = 1; i < BN_U_W4_LEN; ++i) {           // wave-uniform: u is a public constant
     BN_SET_STEP_PRIORITY(i >> 1);                    // half the rate of the Miller loop's cycle (measured: -1.3 % here)
     fp12_cyclotomic_sqr_hot(acc, acc);
     const int d = C_U_W4[i];
     if (d != 0) {                                    // ONE multiplication site: the inlined body exists once
-      const Fp12* m = &odd[(d < 0 ? -d : d) >> 1];
+      const int ad = d < 0 ? -d : d;
+      const Fp12* m = &tab[ad == 1 ? 0 : ad == 15 ? 1 : 2];
       if (d < 0) { fp12_conj(t, *m); m = &t; }
       fp12_mul_hot(acc, acc, *m);
     }

@@ -305,21 +305,43 @@ def main():
     o.append("#define BN_U_NAF_LEN %d" % len(unaf))
     o.append("BN_CONST signed char C_U_NAF[BN_U_NAF_LEN] = {%s};  /* NAF digits of u after the leading 1, MSB first (weight %d) */" %
              (", ".join(str(d) for d in unaf), sum(1 for d in unaf if d)))
-    w4 = []
-    k = U
-    while k:
-        z = 0
-        if k & 1:
-            z = k % 16
-            if z >= 8:
-                z -= 16
-            k -= z
-        w4.append(z)
-        k >>= 1
-    w4.reverse()
-    assert sum(d << (len(w4) - 1 - i) for i, d in enumerate(w4)) == U and w4[0] > 0
+    # exponentiation by u in the cyclotomic subgroup (inverse = conjugate): signed digits from the set {1, 15, 19} found by a
+    # search over small odd digit sets (cost = table multiplications + non-zero digits): 2 + 12 - 1 = 13 multiplications
+    # against 3 + 14 - 1 = 16 for width-4 signed windows.  Table: a^2, a^4, a^8, a^16 (4 squarings), a^15 = a^16 / a,
+    # a^19 = a^15 * a^4.  Digits by dynamic programming over u = sum d_i 2^i, d_i in {0, +-1, +-15, +-19}, fewest non-zero.
+    import functools
+    import sys
+    sys.setrecursionlimit(10000)
+    DSET = (1, 15, 19)
+
+    @functools.lru_cache(None)
+    def best(m):
+        """(non-zero digits, digit list LSB first) for m"""
+        if m == 0:
+            return (0, ())
+        if m % 2 == 0:
+            c, ds = best(m // 2)
+            return (c, (0,) + ds)
+        cand = None
+        for d in DSET:
+            for sd in (d, -d):
+                if m == sd:
+                    r = (1, (sd,))
+                elif abs((m - sd) // 2) < abs(m):
+                    c, ds = best((m - sd) // 2)
+                    r = (c + 1, (sd,) + ds)
+                else:
+                    continue
+                if cand is None or r[0] < cand[0] or (r[0] == cand[0] and len(r[1]) < len(cand[1])):
+                    cand = r
+        return cand
+    nz, digs = best(U)
+    w4 = list(reversed(digs))
+    while w4[0] == 0:
+        w4.pop(0)
+    assert sum(d << (len(w4) - 1 - i) for i, d in enumerate(w4)) == U and w4[0] > 0 and nz == 12
     o.append("#define BN_U_W4_LEN %d" % len(w4))
-    o.append("BN_CONST signed char C_U_W4[BN_U_W4_LEN] = {%s};  /* width-4 signed window digits of u (odd, |d| <= 7), MSB first, %d non-zero */" %
+    o.append("BN_CONST signed char C_U_W4[BN_U_W4_LEN] = {%s};  /* signed digits of u from {0, +-1, +-15, +-19}, MSB first, %d non-zero */" %
              (", ".join(str(d) for d in w4), sum(1 for d in w4 if d)))
     o.append("/* line coefficients (c0 -> *yP, c1 -> *xP, c2 == 1) for Q = -G2::one(), in order of use */")
     o.append("BN_CONST int32_t C_NEG_G2_LINES[BN_N_FIXED_LINES][3][2][BN_LIMBS] = {")
