@@ -103,28 +103,29 @@ def measured_traffic(kernel):
             "fetch_kib_raw": k["FETCH_SIZE"], "write_kib_raw": k["WRITE_SIZE"], "batch": k.get("batch"), "source": "profiles/pmc_latest.json"}
 
 
-def measured_valu_issue(kernel, lane_products, probe):
-    """Cost-weighted VALU issue utilisation of `kernel` from the PMC summary and this run's issue-rate probe:
-    SQ_INSTS_VALU wave instructions split into the multiplier class (v_mad_*64 + v_mul_lo: counted exactly from the
-    per-lane product counts of the host instrumentation x the instructions per product) and everything else, each
-    priced at the cycles per wave instruction the probe measured for its class on this device at two waves per SIMD;
-    utilisation = priced cycles / (SIMDs x kernel cycles), kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs."""
+def measured_valu_issue(kernel, lane_products, probe, kernel_seconds):
+    """Cost-weighted VALU issue utilisation of `kernel`: SQ_INSTS_VALU wave instructions (PMC summary) split into the
+    multiplier class (v_mad_*64 + v_mul_lo: counted exactly from the per-lane product counts of the host instrumentation
+    x the instructions per product) and everything else, each priced at the SECONDS per wave instruction and SIMD the
+    issue-rate probe of this run measured for its class (two waves per SIMD, like the kernel), against the kernel's own
+    duration in this run:  utilisation = (N_mul x t_mul + N_other x t_other) x waves / (SIMDs x kernel seconds).
+    Both sides are wall-clock, so the chip's clock under load cancels; a value near (or slightly above) 1 says the
+    kernel issues its instruction mix as fast as the separate single-instruction probes do — it is issue-bound."""
     k = _pmc(kernel)
-    if not k or "SQ_INSTS_VALU" not in k or not probe:
+    if not k or "SQ_INSTS_VALU" not in k or not probe or not lane_products:
         return None
-    cycles = k["GRBM_GUI_ACTIVE"] / 8.0
     per_wave = k["SQ_INSTS_VALU"] / k["SQ_WAVES"]
     n_mul = lane_products["dual"] * (MADS_DUAL + MUL_LO_PER_PRODUCT) + lane_products["single"] * (MADS_SINGLE + MUL_LO_PER_PRODUCT)
     n_other = max(per_wave - n_mul, 0.0)
-    # the probe's rates are wall-clock; convert to cycles of THIS kernel's clock (kernel cycles / kernel seconds)
-    c_mul, c_other = probe["cycles_per_wave_inst_mad"], probe["cycles_per_wave_inst_add"]
-    priced = (n_mul * c_mul + n_other * c_other) * k["SQ_WAVES"]
+    t_mul, t_other = probe["n_simd"] / probe["mad_u64_u32_wave_inst_per_s"], probe["n_simd"] / probe["add_u32_wave_inst_per_s"]
+    priced = (n_mul * t_mul + n_other * t_other) * k["SQ_WAVES"] / probe["n_simd"]
     return {"valu_wave_instructions_per_launch": k["SQ_INSTS_VALU"], "per_wave": per_wave, "multiplier_class_per_wave": n_mul,
-            "other_per_wave": n_other, "cycles_per_wave_inst": {"multiplier_class": c_mul, "other": c_other},
-            "kernel_cycles": cycles, "utilisation": priced / (probe["n_simd"] * cycles),
-            "utilisation_flat_4_cycles": 4.0 * k["SQ_INSTS_VALU"] / (probe["n_simd"] * cycles),
-            "note": "cost-weighted: (N_mul x c_mul + N_other x c_other) / (SIMDs x GRBM_GUI_ACTIVE / 8); c_* from bn254_probe_issue_rate "
-                    "in this process at 2.4 GHz nominal; source profiles/pmc_latest.json"}
+            "other_per_wave": n_other, "multiplier_class_share": n_mul / per_wave,
+            "ns_per_wave_inst_per_simd": {"multiplier_class": 1e9 * t_mul, "other": 1e9 * t_other},
+            "kernel_ms_this_run": 1e3 * kernel_seconds, "utilisation": priced / kernel_seconds,
+            "utilisation_flat_4_cycles": 4.0 * k["SQ_INSTS_VALU"] / (probe["n_simd"] * k["GRBM_GUI_ACTIVE"] / 8.0) if "GRBM_GUI_ACTIVE" in k else None,
+            "note": "cost-weighted, wall-clock on both sides; instruction counts from profiles/pmc_latest.json (same command, PMC pass), "
+                    "issue costs from bn254_probe_issue_rate in this process"}
 
 
 def issue_probe(eng):
@@ -136,8 +137,7 @@ def issue_probe(eng):
     return {"n_simd": simds, "waves_per_simd": 2, "mad_u64_u32_wave_inst_per_s": mad, "add_u32_wave_inst_per_s": add,
             "mul_lo_u32_wave_inst_per_s": mul_lo, "mad_u64_u32_wave_inst_per_s_8_waves": mad8,
             "peak_mac32_measured": 64.0 * max(mad, mad8),
-            "cycles_per_wave_inst_mad": simds * 2.4e9 / mad, "cycles_per_wave_inst_add": simds * 2.4e9 / add,
-            "cycles_per_wave_inst_mul_lo": simds * 2.4e9 / mul_lo}
+            "cycles_per_wave_inst_at_2p4GHz": {"mad_u64_u32": simds * 2.4e9 / mad, "add_u32": simds * 2.4e9 / add, "mul_lo_u32": simds * 2.4e9 / mul_lo}}
 
 
 def other_workloads(args, torch, eng, dev, stream):
@@ -530,7 +530,7 @@ def run_verify(args, R):
             "issue_probe": probe,
             "traffic": (traffic or {}).get("bytes_per_launch"),   # HBM bytes per launch (PMC), private-segment traffic
             "traffic_detail": traffic,
-            "valu_issue": measured_valu_issue(kname, lane_products, probe) if lane_products else None,
+            "valu_issue": measured_valu_issue(kname, lane_products, probe, k_avg[dom] * 1e-3),
             "kernel_ms": k_avg,
             "mac32_per_verify": {"miller_loop": FP_MUL_MILLER * MAC32_PER_FP_MUL, "final_exp": FP_MUL_FINAL_EXP * MAC32_PER_FP_MUL,
                                  "hash_to_g1_mean": (FP_MUL_HASH_FILTER * 2.12 + FP_MUL_HASH_FINISH) * MAC32_PER_FP_MUL, "decode": FP_MUL_DECODE * MAC32_PER_FP_MUL},

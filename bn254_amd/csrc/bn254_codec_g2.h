@@ -27,9 +27,10 @@ BN_DEV void u512_divmod_q(U256& hi, U256& lo, bool& hi_overflow, const uint32_t*
   for (int i = 0; i < 8; ++i) { hi.w[i] = quo[i]; lo.w[i] = rem[i]; }
 }
 // G2 (65 B): sign || BE64(x.im * q + x.re), sign 0x0b iff u512(y) > u512(-y), else 0x0a.
-// bn::G2::from_compressed as used at /root/reference/src/types.rs:92: bad sign or x.im >= q ->
-// InvalidEncoding(3); no root / not in the order-r subgroup -> NotMemberError(6) (the caller runs the
-// wave-uniform subgroup ladder).
+// bn::G2::from_compressed as used at /root/reference/src/types.rs:92, in the order that decoder works: x.im >= q (the
+// U512 does not split) -> InvalidEncoding(3); no square root -> NotMemberError(6); a sign byte other than 0x0a / 0x0b
+// -> InvalidEncoding(3); not in the order-r subgroup -> NotMemberError(6) (the caller runs the wave-uniform subgroup
+// ladder).  An input with two faults reports the first in this order (oracle/bn254_model.py: g2_from_compressed).
 BN_DEV uint8_t decompress_g2(G2Affine& pt, const uint8_t* b) {
   uint8_t sign = b[0];
   uint32_t v[16];
@@ -40,7 +41,7 @@ BN_DEV uint8_t decompress_g2(G2Affine& pt, const uint8_t* b) {
   U256 hi, lo;
   bool overflow;
   u512_divmod_q(hi, lo, overflow, v);
-  bool enc_ok = (sign == 0x0a || sign == 0x0b) && !overflow && !u256_geq(hi.w, C_Q);
+  bool split_ok = !overflow && !u256_geq(hi.w, C_Q), sign_ok = sign == 0x0a || sign == 0x0b;
   Fp2 x = fp2_make(fp_from_u256(lo), fp_from_u256(hi));
   Fp2 rhs = fp2_add(fp2_mul(fp2_sqr(x), x), fp2_load_const(C_TWIST_B));
   Fp2 y;
@@ -51,8 +52,9 @@ BN_DEV uint8_t decompress_g2(G2Affine& pt, const uint8_t* b) {
   pt.x = x;
   pt.y = fp2_select(y_gt == want_gt, y, yn);
   pt.inf = false;
-  if (!enc_ok) return ST_INVALID_ENCODING;
+  if (!split_ok) return ST_INVALID_ENCODING;
   if (!has_root) return ST_NOT_MEMBER;
+  if (!sign_ok) return ST_INVALID_ENCODING;
   return ST_OK;
 }
 

@@ -779,6 +779,8 @@ struct bn254_ctx {
   int hash_max_tries; // test knob: counters tried before HashToPointError (0 = the reference's 255)
   hipEvent_t ev[5];
   int ev_valid;
+  hipStream_t copy_stream;   // host-pointer verify: signatures and keys cross PCIe here while the hash rounds run on `stream`
+  hipEvent_t copy_done;
 };
 
 
@@ -905,9 +907,13 @@ int bn254_ctx_create(int hip_device, bn254_ctx** out) {
   c->rand_min_batch = RAND_MIN_BATCH_DEFAULT;
   c->device = hip_device;
   hipError_t err = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (err == hipSuccess) err = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
+  if (err == hipSuccess) err = hipEventCreateWithFlags(&c->copy_done, hipEventDisableTiming);
   for (int i = 0; i < 5 && err == hipSuccess; ++i) err = hipEventCreate(&c->ev[i]);
   if (err != hipSuccess) {
     for (int i = 0; i < 5; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    if (c->copy_done) (void)hipEventDestroy(c->copy_done);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return -(int)err;
@@ -928,6 +934,9 @@ void bn254_ctx_destroy(bn254_ctx* c) {
   for (int i = 0; i < 3; ++i) { if (c->pool[i].planes) (void)hipFree(c->pool[i].planes); if (c->pool[i].st) (void)hipFree(c->pool[i].st); }
   for (int i = 0; i < 8; ++i) if (c->stage[i]) (void)hipFree(c->stage[i]);
   for (int i = 0; i < 5; ++i) (void)hipEventDestroy(c->ev[i]);
+  (void)hipEventDestroy(c->copy_done);
+  (void)hipStreamSynchronize(c->copy_stream);
+  (void)hipStreamDestroy(c->copy_stream);
   (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -1041,6 +1050,10 @@ int bn254_batch_verify_compressed(bn254_ctx* c, const uint8_t* msgs, const uint6
   return 0;
 }
 
+// Host-buffer entry point.  The hash-to-G1 rounds need only the messages, so those cross PCIe first and the hash
+// kernels start at once; signatures and public keys (5/6 of the bytes) follow on a second stream while the hash runs,
+// and the decode kernels wait for them on an event.  What is left exposed of the transfer is the message copy and the
+// status bytes coming back.
 int bn254_batch_verify(bn254_ctx* c, const uint8_t* msgs, const uint64_t* off, const uint8_t* sigs, const uint8_t* pks, size_t n,
                        uint32_t flags, uint8_t* status) {
   if (!c || (n && (!off || !sigs || !pks || !status))) return BN254_E_BAD_ARGUMENT;
@@ -1048,13 +1061,50 @@ int bn254_batch_verify(bn254_ctx* c, const uint8_t* msgs, const uint64_t* off, c
   HIP_TRY(hipSetDevice(c->device));
   if (!offsets_ok(off, n)) return BN254_E_BAD_ARGUMENT;
   size_t msg_bytes = (size_t)off[n];
+  if (msg_bytes && !msgs) return BN254_E_BAD_ARGUMENT;
   int rc;
-  if ((rc = stage_in(c, 0, msgs, msg_bytes))) return rc;
-  if ((rc = stage_in(c, 1, off, (n + 1) * sizeof(uint64_t)))) return rc;
-  if ((rc = stage_in(c, 2, sigs, n * 64))) return rc;
-  if ((rc = stage_in(c, 3, pks, n * 128))) return rc;
-  if ((rc = stage_reserve(c, 4, n))) return rc;
-  if ((rc = bn254_batch_verify_device(c, c->stage[0], (const uint64_t*)c->stage[1], c->stage[2], c->stage[3], n, flags, c->stage[4], nullptr))) return rc;
+  bool split = c->split_miller && n <= BN_SPLIT_MAX_N;
+  if (split) {                                       // A/B layout: plain staging, then the device entry point
+    if ((rc = stage_in(c, 0, msgs, msg_bytes))) return rc;
+    if ((rc = stage_in(c, 1, off, (n + 1) * sizeof(uint64_t)))) return rc;
+    if ((rc = stage_in(c, 2, sigs, n * 64))) return rc;
+    if ((rc = stage_in(c, 3, pks, n * 128))) return rc;
+    if ((rc = stage_reserve(c, 4, n))) return rc;
+    if ((rc = bn254_batch_verify_device(c, c->stage[0], (const uint64_t*)c->stage[1], c->stage[2], c->stage[3], n, flags, c->stage[4], nullptr))) return rc;
+    if ((rc = stage_out(c, 4, status, n))) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+  }
+  if ((rc = ws_reserve(c, n))) return rc;
+  for (int slot = 0; slot < 5; ++slot) {
+    const size_t need[5] = {msg_bytes ? msg_bytes : 1, (n + 1) * sizeof(uint64_t), n * 64, n * 128, n};
+    if ((rc = stage_reserve(c, slot, need[slot]))) return rc;
+  }
+  hipStream_t s = c->stream;
+  PROF_MARK(0);
+  if (msg_bytes) HIP_TRY(hipMemcpyAsync(c->stage[0], msgs, msg_bytes, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(c->stage[1], off, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+  if ((rc = launch_hash_rounds(c, s, c->stage[0], (const uint64_t*)c->stage[1], n, PL_P2X, BY_P2_INF, nullptr))) return rc;
+  HIP_TRY(hipMemcpyAsync(c->stage[2], sigs, n * 64, hipMemcpyHostToDevice, c->copy_stream));
+  HIP_TRY(hipMemcpyAsync(c->stage[3], pks, n * 128, hipMemcpyHostToDevice, c->copy_stream));
+  HIP_TRY(hipEventRecord(c->copy_done, c->copy_stream));
+  HIP_TRY(hipStreamWaitEvent(s, c->copy_done, 0));
+  PROF_MARK(1);
+  k_decode_g1<<<grid_for(n), BN_WAVE, 0, s>>>(c->stage[2], n, flags, c->ws, PL_P1X, BY_P1_INF, 0);
+  if ((rc = launch_decode_g2(c, s, c->stage[3], n, flags, 1))) return rc;
+  PROF_MARK(2);
+  if (c->pair_lanes) {
+    if ((rc = bn254_pair_miller_verify(n, c->ws, nullptr, nullptr, s))) return rc;
+    PROF_MARK(3);
+    if ((rc = bn254_pair_final_exp(n, c->ws, 1, c->stage[4], nullptr, nullptr, s))) return rc;
+  } else {
+    k_miller_verify<<<grid_for(n), BN_WAVE, 0, s>>>(n, c->ws, nullptr, nullptr);
+    PROF_MARK(3);
+    k_final_exp<<<grid_for(n), BN_WAVE, 0, s>>>(n, 1, 1, 1, c->ws, 1, nullptr, c->stage[4], 0, 0, nullptr, nullptr);
+  }
+  PROF_MARK(4);
+  if (c->profiling) c->ev_valid = 1;                 // host path: ms[0] = transfer + hash, ms[1] = decode
+  HIP_TRY(hipGetLastError());
   if ((rc = stage_out(c, 4, status, n))) return rc;
   HIP_TRY(hipStreamSynchronize(c->stream));
   return 0;

@@ -79,8 +79,10 @@ BN_DEV void encode_fp12(uint8_t* b, const Fp12& f) {
 }
 // ---- compressed encodings (/root/reference/src/utils.rs:84-104, :130-158) ----
 // G1 (33 B): 0x02 (y even) / 0x03 (y odd) || x BE32.   bn::G1::from_compressed as used at
-// /root/reference/src/types.rs:234 and src/utils.rs:60: bad prefix -> InvalidEncoding(3);
-// x >= q or no square root -> NotMemberError(6).  Byte loads: the 33-byte stride is unaligned.
+// /root/reference/src/types.rs:234 and src/utils.rs:60, in the order that decoder works: x >= q -> NotMemberError(6)
+// (Fq::from_slice), no square root -> NotMemberError(6), and only then a prefix other than 0x02 / 0x03 ->
+// InvalidEncoding(3) — an input with two faults reports the first in this order (oracle/bn254_model.py:
+// g1_from_compressed).  Byte loads: the 33-byte stride is unaligned.
 BN_DEV uint8_t decompress_g1(G1Affine& pt, const uint8_t* b) {
   uint8_t sign = b[0];
   U256 xw;
@@ -99,8 +101,8 @@ BN_DEV uint8_t decompress_g1(G1Affine& pt, const uint8_t* b) {
   bool odd = yp.w[0] & 1;
   if (odd != (sign == 3)) y = fp_neg(y);
   pt.x = x; pt.y = y; pt.inf = false;
-  if (!ok_sign) return ST_INVALID_ENCODING;
   if (!in_range || !has_root) return ST_NOT_MEMBER;
+  if (!ok_sign) return ST_INVALID_ENCODING;
   return ST_OK;
 }
 }  // namespace bn254

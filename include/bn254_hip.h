@@ -186,9 +186,13 @@ int bn254_batch_aggregate_verify_device(bn254_ctx *ctx, const uint8_t *d_msgs, c
                                         const uint32_t *d_signer_idx, size_t n, uint32_t flags, uint8_t *d_status, void *stream);
 
 /* compressed wire formats (src/utils.rs:84-104, :130-158): out = uncompressed point, status as
- * bn::G1::from_compressed / bn::G2::from_compressed report through src/types.rs:91-93, :233-237:
- * bad prefix byte (G1: 0x02/0x03, G2: 0x0a/0x0b) or x.im >= q -> 3 InvalidEncoding; x >= q, no square
- * root, or (G2) not in the order-r subgroup -> 6 NotMemberError. */
+ * bn::G1::from_compressed / bn::G2::from_compressed report through src/types.rs:91-93, :233-237, checked in the order
+ * those decoders work (an input with several faults reports the first):
+ *   G1: x >= q -> 6 NotMemberError; no square root -> 6; prefix byte not 0x02 / 0x03 -> 3 InvalidEncoding.
+ *   G2: x.im >= q (the U512 does not split) -> 3 InvalidEncoding; no square root -> 6; sign byte not 0x0a / 0x0b -> 3;
+ *       not in the order-r subgroup -> 6.
+ * (x.im >= q is InvalidU512Encoding upstream as recalled in SURVEY.md Appendix B; the zeropool-bn source is not
+ * available here to confirm whether it surfaces as InvalidEncoding or NotMember through src/error.rs:31-55.) */
 int bn254_batch_g1_decompress(bn254_ctx *ctx, const uint8_t *in /* n*33 */, size_t n, uint8_t *out /* n*64 */, uint8_t *status);
 int bn254_batch_g2_decompress(bn254_ctx *ctx, const uint8_t *in /* n*65 */, size_t n, uint8_t *out /* n*128 */, uint8_t *status);
 

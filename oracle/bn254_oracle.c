@@ -1112,10 +1112,11 @@ API int bn254o_g1_compress(const u8 *p64, u8 *out33) {
 API int bn254o_g1_decompress(const u8 *in33, u8 *out64) {
   ensure_init();
   fp x, y, rhs;
-  if (in33[0] != 2 && in33[0] != 3) return ST_INVALID_ENCODING;
+  /* order of bn::G1::from_compressed (oracle/bn254_model.py: g1_from_compressed): range, square root, then the prefix */
   if (!fp_from_be(&x, in33 + 1)) return ST_NOT_MEMBER;
   fp_sqr(&rhs, &x); fp_mul(&rhs, &rhs, &x); fp_add(&rhs, &rhs, &FP_B);
   if (!fp_sqrt(&y, &rhs)) return ST_NOT_MEMBER;
+  if (in33[0] != 2 && in33[0] != 3) return ST_INVALID_ENCODING;
   u64 yi[4]; fp_to_u256(yi, &y);
   if ((int)(yi[0] & 1) != (in33[0] == 3)) fp_neg(&y, &y);
   fp_to_be(out64, &x); fp_to_be(out64 + 32, &y); return ST_OK;

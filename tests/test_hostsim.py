@@ -90,9 +90,31 @@ def _codec_cases(kats, derived):
         x += 1
     off = H(derived["g2_not_in_subgroup"])
     w = [int.from_bytes(off[i:i + 32], "big") for i in range(0, 128, 32)]
-    bad_g1 = [(b"\x04" + bytes(32), 3), (b"\x02" + m.Q.to_bytes(32, "big"), 6), (b"\x02" + x.to_bytes(32, "big"), 6)]
-    bad_g2 = [(b"\x0c" + H(derived["g2_generator_compressed"])[1:], 3), (m.g2_to_compressed(((w[0], w[1]), (w[2], w[3]))), 6),
-              (b"\x0a" + (m.Q * m.Q + 5).to_bytes(64, "big"), 3)]
+    def st_of(fn, data):
+        try:
+            fn(data)
+            return 0
+        except m.Bn254Error as e:
+            return e.code
+    gx = H(kats["sign"][0]["signature_compressed"])[1:]                       # x of a valid point
+    g2c = H(derived["g2_generator_compressed"])
+    offc = m.g2_to_compressed(((w[0], w[1]), (w[2], w[3])))
+    x2 = None                                                                  # an Fq2 x without a point on the twist
+    for k in range(2, 50):
+        cand = (b"\x0a" + (k * m.Q + 7).to_bytes(64, "big"))
+        if st_of(m.g2_from_compressed, cand) == m.ERR_NOT_MEMBER and m.f2_sqrt(m.f2_add(m.f2_mul(m.f2_mul((7, k), (7, k)), (7, k)), m.B2)) is None:
+            x2 = cand[1:]
+            break
+    assert x2 is not None
+    # single faults, then DOUBLE faults: the decoders report the first in their own order (range, root, prefix[, subgroup])
+    g1_datas = [b"\x04" + gx, b"\x02" + m.Q.to_bytes(32, "big"), b"\x02" + x.to_bytes(32, "big"),
+                b"\x04" + m.Q.to_bytes(32, "big"), b"\x07" + x.to_bytes(32, "big"), b"\x00" + bytes(32), b"\x04" + (m.Q + 5).to_bytes(32, "big")]
+    g2_datas = [b"\x0c" + g2c[1:], offc, b"\x0a" + (m.Q * m.Q + 5).to_bytes(64, "big"),
+                b"\x0c" + (m.Q * m.Q + 5).to_bytes(64, "big"), b"\x0c" + x2, b"\x0a" + x2, b"\x0c" + offc[1:], b"\x00" + bytes(64)]
+    bad_g1 = [(d, st_of(m.g1_from_compressed, d)) for d in g1_datas]
+    bad_g2 = [(d, st_of(m.g2_from_compressed, d)) for d in g2_datas]
+    assert [st for _, st in bad_g1[:5]] == [3, 6, 6, 6, 6] and all(st for _, st in bad_g1)
+    assert [st for _, st in bad_g2[:6]] == [3, 6, 3, 3, 6, 6] and all(st for _, st in bad_g2)
     return g1, g2, bad_g1, bad_g2
 
 
