@@ -418,7 +418,7 @@ BN_DEVN BN_LIMB_VEC fp_sqr_impl(BN_LIMB_VEC a) {
 #if defined(BN_TRACK_BOUNDS) && !defined(__HIPCC__)
 // the m*q part of a column (9 balanced x balanced digit products) plus the carry from the column below
 #define BN_COL_EXTRA ((double)BN_LIMBS * BN_T * BN_T + 137438953472.0 /* 2^37 */)
-#define BN_VALUE_CAP 64.0   /* |value| / q allowed for a product output: its top limb stays below 2^28 */
+#define BN_VALUE_CAP 500.0  /* |value| / q allowed for a product output: its top limb (value x 3.17e6) must stay inside int32; the column bound sees that limb too */
 static inline void bn_trk_mul(Fp& r, const Fp& a, const Fp& b) {
   double A = bn_absmax(a), B = bn_absmax(b);
   double col = (double)BN_LIMBS * A * B + BN_COL_EXTRA;
