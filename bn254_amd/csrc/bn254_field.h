@@ -319,6 +319,31 @@ BN_DEV Fp fp_reduce_weak(const Fp& a) {
   return r;
 }
 
+// weak_reduce(cx * x + cy * y) for small integer factors, in one carry pass with 64-bit limb accumulation: x and y may be
+// lazy and the combination need not fit int32 limb-wise (3 * (a 4-fold lazy value) does not).  Three multiply-adds per
+// limb; replaces carry(x), the 32-bit combination and fp_reduce_weak (Granger-Scott squaring: 3 t -+ 2 a).
+BN_DEV Fp fp_lin2_reduce(const Fp& x, int32_t cx, const Fp& y, int32_t cy) {
+  const int32_t q[BN_LIMBS] = BN_QL_ARRAY;
+  const int32_t top = x.v[BN_LIMBS - 1] * cx + y.v[BN_LIMBS - 1] * cy;
+  const int32_t k = (int32_t)(((int64_t)(top + BN_WEAK_HALF) * BN_WEAK_KMUL) >> 32);
+  int64_t carry = 0;
+  Fp r;
+#pragma unroll
+  for (int i = 0; i < BN_LIMBS; ++i) {
+    int64_t acc = carry + (int64_t)x.v[i] * cx + (int64_t)y.v[i] * cy - (int64_t)k * q[i];
+    if (i < BN_LIMBS - 1) {
+      r.v[i] = bn_digit((uint32_t)acc);
+      carry = (acc + BN_HALF) >> BN_W;
+    } else {
+      r.v[i] = (int32_t)acc;
+    }
+  }
+  BN_TRK(double vv_ = std::fabs((double)cx) * bn_vabs(x) + std::fabs((double)cy) * bn_vabs(y);
+         if (std::fabs((double)cx) * x.bd.top + std::fabs((double)cy) * y.bd.top + 4194304.0 >= 2147483648.0 || vv_ > 600.0) bn_bound_fail("lin2_reduce input", vv_);
+         bn_set_tight(r, -0.0003 * vv_ - 0.51, 0.0003 * vv_ + 0.51));
+  return r;
+}
+
 // Montgomery product a*b*R^-1 (mod q), product scanning.  Columns are accumulated in a signed
 // 64-bit register; m_k = the balanced digit of (column * -q^-1) makes each column divisible by 2^29.
 #if defined(__HIPCC__)
@@ -622,6 +647,9 @@ BN_DEV Fp2 fp2_dbl(const Fp2& a) { return fp2_add(a, a); }
 BN_DEV Fp2 fp2_conj(const Fp2& a) { Fp2 r; r.c0 = a.c0; r.c1 = fp_neg(a.c1); return r; }
 BN_DEV Fp2 fp2_norm(const Fp2& a) { Fp2 r; r.c0 = fp_norm(a.c0); r.c1 = fp_norm(a.c1); return r; }
 BN_DEV Fp2 fp2_reduce_weak(const Fp2& a) { Fp2 r; r.c0 = fp_reduce_weak(a.c0); r.c1 = fp_reduce_weak(a.c1); return r; }
+BN_DEV Fp2 fp2_lin2_reduce(const Fp2& x, int32_t cx, const Fp2& y, int32_t cy) {
+  Fp2 r; r.c0 = fp_lin2_reduce(x.c0, cx, y.c0, cy); r.c1 = fp_lin2_reduce(x.c1, cx, y.c1, cy); return r;
+}
 BN_DEV bool fp2_is_zero(const Fp2& a) { return fp_is_zero(a.c0) && fp_is_zero(a.c1); }
 BN_DEV bool fp2_eq(const Fp2& a, const Fp2& b) { return fp_eq(a.c0, b.c0) && fp_eq(a.c1, b.c1); }
 BN_DEV Fp2 fp2_select(bool c, const Fp2& a, const Fp2& b) { Fp2 r; r.c0 = fp_select(c, a.c0, b.c0); r.c1 = fp_select(c, a.c1, b.c1); return r; }
@@ -905,24 +933,25 @@ template <int S> BN_DEV void fp4_sqr(Fp2& r0, Fp2& r1, const Fp2& a, const Fp2& 
   r0 = NS(S + 2, fp2_add(a2, fp2_mul_xi(b2)));
 }
 // Granger-Scott squaring for the cyclotomic subgroup (after the easy part of the final exp.).
-// The outputs 3t -+ 2a are linear in a and xi-fold in the squares, so every output is weakly reduced (site default):
-// across a run of squarings the values stay below ~0.6 q.
-BN_DEV void fp12_cyclotomic_sqr_body(Fp12& r, const Fp12& a) {       // sites 170 .. 189
+// The outputs 3t -+ 2a are linear in a and xi-fold in the squares, so every output is weakly reduced
+// (fp2_lin2_reduce): across a run of squarings the values stay below ~0.6 q.
+template <int S> BN_DEV void fp12_cyclotomic_sqr_body(Fp12& r, const Fp12& a) {       // sites S .. S+15 (170.., 240..)
   Fp2 t0, t1, t2, t3, t4, t5;
-  fp4_sqr<170>(t0, t1, a.c0.c0, a.c1.c1);
-  fp4_sqr<173>(t2, t3, a.c1.c0, a.c0.c2);
-  fp4_sqr<176>(t4, t5, a.c0.c1, a.c1.c2);
+  fp4_sqr<S>(t0, t1, a.c0.c0, a.c1.c1);
+  fp4_sqr<S + 3>(t2, t3, a.c1.c0, a.c0.c2);
+  fp4_sqr<S + 6>(t4, t5, a.c0.c1, a.c1.c2);
   Fp12 o;
-  o.c0.c0 = NR(180, fp2_add(fp2_dbl(fp2_sub(t0, a.c0.c0)), t0));
-  o.c1.c1 = NR(181, fp2_add(fp2_dbl(fp2_add(t1, a.c1.c1)), t1));
-  t5 = NS(179, fp2_mul_xi(t5));
-  o.c1.c0 = NR(182, fp2_add(fp2_dbl(fp2_add(t5, a.c1.c0)), t5));
-  o.c0.c2 = NR(183, fp2_add(fp2_dbl(fp2_sub(t4, a.c0.c2)), t4));
-  o.c0.c1 = NR(184, fp2_add(fp2_dbl(fp2_sub(t2, a.c0.c1)), t2));
-  o.c1.c2 = NR(185, fp2_add(fp2_dbl(fp2_add(t3, a.c1.c2)), t3));
+  // outputs 3 t -+ 2 a: one fused pass each (combination, carry and weak reduction), so the t's may stay lazy
+  o.c0.c0 = fp2_lin2_reduce(t0, 3, a.c0.c0, -2);
+  o.c1.c1 = fp2_lin2_reduce(t1, 3, a.c1.c1, 2);
+  t5 = NS(S + 9, fp2_mul_xi(t5));
+  o.c1.c0 = fp2_lin2_reduce(t5, 3, a.c1.c0, 2);
+  o.c0.c2 = fp2_lin2_reduce(t4, 3, a.c0.c2, -2);
+  o.c0.c1 = fp2_lin2_reduce(t2, 3, a.c0.c1, -2);
+  o.c1.c2 = fp2_lin2_reduce(t3, 3, a.c1.c2, 2);
   r = o;
 }
-BN_DEVN void fp12_cyclotomic_sqr(Fp12& r, const Fp12& a) { fp12_cyclotomic_sqr_body(r, a); }
-BN_DEVF void fp12_cyclotomic_sqr_hot(Fp12& r, const Fp12& a) { fp12_cyclotomic_sqr_body(r, a); }  // the loop of fp12_pow_u
+BN_DEVN void fp12_cyclotomic_sqr(Fp12& r, const Fp12& a) { fp12_cyclotomic_sqr_body<170>(r, a); }
+BN_DEVF void fp12_cyclotomic_sqr_hot(Fp12& r, const Fp12& a) { fp12_cyclotomic_sqr_body<170>(r, a); }      // the loop of fp12_pow_u
 
 }  // namespace bn254

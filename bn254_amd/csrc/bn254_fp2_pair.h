@@ -100,6 +100,9 @@ BN_DEV Fp2 fp2_dbl(const Fp2& a) { return fp2_add(a, a); }
 BN_DEV Fp2 fp2_conj(const Fp2& a) { Fp2 r; BN_FOR_ROLES(k) r.c[k] = fp_select(bn_role_im(k), fp_neg(a.c[k]), a.c[k]); return r; }
 BN_DEV Fp2 fp2_norm(const Fp2& a) { Fp2 r; BN_FOR_ROLES(k) r.c[k] = fp_norm(a.c[k]); return r; }
 BN_DEV Fp2 fp2_reduce_weak(const Fp2& a) { Fp2 r; BN_FOR_ROLES(k) r.c[k] = fp_reduce_weak(a.c[k]); return r; }
+BN_DEV Fp2 fp2_lin2_reduce(const Fp2& x, int32_t cx, const Fp2& y, int32_t cy) {
+  Fp2 r; BN_FOR_ROLES(k) r.c[k] = fp_lin2_reduce(x.c[k], cx, y.c[k], cy); return r;
+}
 BN_DEV bool fp2_is_zero(const Fp2& a) { bool z = true; BN_FOR_ROLES(k) z = fp_is_zero(a.c[k]) && z; return bn_pair_and(z); }
 BN_DEV bool fp2_eq(const Fp2& a, const Fp2& b) { return fp2_is_zero(fp2_sub(a, b)); }
 BN_DEV Fp2 fp2_select(bool c, const Fp2& a, const Fp2& b) { Fp2 r; BN_FOR_ROLES(k) r.c[k] = fp_select(c, a.c[k], b.c[k]); return r; }

@@ -50,7 +50,7 @@ elif which == "msum":
 elif which == "codec":
     o = buf(64); assert hs.hs_g1_decompress(H(k["sign"][0]["signature_compressed"]), o) == 0
     o = buf(128); assert hs.hs_g2_decompress(H(k["g2_compressed_roundtrip"]["hex"]), o) == 0
-    assert hs.hs_g2_decompress(b"\x0c" + bytes(64), o) == 3
+    assert hs.hs_g2_decompress(b"\x0c" + H(k["g2_compressed_roundtrip"]["hex"])[1:], o) == 3      # valid x, bad sign byte
 elif which == "randomized":
     # one ragged group with invalid members (combined check fails -> exact kernels), then its valid members only
     for cases in (d["verify_cases"], [v for v in d["verify_cases"] if v["status"] == 0]):
