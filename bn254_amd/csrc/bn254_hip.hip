@@ -264,7 +264,10 @@ KERNEL void k_final_exp(size_t n, size_t k, size_t item_stride, size_t pair_stri
   }
   if (st == ST_OK && use_hash) st = ws_byte(ws, BY_ST_HASH, i);
   __shared__ Fp12Slot lds_acc[BN_WAVE];
-  if (!raw_only) final_exponentiation(f, f, lds_acc[threadIdx.x].v);
+  if (!raw_only) {
+    if (gt_out) final_exponentiation(f, f, lds_acc[threadIdx.x].v);        // canonical Gt: exact exponent
+    else final_exponentiation_check(f, f, lds_acc[threadIdx.x].v);          // == one test only: shorter chain
+  }
   if (gt_out) encode_fp12(gt_out + 384 * i, f);
   if (status_out) status_out[i] = st != ST_OK ? st : (fp12_is_one(f) ? (uint8_t)ST_OK : (uint8_t)ST_VERIFICATION_FAILED);
 }

@@ -209,7 +209,11 @@ KERNEL_PAIR void k_final_exp_pair(size_t n, size_t k, size_t item_stride, size_t
   }
   if (st == ST_OK && use_hash) st = ws_byte(ws, BY_ST_HASH, i);
   __shared__ Fp12PairSlot lds_acc[BN_PAIR_WG];
-  if (!raw_only) final_exponentiation<true>(f, f, lds_acc[threadIdx.x].v);
+  if (!raw_only) {
+    // canonical Gt bytes need the exact exponent; the == one test alone takes the shorter chain (wave-uniform branch)
+    if (gt_out) final_exponentiation<true>(f, f, lds_acc[threadIdx.x].v);
+    else final_exponentiation_check<true>(f, f, lds_acc[threadIdx.x].v);
+  }
   const unsigned role = threadIdx.x & 1u;
   if (gt_out) {
     const Fp2* c[6] = {&f.c0.c0, &f.c0.c1, &f.c0.c2, &f.c1.c0, &f.c1.c1, &f.c1.c2};

@@ -250,17 +250,23 @@ BN_DEVN void fp12_pow_u(Fp12& r, const Fp12& a, Fp12& acc) {
   r = acc;
 }
 
-// f^((q^12-1)/r): easy part (q^6-1)(q^2+1), then the exact hard part (q^4-q^2+1)/r =
-// q^3 + (6u^2+1) q^2 + (-36u^3-18u^2-12u+1) q + (-36u^3-30u^2-18u-2) by the vectorial
-// addition chain y0 * y1^2 * y2^6 * y3^12 * y4^18 * y5^30 * y6^36.
-template <bool ACC_LDS = false>
-BN_DEVN void final_exponentiation(Fp12& r, const Fp12& fin, Fp12& acc) {
-  Fp12 f, t, a, b;
+// easy part of the final exponentiation: f^((q^6 - 1)(q^2 + 1)), one Fq12 inversion
+BN_DEV void final_exp_easy(Fp12& f, const Fp12& fin) {
+  Fp12 t, a;
   fp12_inv(t, fin);
   fp12_conj(a, fin);
   fp12_mul(f, a, t);
   fp12_frob(t, f, 2);
   fp12_mul(f, t, f);
+}
+// f^((q^12-1)/r): easy part (q^6-1)(q^2+1), then the EXACT hard part (q^4-q^2+1)/r =
+// q^3 + (6u^2+1) q^2 + (-36u^3-18u^2-12u+1) q + (-36u^3-30u^2-18u-2) by the vectorial
+// addition chain y0 * y1^2 * y2^6 * y3^12 * y4^18 * y5^30 * y6^36 (13 multiplications, 4 squarings, 6 Frobenius maps
+// beside the three exponentiations by u).  This is the canonical Gt value of the pairing API.
+template <bool ACC_LDS = false>
+BN_DEVN void final_exponentiation(Fp12& r, const Fp12& fin, Fp12& acc) {
+  Fp12 f, a, b;
+  final_exp_easy(f, fin);
   Fp12 fu, fu2, fu3, y0, y1, y2, y3, y4, y5, y6;
   fp12_pow_u<ACC_LDS>(fu, f, acc);
   fp12_pow_u<ACC_LDS>(fu2, fu, acc);
@@ -281,6 +287,41 @@ BN_DEVN void final_exponentiation(Fp12& r, const Fp12& fin, Fp12& acc) {
   fp12_mul(t0, t1, y1); fp12_mul(t1, t1, y0);
   fp12_cyclotomic_sqr(t0, t0);
   fp12_mul(r, t0, t1);
+}
+// The same test with a cheaper hard part — for the == Gt::one() comparison of ECDSA::verify / check_public_keys
+// (/root/reference/src/ecdsa.rs:59, :88) ONLY: f^(m (q^12-1)/r) with m = 2u(6u^2+3u+1) by the chain of Fuentes-Castaneda,
+// Knapp, Rodriguez-Henriquez ("Faster hashing to G2", 2011): 10 multiplications, 3 squarings and 3 Frobenius maps beside
+// the three exponentiations by u.  m < r and r is prime, so the result is one exactly when the exact value is one; the
+// VALUE differs from the canonical Gt, which is why the pairing API keeps final_exponentiation above.
+//   lambda = (12u^3+12u^2+6u+1) + (12u^3+6u^2+4u) q + (12u^3+6u^2+6u) q^2 + (12u^3+6u^2+4u-1) q^3
+template <bool ACC_LDS = false>
+BN_DEVN void final_exponentiation_check(Fp12& r, const Fp12& fin, Fp12& acc) {
+  Fp12 f, t, y1, y3, y4, a, y8, y9, y11;
+  final_exp_easy(f, fin);
+  fp12_pow_u<ACC_LDS>(t, f, acc);
+  fp12_conj(t, t);                                  // f^-u
+  fp12_cyclotomic_sqr(y1, t);                       // f^-2u
+  fp12_cyclotomic_sqr(t, y1);                       // f^-4u
+  fp12_mul(y3, t, y1);                              // f^-6u
+  fp12_pow_u<ACC_LDS>(t, y3, acc);
+  fp12_conj(y4, t);                                 // f^(6u^2)
+  fp12_cyclotomic_sqr(t, y4);                       // f^(12u^2)
+  fp12_pow_u<ACC_LDS>(a, t, acc);                   // f^(12u^3)
+  fp12_conj(y3, y3);                                // f^(6u)
+  BN_SET_STEP_PRIORITY(2);   // the short tail: whoever is still here is behind
+  fp12_mul(t, a, y4);                               // f^(12u^3+6u^2)
+  fp12_mul(y8, t, y3);                              // f^(12u^3+6u^2+6u)
+  fp12_mul(y9, y8, y1);                             // f^(12u^3+6u^2+4u)
+  fp12_mul(t, y8, y4);                              // f^(12u^3+12u^2+6u)
+  fp12_mul(y11, t, f);                              // f^(12u^3+12u^2+6u+1)
+  fp12_frob(t, y9, 1);
+  fp12_mul(y11, t, y11);
+  fp12_frob(t, y8, 2);
+  fp12_mul(y11, t, y11);
+  fp12_conj(t, f);
+  fp12_mul(t, t, y9);                               // f^(12u^3+6u^2+4u-1)
+  fp12_frob(a, t, 3);
+  fp12_mul(r, a, y11);
 }
 
 }  // namespace bn254

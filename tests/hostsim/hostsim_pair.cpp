@@ -50,8 +50,12 @@ int hp_verify_decoded(const uint8_t* h64, const uint8_t* sig64, const uint8_t* p
   load_g1(h, h64); load_g1(sig, sig64); load_g2(pk, pk128);
   Fp12 f, acc;
   miller_loop<true, true>(f, h, pk, sig);
-  final_exponentiation(f, f, acc);
-  return fp12_is_one(f) ? 0 : 9;
+  Fp12 g;
+  final_exponentiation_check(g, f, acc);            // what k_final_exp_pair runs for a status
+  final_exponentiation(f, f, acc);                   // the exact value must agree on "is one"
+  const bool one_check = fp12_is_one(g), one_exact = fp12_is_one(f);
+  if (one_check != one_exact) return 255;
+  return one_check ? 0 : 9;
 }
 // Products per LANE of the pair kernels for one verify / one pairing (both roles run here in sequence, so totals / 2):
 // out = {miller_verify dual, single, final_exp dual, single, miller_var dual, single}.  "single" includes squares.
@@ -65,7 +69,7 @@ void hp_lane_counts(const uint8_t* h64, const uint8_t* sig64, const uint8_t* pk1
   miller_loop<true, true>(f, h, pk, sig);
   out6[0] = (bn_fp_dual_counter - d0) / 2; out6[1] = ((bn_fp_mul_counter - m0) - (bn_fp_dual_counter - d0)) / 2;
   m0 = bn_fp_mul_counter; d0 = bn_fp_dual_counter;
-  final_exponentiation(g, f, acc);
+  final_exponentiation_check(g, f, acc);
   bool one = fp12_is_one(g);
   (void)one;
   out6[2] = (bn_fp_dual_counter - d0) / 2; out6[3] = ((bn_fp_mul_counter - m0) - (bn_fp_dual_counter - d0)) / 2;
