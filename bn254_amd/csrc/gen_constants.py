@@ -289,6 +289,11 @@ def main():
                  (name, name, ", ".join("{%d, %d}" % op for op in ops), sum(op[0] for op in ops), sum(1 for op in ops[1:] if op[1])))
     o.append("BN_CONST int32_t C_QL[BN_LIMBS] = %s;           /* q as balanced limbs (plain) */" % c_fp(Q, False))
     o.append("BN_CONST int32_t C_R2[BN_LIMBS] = %s;           /* R^2 mod q, plain limbs: to_mont(x) = mul(x, R2) */" % c_fp(MONT_R * MONT_R % Q, False))
+    o.append("BN_CONST int32_t C_R3[BN_LIMBS] = %s;           /* R^3 mod q, plain limbs: mul(plain inverse of a Montgomery value, R3) = its Montgomery inverse */" % c_fp(pow(MONT_R, 3, Q), False))
+    o.append("BN_CONST int32_t C_QF[BN_LIMBS] = {%s};         /* q as plain digits in [0, 2^%d) (fp_inv: division steps) */" % (", ".join("%d" % w for w in limbs_floor(Q)), LIMB_BITS))
+    for i, w in enumerate(limbs_floor(Q)):
+        o.append("#define C_QF_%d %d" % (i, w))
+    o.append("#define BN_QINV 0x%07xu   /* q^-1 mod 2^%d */" % (pow(Q, -1, 1 << LIMB_BITS), LIMB_BITS))
     o.append("BN_CONST int32_t C_ONE[BN_LIMBS] = %s;          /* 1 (Montgomery) */" % c_fp(1))
     o.append("BN_CONST int32_t C_THREE[BN_LIMBS] = %s;        /* curve b = 3 */" % c_fp(3))
     o.append("BN_CONST int32_t C_TWIST_B[2][BN_LIMBS] = %s;   /* 3/xi */" % c_fp2(TWIST_B))
