@@ -41,9 +41,9 @@ FP_MUL_DECODE = 19
 FP_MUL_HASH_FILTER = 4             # per tested counter: x -> Montgomery, x^3 + 3, back to an integer for the Jacobi symbol
 FP_MUL_HASH_FINISH = 311           # once per message: the square-root exponentiation of the winning counter + checks
 FP_MUL_MILLER = 11138
-FP_MUL_FINAL_EXP = 6657            # status-only chain (Fuentes-Castaneda hard part, exponentiations by u over the digits {1, 15, 19}); incl. 12 canonicalisations for the == 1 test. The exact chain of the pairing API: 6909
+FP_MUL_FINAL_EXP = 6351            # status-only chain (Fuentes-Castaneda hard part, exponentiations by u over the digits {1, 15, 19}); incl. 12 canonicalisations for the == 1 test; the one Fq inversion is by division steps (~2.3 k multiply-adds, not counted as products)
 FP_MUL_MILLER_SINGLE = 8419        # one variable pair (configs[3] pairing workload), same instrumentation
-FP_MUL_FINAL_EXP_EXACT = 6909      # the exact final exponentiation (canonical Gt) of the pairing workload
+FP_MUL_FINAL_EXP_EXACT = 6603      # the exact final exponentiation (canonical Gt) of the pairing workload
 MAC32_PER_FP_MUL = 136             # ALGORITHMIC unit: an 8x32-bit Montgomery product = 2*8*8 + 8 MAC32.
 # What the pair-layout kernels actually issue per lane (tests/test_workcount.py: hp_lane_counts): multiply-add
 # instructions per dual product / single product / square of the device's limb representation.
