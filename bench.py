@@ -333,8 +333,14 @@ class Rank:
             raise SystemExit("bench.py needs a HIP device (bn254_amd has no CPU fallback)")
         torch.cuda.set_device(self.local_rank)
         self.dev = torch.device("cuda", self.local_rank)
-        if self.world > 1:
+        # BN254_BENCH_FORCE_DIST=1 (test knob): run the collectives even in a 1-rank job, so that the RCCL path (stream
+        # ordering, all_gather_into_tensor / all_reduce on device tensors) can be exercised on a one-GPU box
+        self.dist_on = self.world > 1 or os.environ.get("BN254_BENCH_FORCE_DIST") == "1"
+        if self.dist_on:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             if self.backend == "nccl":
                 dist.init_process_group(backend="nccl", device_id=self.dev)
@@ -367,7 +373,7 @@ class Rank:
             torch.cuda.synchronize()
             if after_warmup:
                 after_warmup()
-            if self.world > 1:
+            if self.dist_on:
                 dist.barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -375,18 +381,18 @@ class Rank:
                 step(warmup + k)
                 if per_step:
                     per_step()
-            if self.world > 1:
+            if self.dist_on:
                 dist.barrier()
             torch.cuda.synchronize()
             elapsed = time.perf_counter() - t0
-        if self.world > 1:
+        if self.dist_on:
             t = torch.tensor([elapsed], dtype=torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         return elapsed
 
     def finish(self):
-        if self.world > 1:
+        if self.dist_on:
             self.dist.barrier()
             self.dist.destroy_process_group()
 
@@ -444,14 +450,14 @@ def run_verify(args, R):
         d_sigs = [to_dev(sig_sets[0]), to_dev(sig_sets[1])]
         d_pks = to_dev(pks)
         d_status = torch.zeros(n, dtype=torch.uint8, device=dev)
-        d_all = torch.zeros(n * world, dtype=torch.uint8, device=dev) if world > 1 else None
+        d_all = torch.zeros(n * world, dtype=torch.uint8, device=dev) if R.dist_on else None
     sh = R.stream.cuda_stream
     assert sh != 0
 
     def step(k):
         eng.batch_verify_device(d_msgs.data_ptr(), d_off.data_ptr(), d_sigs[k & 1].data_ptr(), d_pks.data_ptr(), n, d_status.data_ptr(),
                                 flags=0, stream=sh)
-        if world > 1:
+        if R.dist_on:
             R.gather(d_status, d_all)                        # the only collective
 
     checks = {"steps_checked": 0, "mismatches": 0}
@@ -461,7 +467,7 @@ def run_verify(args, R):
         torch.cuda.synchronize()
         got = bytes(d_status.cpu().numpy())
         bad = int(got != expected_for(rank, step_index))
-        if world > 1:
+        if R.dist_on:
             allst = bytes(d_all.cpu().numpy())
             for r in range(world):
                 bad += int(allst[r * n:(r + 1) * n] != expected_for(r, step_index))
@@ -503,8 +509,8 @@ def run_verify(args, R):
         "config": {"workload": "configs[1]: batch of 65536 independent e(H(m),pk)*e(sig,-G2)==1 verifies per GPU "
                                "(32-byte messages, 1/64 corrupted, pattern alternates per step and differs per rank), 2 pairings per verify",
                    "batch_per_gpu": n, "verifies_per_s": verifies_per_s,
-                   "bit_exact_vs_expected": checks["mismatches"] == 0, "status_vectors_checked": checks["steps_checked"] * (1 + (world if world > 1 else 0)),
-                   "collective": "all_gather_into_tensor(status bytes) per step over %s" % R.backend if world > 1 else None},
+                   "bit_exact_vs_expected": checks["mismatches"] == 0, "status_vectors_checked": checks["steps_checked"] * (1 + (world if R.dist_on else 0)),
+                   "collective": "all_gather_into_tensor(status bytes) per step over %s" % R.backend if R.dist_on else None},
     }
 
     if rank == 0:
@@ -602,7 +608,7 @@ def run_pairing(args, R):
         d_g2 = torch.from_numpy(Qn[qi].reshape(-1).copy()).to(dev)
         d_gt = torch.empty(n * 384, dtype=torch.uint8, device=dev)
         d_st = torch.zeros(n, dtype=torch.uint8, device=dev)
-        d_all = torch.zeros(n * world, dtype=torch.uint8, device=dev) if world > 1 else None
+        d_all = torch.zeros(n * world, dtype=torch.uint8, device=dev) if R.dist_on else None
     eng.reserve(n)
     sh = R.stream.cuda_stream
     state = {"sum": None, "sums": set()}
@@ -610,7 +616,7 @@ def run_pairing(args, R):
     def step(k):
         eng.batch_pairing_device(d_g1.data_ptr(), d_g2.data_ptr(), n, 1, d_gt.data_ptr(), d_st.data_ptr(), stream=sh)
         local = gt_checksum(d_gt)
-        if world > 1:
+        if R.dist_on:
             R.gather(d_st, d_all)
         state["sum"] = R.allreduce_checksum(local)           # 8-byte all-reduce (a host read: ends the step)
         state["sums"].add(state["sum"])
@@ -618,7 +624,7 @@ def run_pairing(args, R):
     def after_warmup():
         torch.cuda.synchronize()
         assert int(d_st.min()) == 9 and int(d_st.max()) == 9, "a pairing of two non-identity points came out as one"
-        if world > 1:
+        if R.dist_on:
             assert int(d_all.min()) == 9 and int(d_all.max()) == 9
 
     elapsed = R.time_steps(step, args.steps, args.warmup, after_warmup)
@@ -642,7 +648,7 @@ def run_pairing(args, R):
         "config": {"workload": "configs[3]: independent pairings e(P_i,Q_i) sharded over the GPUs, %d per GPU (pool of %d P x %d Q combined by "
                                "index), 1 Miller loop + 1 final exponentiation each, Gt stays in HBM" % (n, pool, pool),
                    "batch_per_gpu": n, "gt_checksum_u64": "%016x" % state["sum"], "duplicate_inputs_equal_gt": dup_ok,
-                   "collective": ("all_gather_into_tensor(status bytes) + all_reduce(sum, 8-byte Gt checksum) per step over %s" % R.backend) if world > 1 else None},
+                   "collective": ("all_gather_into_tensor(status bytes) + all_reduce(sum, 8-byte Gt checksum) per step over %s" % R.backend) if R.dist_on else None},
     }
     if rank == 0:
         ms = 1e3 * elapsed / args.steps

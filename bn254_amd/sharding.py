@@ -20,7 +20,7 @@ def gather_status(local_status, n_total=None, out=None):
     import torch
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return local_status if n_total is None else local_status[:n_total]
     world = dist.get_world_size()
     if out is None:
@@ -35,7 +35,7 @@ def failure_count(status):
     import torch.distributed as dist
 
     c = (status != 0).sum().to(torch.int64).reshape(1)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
     return int(c.item())
 
@@ -54,6 +54,6 @@ def allreduce_checksum(local_sum):
     import torch.distributed as dist
 
     t = local_sum.clone()
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return int(t.item()) & 0xFFFFFFFFFFFFFFFF

@@ -171,3 +171,19 @@ def test_bench_gpus2_pairing_command_line_checksum_vs_oracle():
         assert st == bytes([9]) * n
         total += int(np.frombuffer(gt, dtype="<u8").sum(dtype=np.uint64))
     assert "%016x" % (total % (1 << 64)) == r["config"]["gt_checksum_u64"]
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_bench_rccl_collectives_on_one_rank():
+    """the RCCL path itself (backend "nccl": all_gather_into_tensor of the status bytes, all_reduce of the checksum,
+    barrier, all on the bench's explicit stream) in a 1-rank job — two ranks cannot share one GPU under RCCL, so this
+    is what a one-GPU box can exercise of it; the N-rank logic is covered by the gloo tests above"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "BN254_BENCH_BACKEND")}
+    env.update(BN254_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for extra, key in ((["--batch", "4096"], "bit_exact_vs_expected"), (["--workload", "pairing", "--batch", "2048"], "duplicate_inputs_equal_gt")):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"] + extra, env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=540)
+        assert p.returncode == 0, p.stderr[-2000:]
+        r = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+        assert r["n_gpus"] == 1 and r["config"][key] is True and "nccl" in r["config"]["collective"]
