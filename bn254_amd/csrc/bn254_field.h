@@ -444,9 +444,18 @@ BN_DEVN BN_LIMB_VEC fp_sqr_impl(BN_LIMB_VEC a) {
 // the m*q part of a column (9 balanced x balanced digit products) plus the carry from the column below
 #define BN_COL_EXTRA ((double)BN_LIMBS * BN_T * BN_T + 137438953472.0 /* 2^37 */)
 #define BN_VALUE_CAP 500.0  /* |value| / q allowed for a product output: its top limb (value x 3.17e6) must stay inside int32; the column bound sees that limb too */
+// Largest a*b column of a 9 x 9 limb product, with the top limbs bounded separately: columns 0..7 hold at most 8
+// products of ordinary limbs; column 8 has 7 of those plus a_0 b_8 and a_8 b_0; columns 9..15 fewer of each; column 16
+// is a_8 b_8 alone.  (The top limb carries the VALUE — |top| ~ |v/q| * 3.17e6 — so a large value costs two terms of a
+// column, not nine: this is what lets operands of a few hundred q through without a weak reduction.)
+static inline double bn_limb_abs(const Fp& a) { return std::fmax(std::fabs(a.bd.lo), std::fabs(a.bd.hi)); }
+static inline double bn_col_ab(const Fp& a, const Fp& b) {
+  double A = bn_limb_abs(a), B = bn_limb_abs(b), At = a.bd.top, Bt = b.bd.top;
+  return std::fmax(std::fmax(8.0 * A * B, 7.0 * A * B + A * Bt + At * B), At * Bt);
+}
 static inline void bn_trk_mul(Fp& r, const Fp& a, const Fp& b) {
   double A = bn_absmax(a), B = bn_absmax(b);
-  double col = (double)BN_LIMBS * A * B + BN_COL_EXTRA;
+  double col = bn_col_ab(a, b) + BN_COL_EXTRA;
   if (col >= 9223372036854775808.0) { if (!bn_bound_soft) fprintf(stderr, "  limbs %g x %g (units of 2^28)\n", A / BN_T, B / BN_T); bn_bound_fail("mul column overflow: 9*A*B", col); }
   double vv = bn_vabs(a) * bn_vabs(b) / BN_R_OVER_Q;   // |a||b| / (q R) in units of q
   if (vv > BN_VALUE_CAP) { if (!bn_bound_soft) fprintf(stderr, "  |a| < %g q, |b| < %g q, limbs %g %g\n", bn_vabs(a), bn_vabs(b), A / BN_T, B / BN_T); bn_bound_fail("mul value bound |a||b|/(qR)", vv); }
@@ -737,9 +746,8 @@ BN_DEV bool fp2_eq(const Fp2& a, const Fp2& b) { return fp_eq(a.c0, b.c0) && fp_
 BN_DEV Fp2 fp2_select(bool c, const Fp2& a, const Fp2& b) { Fp2 r; r.c0 = fp_select(c, a.c0, b.c0); r.c1 = fp_select(c, a.c1, b.c1); return r; }
 #if defined(BN_TRACK_BOUNDS) && !defined(__HIPCC__)
 static inline void bn_trk_fp2mul(Fp2& r, const Fp2& a, const Fp2& b) {
-  double A0 = bn_absmax(a.c0), A1 = bn_absmax(a.c1), B0 = bn_absmax(b.c0), B1 = bn_absmax(b.c1);
   double extra = BN_COL_EXTRA;
-  double col_re = (double)BN_LIMBS * (A0 * B0 + A1 * B1) + extra, col_im = (double)BN_LIMBS * (A0 * B1 + A1 * B0) + extra;
+  double col_re = bn_col_ab(a.c0, b.c0) + bn_col_ab(a.c1, b.c1) + extra, col_im = bn_col_ab(a.c0, b.c1) + bn_col_ab(a.c1, b.c0) + extra;
   if (col_re >= 9223372036854775808.0 || col_im >= 9223372036854775808.0) bn_bound_fail("fp2_mul column overflow", std::fmax(col_re, col_im));
   auto prod = [](const Fp& x, const Fp& y, double& lo, double& hi) {
     double c[4] = {x.bd.vlo * y.bd.vlo, x.bd.vlo * y.bd.vhi, x.bd.vhi * y.bd.vlo, x.bd.vhi * y.bd.vhi};

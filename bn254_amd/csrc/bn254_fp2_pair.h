@@ -46,7 +46,7 @@ BN_DEV bool bn_pair_and(bool x) { return x; }
 // r = Montgomery-reduce(x0*y0 + x1*y1): the per-lane half of an Fq2 product
 #if defined(BN_TRACK_BOUNDS) && !defined(__HIPCC__)
 static inline void bn_trk_dual(Fp& r, const Fp& x0, const Fp& y0, const Fp& x1, const Fp& y1) {
-  double col = (double)BN_LIMBS * (bn_absmax(x0) * bn_absmax(y0) + bn_absmax(x1) * bn_absmax(y1)) + BN_COL_EXTRA;
+  double col = bn_col_ab(x0, y0) + bn_col_ab(x1, y1) + BN_COL_EXTRA;
   if (col >= 9223372036854775808.0) {
     if (!bn_bound_soft) fprintf(stderr, "  limbs %g x %g + %g x %g (units of 2^28)\n", bn_absmax(x0) / BN_T, bn_absmax(y0) / BN_T, bn_absmax(x1) / BN_T, bn_absmax(y1) / BN_T);
     bn_bound_fail("pair product column overflow", col);
