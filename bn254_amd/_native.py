@@ -10,7 +10,7 @@ import subprocess
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_PKG, "csrc")
 LIB_PATH = os.environ.get("BN254_LIB", os.path.join(_PKG, "libbn254hip.so"))   # BN254_LIB: A/B-test another build
-_SOURCES = ["bn254_hip.hip", "bn254_pair.hip", "bn254_ws.h", "bn254_fp2_pair.h", "bn254_codec_g2.h", "bn254_norm_sites.h", "bn254_field.h", "bn254_curve.h", "bn254_pairing.h", "bn254_hash.h", "bn254_io.h", "gen_constants.py"]
+_SOURCES = ["bn254_hip.hip", "bn254_pair.hip", "bn254_trio.hip", "bn254_ws.h", "bn254_fp2_pair.h", "bn254_codec_g2.h", "bn254_norm_sites.h", "bn254_field.h", "bn254_curve.h", "bn254_pairing.h", "bn254_hash.h", "bn254_io.h", "gen_constants.py"]
 
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-Wl,--no-undefined"]   # a missing translation unit fails at link time
 
@@ -31,7 +31,7 @@ def build(force=False, verbose=False):
         subprocess.check_call(["python3", gen], stdout=None if verbose else subprocess.DEVNULL)
     if force or _stale():
         hipcc = os.environ.get("HIPCC", "hipcc")
-        cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB_PATH, os.path.join(_CSRC, "bn254_hip.hip"), os.path.join(_CSRC, "bn254_pair.hip")]
+        cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB_PATH, os.path.join(_CSRC, "bn254_hip.hip"), os.path.join(_CSRC, "bn254_pair.hip"), os.path.join(_CSRC, "bn254_trio.hip")]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

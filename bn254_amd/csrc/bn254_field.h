@@ -923,6 +923,7 @@ BN_DEV bool fp12_is_one(const Fp12& a) {
   return fp2_eq(a.c0.c0, fp2_one()) && fp2_is_zero(a.c0.c1) && fp2_is_zero(a.c0.c2) && fp2_is_zero(a.c1.c0) &&
          fp2_is_zero(a.c1.c1) && fp2_is_zero(a.c1.c2);
 }
+#if !defined(BN_TRIO_FORMULAS)
 BN_DEV void fp12_mul_body(Fp12& r, const Fp12& a, const Fp12& b) {  // sites 20 .. 49
   // Order chosen for register pressure (values that live across the product calls must sit in the ~110 callee-saved
   // VGPRs): the Karatsuba product of the sums first, while nothing else is alive, then one Fq6 product at a time.
@@ -944,6 +945,119 @@ BN_DEV void fp12_mul_body(Fp12& r, const Fp12& a, const Fp12& b) {  // sites 20 
 }
 BN_DEVN void fp12_mul(Fp12& r, const Fp12& a, const Fp12& b) { fp12_mul_body(r, a, b); }
 BN_DEVF void fp12_mul_hot(Fp12& r, const Fp12& a, const Fp12& b) { fp12_mul_body(r, a, b); }     // the loop of fp12_pow_u
+#endif
+// ---- the three-pair ("octet") layout for small batches: bn254_trio.hip ----------------------------------------------
+// One verify is carried by the eight lanes of an octet: lane pairs 0, 1, 2 each run ONE of the three Fq6 products of a
+// Karatsuba Fq12 multiplication (P0 = a0 b0, P1 = a1 b1, P2 = (a0 + a1)(b0 + b1)) and exchange the results through LDS;
+// everything else is replicated in the pairs (the fourth pair shadows pair 0 in these operations and is a fourth worker
+// in the Fq2-level rounds of the twist-point steps).  A wave that has its SIMD to itself issues a multiply-add only every
+// ~4.4 ns, so latency for a small batch is instructions per LANE: this layout cuts them ~2.5-fold.
+// BN_TRIO_FORMULAS selects the FORMULAS of that layout (Fq12 squaring and the two-line multiplication as the generic
+// Karatsuba product fp12_kmul) in any build — the host emulations use it to run the same arithmetic, bound tracker
+// included, with the three products computed one after the other; BN_TRIO_DEVICE adds the lane-group machinery.
+#if defined(BN_TRIO_DEVICE)
+}  // namespace bn254
+extern __shared__ int32_t bn_trio_lds[];          // dynamic LDS of the octet kernels: [accumulator slots | Fq6 exchange | Fq2 exchange]
+namespace bn254 {
+#define BN_TRIO_WG 256
+#define BN_TRIO_F_WORDS (6 * BN_LIMBS + 1)                         // accumulator slot per lane (odd stride)
+#define BN_TRIO_X6_OFF (BN_TRIO_WG * BN_TRIO_F_WORDS)              // Fq6 exchange: [octet][lane of the octet][27], octet stride 216
+#define BN_TRIO_X6_STRIDE (8 * 3 * BN_LIMBS)
+#define BN_TRIO_X2_OFF (BN_TRIO_X6_OFF + (BN_TRIO_WG / 8) * BN_TRIO_X6_STRIDE)   // Fq2 exchange: [octet][lane][9], octet stride 72
+#define BN_TRIO_X2_STRIDE (8 * BN_LIMBS)
+#define BN_TRIO_LDS_WORDS (BN_TRIO_X2_OFF + (BN_TRIO_WG / 8) * BN_TRIO_X2_STRIDE)
+BN_DEV int trio_pair() { return (int)((threadIdx.x >> 1) & 3u); }                 // lane pair within the octet, 0..3
+BN_DEV int trio_g3() { const int g = trio_pair(); return g == 3 ? 0 : g; }        // Fq6-level group: pair 3 shadows pair 0
+// x = (g == 0 ? lo : g == 1 ? hi : lo + hi), word by word (2 selects + 1 add)
+BN_DEV Fp2 trio_pick2(const Fp2& lo, const Fp2& hi, int g) {
+  Fp2 r;
+#pragma unroll
+  for (int i = 0; i < BN_LIMBS; ++i) {
+    const int32_t a = lo.c[0].v[i], b = hi.c[0].v[i];
+    r.c[0].v[i] = (g == 1 ? b : a) + (g == 2 ? b : 0);
+  }
+  return r;
+}
+BN_DEV void trio_pick6(Fp6& r, const Fp6& lo, const Fp6& hi, int g) {
+  r.c0 = trio_pick2(lo.c0, hi.c0, g); r.c1 = trio_pick2(lo.c1, hi.c1, g); r.c2 = trio_pick2(lo.c2, hi.c2, g);
+}
+// every pair publishes its Fq6 result, then reads those of pairs 0, 1, 2 (same role).  All eight lanes of an octet are
+// in one wave and a wave's LDS instructions execute in order, so no barrier is involved; volatile keeps the compiler
+// from reordering or merging the accesses.
+BN_DEV void trio_share6(const Fp6& p, Fp6& p0, Fp6& p1, Fp6& p2) {
+  volatile int32_t* base = bn_trio_lds + BN_TRIO_X6_OFF + (threadIdx.x >> 3) * BN_TRIO_X6_STRIDE;
+  volatile int32_t* mine = base + (threadIdx.x & 7u) * (3 * BN_LIMBS);
+  const Fp2* src[3] = {&p.c0, &p.c1, &p.c2};
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int i = 0; i < BN_LIMBS; ++i) mine[c * BN_LIMBS + i] = src[c]->c[0].v[i];
+  const unsigned role = threadIdx.x & 1u;
+  Fp6* dst[3] = {&p0, &p1, &p2};
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+    volatile int32_t* from = base + (2 * g + role) * (3 * BN_LIMBS);
+    Fp2* d[3] = {&dst[g]->c0, &dst[g]->c1, &dst[g]->c2};
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int i = 0; i < BN_LIMBS; ++i) d[c]->c[0].v[i] = from[c * BN_LIMBS + i];
+  }
+}
+// the same for one Fq2 value per pair, four pairs
+BN_DEV void trio_share2x4(const Fp2& p, Fp2& r0, Fp2& r1, Fp2& r2, Fp2& r3) {
+  volatile int32_t* base = bn_trio_lds + BN_TRIO_X2_OFF + (threadIdx.x >> 3) * BN_TRIO_X2_STRIDE;
+  volatile int32_t* mine = base + (threadIdx.x & 7u) * BN_LIMBS;
+#pragma unroll
+  for (int i = 0; i < BN_LIMBS; ++i) mine[i] = p.c[0].v[i];
+  const unsigned role = threadIdx.x & 1u;
+  Fp2* dst[4] = {&r0, &r1, &r2, &r3};
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    volatile int32_t* from = base + (2 * g + role) * BN_LIMBS;
+#pragma unroll
+    for (int i = 0; i < BN_LIMBS; ++i) dst[g]->c[0].v[i] = from[i];
+  }
+}
+#endif
+// r = a * b in Fq12, Karatsuba over Fq6.  Sites S .. S+15.  On the device of the octet layout the three Fq6 products run
+// in three lane pairs; elsewhere one after the other (same values, same sites).
+template <int S> BN_DEV void fp12_kmul(Fp12& r, const Fp12& a, const Fp12& b) {
+  Fp6 p0, p1, p2;
+#if defined(BN_TRIO_DEVICE)
+  {
+    const int g = trio_g3();
+    Fp6 x, y, p;
+    trio_pick6(x, a.c0, a.c1, g);
+    trio_pick6(y, b.c0, b.c1, g);
+    fp6_site_n<S>(x, x); fp6_site_n<S + 3>(y, y);   // what pair 2 needs for its sums; a carry of a tight value changes nothing
+    fp6_mul<S + 6>(p, x, y);
+    trio_share6(p, p0, p1, p2);
+  }
+#else
+  {
+    Fp6 s, t;
+    fp6_mul<S + 6>(p0, a.c0, b.c0);
+    fp6_mul<S + 6>(p1, a.c1, b.c1);
+    fp6_add(s, a.c0, a.c1); fp6_site_n<S>(s, s);
+    fp6_add(t, b.c0, b.c1); fp6_site_n<S + 3>(t, t);
+    fp6_mul<S + 6>(p2, s, t);
+  }
+#endif
+  Fp6 u, w;
+  fp6_sub(u, p2, p0);
+  fp6_sub(u, u, p1);
+  fp6_mul_v(w, p1);
+  fp6_add(w, p0, w);
+  fp6_site_r<S + 10>(r.c0, w);
+  fp6_site_r<S + 13>(r.c1, u);
+}
+#if defined(BN_TRIO_FORMULAS)
+BN_DEV void fp12_mul_body(Fp12& r, const Fp12& a, const Fp12& b) { fp12_kmul<260>(r, a, b); }    // sites 260 .. 275
+BN_DEVN void fp12_mul(Fp12& r, const Fp12& a, const Fp12& b) { fp12_mul_body(r, a, b); }
+BN_DEVF void fp12_mul_hot(Fp12& r, const Fp12& a, const Fp12& b) { fp12_mul_body(r, a, b); }
+BN_DEVH void fp12_sqr(Fp12& r, const Fp12& a) { fp12_kmul<280>(r, a, a); }                       // sites 280 .. 295
+#else
 BN_DEVH void fp12_sqr(Fp12& r, const Fp12& a) {                       // sites 50 .. 79
   Fp6 ab, s, t, u;
   fp6_mul<50>(ab, a.c0, a.c1);
@@ -958,6 +1072,7 @@ BN_DEVH void fp12_sqr(Fp12& r, const Fp12& a) {                       // sites 5
   fp6_add(s, ab, ab);
   fp6_site_r<67>(r.c1, s);
 }
+#endif
 // the negated half keeps balanced digits balanced: no carry needed
 BN_DEV void fp12_conj(Fp12& r, const Fp12& a) { r.c0 = a.c0; fp6_neg(r.c1, a.c1); }
 BN_DEVN void fp12_inv(Fp12& r, const Fp12& a) {                       // sites 80 .. 109
@@ -986,6 +1101,13 @@ BN_DEVN void fp12_mul_line(Fp12& r, const Fp12& f, const Fp2& l0, const Fp2& l1,
   fp6_site_r<123>(r.c1, u);
 }
 // f * (b0 + b1 w): b0 a full Fq6, b1 = b10 + b11 v — the shape of a product of two lines; the b's tight
+#if defined(BN_TRIO_FORMULAS)
+BN_DEVH void fp12_mul_line2(Fp12& r, const Fp12& f, const Fp6& b0, const Fp2& b10, const Fp2& b11) {   // sites 300 .. 315
+  Fp12 b;
+  b.c0 = b0; b.c1.c0 = b10; b.c1.c1 = b11; b.c1.c2 = fp2_zero();
+  fp12_kmul<300>(r, f, b);
+}
+#else
 BN_DEVH void fp12_mul_line2(Fp12& r, const Fp12& f, const Fp6& b0, const Fp2& b10, const Fp2& b11) {   // sites 140 .. 169
   Fp6 t0, t1, s, u, bs;
   fp6_mul<140>(t0, f.c0, b0);
@@ -1000,6 +1122,7 @@ BN_DEVH void fp12_mul_line2(Fp12& r, const Fp12& f, const Fp6& b0, const Fp2& b1
   fp6_site_r<156>(r.c0, s);
   fp6_site_r<159>(r.c1, u);
 }
+#endif
 // coefficient k of w^k in the polynomial basis: c[2i] = c0.c_i, c[2i+1] = c1.c_i
 BN_DEV Fp2& fp12_coef(Fp12& a, int k) {
   Fp6& h = (k & 1) ? a.c1 : a.c0;
@@ -1027,9 +1150,36 @@ template <int S> BN_DEV void fp4_sqr(Fp2& r0, Fp2& r1, const Fp2& a, const Fp2& 
 // (fp2_lin2_reduce): across a run of squarings the values stay below ~0.6 q.
 template <int S> BN_DEV void fp12_cyclotomic_sqr_body(Fp12& r, const Fp12& a) {       // sites S .. S+15 (170.., 240..)
   Fp2 t0, t1, t2, t3, t4, t5;
+#if defined(BN_TRIO_DEVICE)
+  {
+    // octet layout: the three Fq4 squarings in three lane pairs (sites S+20 .. S+22: the safe defaults, this instance
+    // stands for all three of the serial form), results exchanged through LDS; the six outputs are replicated
+    const int g = trio_g3();
+    Fp2 x, y, e, o;
+#pragma unroll
+    for (int i = 0; i < BN_LIMBS; ++i) {
+      x.c[0].v[i] = g == 0 ? a.c0.c0.c[0].v[i] : g == 1 ? a.c1.c0.c[0].v[i] : a.c0.c1.c[0].v[i];
+      y.c[0].v[i] = g == 0 ? a.c1.c1.c[0].v[i] : g == 1 ? a.c0.c2.c[0].v[i] : a.c1.c2.c[0].v[i];
+    }
+    fp4_sqr<S + 20>(e, o, x, y);
+    volatile int32_t* base = bn_trio_lds + BN_TRIO_X6_OFF + (threadIdx.x >> 3) * BN_TRIO_X6_STRIDE;
+    volatile int32_t* mine = base + (threadIdx.x & 7u) * (3 * BN_LIMBS);
+#pragma unroll
+    for (int i = 0; i < BN_LIMBS; ++i) { mine[i] = e.c[0].v[i]; mine[BN_LIMBS + i] = o.c[0].v[i]; }
+    const unsigned role = threadIdx.x & 1u;
+    Fp2* dst[6] = {&t0, &t1, &t2, &t3, &t4, &t5};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      volatile int32_t* from = base + (2 * k + role) * (3 * BN_LIMBS);
+#pragma unroll
+      for (int i = 0; i < BN_LIMBS; ++i) { dst[2 * k]->c[0].v[i] = from[i]; dst[2 * k + 1]->c[0].v[i] = from[BN_LIMBS + i]; }
+    }
+  }
+#else
   fp4_sqr<S>(t0, t1, a.c0.c0, a.c1.c1);
   fp4_sqr<S + 3>(t2, t3, a.c1.c0, a.c0.c2);
   fp4_sqr<S + 6>(t4, t5, a.c0.c1, a.c1.c2);
+#endif
   Fp12 o;
   // outputs 3 t -+ 2 a: one fused pass each (combination, carry and weak reduction), so the t's may stay lazy
   o.c0.c0 = fp2_lin2_reduce(t0, 3, a.c0.c0, -2);

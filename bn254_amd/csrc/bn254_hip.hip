@@ -780,6 +780,7 @@ struct bn254_ctx {
   int rand_min_batch;      // randomised verify: batches below this size run the exact kernels (default RAND_MIN_BATCH_DEFAULT)
   int rand_items_per_lane; // randomised verify: 0 = by batch size, 1 or 2 forced (A/B and tests)
   int hash_max_tries; // test knob: counters tried before HashToPointError (0 = the reference's 255)
+  int trio_max_batch; // verify / check_public_keys batches up to this size run in the octet layout (bn254_trio.hip); 0 = never
   hipEvent_t ev[5];
   int ev_valid;
   hipStream_t copy_stream;   // host-pointer verify: signatures and keys cross PCIe here while the hash rounds run on `stream`
@@ -908,6 +909,7 @@ int bn254_ctx_create(int hip_device, bn254_ctx** out) {
   memset(c, 0, sizeof *c);
   c->pair_lanes = 1;
   c->rand_min_batch = RAND_MIN_BATCH_DEFAULT;
+  c->trio_max_batch = TRIO_MAX_BATCH_DEFAULT;
   c->device = hip_device;
   hipError_t err = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (err == hipSuccess) err = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
@@ -961,6 +963,7 @@ int bn254_ctx_set_option(bn254_ctx* c, int option, int value) {
   if (option == BN254_OPT_PAIR_LANES) { c->pair_lanes = value != 0; return 0; }
   if (option == BN254_OPT_RAND_MIN_BATCH) { if (value < 0) return BN254_E_BAD_ARGUMENT; c->rand_min_batch = value; return 0; }
   if (option == BN254_OPT_RAND_ITEMS_PER_LANE) { if (value < 0 || value > 2) return BN254_E_BAD_ARGUMENT; c->rand_items_per_lane = value; return 0; }
+  if (option == BN254_OPT_TRIO_MAX_BATCH) { if (value < 0) return BN254_E_BAD_ARGUMENT; c->trio_max_batch = value; return 0; }
   if (option == BN254_OPT_HASH_MAX_TRIES) { if (value < 0 || value > 255) return BN254_E_BAD_ARGUMENT; c->hash_max_tries = value; return 0; }
   return BN254_E_BAD_ARGUMENT;
 }
@@ -972,6 +975,21 @@ int bn254_ctx_last_kernel_ms(bn254_ctx* c, float ms[4]) {
 }
 
 #define PROF_MARK(idx) do { if (c->profiling) HIP_TRY(hipEventRecord(c->ev[idx], s)); } while (0)
+
+// Miller loop + final exponentiation of a verify-shaped batch on lane pairs, or — for batches that cannot fill the chip —
+// in the octet layout (three lane pairs share the Fq6 products of every Fq12 operation: fewer instructions per lane,
+// which is what latency is made of when a wave has its SIMD to itself).  Same status bytes either way.
+static int launch_pair_or_trio(bn254_ctx* c, hipStream_t s, size_t n, int use_hash, uint8_t* d_status, int mode, bool mark) {
+  int rc;
+  if (c->trio_max_batch > 0 && n <= (size_t)c->trio_max_batch) {
+    if ((rc = bn254_trio_miller_verify(n, c->ws, s, mode))) return rc;
+    if (mark) PROF_MARK(3);
+    return bn254_trio_final_exp(n, c->ws, use_hash, d_status, s);
+  }
+  if ((rc = bn254_pair_miller_verify(n, c->ws, nullptr, nullptr, s, mode))) return rc;
+  if (mark) PROF_MARK(3);
+  return bn254_pair_final_exp(n, c->ws, use_hash, d_status, nullptr, nullptr, s);
+}
 
 // decode kernels have filled the P1 / Q planes and BY_ST_DECODE: hash, Miller loop, final exponentiation
 static int verify_after_decode(bn254_ctx* c, hipStream_t s, const uint8_t* d_msgs, const uint64_t* d_off, size_t n, uint8_t* d_status, bool split) {
@@ -985,9 +1003,7 @@ static int verify_after_decode(bn254_ctx* c, hipStream_t s, const uint8_t* d_msg
     PROF_MARK(3);
     k_final_exp<<<g, BN_WAVE, 0, s>>>(n, 2, 1, c->ws.stride / 2, c->ws, 1, nullptr, d_status, 0, 0, nullptr, nullptr);
   } else if (c->pair_lanes) {
-    if ((rc = bn254_pair_miller_verify(n, c->ws, nullptr, nullptr, s))) return rc;
-    PROF_MARK(3);
-    if ((rc = bn254_pair_final_exp(n, c->ws, 1, d_status, nullptr, nullptr, s))) return rc;
+    if ((rc = launch_pair_or_trio(c, s, n, 1, d_status, 0, true))) return rc;
   } else {
     k_miller_verify<<<g, BN_WAVE, 0, s>>>(n, c->ws, nullptr, nullptr);
     PROF_MARK(3);
@@ -1097,9 +1113,7 @@ int bn254_batch_verify(bn254_ctx* c, const uint8_t* msgs, const uint64_t* off, c
   if ((rc = launch_decode_g2(c, s, c->stage[3], n, flags, 1))) return rc;
   PROF_MARK(2);
   if (c->pair_lanes) {
-    if ((rc = bn254_pair_miller_verify(n, c->ws, nullptr, nullptr, s))) return rc;
-    PROF_MARK(3);
-    if ((rc = bn254_pair_final_exp(n, c->ws, 1, c->stage[4], nullptr, nullptr, s))) return rc;
+    if ((rc = launch_pair_or_trio(c, s, n, 1, c->stage[4], 0, true))) return rc;
   } else {
     k_miller_verify<<<grid_for(n), BN_WAVE, 0, s>>>(n, c->ws, nullptr, nullptr);
     PROF_MARK(3);
@@ -1306,8 +1320,7 @@ int bn254_batch_check_public_keys(bn254_ctx* c, const uint8_t* pk_g2, const uint
   if ((rc = launch_decode_g2(c, s, c->stage[0], n, flags, 0))) return rc;       // ecdsa.rs:82: pk_g2 first
   k_decode_g1<<<g, BN_WAVE, 0, s>>>(c->stage[1], n, flags, c->ws, PL_P1X, BY_P1_INF, 1);
   if (c->pair_lanes) {
-    if ((rc = bn254_pair_miller_verify(n, c->ws, nullptr, nullptr, s, 1))) return rc;
-    if ((rc = bn254_pair_final_exp(n, c->ws, 0, c->stage[2], nullptr, nullptr, s))) return rc;
+    if ((rc = launch_pair_or_trio(c, s, n, 0, c->stage[2], 1, false))) return rc;
   } else {
     k_miller_cpk<<<g, BN_WAVE, 0, s>>>(n, c->ws);
     k_final_exp<<<g, BN_WAVE, 0, s>>>(n, 1, 1, 1, c->ws, 0, nullptr, c->stage[2], 0, 0, nullptr, nullptr);

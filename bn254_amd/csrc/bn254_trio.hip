@@ -1,0 +1,80 @@
+// Third device translation unit of libbn254hip.so: ECDSA::verify (/root/reference/src/ecdsa.rs:49-64) for SMALL batches,
+// one verify per OCTET of lanes.  Same tower / pairing source as bn254_pair.hip in the pair layout of the Fq2 values, but
+// the three Fq6 products of every Karatsuba Fq12 operation (fp12_kmul: Fq12 squaring, the two-line multiplication, the
+// multiplications of the final exponentiation) and the three Fq4 squarings of a cyclotomic squaring run in three lane
+// pairs at once and are exchanged through LDS (bn254_field.h: BN_TRIO_DEVICE); everything else is replicated in the
+// pairs.  A wave that has its SIMD to itself issues a multiply-add only every ~4.4 ns, so for a batch that cannot fill
+// the chip latency is instructions per LANE; this layout has ~2 times fewer of them than the pair layout.  256-thread
+// workgroups (32 verifies), 91 KB of LDS -> one workgroup per CU, one wave per SIMD.
+#include <hip/hip_runtime.h>
+
+#define BN_SPLIT_FP2 1
+#define BN_PAIR_SQR_DPP_ASM 1
+#define BN_INLINE_FP12_HOT 1
+#define BN_INLINE_FE_HOT 1
+#define BN_TRIO_FORMULAS 1
+#define BN_TRIO_DEVICE 1
+#define bn254 bn254_trio   // own namespace: same types as bn254_pair, different routines
+#include "bn254_pairing.h"
+
+using namespace bn254;
+
+#include "bn254_ws.h"
+
+#define KERNEL_TRIO __global__ __launch_bounds__(BN_TRIO_WG) __attribute__((amdgpu_waves_per_eu(1, 1)))
+
+struct Fp12TrioSlot { Fp12 v; int32_t pad; };
+static_assert(sizeof(Fp12TrioSlot) == BN_TRIO_F_WORDS * 4, "accumulator slot: 6 x 9 limbs + 1 pad word");
+
+__device__ __forceinline__ Fp2 ws_load_fp2_role(const Ws& ws, int plane_re, size_t i) {
+  Fp2 r;
+  r.c[0] = ws_load_fp(ws, plane_re + (int)(threadIdx.x & 1u), i);
+  return r;
+}
+
+// f = miller(H(m), pk) * miller(sig, -G2) for item = lane >> 3; the eight lanes of an octet take every branch together.
+// mode 1 = check_public_keys (/root/reference/src/ecdsa.rs:80-86), as in k_miller_verify_pair.
+KERNEL_TRIO void k_miller_verify_trio(size_t n, Ws ws, int mode) {
+  const size_t i = ((size_t)blockIdx.x * BN_TRIO_WG + threadIdx.x) >> 3;
+  if (i >= n) return;
+  G1Affine sig, h;
+  G2Affine pk;
+  ws_load_g1(ws, PL_P1X, BY_P1_INF, i, sig);
+  if (mode == 1) { h.x = fp_load_const(C_G1_GEN[0]); h.y = fp_load_const(C_G1_GEN[1]); h.inf = false; }   // wave-uniform
+  else ws_load_g1(ws, PL_P2X, BY_P2_INF, i, h);
+  pk.x = ws_load_fp2_role(ws, PL_QX0, i);
+  pk.y = ws_load_fp2_role(ws, PL_QY0, i);
+  pk.inf = ws_byte(ws, BY_Q_INF, i) != 0;
+  Fp12& f = ((Fp12TrioSlot*)bn_trio_lds)[threadIdx.x].v;
+  miller_loop<true, true, true>(f, h, pk, sig);
+  if (trio_pair() == 0) {                            // the four pairs hold the same f
+    const Fp2* c[6] = {&f.c0.c0, &f.c0.c1, &f.c0.c2, &f.c1.c0, &f.c1.c1, &f.c1.c2};
+#pragma unroll
+    for (int k = 0; k < 6; ++k) ws_store_fp(ws, PL_F0 + 2 * k + (int)(threadIdx.x & 1u), i, c[k]->c[0]);
+  }
+}
+// final exponentiation (status-only chain) + comparison with one for item = lane >> 3
+KERNEL_TRIO void k_final_exp_trio(size_t n, Ws ws, int use_hash, uint8_t* status_out) {
+  const size_t i = ((size_t)blockIdx.x * BN_TRIO_WG + threadIdx.x) >> 3;
+  if (i >= n) return;
+  Fp12 f;
+  Fp2* c[6] = {&f.c0.c0, &f.c0.c1, &f.c0.c2, &f.c1.c0, &f.c1.c1, &f.c1.c2};
+#pragma unroll
+  for (int k = 0; k < 6; ++k) *c[k] = ws_load_fp2_role(ws, PL_F0 + 2 * k, i);
+  uint8_t st = ws_byte(ws, BY_ST_DECODE, i);
+  if (st == ST_OK && use_hash) st = ws_byte(ws, BY_ST_HASH, i);
+  final_exponentiation_check<true>(f, f, ((Fp12TrioSlot*)bn_trio_lds)[threadIdx.x].v);
+  const bool one = fp12_is_one(f);   // combined over the pair
+  if ((threadIdx.x & 7u) == 0) status_out[i] = st != ST_OK ? st : (one ? (uint8_t)ST_OK : (uint8_t)ST_VERIFICATION_FAILED);
+}
+
+int bn254_trio_miller_verify(size_t n, Ws ws, hipStream_t s, int mode) {
+  k_miller_verify_trio<<<(unsigned)((8 * n + BN_TRIO_WG - 1) / BN_TRIO_WG), BN_TRIO_WG, BN_TRIO_LDS_WORDS * sizeof(int32_t), s>>>(n, ws, mode);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+int bn254_trio_final_exp(size_t n, Ws ws, int use_hash, uint8_t* status_out, hipStream_t s) {
+  k_final_exp_trio<<<(unsigned)((8 * n + BN_TRIO_WG - 1) / BN_TRIO_WG), BN_TRIO_WG, BN_TRIO_LDS_WORDS * sizeof(int32_t), s>>>(n, ws, use_hash, status_out);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}

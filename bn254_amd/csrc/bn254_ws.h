@@ -4,6 +4,7 @@
 
 #define BN_WAVE 64
 #define BN_SPLIT_MAX_N ((size_t)98304)   // <= 1.5 waves per SIMD with one lane per verify
+#define TRIO_MAX_BATCH_DEFAULT 0                    // octet layout for small batches: off until set (BN254_OPT_TRIO_MAX_BATCH)
 #define RAND_MIN_BATCH_DEFAULT 131072              // randomised verify pays off from about here
 #define RAND_TWO_PER_LANE_MIN_N ((size_t)131072)   // randomised verify: two items per lane once that still fills 1024 SIMDs
 // Register budget: amdgpu_waves_per_eu(W, W) on the kernels is propagated to every device function
@@ -92,3 +93,7 @@ __attribute__((visibility("hidden"))) int bn254_pair_aggregate(const uint32_t* t
                                                                size_t n_signers, size_t n_msgs, Pool pk_pool, Pool sig_pool, Pool h_pool, Ws ws, hipStream_t s);
 __attribute__((visibility("hidden"))) int bn254_pair_decode_g2(const uint8_t* pts, size_t n, uint32_t flags, Ws ws, int accumulate, hipStream_t s);
 __attribute__((visibility("hidden"))) int bn254_pair_decompress_g2(const uint8_t* in, size_t n, Ws ws, hipStream_t s);
+
+// entry points of bn254_trio.hip (octet layout for small batches)
+__attribute__((visibility("hidden"))) int bn254_trio_miller_verify(size_t n, Ws ws, hipStream_t s, int mode = 0);
+__attribute__((visibility("hidden"))) int bn254_trio_final_exp(size_t n, Ws ws, int use_hash, uint8_t* status_out, hipStream_t s);

@@ -227,6 +227,9 @@ int bn254_ctx_set_profiling(bn254_ctx *ctx, int enabled);
                                      group failed the pairing check).  Default 131072, the measured break-even on an MI355X; 0 = always randomised */
 #define BN254_OPT_PAIR_LANES 4 /* verify: Miller loop + final exponentiation on lane pairs, two waves per SIMD (default 1); 0 = one lane per verify */
 #define BN254_OPT_RAND_ITEMS_PER_LANE 3 /* randomised verify: items per lane in the Miller kernel; 0 = by batch size (default), 1, 2 */
+#define BN254_OPT_TRIO_MAX_BATCH 6 /* verify / check_public_keys batches of up to this many items run in the OCTET layout (eight lanes per item: the
+                                     three Fq6 products of every Fq12 operation in three lane pairs) — fewer instructions per lane, i.e. lower
+                                     latency when the batch cannot fill the chip anyway; same status bytes.  0 = never */
 #define BN254_OPT_HASH_MAX_TRIES 2 /* test knob: counters tried before HashToPointError; 0 = 255 as in src/hash.rs:40 */
 int bn254_ctx_set_option(bn254_ctx *ctx, int option, int value);
 int bn254_ctx_last_kernel_ms(bn254_ctx *ctx, float ms[4]);
