@@ -982,44 +982,72 @@ BN_DEV void trio_pick6(Fp6& r, const Fp6& lo, const Fp6& hi, int g) {
   r.c0 = trio_pick2(lo.c0, hi.c0, g); r.c1 = trio_pick2(lo.c1, hi.c1, g); r.c2 = trio_pick2(lo.c2, hi.c2, g);
 }
 // every pair publishes its Fq6 result, then reads those of pairs 0, 1, 2 (same role).  All eight lanes of an octet are
-// in one wave and a wave's LDS instructions execute in order, so no barrier is involved; volatile keeps the compiler
-// from reordering or merging the accesses.
+// in one wave and a wave's LDS instructions execute in order, so no barrier is involved; the wavefront-scope fences keep
+// the compiler from moving the reads above the writes (or the next exchange's writes above these reads).  The array is
+// indexed directly so that the accesses stay LDS instructions (ds_write / ds_read), batched under one wait.
+#define BN_TRIO_FENCE() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 BN_DEV void trio_share6(const Fp6& p, Fp6& p0, Fp6& p1, Fp6& p2) {
-  volatile int32_t* base = bn_trio_lds + BN_TRIO_X6_OFF + (threadIdx.x >> 3) * BN_TRIO_X6_STRIDE;
-  volatile int32_t* mine = base + (threadIdx.x & 7u) * (3 * BN_LIMBS);
+  const unsigned base = BN_TRIO_X6_OFF + (threadIdx.x >> 3) * BN_TRIO_X6_STRIDE, mine = base + (threadIdx.x & 7u) * (3 * BN_LIMBS);
   const Fp2* src[3] = {&p.c0, &p.c1, &p.c2};
+  BN_TRIO_FENCE();
 #pragma unroll
   for (int c = 0; c < 3; ++c)
 #pragma unroll
-    for (int i = 0; i < BN_LIMBS; ++i) mine[c * BN_LIMBS + i] = src[c]->c[0].v[i];
+    for (int i = 0; i < BN_LIMBS; ++i) bn_trio_lds[mine + c * BN_LIMBS + i] = src[c]->c[0].v[i];
+  BN_TRIO_FENCE();
   const unsigned role = threadIdx.x & 1u;
   Fp6* dst[3] = {&p0, &p1, &p2};
 #pragma unroll
   for (int g = 0; g < 3; ++g) {
-    volatile int32_t* from = base + (2 * g + role) * (3 * BN_LIMBS);
+    const unsigned from = base + (2 * g + role) * (3 * BN_LIMBS);
     Fp2* d[3] = {&dst[g]->c0, &dst[g]->c1, &dst[g]->c2};
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
-      for (int i = 0; i < BN_LIMBS; ++i) d[c]->c[0].v[i] = from[c * BN_LIMBS + i];
+      for (int i = 0; i < BN_LIMBS; ++i) d[c]->c[0].v[i] = bn_trio_lds[from + c * BN_LIMBS + i];
   }
+  BN_TRIO_FENCE();
 }
 // the same for one Fq2 value per pair, four pairs
 BN_DEV void trio_share2x4(const Fp2& p, Fp2& r0, Fp2& r1, Fp2& r2, Fp2& r3) {
-  volatile int32_t* base = bn_trio_lds + BN_TRIO_X2_OFF + (threadIdx.x >> 3) * BN_TRIO_X2_STRIDE;
-  volatile int32_t* mine = base + (threadIdx.x & 7u) * BN_LIMBS;
+  const unsigned base = BN_TRIO_X2_OFF + (threadIdx.x >> 3) * BN_TRIO_X2_STRIDE, mine = base + (threadIdx.x & 7u) * BN_LIMBS;
+  BN_TRIO_FENCE();
 #pragma unroll
-  for (int i = 0; i < BN_LIMBS; ++i) mine[i] = p.c[0].v[i];
+  for (int i = 0; i < BN_LIMBS; ++i) bn_trio_lds[mine + i] = p.c[0].v[i];
+  BN_TRIO_FENCE();
   const unsigned role = threadIdx.x & 1u;
   Fp2* dst[4] = {&r0, &r1, &r2, &r3};
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
-    volatile int32_t* from = base + (2 * g + role) * BN_LIMBS;
+    const unsigned from = base + (2 * g + role) * BN_LIMBS;
 #pragma unroll
-    for (int i = 0; i < BN_LIMBS; ++i) dst[g]->c[0].v[i] = from[i];
+    for (int i = 0; i < BN_LIMBS; ++i) dst[g]->c[0].v[i] = bn_trio_lds[from + i];
   }
+  BN_TRIO_FENCE();
 }
 #endif
+// One ROUND of the octet layout: four independent Fq2 products, one per lane pair, results exchanged so that every pair
+// has all four afterwards (the twist-point steps and the line preparation are written as such rounds,
+// bn254_pairing.h: miller_verify_rounds).  Elsewhere: the four products one after the other — same values.
+BN_DEV void trio4(Fp2& r0, Fp2& r1, Fp2& r2, Fp2& r3, const Fp2& x0, const Fp2& y0, const Fp2& x1, const Fp2& y1, const Fp2& x2,
+                  const Fp2& y2, const Fp2& x3, const Fp2& y3) {
+#if defined(BN_TRIO_DEVICE)
+  const int g = trio_pair();
+  Fp2 x, y;
+#pragma unroll
+  for (int i = 0; i < BN_LIMBS; ++i) {
+    x.c[0].v[i] = (g & 2) ? ((g & 1) ? x3.c[0].v[i] : x2.c[0].v[i]) : ((g & 1) ? x1.c[0].v[i] : x0.c[0].v[i]);
+    y.c[0].v[i] = (g & 2) ? ((g & 1) ? y3.c[0].v[i] : y2.c[0].v[i]) : ((g & 1) ? y1.c[0].v[i] : y0.c[0].v[i]);
+  }
+  trio_share2x4(fp2_mul(x, y), r0, r1, r2, r3);
+#else
+  Fp2 a = fp2_mul(x0, y0), b = fp2_mul(x1, y1), c = fp2_mul(x2, y2), d = fp2_mul(x3, y3);
+  r0 = a; r1 = b; r2 = c; r3 = d;
+#endif
+}
+// an Fq scalar as an Fq2 value (k + 0 i), so that a scaling by it can ride in a round as an ordinary Fq2 product
+BN_DEV Fp2 fp2_from_fp(const Fp& k) { return fp2_make(k, fp_zero()); }
+
 // r = a * b in Fq12, Karatsuba over Fq6.  Sites S .. S+15.  On the device of the octet layout the three Fq6 products run
 // in three lane pairs; elsewhere one after the other (same values, same sites).
 template <int S> BN_DEV void fp12_kmul(Fp12& r, const Fp12& a, const Fp12& b) {
@@ -1162,18 +1190,20 @@ template <int S> BN_DEV void fp12_cyclotomic_sqr_body(Fp12& r, const Fp12& a) { 
       y.c[0].v[i] = g == 0 ? a.c1.c1.c[0].v[i] : g == 1 ? a.c0.c2.c[0].v[i] : a.c1.c2.c[0].v[i];
     }
     fp4_sqr<S + 20>(e, o, x, y);
-    volatile int32_t* base = bn_trio_lds + BN_TRIO_X6_OFF + (threadIdx.x >> 3) * BN_TRIO_X6_STRIDE;
-    volatile int32_t* mine = base + (threadIdx.x & 7u) * (3 * BN_LIMBS);
+    const unsigned base = BN_TRIO_X6_OFF + (threadIdx.x >> 3) * BN_TRIO_X6_STRIDE, mine = base + (threadIdx.x & 7u) * (3 * BN_LIMBS);
+    BN_TRIO_FENCE();
 #pragma unroll
-    for (int i = 0; i < BN_LIMBS; ++i) { mine[i] = e.c[0].v[i]; mine[BN_LIMBS + i] = o.c[0].v[i]; }
+    for (int i = 0; i < BN_LIMBS; ++i) { bn_trio_lds[mine + i] = e.c[0].v[i]; bn_trio_lds[mine + BN_LIMBS + i] = o.c[0].v[i]; }
+    BN_TRIO_FENCE();
     const unsigned role = threadIdx.x & 1u;
     Fp2* dst[6] = {&t0, &t1, &t2, &t3, &t4, &t5};
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      volatile int32_t* from = base + (2 * k + role) * (3 * BN_LIMBS);
+      const unsigned from = base + (2 * k + role) * (3 * BN_LIMBS);
 #pragma unroll
-      for (int i = 0; i < BN_LIMBS; ++i) { dst[2 * k]->c[0].v[i] = from[i]; dst[2 * k + 1]->c[0].v[i] = from[BN_LIMBS + i]; }
+      for (int i = 0; i < BN_LIMBS; ++i) { dst[2 * k]->c[0].v[i] = bn_trio_lds[from + i]; dst[2 * k + 1]->c[0].v[i] = bn_trio_lds[from + BN_LIMBS + i]; }
     }
+    BN_TRIO_FENCE();
   }
 #else
   fp4_sqr<S>(t0, t1, a.c0.c0, a.c1.c1);

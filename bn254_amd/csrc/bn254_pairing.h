@@ -160,6 +160,116 @@ BN_DEVM void miller_loop(Fp12& f, const G1Affine& pa, const G2Affine& qa, const 
   else if constexpr (HAS_B) { fixed_line(l, idx++); mul_by_line(f, l, pb.x, pb.y, skip_b); }
 }
 
+#if defined(BN_TRIO_FORMULAS)
+// ---- ECDSA::verify's Miller loop in ROUNDS (octet layout, bn254_trio.hip) ------------------------------------------
+// f = miller(pa, qa) * miller(pb, -G2), the same values as miller_loop<true, true>: the same formulas for the twist point,
+// the lines and their product, the same carry sites (200 .. 227), but scheduled as rounds of four independent Fq2 products
+// (trio4: one per lane pair of the octet) so that a loop step costs 5 product-times + two Karatsuba Fq12 operations
+// (6 each) where the serial pair layout spends 48.  The scalings by the coordinates of pa / pb ride along as Fq2 products
+// with (k + 0 i).
+struct TrioLines { Fp2 l0, l1, l2, m0, m1, w3p, w4p; };
+// the line product (l0 + l1 w + l2 w^3)(m0 + m1 w + w^3) and f <- f * it; l2 m0 and l2 m1 have been computed by the caller's rounds
+BN_DEV void trio_finish_lines(Fp12& f, const TrioLines& L, bool skip_b, bool any_skip) {
+  Fp2 v0, v1, x01p, unused;
+  trio4(v0, v1, x01p, unused, L.l0, L.m0, L.l1, L.m1, fp2_add(L.l0, L.l1), fp2_add(L.m0, L.m1), L.l0, L.m0);
+  Fp2 x01 = fp2_sub(fp2_sub(x01p, v0), v1);
+  Fp2 w0 = fp2_add(v0, fp2_mul_xi(L.l2));
+  Fp2 w3 = fp2_add(L.l0, L.w3p);
+  Fp2 w4 = fp2_add(L.l1, L.w4p);
+  Fp6 b0;
+  b0.c0 = NS(224, w0); b0.c1 = v1; b0.c2 = NS(225, w4);
+  Fp2 b10 = NS(226, x01), b11 = NS(227, w3);
+  if (any_skip) {
+    b0.c0 = fp2_select(skip_b, L.l0, b0.c0);
+    b0.c1 = fp2_select(skip_b, fp2_zero(), b0.c1);
+    b0.c2 = fp2_select(skip_b, fp2_zero(), b0.c2);
+    b10 = fp2_select(skip_b, L.l1, b10);
+    b11 = fp2_select(skip_b, L.l2, b11);
+  }
+  fp12_mul_line2(f, f, b0, b10, b11);
+}
+// T <- 2T with its line, the table line idx, their product into f (dbl_step + mul_by_two_lines of the serial form)
+BN_DEV void trio_dbl_round(Fp12& f, G2Proj& t, int idx, const Fp2& PAX, const Fp2& PAY, const Fp2& PBX, const Fp2& PBY, bool skip_a,
+                           bool skip_b, bool any_skip) {
+  TrioLines L;
+  Fp2 xy, b, c, e, hh, x2, e2, ox, oz, oy2;
+  const Fp2 C0 = fp2_load_const(C_NEG_G2_LINES[idx][0]), C1 = fp2_load_const(C_NEG_G2_LINES[idx][1]);
+  trio4(xy, b, c, L.m0, t.x, t.y, t.y, t.y, t.z, t.z, C0, PBY);
+  const Fp2 yz = NS(200, fp2_add(t.y, t.z));
+  trio4(e, hh, x2, L.m1, c, fp2_load_const(C_TWIST_3B), yz, yz, t.x, t.x, C1, PBX);
+  const Fp2 f3 = fp2_add(fp2_dbl(e), e);
+  const Fp2 h = fp2_sub(fp2_sub(hh, b), c);
+  const Fp2 c1 = fp2_neg(fp2_add(fp2_dbl(x2), x2));
+  L.l2 = NS(223, fp2_sub(b, e));
+  if (any_skip) L.l2 = fp2_select(skip_a, fp2_zero(), L.l2);
+  trio4(e2, ox, oz, L.l1, e, e, fp2_dbl(xy), NS(202, fp2_sub(b, f3)), b, h, c1, PAX);
+  const Fp2 bf = NS(204, fp2_add(b, f3));
+  trio4(oy2, L.l0, L.w3p, L.w4p, bf, bf, h, PAY, L.l2, L.m0, L.l2, L.m1);
+  const Fp2 e2x4 = NS(201, fp2_dbl(fp2_dbl(e2)));
+  t.y = NS(205, fp2_sub(oy2, fp2_add(fp2_dbl(e2x4), e2x4)));
+  t.x = NS(203, ox);
+  t.z = NS(206, fp2_dbl(fp2_dbl(oz)));
+  if (any_skip) {
+    L.l0 = fp2_select(skip_a, fp2_one(), L.l0);
+    L.l1 = fp2_select(skip_a, fp2_zero(), L.l1);
+  }
+  trio_finish_lines(f, L, skip_b, any_skip);
+}
+// T <- T + (qx, qy) with its line, the table line idx, their product into f (add_step + mul_by_two_lines)
+BN_DEV void trio_add_round(Fp12& f, G2Proj& t, const Fp2& qx, const Fp2& qy, int idx, const Fp2& PAX, const Fp2& PAY, const Fp2& PBX,
+                           const Fp2& PBY, bool skip_a, bool skip_b, bool any_skip) {
+  TrioLines L;
+  Fp2 t1, t2, c, d, ca, cb, e, ff, g, ox, oy1, oy2, oz, v0;
+  const Fp2 C0 = fp2_load_const(C_NEG_G2_LINES[idx][0]), C1 = fp2_load_const(C_NEG_G2_LINES[idx][1]);
+  trio4(t1, t2, L.m0, L.m1, qy, t.z, qx, t.z, C0, PBY, C1, PBX);
+  const Fp2 theta = NS(210, fp2_sub(t.y, t1)), mu = NS(211, fp2_sub(t.x, t2));
+  trio4(c, d, ca, cb, theta, theta, mu, mu, theta, qx, mu, qy);
+  L.l2 = NS(223, fp2_sub(ca, cb));
+  if (any_skip) L.l2 = fp2_select(skip_a, fp2_zero(), L.l2);
+  trio4(e, ff, g, L.l1, mu, d, t.z, c, t.x, d, fp2_neg(theta), PAX);
+  const Fp2 h = NS(212, fp2_sub(fp2_sub(fp2_add(e, ff), g), g));
+  trio4(ox, oy1, L.l0, L.w3p, mu, h, theta, NS(213, fp2_sub(g, h)), mu, PAY, L.l2, L.m0);
+  trio4(oy2, oz, L.w4p, v0, e, t.y, t.z, e, L.l2, L.m1, mu, mu);      // the fourth product is not used
+  t.x = ox;
+  t.y = NS(214, fp2_sub(oy1, oy2));
+  t.z = oz;
+  if (any_skip) {
+    L.l0 = fp2_select(skip_a, fp2_one(), L.l0);
+    L.l1 = fp2_select(skip_a, fp2_zero(), L.l1);
+  }
+  trio_finish_lines(f, L, skip_b, any_skip);
+}
+template <bool F_LDS = false>
+BN_DEVM void miller_verify_rounds(Fp12& f, const G1Affine& pa, const G2Affine& qa, const G1Affine& pb) {
+  if constexpr (F_LDS) BN_ASSUME_LDS(&f);
+  fp12_set_one(f);
+  G2Proj t;
+  const bool skip_a = pa.inf || qa.inf, skip_b = pb.inf;
+#if defined(__HIPCC__)
+  const bool any_skip = __builtin_amdgcn_ballot_w64(skip_a || skip_b) != 0;   // wave-uniform
+#else
+  const bool any_skip = skip_a || skip_b;
+#endif
+  t.x = qa.x; t.y = qa.y; t.z = fp2_one();
+  const Fp2 qa_yneg = fp2_neg(qa.y);
+  const Fp2 PAX = fp2_from_fp(pa.x), PAY = fp2_from_fp(pa.y), PBX = fp2_from_fp(pb.x), PBY = fp2_from_fp(pb.y);
+  int idx = 0;
+  for (int d = 0; d < 64; ++d) {
+    fp12_sqr(f, f);
+    trio_dbl_round(f, t, idx++, PAX, PAY, PBX, PBY, skip_a, skip_b, any_skip);
+    const int digit = C_ATE_NAF[d];
+    if (digit != 0)    // wave-uniform
+      trio_add_round(f, t, qa.x, fp2_select(digit > 0, qa.y, qa_yneg), idx++, PAX, PAY, PBX, PBY, skip_a, skip_b, any_skip);
+  }
+  // + pi(Q), - pi^2(Q)
+  Fp2 q1x, q1y, q2x, unused;
+  trio4(q1x, q1y, q2x, unused, fp2_conj(qa.x), fp2_load_const(C_TW_FROB_X1), fp2_conj(qa.y), fp2_load_const(C_TW_FROB_Y1), qa.x,
+        fp2_load_const(C_TW_FROB_X2), qa.x, qa.x);
+  trio_add_round(f, t, q1x, q1y, idx++, PAX, PAY, PBX, PBY, skip_a, skip_b, any_skip);
+  trio_add_round(f, t, q2x, qa.y, idx++, PAX, PAY, PBX, PBY, skip_a, skip_b, any_skip);
+}
+#endif
+
 // f <- f * lineA(pa) * lineC(pc) for two variable lines: 6 Fq2 products for the line product (Karatsuba over
 // the three coefficients) + 17 for f * (5-term element), against 2 x 13 one line at a time.
 BN_DEV void mul_by_two_var_lines(Fp12& f, const LineCoef& la, const Fp& pax, const Fp& pay, bool skip_a, const LineCoef& lc, const Fp& pcx,

@@ -2,8 +2,9 @@
 // one verify per OCTET of lanes.  Same tower / pairing source as bn254_pair.hip in the pair layout of the Fq2 values, but
 // the three Fq6 products of every Karatsuba Fq12 operation (fp12_kmul: Fq12 squaring, the two-line multiplication, the
 // multiplications of the final exponentiation) and the three Fq4 squarings of a cyclotomic squaring run in three lane
-// pairs at once and are exchanged through LDS (bn254_field.h: BN_TRIO_DEVICE); everything else is replicated in the
-// pairs.  A wave that has its SIMD to itself issues a multiply-add only every ~4.4 ns, so for a batch that cannot fill
+// pairs at once, and the twist-point steps with the line preparation run as rounds of FOUR independent Fq2 products, one
+// per lane pair (bn254_pairing.h: miller_verify_rounds); results are exchanged through LDS (bn254_field.h:
+// BN_TRIO_DEVICE).  Everything else is replicated in the pairs.  A wave that has its SIMD to itself issues a multiply-add only every ~4.4 ns, so for a batch that cannot fill
 // the chip latency is instructions per LANE; this layout has ~2 times fewer of them than the pair layout.  256-thread
 // workgroups (32 verifies), 91 KB of LDS -> one workgroup per CU, one wave per SIMD.
 #include <hip/hip_runtime.h>
@@ -46,7 +47,7 @@ KERNEL_TRIO void k_miller_verify_trio(size_t n, Ws ws, int mode) {
   pk.y = ws_load_fp2_role(ws, PL_QY0, i);
   pk.inf = ws_byte(ws, BY_Q_INF, i) != 0;
   Fp12& f = ((Fp12TrioSlot*)bn_trio_lds)[threadIdx.x].v;
-  miller_loop<true, true, true>(f, h, pk, sig);
+  miller_verify_rounds<true>(f, h, pk, sig);        // steps and line preparation as rounds of four Fq2 products
   if (trio_pair() == 0) {                            // the four pairs hold the same f
     const Fp2* c[6] = {&f.c0.c0, &f.c0.c1, &f.c0.c2, &f.c1.c0, &f.c1.c1, &f.c1.c2};
 #pragma unroll

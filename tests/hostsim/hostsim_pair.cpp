@@ -49,7 +49,20 @@ int hp_verify_decoded(const uint8_t* h64, const uint8_t* sig64, const uint8_t* p
   G2Affine pk;
   load_g1(h, h64); load_g1(sig, sig64); load_g2(pk, pk128);
   Fp12 f, acc;
+#if defined(BN_TRIO_FORMULAS)
+  miller_verify_rounds(f, h, pk, sig);               // the round-structured loop of the octet layout (bn254_trio.hip)
+  {
+    Fp12 f2;                                         // ... must give the very Miller value of the generic loop
+    miller_loop<true, true>(f2, h, pk, sig);
+    Fp12 d1, d2;
+    final_exponentiation(d1, f, acc); final_exponentiation(d2, f2, acc);
+    const Fp2* a[6] = {&d1.c0.c0, &d1.c0.c1, &d1.c0.c2, &d1.c1.c0, &d1.c1.c1, &d1.c1.c2};
+    const Fp2* b[6] = {&d2.c0.c0, &d2.c0.c1, &d2.c0.c2, &d2.c1.c0, &d2.c1.c1, &d2.c1.c2};
+    for (int k = 0; k < 6; ++k) if (!fp2_eq(*a[k], *b[k])) return 254;
+  }
+#else
   miller_loop<true, true>(f, h, pk, sig);
+#endif
   Fp12 g;
   final_exponentiation_check(g, f, acc);            // what k_final_exp_pair runs for a status
   final_exponentiation(f, f, acc);                   // the exact value must agree on "is one"

@@ -363,6 +363,47 @@ def test_pair_lanes_and_single_lane_agree(eng, derived):
             eng.set_option(OPT_PAIR_LANES, 1)
 
 
+def test_octet_and_pair_layouts_agree_with_oracle(eng, c, derived, kats):
+    """small batches run in the OCTET layout (eight lanes per verify, bn254_trio.hip; default up to 8192 items), larger
+    ones on lane pairs: both against the golden cases, the oracle on ragged sizes with faults of every class, and
+    check_public_keys; the threshold itself (8192 octet, 8193 pairs) gives the same bytes on either side"""
+    from bn254_amd.engine import OPT_TRIO_MAX_BATCH
+    from tests.datagen import make_verify_batch
+    cs = derived["verify_cases"]
+    args = ([H(v["message_hex"]) for v in cs], b"".join(H(v["sig"]) for v in cs), b"".join(H(v["pk"]) for v in cs))
+    want = [v["status"] for v in cs]
+    batches = []
+    for n in (1, 2, 7, 9, 65, 1000 + 27):
+        msgs, sigs, pks, expected = make_verify_batch(eng, n, corrupt_every=3 if n > 2 else 0)
+        sigs = bytearray(sigs)
+        if n >= 9:
+            sigs[64 * 4:64 * 5] = bytes(64)                   # identity signature
+            sigs[64 * 8 + 40] ^= 2                            # off-curve y
+        if n >= 65:
+            sigs[64 * 20:64 * 20 + 32] = b"\xff" * 32          # x >= q
+            pks = bytearray(pks); pks[128 * 11:128 * 12] = bytes(128); pks[128 * 13 + 3] ^= 1; pks = bytes(pks)   # identity / off-twist keys
+        sigs = bytes(sigs)
+        oracle, _ = c.batch_verify(msgs, sigs, pks, flags=1, nthreads=8)
+        batches.append((msgs, sigs, pks, oracle))
+    assert {0, 9} <= set(batches[-1][3]) and len(set(batches[-1][3])) >= 4
+    cpk = kats["check_public_keys"]
+    g2s = b"".join(c.public_key_g2(H(v["sk_g2"])) for v in cpk) * 3
+    g1s = b"".join(c.public_key_g1(H(v["sk_g1"])) for v in cpk) * 3
+    cpk_want = bytes(v["status"] for v in cpk) * 3
+    edge = make_verify_batch(eng, 8193, corrupt_every=11)
+    try:
+        for lim in (1 << 20, 0, 8192):
+            eng.set_option(OPT_TRIO_MAX_BATCH, lim)
+            assert list(eng.batch_verify(*args, flags=1)) == want, lim
+            for msgs, sigs, pks, oracle in batches:
+                assert eng.batch_verify(msgs, sigs, pks, flags=1) == oracle, (lim, len(msgs))
+            assert eng.batch_check_public_keys(g2s, g1s, len(cpk) * 3) == cpk_want, lim
+            assert eng.batch_verify(edge[0], edge[1], edge[2]) == edge[3], lim
+            assert eng.batch_verify(edge[0][:8192], edge[1][:8192 * 64], edge[2][:8192 * 128]) == edge[3][:8192], lim
+    finally:
+        eng.set_option(OPT_TRIO_MAX_BATCH, 8192)
+
+
 def test_malformed_inputs_fuzz_vs_oracle(eng, c, derived):
     """3000 verifies whose signature / public key bytes are valid, mutated (bit flips, coordinate >= q,
     swapped coordinates, zeros) or random: every status byte must equal the oracle's, with and without the

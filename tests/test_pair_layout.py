@@ -121,3 +121,47 @@ print("ok")
 def test_pair_layout_bounds_hold(pair_lib):
     p = subprocess.run([sys.executable, "-c", DRIVER, ROOT], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and p.stdout.strip() == "ok", (p.stdout[-500:], p.stderr[-2000:])
+
+
+# ---- the octet layout for small batches (bn254_trio.hip): its FORMULAS on the host -------------------------------------
+# -DBN_TRIO_FORMULAS compiles the same pair emulation with the Fq12 product / squaring / two-line multiplication as the
+# generic Karatsuba product the octet kernels spread over three lane pairs, and hp_verify_decoded additionally runs the
+# round-structured Miller loop of the octet kernel (miller_verify_rounds: doubling / addition steps as rounds of four
+# Fq2 products) and returns 254 when its accumulator differs from the generic loop's.
+@pytest.fixture(scope="module")
+def trio_lib():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "hostsim"), "libhostsim_trio.so", "libhostsim_trio_bounds.so"])
+    return ctypes.CDLL(os.path.join(ROOT, "tests", "hostsim", "libhostsim_trio.so"))
+
+
+def test_octet_formulas_verify_and_gt_match_oracle(trio_lib, derived):
+    n = 0
+    for v in derived["verify_cases"]:
+        if v["status"] not in (0, 9):
+            continue
+        st, h, _ = c.hash_to_g1(H(v["message_hex"]))
+        assert trio_lib.hp_verify_decoded(h, H(v["sig"]), H(v["pk"])) == v["status"], v["name"]
+        n += 1
+    assert n >= 10
+    for v in derived["pairing_gt"]:
+        out = ctypes.create_string_buffer(384)
+        trio_lib.hp_pairing(H(v["g1"]), H(v["g2"]), out)
+        assert out.raw.hex() == v["gt"]
+    # random signed tuples, valid and with a foreign key: both Miller loops agree and give the oracle's status
+    import hashlib
+    g1, g2 = c.g1_generator(), c.g2_generator()
+    for i in range(6):
+        sk = hashlib.sha256(b"octet-sk%d" % i).digest()
+        msg = b"octet-msg-%d" % i
+        _, h, _ = c.hash_to_g1(msg)
+        sig, pk = c.g1_mul(h, sk), c.g2_mul(g2, sk)
+        assert trio_lib.hp_verify_decoded(h, sig, pk) == 0
+        assert trio_lib.hp_verify_decoded(h, sig, c.g2_mul(g2, hashlib.sha256(sk).digest())) == 9
+        assert trio_lib.hp_verify_decoded(h, bytes(64), pk) == 9          # identity signature
+        assert trio_lib.hp_verify_decoded(h, c.g1_mul(g1, sk), bytes(128)) == 9   # identity key
+
+
+def test_octet_formulas_bounds_hold(trio_lib):
+    p = subprocess.run([sys.executable, "-c", DRIVER.replace("libhostsim_pair_bounds.so", "libhostsim_trio_bounds.so"), ROOT],
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and p.stdout.strip() == "ok", (p.stdout[-500:], p.stderr[-2000:])

@@ -14,7 +14,8 @@ from tests.datagen import make_verify_batch  # noqa: E402
 
 eng = bn254_amd.Engine(0)
 out = []
-for n in (1, 7, 64, 200, 1024, 4096, 8192):
+SIZES = [int(x) for x in os.environ.get("TRIO_SIZES", "1,7,64,200,1024,4096,8192").split(",")]
+for n in SIZES:
     msgs, sigs, pks, expected = make_verify_batch(eng, n, corrupt_every=5 if n > 4 else 0)
     sigs = bytearray(sigs)
     if n >= 64:
