@@ -946,15 +946,16 @@ BN_DEV void fp12_mul_body(Fp12& r, const Fp12& a, const Fp12& b) {  // sites 20 
 BN_DEVN void fp12_mul(Fp12& r, const Fp12& a, const Fp12& b) { fp12_mul_body(r, a, b); }
 BN_DEVF void fp12_mul_hot(Fp12& r, const Fp12& a, const Fp12& b) { fp12_mul_body(r, a, b); }     // the loop of fp12_pow_u
 #endif
-// ---- the three-pair ("octet") layout for small batches: bn254_trio.hip ----------------------------------------------
-// One verify is carried by the eight lanes of an octet: lane pairs 0, 1, 2 each run ONE of the three Fq6 products of a
-// Karatsuba Fq12 multiplication (P0 = a0 b0, P1 = a1 b1, P2 = (a0 + a1)(b0 + b1)) and exchange the results through LDS;
-// everything else is replicated in the pairs (the fourth pair shadows pair 0 in these operations and is a fourth worker
-// in the Fq2-level rounds of the twist-point steps).  A wave that has its SIMD to itself issues a multiply-add only every
-// ~4.4 ns, so latency for a small batch is instructions per LANE: this layout cuts them ~2.5-fold.
-// BN_TRIO_FORMULAS selects the FORMULAS of that layout (Fq12 squaring and the two-line multiplication as the generic
-// Karatsuba product fp12_kmul) in any build — the host emulations use it to run the same arithmetic, bound tracker
-// included, with the three products computed one after the other; BN_TRIO_DEVICE adds the lane-group machinery.
+// ---- the "octet" layout for small batches: bn254_trio.hip ------------------------------------------------------------
+// One verify is carried by the eight lanes (four lane pairs) of an octet.  A wave that has its SIMD to itself issues a
+// multiply-add only every ~4.4 ns, so the latency of a small batch is instructions per LANE; the octet spreads them:
+//   * an Fq12 product as its four Fq6 products, one per pair, recombined in two exchanges (fp12_kmul4);
+//   * a cyclotomic squaring as three Fq4 squarings, each pair also forming the two outputs that come from its square;
+//   * the Miller loop of a verify as rounds of four independent Fq2 products, one per pair (trio4; bn254_pairing.h:
+//     miller_verify_rounds), everything linear replicated in the pairs.
+// Values are exchanged through LDS.  BN_TRIO_FORMULAS selects the FORMULAS of that layout in any build — the host
+// emulations use it to run the same arithmetic, bound tracker included, with the products of a group computed one after
+// the other; BN_TRIO_DEVICE adds the lane-group machinery.
 #if defined(BN_TRIO_DEVICE)
 }  // namespace bn254
 extern __shared__ int32_t bn_trio_lds[];          // dynamic LDS of the octet kernels: [accumulator slots | Fq6 exchange | Fq2 exchange]
@@ -968,47 +969,12 @@ namespace bn254 {
 #define BN_TRIO_LDS_WORDS (BN_TRIO_X2_OFF + (BN_TRIO_WG / 8) * BN_TRIO_X2_STRIDE)
 BN_DEV int trio_pair() { return (int)((threadIdx.x >> 1) & 3u); }                 // lane pair within the octet, 0..3
 BN_DEV int trio_g3() { const int g = trio_pair(); return g == 3 ? 0 : g; }        // Fq6-level group: pair 3 shadows pair 0
-// x = (g == 0 ? lo : g == 1 ? hi : lo + hi), word by word (2 selects + 1 add)
-BN_DEV Fp2 trio_pick2(const Fp2& lo, const Fp2& hi, int g) {
-  Fp2 r;
-#pragma unroll
-  for (int i = 0; i < BN_LIMBS; ++i) {
-    const int32_t a = lo.c[0].v[i], b = hi.c[0].v[i];
-    r.c[0].v[i] = (g == 1 ? b : a) + (g == 2 ? b : 0);
-  }
-  return r;
-}
-BN_DEV void trio_pick6(Fp6& r, const Fp6& lo, const Fp6& hi, int g) {
-  r.c0 = trio_pick2(lo.c0, hi.c0, g); r.c1 = trio_pick2(lo.c1, hi.c1, g); r.c2 = trio_pick2(lo.c2, hi.c2, g);
-}
-// every pair publishes its Fq6 result, then reads those of pairs 0, 1, 2 (same role).  All eight lanes of an octet are
-// in one wave and a wave's LDS instructions execute in order, so no barrier is involved; the wavefront-scope fences keep
-// the compiler from moving the reads above the writes (or the next exchange's writes above these reads).  The array is
-// indexed directly so that the accesses stay LDS instructions (ds_write / ds_read), batched under one wait.
+// Exchanges: all eight lanes of an octet are in one wave and a wave's LDS instructions execute in order, so no barrier is
+// involved; the wavefront-scope fences keep the compiler from moving the reads above the writes (or the next
+// exchange's writes above these reads).  The array is indexed directly so that the accesses stay LDS instructions
+// (ds_write / ds_read), batched under one wait.
 #define BN_TRIO_FENCE() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
-BN_DEV void trio_share6(const Fp6& p, Fp6& p0, Fp6& p1, Fp6& p2) {
-  const unsigned base = BN_TRIO_X6_OFF + (threadIdx.x >> 3) * BN_TRIO_X6_STRIDE, mine = base + (threadIdx.x & 7u) * (3 * BN_LIMBS);
-  const Fp2* src[3] = {&p.c0, &p.c1, &p.c2};
-  BN_TRIO_FENCE();
-#pragma unroll
-  for (int c = 0; c < 3; ++c)
-#pragma unroll
-    for (int i = 0; i < BN_LIMBS; ++i) bn_trio_lds[mine + c * BN_LIMBS + i] = src[c]->c[0].v[i];
-  BN_TRIO_FENCE();
-  const unsigned role = threadIdx.x & 1u;
-  Fp6* dst[3] = {&p0, &p1, &p2};
-#pragma unroll
-  for (int g = 0; g < 3; ++g) {
-    const unsigned from = base + (2 * g + role) * (3 * BN_LIMBS);
-    Fp2* d[3] = {&dst[g]->c0, &dst[g]->c1, &dst[g]->c2};
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-#pragma unroll
-      for (int i = 0; i < BN_LIMBS; ++i) d[c]->c[0].v[i] = bn_trio_lds[from + c * BN_LIMBS + i];
-  }
-  BN_TRIO_FENCE();
-}
-// the same for one Fq2 value per pair, four pairs
+// every pair publishes one Fq2 value and reads those of the four pairs (same role)
 BN_DEV void trio_share2x4(const Fp2& p, Fp2& r0, Fp2& r1, Fp2& r2, Fp2& r3) {
   const unsigned base = BN_TRIO_X2_OFF + (threadIdx.x >> 3) * BN_TRIO_X2_STRIDE, mine = base + (threadIdx.x & 7u) * BN_LIMBS;
   BN_TRIO_FENCE();
@@ -1045,47 +1011,112 @@ BN_DEV void trio4(Fp2& r0, Fp2& r1, Fp2& r2, Fp2& r3, const Fp2& x0, const Fp2& 
   r0 = a; r1 = b; r2 = c; r3 = d;
 #endif
 }
+// The six Fq2 products of a Karatsuba Fq6 product as a list, so that a caller can place them in rounds: operand K of
+// x (the same K of y is its partner), and the result from the six products (formulas and sites of fp6_mul<S>).
+template <int K> BN_DEV Fp2 fp6_kop(const Fp6& x) {
+  if constexpr (K == 0) return x.c0;
+  else if constexpr (K == 1) return x.c1;
+  else if constexpr (K == 2) return x.c2;
+  else if constexpr (K == 3) return fp2_add(x.c1, x.c2);
+  else if constexpr (K == 4) return fp2_add(x.c0, x.c1);
+  else return fp2_add(x.c0, x.c2);
+}
+template <int S> BN_DEV void fp6_kfin(Fp6& r, const Fp2 (&p)[6]) {   // p: x0y0, x1y1, x2y2, (x1+x2)(y1+y2), (x0+x1)(y0+y1), (x0+x2)(y0+y2)
+  Fp2 c0 = fp2_add(fp2_mul_xi(NS(S, fp2_sub(fp2_sub(p[3], p[1]), p[2]))), p[0]);
+  Fp2 c1 = fp2_add(fp2_sub(fp2_sub(p[4], p[0]), p[1]), fp2_mul_xi(p[2]));
+  Fp2 c2 = fp2_add(fp2_sub(fp2_sub(p[5], p[0]), p[2]), p[1]);
+  r.c0 = NS(S + 1, c0); r.c1 = NS(S + 2, c1); r.c2 = NS(S + 3, c2);
+}
 // an Fq scalar as an Fq2 value (k + 0 i), so that a scaling by it can ride in a round as an ordinary Fq2 product
 BN_DEV Fp2 fp2_from_fp(const Fp& k) { return fp2_make(k, fp_zero()); }
 
-// r = a * b in Fq12, Karatsuba over Fq6.  Sites S .. S+15.  On the device of the octet layout the three Fq6 products run
-// in three lane pairs; elsewhere one after the other (same values, same sites).
-template <int S> BN_DEV void fp12_kmul(Fp12& r, const Fp12& a, const Fp12& b) {
-  Fp6 p0, p1, p2;
+// r = a * b in Fq12 as the FOUR Fq6 products a0 b0, a1 b1, a0 b1, a1 b0 (no operand sums):
+//   r0 = a0 b0 + v a1 b1,  r1 = a0 b1 + a1 b0.                                Sites S .. S+9.
+// On the device of the octet layout lane pair g computes product g; pairs 0, 1 then form r0 and pairs 2, 3 form r1 from
+// each other's products (one instruction stream: out = P_even + (r0 ? v P_odd : P_odd), carried and weakly reduced), and a
+// second exchange hands both halves to every pair — each pair does a quarter of the products and half of the
+// recombination.  Elsewhere: the four products one after the other, same values and sites.
+template <int S> BN_DEV void fp12_kmul4(Fp12& r, const Fp12& a, const Fp12& b) {
 #if defined(BN_TRIO_DEVICE)
+  const int g = trio_pair();
+  Fp6 x, y, p, pe, po;
   {
-    const int g = trio_g3();
-    Fp6 x, y, p;
-    trio_pick6(x, a.c0, a.c1, g);
-    trio_pick6(y, b.c0, b.c1, g);
-    fp6_site_n<S>(x, x); fp6_site_n<S + 3>(y, y);   // what pair 2 needs for its sums; a carry of a tight value changes nothing
-    fp6_mul<S + 6>(p, x, y);
-    trio_share6(p, p0, p1, p2);
+    const Fp2* ax[2][3] = {{&a.c0.c0, &a.c0.c1, &a.c0.c2}, {&a.c1.c0, &a.c1.c1, &a.c1.c2}};
+    const Fp2* bx[2][3] = {{&b.c0.c0, &b.c0.c1, &b.c0.c2}, {&b.c1.c0, &b.c1.c1, &b.c1.c2}};
+    Fp2* xs[3] = {&x.c0, &x.c1, &x.c2};
+    Fp2* ys[3] = {&y.c0, &y.c1, &y.c2};
+    const bool xa1 = (g & 1) != 0, yb1 = g == 1 || g == 2;               // pair 0: a0 b0, 1: a1 b1, 2: a0 b1, 3: a1 b0
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int i = 0; i < BN_LIMBS; ++i) {
+        xs[c]->c[0].v[i] = xa1 ? ax[1][c]->c[0].v[i] : ax[0][c]->c[0].v[i];
+        ys[c]->c[0].v[i] = yb1 ? bx[1][c]->c[0].v[i] : bx[0][c]->c[0].v[i];
+      }
   }
+  fp6_mul<S>(p, x, y);
+  const unsigned base = BN_TRIO_X6_OFF + (threadIdx.x >> 3) * BN_TRIO_X6_STRIDE, mine = base + (threadIdx.x & 7u) * (3 * BN_LIMBS);
+  const unsigned role = threadIdx.x & 1u;
+  auto publish = [&](const Fp6& v) {
+    const Fp2* src[3] = {&v.c0, &v.c1, &v.c2};
+    BN_TRIO_FENCE();
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int i = 0; i < BN_LIMBS; ++i) bn_trio_lds[mine + c * BN_LIMBS + i] = src[c]->c[0].v[i];
+    BN_TRIO_FENCE();
+  };
+  auto fetch = [&](Fp6& v, unsigned pair) {
+    const unsigned from = base + (2 * pair + role) * (3 * BN_LIMBS);
+    Fp2* d[3] = {&v.c0, &v.c1, &v.c2};
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int i = 0; i < BN_LIMBS; ++i) d[c]->c[0].v[i] = bn_trio_lds[from + c * BN_LIMBS + i];
+  };
+  publish(p);
+  fetch(pe, (unsigned)(g & 2));
+  fetch(po, (unsigned)(g | 1));
+  {
+    // v * po = (xi po2, po0, po1) for the r0 pairs, po itself for the r1 pairs
+    const Fp2 t = fp2_mul_xi(po.c2);
+    const bool lo = g < 2;
+    Fp6 q;
+#pragma unroll
+    for (int i = 0; i < BN_LIMBS; ++i) {
+      q.c0.c[0].v[i] = lo ? t.c[0].v[i] : po.c0.c[0].v[i];
+      q.c1.c[0].v[i] = lo ? po.c0.c[0].v[i] : po.c1.c[0].v[i];
+      q.c2.c[0].v[i] = lo ? po.c1.c[0].v[i] : po.c2.c[0].v[i];
+    }
+    fp6_add(q, pe, q);
+    constexpr int m0 = BN_SITE_MODE(S + 4, 2) > BN_SITE_MODE(S + 7, 2) ? BN_SITE_MODE(S + 4, 2) : BN_SITE_MODE(S + 7, 2);
+    constexpr int m1 = BN_SITE_MODE(S + 5, 2) > BN_SITE_MODE(S + 8, 2) ? BN_SITE_MODE(S + 5, 2) : BN_SITE_MODE(S + 8, 2);
+    constexpr int m2 = BN_SITE_MODE(S + 6, 2) > BN_SITE_MODE(S + 9, 2) ? BN_SITE_MODE(S + 6, 2) : BN_SITE_MODE(S + 9, 2);
+    p.c0 = fp2_site(q.c0, m0); p.c1 = fp2_site(q.c1, m1); p.c2 = fp2_site(q.c2, m2);
+  }
+  publish(p);
+  fetch(pe, 0u);
+  fetch(po, 2u);
+  BN_TRIO_FENCE();
+  r.c0 = pe; r.c1 = po;
 #else
-  {
-    Fp6 s, t;
-    fp6_mul<S + 6>(p0, a.c0, b.c0);
-    fp6_mul<S + 6>(p1, a.c1, b.c1);
-    fp6_add(s, a.c0, a.c1); fp6_site_n<S>(s, s);
-    fp6_add(t, b.c0, b.c1); fp6_site_n<S + 3>(t, t);
-    fp6_mul<S + 6>(p2, s, t);
-  }
-#endif
-  Fp6 u, w;
-  fp6_sub(u, p2, p0);
-  fp6_sub(u, u, p1);
+  Fp6 p0, p1, p2, p3, w;
+  fp6_mul<S>(p0, a.c0, b.c0);
+  fp6_mul<S>(p1, a.c1, b.c1);
+  fp6_mul<S>(p2, a.c0, b.c1);
+  fp6_mul<S>(p3, a.c1, b.c0);
   fp6_mul_v(w, p1);
   fp6_add(w, p0, w);
-  fp6_site_r<S + 10>(r.c0, w);
-  fp6_site_r<S + 13>(r.c1, u);
+  fp6_add(p2, p2, p3);
+  fp6_site_r<S + 4>(r.c0, w);
+  fp6_site_r<S + 7>(r.c1, p2);
+#endif
 }
 #if defined(BN_TRIO_FORMULAS)
-BN_DEV void fp12_mul_body(Fp12& r, const Fp12& a, const Fp12& b) { fp12_kmul<260>(r, a, b); }    // sites 260 .. 275
+BN_DEV void fp12_mul_body(Fp12& r, const Fp12& a, const Fp12& b) { fp12_kmul4<260>(r, a, b); }    // sites 260 .. 269
 BN_DEVN void fp12_mul(Fp12& r, const Fp12& a, const Fp12& b) { fp12_mul_body(r, a, b); }
 BN_DEVF void fp12_mul_hot(Fp12& r, const Fp12& a, const Fp12& b) { fp12_mul_body(r, a, b); }
-BN_DEVH void fp12_sqr(Fp12& r, const Fp12& a) { fp12_kmul<280>(r, a, a); }                       // sites 280 .. 295
-#else
+#endif
 BN_DEVH void fp12_sqr(Fp12& r, const Fp12& a) {                       // sites 50 .. 79
   Fp6 ab, s, t, u;
   fp6_mul<50>(ab, a.c0, a.c1);
@@ -1100,7 +1131,6 @@ BN_DEVH void fp12_sqr(Fp12& r, const Fp12& a) {                       // sites 5
   fp6_add(s, ab, ab);
   fp6_site_r<67>(r.c1, s);
 }
-#endif
 // the negated half keeps balanced digits balanced: no carry needed
 BN_DEV void fp12_conj(Fp12& r, const Fp12& a) { r.c0 = a.c0; fp6_neg(r.c1, a.c1); }
 BN_DEVN void fp12_inv(Fp12& r, const Fp12& a) {                       // sites 80 .. 109
@@ -1129,13 +1159,6 @@ BN_DEVN void fp12_mul_line(Fp12& r, const Fp12& f, const Fp2& l0, const Fp2& l1,
   fp6_site_r<123>(r.c1, u);
 }
 // f * (b0 + b1 w): b0 a full Fq6, b1 = b10 + b11 v — the shape of a product of two lines; the b's tight
-#if defined(BN_TRIO_FORMULAS)
-BN_DEVH void fp12_mul_line2(Fp12& r, const Fp12& f, const Fp6& b0, const Fp2& b10, const Fp2& b11) {   // sites 300 .. 315
-  Fp12 b;
-  b.c0 = b0; b.c1.c0 = b10; b.c1.c1 = b11; b.c1.c2 = fp2_zero();
-  fp12_kmul<300>(r, f, b);
-}
-#else
 BN_DEVH void fp12_mul_line2(Fp12& r, const Fp12& f, const Fp6& b0, const Fp2& b10, const Fp2& b11) {   // sites 140 .. 169
   Fp6 t0, t1, s, u, bs;
   fp6_mul<140>(t0, f.c0, b0);
@@ -1150,7 +1173,6 @@ BN_DEVH void fp12_mul_line2(Fp12& r, const Fp12& f, const Fp6& b0, const Fp2& b1
   fp6_site_r<156>(r.c0, s);
   fp6_site_r<159>(r.c1, u);
 }
-#endif
 // coefficient k of w^k in the polynomial basis: c[2i] = c0.c_i, c[2i+1] = c1.c_i
 BN_DEV Fp2& fp12_coef(Fp12& a, int k) {
   Fp6& h = (k & 1) ? a.c1 : a.c0;
@@ -1177,39 +1199,49 @@ template <int S> BN_DEV void fp4_sqr(Fp2& r0, Fp2& r1, const Fp2& a, const Fp2& 
 // The outputs 3t -+ 2a are linear in a and xi-fold in the squares, so every output is weakly reduced
 // (fp2_lin2_reduce): across a run of squarings the values stay below ~0.6 q.
 template <int S> BN_DEV void fp12_cyclotomic_sqr_body(Fp12& r, const Fp12& a) {       // sites S .. S+15 (170.., 240..)
-  Fp2 t0, t1, t2, t3, t4, t5;
 #if defined(BN_TRIO_DEVICE)
-  {
-    // octet layout: the three Fq4 squarings in three lane pairs (sites S+20 .. S+22: the safe defaults, this instance
-    // stands for all three of the serial form), results exchanged through LDS; the six outputs are replicated
-    const int g = trio_g3();
-    Fp2 x, y, e, o;
+  // octet layout: lane pair g = 0, 1, 2 squares one Fq4 element (sites S+20 .. S+22: the safe defaults, this instance
+  // stands for all three of the serial form) AND forms the two outputs that come from it — 3 t -+ 2 a with the weak
+  // reduction — before the exchange, so that this linear work is done once per output instead of in every pair:
+  //   pair 0: (t0, t1) = (a00 + a11 s)^2  ->  r00 = 3 t0 - 2 a00,  r11 = 3 t1 + 2 a11
+  //   pair 1: (t2, t3) = (a10 + a02 s)^2  ->  r01 = 3 t2 - 2 a01,  r12 = 3 t3 + 2 a12
+  //   pair 2: (t4, t5) = (a01 + a12 s)^2  ->  r02 = 3 t4 - 2 a02,  r10 = 3 xi t5 + 2 a10
+  const int g = trio_g3();
+  Fp2 x, y, ae, ao, e, o;
 #pragma unroll
-    for (int i = 0; i < BN_LIMBS; ++i) {
-      x.c[0].v[i] = g == 0 ? a.c0.c0.c[0].v[i] : g == 1 ? a.c1.c0.c[0].v[i] : a.c0.c1.c[0].v[i];
-      y.c[0].v[i] = g == 0 ? a.c1.c1.c[0].v[i] : g == 1 ? a.c0.c2.c[0].v[i] : a.c1.c2.c[0].v[i];
-    }
-    fp4_sqr<S + 20>(e, o, x, y);
-    const unsigned base = BN_TRIO_X6_OFF + (threadIdx.x >> 3) * BN_TRIO_X6_STRIDE, mine = base + (threadIdx.x & 7u) * (3 * BN_LIMBS);
-    BN_TRIO_FENCE();
-#pragma unroll
-    for (int i = 0; i < BN_LIMBS; ++i) { bn_trio_lds[mine + i] = e.c[0].v[i]; bn_trio_lds[mine + BN_LIMBS + i] = o.c[0].v[i]; }
-    BN_TRIO_FENCE();
-    const unsigned role = threadIdx.x & 1u;
-    Fp2* dst[6] = {&t0, &t1, &t2, &t3, &t4, &t5};
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const unsigned from = base + (2 * k + role) * (3 * BN_LIMBS);
-#pragma unroll
-      for (int i = 0; i < BN_LIMBS; ++i) { dst[2 * k]->c[0].v[i] = bn_trio_lds[from + i]; dst[2 * k + 1]->c[0].v[i] = bn_trio_lds[from + BN_LIMBS + i]; }
-    }
-    BN_TRIO_FENCE();
+  for (int i = 0; i < BN_LIMBS; ++i) {
+    x.c[0].v[i] = g == 0 ? a.c0.c0.c[0].v[i] : g == 1 ? a.c1.c0.c[0].v[i] : a.c0.c1.c[0].v[i];
+    y.c[0].v[i] = g == 0 ? a.c1.c1.c[0].v[i] : g == 1 ? a.c0.c2.c[0].v[i] : a.c1.c2.c[0].v[i];
+    ae.c[0].v[i] = g == 0 ? a.c0.c0.c[0].v[i] : g == 1 ? a.c0.c1.c[0].v[i] : a.c0.c2.c[0].v[i];
+    ao.c[0].v[i] = g == 0 ? a.c1.c1.c[0].v[i] : g == 1 ? a.c1.c2.c[0].v[i] : a.c1.c0.c[0].v[i];
   }
+  fp4_sqr<S + 20>(e, o, x, y);
+  const Fp2 oxi = NS(S + 9, fp2_mul_xi(o));
+#pragma unroll
+  for (int i = 0; i < BN_LIMBS; ++i) o.c[0].v[i] = g == 2 ? oxi.c[0].v[i] : o.c[0].v[i];
+  e = fp2_lin2_reduce(e, 3, ae, -2);
+  o = fp2_lin2_reduce(o, 3, ao, 2);
+  const unsigned base = BN_TRIO_X6_OFF + (threadIdx.x >> 3) * BN_TRIO_X6_STRIDE, mine = base + (threadIdx.x & 7u) * (3 * BN_LIMBS);
+  BN_TRIO_FENCE();
+#pragma unroll
+  for (int i = 0; i < BN_LIMBS; ++i) { bn_trio_lds[mine + i] = e.c[0].v[i]; bn_trio_lds[mine + BN_LIMBS + i] = o.c[0].v[i]; }
+  BN_TRIO_FENCE();
+  const unsigned role = threadIdx.x & 1u;
+  Fp12 out;
+  Fp2* dst[6] = {&out.c0.c0, &out.c1.c1, &out.c0.c1, &out.c1.c2, &out.c0.c2, &out.c1.c0};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const unsigned from = base + (2 * k + role) * (3 * BN_LIMBS);
+#pragma unroll
+    for (int i = 0; i < BN_LIMBS; ++i) { dst[2 * k]->c[0].v[i] = bn_trio_lds[from + i]; dst[2 * k + 1]->c[0].v[i] = bn_trio_lds[from + BN_LIMBS + i]; }
+  }
+  BN_TRIO_FENCE();
+  r = out;
 #else
+  Fp2 t0, t1, t2, t3, t4, t5;
   fp4_sqr<S>(t0, t1, a.c0.c0, a.c1.c1);
   fp4_sqr<S + 3>(t2, t3, a.c1.c0, a.c0.c2);
   fp4_sqr<S + 6>(t4, t5, a.c0.c1, a.c1.c2);
-#endif
   Fp12 o;
   // outputs 3 t -+ 2 a: one fused pass each (combination, carry and weak reduction), so the t's may stay lazy
   o.c0.c0 = fp2_lin2_reduce(t0, 3, a.c0.c0, -2);
@@ -1220,6 +1252,7 @@ template <int S> BN_DEV void fp12_cyclotomic_sqr_body(Fp12& r, const Fp12& a) { 
   o.c0.c1 = fp2_lin2_reduce(t2, 3, a.c0.c1, -2);
   o.c1.c2 = fp2_lin2_reduce(t3, 3, a.c1.c2, 2);
   r = o;
+#endif
 }
 BN_DEVN void fp12_cyclotomic_sqr(Fp12& r, const Fp12& a) { fp12_cyclotomic_sqr_body<170>(r, a); }
 BN_DEVF void fp12_cyclotomic_sqr_hot(Fp12& r, const Fp12& a) { fp12_cyclotomic_sqr_body<170>(r, a); }      // the loop of fp12_pow_u

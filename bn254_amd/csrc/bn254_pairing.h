@@ -162,82 +162,147 @@ BN_DEVM void miller_loop(Fp12& f, const G1Affine& pa, const G2Affine& qa, const 
 
 #if defined(BN_TRIO_FORMULAS)
 // ---- ECDSA::verify's Miller loop in ROUNDS (octet layout, bn254_trio.hip) ------------------------------------------
-// f = miller(pa, qa) * miller(pb, -G2), the same values as miller_loop<true, true>: the same formulas for the twist point,
-// the lines and their product, the same carry sites (200 .. 227), but scheduled as rounds of four independent Fq2 products
-// (trio4: one per lane pair of the octet) so that a loop step costs 5 product-times + two Karatsuba Fq12 operations
-// (6 each) where the serial pair layout spends 48.  The scalings by the coordinates of pa / pb ride along as Fq2 products
-// with (k + 0 i).
-struct TrioLines { Fp2 l0, l1, l2, m0, m1, w3p, w4p; };
-// the line product (l0 + l1 w + l2 w^3)(m0 + m1 w + w^3) and f <- f * it; l2 m0 and l2 m1 have been computed by the caller's rounds
-BN_DEV void trio_finish_lines(Fp12& f, const TrioLines& L, bool skip_b, bool any_skip) {
-  Fp2 v0, v1, x01p, unused;
-  trio4(v0, v1, x01p, unused, L.l0, L.m0, L.l1, L.m1, fp2_add(L.l0, L.l1), fp2_add(L.m0, L.m1), L.l0, L.m0);
-  Fp2 x01 = fp2_sub(fp2_sub(x01p, v0), v1);
-  Fp2 w0 = fp2_add(v0, fp2_mul_xi(L.l2));
-  Fp2 w3 = fp2_add(L.l0, L.w3p);
-  Fp2 w4 = fp2_add(L.l1, L.w4p);
-  Fp6 b0;
-  b0.c0 = NS(224, w0); b0.c1 = v1; b0.c2 = NS(225, w4);
-  Fp2 b10 = NS(226, x01), b11 = NS(227, w3);
+// f = miller(pa, qa) * miller(pb, -G2), the same values as miller_loop<true, true>, with EVERY Fq2 product of a loop step
+// scheduled into rounds of four independent products (trio4: one per lane pair of the octet, results exchanged):
+//   doubling step  48 products = 12 rounds: the line of 2T and its product with the table line (16), f^2 by the complex
+//                  method as two Karatsuba Fq6 products (12), (f^2) * (line product) as Karatsuba over Fq6 with the
+//                  sparse half (17), and the three products that only the NEXT step's T needs in the free slots (3);
+//   addition step  39 products = 10 rounds: lines first (13), then the rest of T + Q (9) beside f * (line product) (17).
+// The serial pair layout spends 48 / 41 product-times on the same steps.  The formulas of the twist point and the lines
+// are those of dbl_step / add_step / mul_by_two_lines with their carry sites (200 .. 227); the Fq12 parts have their own
+// (400 ..).  The scalings by the coordinates of pa / pb ride along as Fq2 products with (k + 0 i).
+#define BN_KOP(X, Y, K) fp6_kop<K>(X), fp6_kop<K>(Y)
+struct TrioLineProduct { Fp6 b0; Fp2 b10, b11; };      // (l0 + l1 w + l2 w^3)(m0 + m1 w + w^3) = b0 + (b10 + b11 v) w
+// from the round results v0 = l0 m0, v1 = l1 m1, w3p = l2 m0, w4p = l2 m1: everything but b10 ...
+BN_DEV void trio_line_product(TrioLineProduct& L, const Fp2& l0, const Fp2& l1, const Fp2& l2, const Fp2& v0, const Fp2& v1, const Fp2& w3p,
+                              const Fp2& w4p, bool skip_b, bool any_skip) {
+  L.b0.c0 = NS(224, fp2_add(v0, fp2_mul_xi(l2))); L.b0.c1 = v1; L.b0.c2 = NS(225, fp2_add(l1, w4p));
+  L.b11 = NS(227, fp2_add(l0, w3p));
   if (any_skip) {
-    b0.c0 = fp2_select(skip_b, L.l0, b0.c0);
-    b0.c1 = fp2_select(skip_b, fp2_zero(), b0.c1);
-    b0.c2 = fp2_select(skip_b, fp2_zero(), b0.c2);
-    b10 = fp2_select(skip_b, L.l1, b10);
-    b11 = fp2_select(skip_b, L.l2, b11);
+    L.b0.c0 = fp2_select(skip_b, l0, L.b0.c0);
+    L.b0.c1 = fp2_select(skip_b, fp2_zero(), L.b0.c1);
+    L.b0.c2 = fp2_select(skip_b, fp2_zero(), L.b0.c2);
+    L.b11 = fp2_select(skip_b, l2, L.b11);
   }
-  fp12_mul_line2(f, f, b0, b10, b11);
 }
-// T <- 2T with its line, the table line idx, their product into f (dbl_step + mul_by_two_lines of the serial form)
-BN_DEV void trio_dbl_round(Fp12& f, G2Proj& t, int idx, const Fp2& PAX, const Fp2& PAY, const Fp2& PBX, const Fp2& PBY, bool skip_a,
-                           bool skip_b, bool any_skip) {
-  TrioLines L;
-  Fp2 xy, b, c, e, hh, x2, e2, ox, oz, oy2;
+// ... and b10 = l0 m1 + l1 m0 from x01p = (l0 + l1)(m0 + m1)
+BN_DEV void trio_line_product_b10(TrioLineProduct& L, const Fp2& l1, const Fp2& v0, const Fp2& v1, const Fp2& x01p, bool skip_b, bool any_skip) {
+  L.b10 = NS(226, fp2_sub(fp2_sub(x01p, v0), v1));
+  if (any_skip) L.b10 = fp2_select(skip_b, l1, L.b10);
+}
+// g * (b0 + b1 w) from its 17 products: t0 = g0 b0 (Karatsuba, 6), u = (g0 + g1)(b0 + b1) (6), t1 = g1 (b10 + b11 v) (5:
+// g10 b10, g11 b11, g12 b11, (g10 + g11)(b10 + b11), g12 b10).  Sites 426 .. 445.
+struct TrioLineMul { Fp6 sg, bs; Fp2 sb; };
+BN_DEV void trio_line_mul_prepare(TrioLineMul& M, const Fp12& g, const TrioLineProduct& L) {
+  fp6_add(M.sg, g.c0, g.c1); fp6_site_n<420>(M.sg, M.sg);
+  M.bs.c0 = NS(423, fp2_add(L.b0.c0, L.b10)); M.bs.c1 = NS(424, fp2_add(L.b0.c1, L.b11)); M.bs.c2 = L.b0.c2;
+  M.sb = fp2_add(L.b10, L.b11);
+}
+BN_DEV void trio_line_mul_finish(Fp12& r, const Fp2 (&pt0)[6], const Fp2 (&pu)[6], const Fp2 (&pt1)[5]) {
+  Fp6 t0, t1, u, s;
+  fp6_kfin<426>(t0, pt0);
+  fp6_kfin<430>(u, pu);
+  t1.c0 = NS(434, fp2_add(fp2_mul_xi(pt1[2]), pt1[0]));
+  t1.c1 = NS(435, fp2_sub(fp2_sub(pt1[3], pt1[0]), pt1[1]));
+  t1.c2 = NS(436, fp2_add(pt1[4], pt1[1]));
+  fp6_sub(u, u, t0);
+  fp6_sub(u, u, t1);
+  fp6_mul_v(s, t1);
+  fp6_add(s, t0, s);
+  fp6_site_r<437>(r.c0, s);
+  fp6_site_r<440>(r.c1, u);
+}
+// one doubling step: f <- f^2 * line_{2T}(pa) * tableline_idx(pb), T <- 2T
+BN_DEV void trio_dbl_iter(Fp12& f, G2Proj& t, int idx, const Fp2& PAX, const Fp2& PAY, const Fp2& PBX, const Fp2& PBY, bool skip_a,
+                          bool skip_b, bool any_skip) {
   const Fp2 C0 = fp2_load_const(C_NEG_G2_LINES[idx][0]), C1 = fp2_load_const(C_NEG_G2_LINES[idx][1]);
-  trio4(xy, b, c, L.m0, t.x, t.y, t.y, t.y, t.z, t.z, C0, PBY);
+  // rounds 1-4: the two lines and their product (dbl_step's formulas; what only T needs is left for round 12)
+  Fp2 b, c, m0, x2, e, hh, m1, l1, l0, w3p, w4p, xy, v0, v1, x01p, e2;
+  trio4(b, c, m0, x2, t.y, t.y, t.z, t.z, C0, PBY, t.x, t.x);
   const Fp2 yz = NS(200, fp2_add(t.y, t.z));
-  trio4(e, hh, x2, L.m1, c, fp2_load_const(C_TWIST_3B), yz, yz, t.x, t.x, C1, PBX);
-  const Fp2 f3 = fp2_add(fp2_dbl(e), e);
+  trio4(e, hh, m1, l1, c, fp2_load_const(C_TWIST_3B), yz, yz, C1, PBX, fp2_neg(fp2_add(fp2_dbl(x2), x2)), PAX);
   const Fp2 h = fp2_sub(fp2_sub(hh, b), c);
-  const Fp2 c1 = fp2_neg(fp2_add(fp2_dbl(x2), x2));
-  L.l2 = NS(223, fp2_sub(b, e));
-  if (any_skip) L.l2 = fp2_select(skip_a, fp2_zero(), L.l2);
-  trio4(e2, ox, oz, L.l1, e, e, fp2_dbl(xy), NS(202, fp2_sub(b, f3)), b, h, c1, PAX);
+  Fp2 l2 = NS(223, fp2_sub(b, e));
+  if (any_skip) l2 = fp2_select(skip_a, fp2_zero(), l2);
+  trio4(l0, w3p, w4p, xy, h, PAY, l2, m0, l2, m1, t.x, t.y);
+  if (any_skip) {
+    l0 = fp2_select(skip_a, fp2_one(), l0);
+    l1 = fp2_select(skip_a, fp2_zero(), l1);
+  }
+  trio4(v0, v1, x01p, e2, l0, m0, l1, m1, fp2_add(l0, l1), fp2_add(m0, m1), e, e);
+  TrioLineProduct L;
+  trio_line_product(L, l0, l1, l2, v0, v1, w3p, w4p, skip_b, any_skip);
+  trio_line_product_b10(L, l1, v0, v1, x01p, skip_b, any_skip);
+  // rounds 5-7: g = f^2, complex method: ab = f0 f1, u = (f0 + f1)(f0 + v f1); g0 = u - ab - v ab, g1 = 2 ab.  Sites 400 .. 419
+  Fp12 g;
+  {
+    Fp6 s, w, ab, u;
+    fp6_add(s, f.c0, f.c1); fp6_site_n<400>(s, s);
+    fp6_mul_v(w, f.c1); fp6_add(w, w, f.c0); fp6_site_n<403>(w, w);
+    Fp2 pa[6], pu[6];
+    trio4(pa[0], pa[1], pa[2], pa[3], BN_KOP(f.c0, f.c1, 0), BN_KOP(f.c0, f.c1, 1), BN_KOP(f.c0, f.c1, 2), BN_KOP(f.c0, f.c1, 3));
+    trio4(pa[4], pa[5], pu[0], pu[1], BN_KOP(f.c0, f.c1, 4), BN_KOP(f.c0, f.c1, 5), BN_KOP(s, w, 0), BN_KOP(s, w, 1));
+    trio4(pu[2], pu[3], pu[4], pu[5], BN_KOP(s, w, 2), BN_KOP(s, w, 3), BN_KOP(s, w, 4), BN_KOP(s, w, 5));
+    fp6_kfin<406>(ab, pa);
+    fp6_kfin<410>(u, pu);
+    fp6_sub(u, u, ab);
+    fp6_mul_v(s, ab);
+    fp6_sub(u, u, s);
+    fp6_site_r<414>(g.c0, u);
+    fp6_add(s, ab, ab);
+    fp6_site_r<417>(g.c1, s);
+  }
+  // rounds 8-12: f = g * L, and T <- 2T in the three free slots
+  TrioLineMul M;
+  trio_line_mul_prepare(M, g, L);
+  Fp2 pt0[6], pu[6], pt1[5], ox, oz, oy2;
+  trio4(pt0[0], pt0[1], pt0[2], pt0[3], BN_KOP(g.c0, L.b0, 0), BN_KOP(g.c0, L.b0, 1), BN_KOP(g.c0, L.b0, 2), BN_KOP(g.c0, L.b0, 3));
+  trio4(pt0[4], pt0[5], pu[0], pu[1], BN_KOP(g.c0, L.b0, 4), BN_KOP(g.c0, L.b0, 5), BN_KOP(M.sg, M.bs, 0), BN_KOP(M.sg, M.bs, 1));
+  trio4(pu[2], pu[3], pu[4], pu[5], BN_KOP(M.sg, M.bs, 2), BN_KOP(M.sg, M.bs, 3), BN_KOP(M.sg, M.bs, 4), BN_KOP(M.sg, M.bs, 5));
+  trio4(pt1[0], pt1[1], pt1[2], pt1[3], g.c1.c0, L.b10, g.c1.c1, L.b11, g.c1.c2, L.b11, fp2_add(g.c1.c0, g.c1.c1), M.sb);
+  const Fp2 f3 = fp2_add(fp2_dbl(e), e);
   const Fp2 bf = NS(204, fp2_add(b, f3));
-  trio4(oy2, L.l0, L.w3p, L.w4p, bf, bf, h, PAY, L.l2, L.m0, L.l2, L.m1);
+  trio4(pt1[4], ox, oz, oy2, g.c1.c2, L.b10, fp2_dbl(xy), NS(202, fp2_sub(b, f3)), b, h, bf, bf);
+  trio_line_mul_finish(f, pt0, pu, pt1);
   const Fp2 e2x4 = NS(201, fp2_dbl(fp2_dbl(e2)));
   t.y = NS(205, fp2_sub(oy2, fp2_add(fp2_dbl(e2x4), e2x4)));
   t.x = NS(203, ox);
   t.z = NS(206, fp2_dbl(fp2_dbl(oz)));
-  if (any_skip) {
-    L.l0 = fp2_select(skip_a, fp2_one(), L.l0);
-    L.l1 = fp2_select(skip_a, fp2_zero(), L.l1);
-  }
-  trio_finish_lines(f, L, skip_b, any_skip);
 }
-// T <- T + (qx, qy) with its line, the table line idx, their product into f (add_step + mul_by_two_lines)
-BN_DEV void trio_add_round(Fp12& f, G2Proj& t, const Fp2& qx, const Fp2& qy, int idx, const Fp2& PAX, const Fp2& PAY, const Fp2& PBX,
-                           const Fp2& PBY, bool skip_a, bool skip_b, bool any_skip) {
-  TrioLines L;
-  Fp2 t1, t2, c, d, ca, cb, e, ff, g, ox, oy1, oy2, oz, v0;
+// one addition step: f <- f * line_{T+Q}(pa) * tableline_idx(pb), T <- T + (qx, qy)
+BN_DEV void trio_add_iter(Fp12& f, G2Proj& t, const Fp2& qx, const Fp2& qy, int idx, const Fp2& PAX, const Fp2& PAY, const Fp2& PBX,
+                          const Fp2& PBY, bool skip_a, bool skip_b, bool any_skip) {
   const Fp2 C0 = fp2_load_const(C_NEG_G2_LINES[idx][0]), C1 = fp2_load_const(C_NEG_G2_LINES[idx][1]);
-  trio4(t1, t2, L.m0, L.m1, qy, t.z, qx, t.z, C0, PBY, C1, PBX);
+  Fp2 t1, t2, m0, m1, ca, cb, l1, l0, w3p, w4p, v0, v1, x01p, c, d, e, ff, g, ox, oy1, oy2, oz;
+  Fp2 pt0[6], pu[6], pt1[5], unused;
+  trio4(t1, t2, m0, m1, qy, t.z, qx, t.z, C0, PBY, C1, PBX);
   const Fp2 theta = NS(210, fp2_sub(t.y, t1)), mu = NS(211, fp2_sub(t.x, t2));
-  trio4(c, d, ca, cb, theta, theta, mu, mu, theta, qx, mu, qy);
-  L.l2 = NS(223, fp2_sub(ca, cb));
-  if (any_skip) L.l2 = fp2_select(skip_a, fp2_zero(), L.l2);
-  trio4(e, ff, g, L.l1, mu, d, t.z, c, t.x, d, fp2_neg(theta), PAX);
+  trio4(ca, cb, l1, l0, theta, qx, mu, qy, fp2_neg(theta), PAX, mu, PAY);
+  Fp2 l2 = NS(223, fp2_sub(ca, cb));
+  if (any_skip) {
+    l2 = fp2_select(skip_a, fp2_zero(), l2);
+    l0 = fp2_select(skip_a, fp2_one(), l0);
+    l1 = fp2_select(skip_a, fp2_zero(), l1);
+  }
+  trio4(w3p, w4p, v0, v1, l2, m0, l2, m1, l0, m0, l1, m1);
+  // b0 of the line product needs v0, v1, w4p only: its product with f0 starts beside the last line product
+  TrioLineProduct L;
+  trio_line_product(L, l0, l1, l2, v0, v1, w3p, w4p, skip_b, any_skip);
+  trio4(x01p, c, d, pt0[0], fp2_add(l0, l1), fp2_add(m0, m1), theta, theta, mu, mu, BN_KOP(f.c0, L.b0, 0));
+  trio_line_product_b10(L, l1, v0, v1, x01p, skip_b, any_skip);
+  trio4(e, ff, g, pt0[1], mu, d, t.z, c, t.x, d, BN_KOP(f.c0, L.b0, 1));
   const Fp2 h = NS(212, fp2_sub(fp2_sub(fp2_add(e, ff), g), g));
-  trio4(ox, oy1, L.l0, L.w3p, mu, h, theta, NS(213, fp2_sub(g, h)), mu, PAY, L.l2, L.m0);
-  trio4(oy2, oz, L.w4p, v0, e, t.y, t.z, e, L.l2, L.m1, mu, mu);      // the fourth product is not used
+  trio4(ox, oy1, oy2, oz, mu, h, theta, NS(213, fp2_sub(g, h)), e, t.y, t.z, e);
+  TrioLineMul M;
+  trio_line_mul_prepare(M, f, L);
+  trio4(pt0[2], pt0[3], pt0[4], pt0[5], BN_KOP(f.c0, L.b0, 2), BN_KOP(f.c0, L.b0, 3), BN_KOP(f.c0, L.b0, 4), BN_KOP(f.c0, L.b0, 5));
+  trio4(pu[0], pu[1], pu[2], pu[3], BN_KOP(M.sg, M.bs, 0), BN_KOP(M.sg, M.bs, 1), BN_KOP(M.sg, M.bs, 2), BN_KOP(M.sg, M.bs, 3));
+  trio4(pu[4], pu[5], pt1[0], pt1[1], BN_KOP(M.sg, M.bs, 4), BN_KOP(M.sg, M.bs, 5), f.c1.c0, L.b10, f.c1.c1, L.b11);
+  trio4(pt1[2], pt1[3], pt1[4], unused, f.c1.c2, L.b11, fp2_add(f.c1.c0, f.c1.c1), M.sb, f.c1.c2, L.b10, f.c1.c2, L.b10);
+  trio_line_mul_finish(f, pt0, pu, pt1);
   t.x = ox;
   t.y = NS(214, fp2_sub(oy1, oy2));
   t.z = oz;
-  if (any_skip) {
-    L.l0 = fp2_select(skip_a, fp2_one(), L.l0);
-    L.l1 = fp2_select(skip_a, fp2_zero(), L.l1);
-  }
-  trio_finish_lines(f, L, skip_b, any_skip);
 }
 template <bool F_LDS = false>
 BN_DEVM void miller_verify_rounds(Fp12& f, const G1Affine& pa, const G2Affine& qa, const G1Affine& pb) {
@@ -255,18 +320,17 @@ BN_DEVM void miller_verify_rounds(Fp12& f, const G1Affine& pa, const G2Affine& q
   const Fp2 PAX = fp2_from_fp(pa.x), PAY = fp2_from_fp(pa.y), PBX = fp2_from_fp(pb.x), PBY = fp2_from_fp(pb.y);
   int idx = 0;
   for (int d = 0; d < 64; ++d) {
-    fp12_sqr(f, f);
-    trio_dbl_round(f, t, idx++, PAX, PAY, PBX, PBY, skip_a, skip_b, any_skip);
+    trio_dbl_iter(f, t, idx++, PAX, PAY, PBX, PBY, skip_a, skip_b, any_skip);
     const int digit = C_ATE_NAF[d];
     if (digit != 0)    // wave-uniform
-      trio_add_round(f, t, qa.x, fp2_select(digit > 0, qa.y, qa_yneg), idx++, PAX, PAY, PBX, PBY, skip_a, skip_b, any_skip);
+      trio_add_iter(f, t, qa.x, fp2_select(digit > 0, qa.y, qa_yneg), idx++, PAX, PAY, PBX, PBY, skip_a, skip_b, any_skip);
   }
   // + pi(Q), - pi^2(Q)
   Fp2 q1x, q1y, q2x, unused;
   trio4(q1x, q1y, q2x, unused, fp2_conj(qa.x), fp2_load_const(C_TW_FROB_X1), fp2_conj(qa.y), fp2_load_const(C_TW_FROB_Y1), qa.x,
         fp2_load_const(C_TW_FROB_X2), qa.x, qa.x);
-  trio_add_round(f, t, q1x, q1y, idx++, PAX, PAY, PBX, PBY, skip_a, skip_b, any_skip);
-  trio_add_round(f, t, q2x, qa.y, idx++, PAX, PAY, PBX, PBY, skip_a, skip_b, any_skip);
+  trio_add_iter(f, t, q1x, q1y, idx++, PAX, PAY, PBX, PBY, skip_a, skip_b, any_skip);
+  trio_add_iter(f, t, q2x, qa.y, idx++, PAX, PAY, PBX, PBY, skip_a, skip_b, any_skip);
 }
 #endif
 

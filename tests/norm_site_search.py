@@ -3,8 +3,8 @@
 
 TEST INFRASTRUCTURE (CPU only).  The tower and pairing code marks every place where a lazy value may have to be
 carried (fp2_norm) or carried and weakly reduced (fp2_reduce_weak) before it meets a product, with a numbered site and
-a safe default.  The bound-tracking host builds of BOTH lane layouts (tests/hostsim/libhostsim_bounds.so,
-libhostsim_pair_bounds.so) read the mode of each site from a table at run time and, in "soft" mode, record a bound
+a safe default.  The bound-tracking host builds of the lane layouts (tests/hostsim/libhostsim_bounds.so,
+libhostsim_pair_bounds.so, and libhostsim_trio_bounds.so with the formulas of the octet layout) read the mode of each site from a table at run time and, in "soft" mode, record a bound
 violation instead of aborting.  The control flow of every formula is data-independent, so one pass of the probe flows
 under the tracker is a proof for that configuration.
 
@@ -46,11 +46,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--check", action="store_true")
     args = ap.parse_args()
-    subprocess.check_call(["make", "-s", "-C", HS, "libhostsim_bounds.so", "libhostsim_pair_bounds.so"])
+    subprocess.check_call(["make", "-s", "-C", HS, "libhostsim_bounds.so", "libhostsim_pair_bounds.so", "libhostsim_trio_bounds.so"])
     from oracle import c_oracle as c
     d = json.load(open(os.path.join(ROOT, "tests", "golden", "derived_vectors.json")))
     H = bytes.fromhex
-    classic, pair = Lib("libhostsim_bounds.so"), Lib("libhostsim_pair_bounds.so")
+    classic, pair, trio = Lib("libhostsim_bounds.so"), Lib("libhostsim_pair_bounds.so"), Lib("libhostsim_trio_bounds.so")
     v = [x for x in d["verify_cases"] if x["status"] == 0][0]
     msg, sig, pk = H(v["message_hex"]), H(v["sig"]), H(v["pk"])
     _, h, _ = c.hash_to_g1(msg)
@@ -70,9 +70,20 @@ def main():
     pair.L.hp_lane_counts.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_ulonglong)]
 
     def probe():
-        for lib in (classic, pair):
+        for lib in (classic, pair, trio):
             lib.failed.value = 0
         o = buf(384)
+        assert trio.L.hp_verify_decoded(h, sig, pk) == 0 or trio.failed.value     # incl. the round-structured Miller loop
+        if trio.failed.value:
+            return False
+        for s_, k_ in ((bytes(64), bytes(128)), (bytes(64), pk), (sig, bytes(128))):      # the skip paths of the rounds
+            trio.L.hp_verify_decoded(h, s_, k_)
+        if trio.failed.value:
+            return False
+        trio.L.hp_pairing(ps[0], qs[0], o)
+        trio.L.hp_pairing_product4(b"".join(ps), b"".join(qs), o)
+        if trio.failed.value:
+            return False
         assert pair.L.hp_verify_decoded(h, sig, pk) == 0 or pair.failed.value
         pair.L.hp_pairing(ps[0], qs[0], o)
         if pair.failed.value:
@@ -96,17 +107,18 @@ def main():
     def set_mode(i, m):
         classic.mode[i] = m
         pair.mode[i] = m
+        trio.mode[i] = m
 
     assert probe(), "the committed / default configuration does not pass the tracker"
     if args.check:
         print("ok: committed table passes")
         return
     # weights: executions per probe in the pair layout (the shipped kernels), classic as a tie-break
-    for lib in (classic, pair):
+    for lib in (classic, pair, trio):
         for i in range(N_SITES):
             lib.hits[i] = 0
     probe()
-    weight = {i: pair.hits[i] * 4 + classic.hits[i] for i in range(N_SITES) if pair.hits[i] or classic.hits[i]}
+    weight = {i: pair.hits[i] * 4 + classic.hits[i] + trio.hits[i] * 2 for i in range(N_SITES) if pair.hits[i] or classic.hits[i] or trio.hits[i]}
     sites = sorted(weight, key=lambda i: -weight[i])
     print("%d sites in the probe flows" % len(sites))
     defaults = {}
@@ -116,7 +128,7 @@ def main():
     total_before = total_after = 0
     for i in sites:
         cur = pair.mode[i]
-        dflt = max(pair.dflt[i], classic.dflt[i])
+        dflt = max(pair.dflt[i], classic.dflt[i], trio.dflt[i])
         eff = cur if cur >= 0 else dflt
         best = None
         for m in (0, 1):
@@ -141,9 +153,9 @@ def main():
              "// (bn254_field.h: NS / NR) whose mode differs from the safe default written in the source.",
              "//   -1 = source default   0 = nothing   1 = carry (fp2_norm)   2 = carry + weak reduction (fp2_reduce_weak)",
              "// Every configuration recorded here has passed the bound tracker on all flows of tests/test_bounds.py and",
-             "// tests/test_pair_layout.py (both lane layouts).",
+             "// tests/test_pair_layout.py (all lane layouts).",
              "#pragma once", "constexpr int bn_site_override(int id) {", "  switch (id) {"]
-    final = {i: int(pair.mode[i]) for i in range(N_SITES) if pair.mode[i] >= 0 and pair.mode[i] != max(pair.dflt[i], classic.dflt[i])}
+    final = {i: int(pair.mode[i]) for i in range(N_SITES) if pair.mode[i] >= 0 and pair.mode[i] != max(pair.dflt[i], classic.dflt[i], trio.dflt[i])}
     for m in (0, 1, 2):
         ids = sorted(i for i, mm in final.items() if mm == m)
         for k in range(0, len(ids), 16):
