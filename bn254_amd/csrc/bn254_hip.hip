@@ -143,12 +143,52 @@ KERNEL_SMALL void k_hash_resolve(Ws ws, int round, uint32_t width, uint32_t max_
     list_out[pos] = i;
   }
 }
+// SMALL batches (n <= HASH_DIRECT_MAX_N): latency, not work, is what counts — the first `width` counters of a message
+// (a power of two <= 32, default 32) are tried in as many lanes of one wave with the square root itself (no filter pass
+// first: SHA-256 + one exponentiation instead of SHA-256 + Jacobi symbol, then SHA-256 + exponentiation in a second
+// kernel), the lowest passing counter writes its point.  A message without one (p = 0.5274^32 = 1.3e-9) is queued as a
+// survivor of "round 0" for the ordinary rounds, which start at counter `width` (and cost it a second exponentiation).
+KERNEL_SMALL void k_hash_direct(const uint8_t* msgs, const uint64_t* off, size_t n, Ws ws, uint32_t width, uint32_t max_ctr, int px,
+                                int inf_plane, uint8_t* tries_out) {
+  const size_t w = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
+  const size_t i = w / width;
+  const uint32_t ctr = (uint32_t)(w % width);
+  bool ok = false;
+  G1Affine p;
+  g1_set_generator(p);
+  if (i < n && ctr < max_ctr) {
+    const uint8_t* msg = msgs + off[i];
+    const uint64_t len = off[i + 1] - off[i];
+    HashState hs;
+    hash_state_init(hs, msg, len);
+    ok = hash_try(p, hs, msg, len, ctr);
+  }
+  const uint64_t pass = __ballot(ok);
+  if (i >= n) return;
+  const uint32_t group = (uint32_t)(pass >> (threadIdx.x & ~(width - 1u))) & (uint32_t)((1ull << width) - 1u);
+  if (group != 0) {
+    if (ctr == (uint32_t)__builtin_ctz(group)) {                    // hash.rs:40-59: the first counter that yields a point
+      ws_store_g1(ws, px, inf_plane, i, p);
+      ws_byte(ws, BY_ST_HASH, i) = (uint8_t)ST_OK;
+      if (tries_out) tries_out[i] = (uint8_t)(ctr + 1);
+      ws.h_best[i] = HASH_DONE;
+    }
+  } else if (ctr == 0) {
+    ws.h_best[i] = HASH_NONE;
+    ws.h_next[i] = (uint8_t)width;
+    if (width < max_ctr) {
+      const uint32_t pos = atomicAdd(&ws.h_cnt[1], 1u);
+      (ws.h_list + ws.stride)[pos] = (uint32_t)i;                   // the list that feeds round 1
+    }
+  }
+}
 // the point of every message: the even root for its winning counter (or the error status)
 KERNEL_SMALL void k_hash_finish(const uint8_t* msgs, const uint64_t* off, size_t n, Ws ws, uint32_t max_ctr, int px, int inf_plane,
                                 uint8_t* tries_out) {
   size_t i = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
   if (i >= n) return;
   const uint32_t best = ws.h_best[i];
+  if (best == HASH_DONE) return;                                   // k_hash_direct
   const uint8_t* msg = msgs + off[i];
   uint64_t len = off[i + 1] - off[i];
   HashState hs;
@@ -780,6 +820,7 @@ struct bn254_ctx {
   int rand_min_batch;      // randomised verify: batches below this size run the exact kernels (default RAND_MIN_BATCH_DEFAULT)
   int rand_items_per_lane; // randomised verify: 0 = by batch size, 1 or 2 forced (A/B and tests)
   int hash_max_tries; // test knob: counters tried before HashToPointError (0 = the reference's 255)
+  int hash_direct_width; // small batches: counters tried at once with the square root itself (k_hash_direct); 0 = rounds only
   int trio_max_batch; // verify / check_public_keys batches up to this size run in the octet layout (bn254_trio.hip); 0 = never
   hipEvent_t ev[5];
   int ev_valid;
@@ -870,6 +911,15 @@ static int launch_hash_rounds(bn254_ctx* c, hipStream_t s, const uint8_t* d_msgs
                               uint8_t* d_tries) {
   const uint32_t max_ctr = c->hash_max_tries ? (uint32_t)c->hash_max_tries : 255u;
   k_hash_init<<<grid_for(n > HASH_MAX_ROUNDS + 1 ? n : HASH_MAX_ROUNDS + 1), BN_WAVE, 0, s>>>(n, c->ws);
+  if (n <= HASH_DIRECT_MAX_N && c->hash_direct_width > 0) {
+    const uint32_t width = (uint32_t)c->hash_direct_width;
+    k_hash_direct<<<grid_for(n * width), BN_WAVE, 0, s>>>(d_msgs, d_off, n, c->ws, width, max_ctr, px, inf_plane, d_tries);
+    if (max_ctr > width)                 // the (rare) survivors: every remaining counter at once (grid-stride beyond 64 of them)
+      k_hash_round<<<grid_for(64 * (max_ctr - width)), BN_WAVE, 0, s>>>(d_msgs, d_off, c->ws, 1, max_ctr - width, max_ctr);
+    k_hash_finish<<<grid_for(n), BN_WAVE, 0, s>>>(d_msgs, d_off, n, c->ws, max_ctr, px, inf_plane, d_tries);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   double expect = (double)n;
   uint32_t consumed = 0;
   for (int round = 0; round < HASH_MAX_ROUNDS && consumed < max_ctr; ++round) {
@@ -910,6 +960,7 @@ int bn254_ctx_create(int hip_device, bn254_ctx** out) {
   c->pair_lanes = 1;
   c->rand_min_batch = RAND_MIN_BATCH_DEFAULT;
   c->trio_max_batch = TRIO_MAX_BATCH_DEFAULT;
+  c->hash_direct_width = HASH_DIRECT_WIDTH_DEFAULT;
   c->device = hip_device;
   hipError_t err = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (err == hipSuccess) err = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
@@ -964,6 +1015,11 @@ int bn254_ctx_set_option(bn254_ctx* c, int option, int value) {
   if (option == BN254_OPT_RAND_MIN_BATCH) { if (value < 0) return BN254_E_BAD_ARGUMENT; c->rand_min_batch = value; return 0; }
   if (option == BN254_OPT_RAND_ITEMS_PER_LANE) { if (value < 0 || value > 2) return BN254_E_BAD_ARGUMENT; c->rand_items_per_lane = value; return 0; }
   if (option == BN254_OPT_TRIO_MAX_BATCH) { if (value < 0) return BN254_E_BAD_ARGUMENT; c->trio_max_batch = value; return 0; }
+  if (option == BN254_OPT_HASH_DIRECT_WIDTH) {
+    if (value < 0 || value > 32 || (value & (value - 1))) return BN254_E_BAD_ARGUMENT;
+    c->hash_direct_width = value;
+    return 0;
+  }
   if (option == BN254_OPT_HASH_MAX_TRIES) { if (value < 0 || value > 255) return BN254_E_BAD_ARGUMENT; c->hash_max_tries = value; return 0; }
   return BN254_E_BAD_ARGUMENT;
 }

@@ -35,6 +35,9 @@ struct Ws {
   uint32_t* h_cnt;    // [HASH_MAX_ROUNDS + 1] number of entries of the list feeding round r
 };
 #define HASH_NONE 0xFFFFFFFFu
+#define HASH_DONE 0xFFFFFFFEu                    // k_hash_direct has already written the point of this message
+#define HASH_DIRECT_WIDTH_DEFAULT 32             // counters tried at once per message by k_hash_direct (lanes of one wave; 1, 2, .. 32)
+#define HASH_DIRECT_MAX_N ((size_t)4096)         // ... for batches that leave the chip mostly idle: 32 n lanes <= two waves per SIMD
 #define HASH_MAX_ROUNDS 64
 #define HASH_MAX_GRID_LANES ((size_t)1 << 24)   // lanes launched per round at most (grid-stride beyond)
 #define HASH_TARGET_LANES ((size_t)1 << 17)    // ~2 waves per SIMD

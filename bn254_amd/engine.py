@@ -18,6 +18,7 @@ OPT_RAND_ITEMS_PER_LANE = 3
 OPT_PAIR_LANES = 4
 OPT_RAND_MIN_BATCH = 5
 OPT_TRIO_MAX_BATCH = 6
+OPT_HASH_DIRECT_WIDTH = 7
 
 
 class NativeError(RuntimeError):

@@ -123,6 +123,38 @@ def test_hash_to_g1_vs_oracle_ragged(eng, c):
         assert (st[i], pts[64 * i:64 * i + 64], tries[i]) == (wst, wpt, wtries), i
 
 
+def test_hash_small_batch_direct_path_and_its_survivors(eng, c):
+    """batches of up to 4096 messages try the first counters of every message at once with the square root itself
+    (k_hash_direct, 32 counters by default); a message that needs more falls through to the ordinary rounds.  Messages with
+    17 and 18 tries (found by a search with the oracle) with the direct width at 32, at 16 (they become survivors), 1 and 0
+    (rounds only), in a large batch (rounds only), and with the counter budget cut to 17"""
+    from bn254_amd.engine import OPT_HASH_DIRECT_WIDTH, OPT_HASH_MAX_TRIES
+    late = [b"late-21102", b"late-32370", b"late-82852"]
+    want_late = [c.hash_to_g1(m) for m in late]
+    assert [w[2] for w in want_late] == [18, 17, 17]
+    small = [b"d%d" % i for i in range(61)] + late + [b""]
+    want = [c.hash_to_g1(m) for m in small]
+    try:
+        for width in (32, 16, 4, 1, 0):
+            eng.set_option(OPT_HASH_DIRECT_WIDTH, width)
+            for msgs in (small, late[:1], small + [b"pad%d" % i for i in range(5000)]):
+                pts, st, tries = eng.batch_hash_to_g1(msgs)
+                for i in range(min(len(msgs), len(small))):
+                    wst, wpt, wtries = want[i] if len(msgs) > 1 else want_late[0]
+                    assert (st[i], pts[64 * i:64 * i + 64], tries[i]) == (wst, wpt, wtries), (width, len(msgs), i)
+            eng.set_option(OPT_HASH_MAX_TRIES, 17)
+            pts, st, tries = eng.batch_hash_to_g1(small)
+            eng.set_option(OPT_HASH_MAX_TRIES, 0)
+            k = len(small) - 4
+            assert (st[k], tries[k], pts[64 * k:64 * k + 64]) == (1, 17, bytes(64)), width               # 18 tries needed: HashToPointError
+            assert (st[k + 1], tries[k + 1], pts[64 * (k + 1):64 * (k + 2)]) == (0, 17, want_late[1][1]), width
+    finally:
+        eng.set_option(OPT_HASH_MAX_TRIES, 0)
+        eng.set_option(OPT_HASH_DIRECT_WIDTH, 32)
+    with pytest.raises(Exception):
+        eng.set_option(OPT_HASH_DIRECT_WIDTH, 24)
+
+
 def test_hash_to_point_error_path(eng, derived):
     """src/hash.rs:62: HashToPointError once the counters are exhausted.  255 failures in a row cannot be
     provoked with real data (p = 0.53^255), so the test knob shrinks the counter budget to 3."""

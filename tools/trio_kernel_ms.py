@@ -8,7 +8,7 @@ from bn254_amd.engine import OPT_TRIO_MAX_BATCH
 from tests.datagen import make_verify_batch
 eng = bn254_amd.Engine(0)
 dev = torch.device("cuda", 0)
-for n in (64, 1024, 8192):
+for n in [int(x) for x in os.environ.get("TRIO_SIZES", "64,1024,8192").split(",")]:
     msgs, sigs, pks, expected = make_verify_batch(eng, n)
     t = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
     d_msgs, d_sigs, d_pks = t(b"".join(msgs)), t(sigs), t(pks)
