@@ -5,12 +5,22 @@ import subprocess
 
 _HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostsim")
 _lib = None
+_built = False
+
+
+def build_all():
+    """all host builds of the device headers the CPU tests load, compiled side by side once per test process (the tracker
+    and sanitizer builds take a minute each; one after the other they were most of the suite's run time)"""
+    global _built
+    if not _built:
+        subprocess.check_call(["make", "-s", "-j", str(min(8, os.cpu_count() or 1)), "-C", _HERE, "all"], stdout=subprocess.DEVNULL)
+        _built = True
 
 
 def lib():
     global _lib
     if _lib is None:
-        subprocess.check_call(["make", "-C", _HERE], stdout=subprocess.DEVNULL)
+        build_all()
         L = ctypes.CDLL(os.path.join(_HERE, "libhostsim.so"))
         cp = ctypes.c_char_p
         L.hs_hash_to_g1.argtypes = [cp, ctypes.c_uint64, cp, ctypes.POINTER(ctypes.c_int)]

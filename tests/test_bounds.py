@@ -75,7 +75,8 @@ print("ok")
 
 @pytest.fixture(scope="module")
 def bounds_lib():
-    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "hostsim"), "libhostsim_bounds.so"], stdout=subprocess.DEVNULL)
+    from tests import hostsim_binding
+    hostsim_binding.build_all()
 
 
 @pytest.mark.parametrize("flow", ["fp", "hash", "pairing", "verify", "group", "subgroup", "codec", "msum", "randomized"])

@@ -16,7 +16,8 @@ H = bytes.fromhex
 
 @pytest.fixture(scope="module")
 def pair_lib():
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "hostsim"), "libhostsim_pair.so", "libhostsim_pair_bounds.so"])
+    from tests import hostsim_binding
+    hostsim_binding.build_all()
     return ctypes.CDLL(os.path.join(ROOT, "tests", "hostsim", "libhostsim_pair.so"))
 
 
@@ -130,7 +131,8 @@ def test_pair_layout_bounds_hold(pair_lib):
 # Fq2 products) and returns 254 when its accumulator differs from the generic loop's.
 @pytest.fixture(scope="module")
 def trio_lib():
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "hostsim"), "libhostsim_trio.so", "libhostsim_trio_bounds.so"])
+    from tests import hostsim_binding
+    hostsim_binding.build_all()
     return ctypes.CDLL(os.path.join(ROOT, "tests", "hostsim", "libhostsim_trio.so"))
 
 

@@ -19,7 +19,8 @@ def test_hostsim_and_oracle_under_asan_ubsan():
     asan, ubsan = _runtime("libasan.so"), _runtime("libubsan.so")
     if not (asan and ubsan):
         pytest.skip("sanitizer runtimes not installed")
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "hostsim"), "libhostsim_san.so", "libhostsim_pair_san.so"])
+    from tests import hostsim_binding
+    hostsim_binding.build_all()
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "libbn254_oracle_asan.so"])
     env = dict(os.environ, LD_PRELOAD=asan + " " + ubsan, ASAN_OPTIONS="detect_leaks=0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "sanitizer_run.py")], env=env,

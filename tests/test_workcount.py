@@ -37,7 +37,8 @@ def test_lane_product_counts_for_bench(derived):
     import json
     import subprocess
     from oracle import c_oracle as c
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "hostsim"), "libhostsim_pair.so"])
+    from tests import hostsim_binding
+    hostsim_binding.build_all()
     L = ctypes.CDLL(os.path.join(ROOT, "tests", "hostsim", "libhostsim_pair.so"))
     L.hp_lane_counts.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_ulonglong)]
     seen = set()
