@@ -820,6 +820,7 @@ struct bn254_ctx {
   int rand_min_batch;      // randomised verify: batches below this size run the exact kernels (default RAND_MIN_BATCH_DEFAULT)
   int rand_items_per_lane; // randomised verify: 0 = by batch size, 1 or 2 forced (A/B and tests)
   int hash_max_tries; // test knob: counters tried before HashToPointError (0 = the reference's 255)
+  int trio_wave_roles; // octet layout: the Miller loop's four lane pairs as the four waves of a workgroup (k_miller_verify_quad) instead of one wave
   int hash_direct_width; // small batches: counters tried at once with the square root itself (k_hash_direct); 0 = rounds only
   int trio_max_batch; // verify / check_public_keys batches up to this size run in the octet layout (bn254_trio.hip); 0 = never
   hipEvent_t ev[5];
@@ -961,6 +962,7 @@ int bn254_ctx_create(int hip_device, bn254_ctx** out) {
   c->rand_min_batch = RAND_MIN_BATCH_DEFAULT;
   c->trio_max_batch = TRIO_MAX_BATCH_DEFAULT;
   c->hash_direct_width = HASH_DIRECT_WIDTH_DEFAULT;
+  c->trio_wave_roles = TRIO_WAVE_ROLES_DEFAULT;
   c->device = hip_device;
   hipError_t err = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (err == hipSuccess) err = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
@@ -1015,6 +1017,7 @@ int bn254_ctx_set_option(bn254_ctx* c, int option, int value) {
   if (option == BN254_OPT_RAND_MIN_BATCH) { if (value < 0) return BN254_E_BAD_ARGUMENT; c->rand_min_batch = value; return 0; }
   if (option == BN254_OPT_RAND_ITEMS_PER_LANE) { if (value < 0 || value > 2) return BN254_E_BAD_ARGUMENT; c->rand_items_per_lane = value; return 0; }
   if (option == BN254_OPT_TRIO_MAX_BATCH) { if (value < 0) return BN254_E_BAD_ARGUMENT; c->trio_max_batch = value; return 0; }
+  if (option == BN254_OPT_TRIO_WAVE_ROLES) { c->trio_wave_roles = value != 0; return 0; }
   if (option == BN254_OPT_HASH_DIRECT_WIDTH) {
     if (value < 0 || value > 32 || (value & (value - 1))) return BN254_E_BAD_ARGUMENT;
     c->hash_direct_width = value;
@@ -1038,7 +1041,7 @@ int bn254_ctx_last_kernel_ms(bn254_ctx* c, float ms[4]) {
 static int launch_pair_or_trio(bn254_ctx* c, hipStream_t s, size_t n, int use_hash, uint8_t* d_status, int mode, bool mark) {
   int rc;
   if (c->trio_max_batch > 0 && n <= (size_t)c->trio_max_batch) {
-    if ((rc = bn254_trio_miller_verify(n, c->ws, s, mode))) return rc;
+    if ((rc = c->trio_wave_roles ? bn254_quad_miller_verify(n, c->ws, s, mode) : bn254_trio_miller_verify(n, c->ws, s, mode))) return rc;
     if (mark) PROF_MARK(3);
     return bn254_trio_final_exp(n, c->ws, use_hash, d_status, s);
   }

@@ -332,6 +332,158 @@ BN_DEVM void miller_verify_rounds(Fp12& f, const G1Affine& pa, const G2Affine& q
   trio_add_iter(f, t, q1x, q1y, idx++, PAX, PAY, PBX, PBY, skip_a, skip_b, any_skip);
   trio_add_iter(f, t, q2x, qa.y, idx++, PAX, PAY, PBX, PBY, skip_a, skip_b, any_skip);
 }
+
+// ---- the same loop as WAVE ROLES ("quad-wave" layout, bn254_trio.hip: k_miller_verify_quad) ------------------------------
+// In the octet layout the four lane pairs of a verify share a wave, so every pair executes every linear instruction
+// (Karatsuba sums, recombinations, carries): half of the loop's instructions.  Here the four pairs of a verify sit in the
+// FOUR WAVES of a workgroup (one per SIMD of a CU, 32 verifies per workgroup) and run different instruction streams,
+// exchanging Fq2 values through LDS mailboxes between workgroup barriers:
+//   wave 3  the twist point: the line of the NEXT step (8 products for a doubling, 6 for an addition) and T's update
+//           (4 / 9), one step ahead of the others — it depends on nothing they compute;
+//   wave 2  the product of that line with the table line (7 products), then t1 = g1 * (b10 + b11 v) (5);
+//   wave 0  ab = f0 f1 (6), g1 = 2ab, then t0 = g0 b0 (6) and the half r0 = t0 + v t1 of the new f;
+//   wave 1  u = (f0 + f1)(f0 + v f1) (6), g0 = u - ab - v ab, then (g0 + g1)(b0 + b1) (6) and r1.
+// Every wave does ~12 products per doubling step and only ITS share of the linear work.  The functions below are the
+// roles' arithmetic — the same formulas and carry sites as the rounds above — as pure functions, so that the host
+// emulation can run them one after the other (miller_verify_quad_model) and prove values and bounds.
+struct QuadDblTmp { Fp2 b, e, h; };
+// wave 3, doubling: the line (l0, l1, l2) of 2T evaluated at pa
+BN_DEV void quad_dbl_line(Fp2& l0, Fp2& l1, Fp2& l2, QuadDblTmp& k, const G2Proj& t, const Fp2& PAX, const Fp2& PAY) {
+  const Fp2 b = fp2_mul(t.y, t.y), c = fp2_mul(t.z, t.z), x2 = fp2_mul(t.x, t.x);
+  const Fp2 yz = NS(200, fp2_add(t.y, t.z));
+  const Fp2 e = fp2_mul(c, fp2_load_const(C_TWIST_3B)), hh = fp2_mul(yz, yz);
+  l1 = fp2_mul(fp2_neg(fp2_add(fp2_dbl(x2), x2)), PAX);
+  const Fp2 h = fp2_sub(fp2_sub(hh, b), c);
+  l2 = NS(223, fp2_sub(b, e));
+  l0 = fp2_mul(h, PAY);
+  k.b = b; k.e = e; k.h = h;
+}
+BN_DEV void quad_dbl_update(G2Proj& t, const QuadDblTmp& k) {
+  const Fp2 e2 = fp2_mul(k.e, k.e), xy = fp2_mul(t.x, t.y);
+  const Fp2 f3 = fp2_add(fp2_dbl(k.e), k.e);
+  const Fp2 bf = NS(204, fp2_add(k.b, f3));
+  const Fp2 ox = fp2_mul(fp2_dbl(xy), NS(202, fp2_sub(k.b, f3))), oz = fp2_mul(k.b, k.h), oy2 = fp2_mul(bf, bf);
+  const Fp2 e2x4 = NS(201, fp2_dbl(fp2_dbl(e2)));
+  t.y = NS(205, fp2_sub(oy2, fp2_add(fp2_dbl(e2x4), e2x4)));
+  t.x = NS(203, ox);
+  t.z = NS(206, fp2_dbl(fp2_dbl(oz)));
+}
+struct QuadAddTmp { Fp2 theta, mu, c, d; };
+// wave 3, addition of (qx, qy): the line of T + Q evaluated at pa
+BN_DEV void quad_add_line(Fp2& l0, Fp2& l1, Fp2& l2, QuadAddTmp& k, const G2Proj& t, const Fp2& qx, const Fp2& qy, const Fp2& PAX, const Fp2& PAY) {
+  const Fp2 t1 = fp2_mul(qy, t.z), t2 = fp2_mul(qx, t.z);
+  k.theta = NS(210, fp2_sub(t.y, t1)); k.mu = NS(211, fp2_sub(t.x, t2));
+  const Fp2 ca = fp2_mul(k.theta, qx), cb = fp2_mul(k.mu, qy);
+  l1 = fp2_mul(fp2_neg(k.theta), PAX);
+  l0 = fp2_mul(k.mu, PAY);
+  l2 = NS(223, fp2_sub(ca, cb));
+}
+// ... and the two squares the update starts from (in the same interval as the line, which is the shorter one of an addition)
+BN_DEV void quad_add_squares(QuadAddTmp& k) { k.c = fp2_mul(k.theta, k.theta); k.d = fp2_mul(k.mu, k.mu); }
+BN_DEV void quad_add_update(G2Proj& t, const QuadAddTmp& k) {
+  const Fp2 e = fp2_mul(k.mu, k.d), ff = fp2_mul(t.z, k.c), g = fp2_mul(t.x, k.d);
+  const Fp2 h = NS(212, fp2_sub(fp2_sub(fp2_add(e, ff), g), g));
+  const Fp2 ox = fp2_mul(k.mu, h), oy1 = fp2_mul(k.theta, NS(213, fp2_sub(g, h))), oy2 = fp2_mul(e, t.y), oz = fp2_mul(t.z, e);
+  t.x = ox;
+  t.y = NS(214, fp2_sub(oy1, oy2));
+  t.z = oz;
+}
+// wave 2: (l0 + l1 w + l2 w^3) * (table line idx at pb); m1 = C1 * x_B of the table line comes from the caller (it does not
+// depend on the step's own line: the wave computes it in the lighter interval of the step before)
+BN_DEV Fp2 quad_table_m1(int idx, const Fp2& PBX) { return fp2_mul(fp2_load_const(C_NEG_G2_LINES[idx][1]), PBX); }
+BN_DEV void quad_line_product(TrioLineProduct& L, Fp2 l0, Fp2 l1, Fp2 l2, int idx, const Fp2& m1, const Fp2& PBY, bool skip_a, bool skip_b,
+                              bool any_skip) {
+  if (any_skip) {
+    l2 = fp2_select(skip_a, fp2_zero(), l2);
+    l0 = fp2_select(skip_a, fp2_one(), l0);
+    l1 = fp2_select(skip_a, fp2_zero(), l1);
+  }
+  const Fp2 m0 = fp2_mul(fp2_load_const(C_NEG_G2_LINES[idx][0]), PBY);
+  const Fp2 w3p = fp2_mul(l2, m0), w4p = fp2_mul(l2, m1), v0 = fp2_mul(l0, m0), v1 = fp2_mul(l1, m1);
+  const Fp2 x01p = fp2_mul(fp2_add(l0, l1), fp2_add(m0, m1));
+  trio_line_product(L, l0, l1, l2, v0, v1, w3p, w4p, skip_b, any_skip);
+  trio_line_product_b10(L, l1, v0, v1, x01p, skip_b, any_skip);
+}
+// the six products of a Karatsuba Fq6 product, one after the other
+BN_DEV void quad_kprod(Fp2 (&p)[6], const Fp6& x, const Fp6& y) {
+  p[0] = fp2_mul(fp6_kop<0>(x), fp6_kop<0>(y)); p[1] = fp2_mul(fp6_kop<1>(x), fp6_kop<1>(y)); p[2] = fp2_mul(fp6_kop<2>(x), fp6_kop<2>(y));
+  p[3] = fp2_mul(fp6_kop<3>(x), fp6_kop<3>(y)); p[4] = fp2_mul(fp6_kop<4>(x), fp6_kop<4>(y)); p[5] = fp2_mul(fp6_kop<5>(x), fp6_kop<5>(y));
+}
+// waves 0 / 1, squaring (sites 400 .. 419 as in trio_dbl_iter)
+BN_DEV void quad_sqr_ab(Fp6& ab, const Fp6& f0, const Fp6& f1) { Fp2 p[6]; quad_kprod(p, f0, f1); fp6_kfin<406>(ab, p); }
+BN_DEV void quad_sqr_u(Fp6& u, const Fp6& f0, const Fp6& f1) {
+  Fp6 s, w;
+  fp6_add(s, f0, f1); fp6_site_n<400>(s, s);
+  fp6_mul_v(w, f1); fp6_add(w, w, f0); fp6_site_n<403>(w, w);
+  Fp2 p[6]; quad_kprod(p, s, w); fp6_kfin<410>(u, p);
+}
+BN_DEV void quad_sqr_g1(Fp6& g1, const Fp6& ab) { Fp6 s; fp6_add(s, ab, ab); fp6_site_r<417>(g1, s); }
+BN_DEV void quad_sqr_g0(Fp6& g0, const Fp6& u, const Fp6& ab) {
+  Fp6 s, t;
+  fp6_sub(t, u, ab); fp6_mul_v(s, ab); fp6_sub(t, t, s);
+  fp6_site_r<414>(g0, t);
+}
+// waves 0 / 1 / 2, g * (b0 + (b10 + b11 v) w) (sites 420 .. 445 as in trio_line_mul_prepare / _finish)
+BN_DEV void quad_mul_t0(Fp6& t0, const Fp6& g0, const Fp6& b0) { Fp2 p[6]; quad_kprod(p, g0, b0); fp6_kfin<426>(t0, p); }
+BN_DEV void quad_mul_uu(Fp6& uu, const Fp6& g0, const Fp6& g1, const TrioLineProduct& L) {
+  Fp12 g; g.c0 = g0; g.c1 = g1;
+  TrioLineMul M;
+  trio_line_mul_prepare(M, g, L);
+  Fp2 p[6]; quad_kprod(p, M.sg, M.bs); fp6_kfin<430>(uu, p);
+}
+BN_DEV void quad_t1_from_products(Fp6& t1, const Fp2 (&p)[5]) {
+  t1.c0 = NS(434, fp2_add(fp2_mul_xi(p[2]), p[0]));
+  t1.c1 = NS(435, fp2_sub(fp2_sub(p[3], p[0]), p[1]));
+  t1.c2 = NS(436, fp2_add(p[4], p[1]));
+}
+BN_DEV void quad_mul_t1(Fp6& t1, const Fp6& g1, const Fp2& b10, const Fp2& b11) {
+  Fp2 p[5];
+  p[0] = fp2_mul(g1.c0, b10); p[1] = fp2_mul(g1.c1, b11); p[2] = fp2_mul(g1.c2, b11);
+  p[3] = fp2_mul(fp2_add(g1.c0, g1.c1), fp2_add(b10, b11)); p[4] = fp2_mul(g1.c2, b10);
+  quad_t1_from_products(t1, p);
+}
+BN_DEV void quad_mul_r0(Fp6& r0, const Fp6& t0, const Fp6& t1) { Fp6 s; fp6_mul_v(s, t1); fp6_add(s, t0, s); fp6_site_r<437>(r0, s); }
+BN_DEV void quad_mul_r1(Fp6& r1, const Fp6& uu, const Fp6& t0, const Fp6& t1) { Fp6 u; fp6_sub(u, uu, t0); fp6_sub(u, u, t1); fp6_site_r<440>(r1, u); }
+// the sequence of steps of the loop: 64 doublings, an addition of +-Q after those with a non-zero digit, then + pi(Q), - pi^2(Q)
+struct QuadSteps { int d, sub, k; };                      // digit index, 0 = doubling / 1 = its addition, step counter
+BN_DEV QuadSteps quad_steps_begin() { QuadSteps s; s.d = 0; s.sub = 0; s.k = 0; return s; }
+// type of the current step: 0 doubling, 1 / -1 addition of +-Q, 2 addition of pi(Q), 3 of -pi^2(Q), 4 = past the end
+BN_DEV int quad_step_type(const QuadSteps& s) { return s.d < 64 ? (s.sub == 0 ? 0 : (int)C_ATE_NAF[s.d]) : s.d == 64 ? 2 : s.d == 65 ? 3 : 4; }
+BN_DEV void quad_step_next(QuadSteps& s) {
+  ++s.k;
+  if (s.d >= 64) { ++s.d; return; }
+  if (s.sub == 0 && C_ATE_NAF[s.d] != 0) { s.sub = 1; return; }
+  s.sub = 0; ++s.d;
+}
+#if !defined(BN_TRIO_DEVICE)
+// host model of the quad-wave kernel: the roles' functions in the order the barriers impose
+BN_DEVM void miller_verify_quad_model(Fp12& f, const G1Affine& pa, const G2Affine& qa, const G1Affine& pb) {
+  fp12_set_one(f);
+  G2Proj t;
+  const bool skip_a = pa.inf || qa.inf, skip_b = pb.inf, any_skip = skip_a || skip_b;
+  t.x = qa.x; t.y = qa.y; t.z = fp2_one();
+  const Fp2 qa_yneg = fp2_neg(qa.y);
+  const Fp2 PAX = fp2_from_fp(pa.x), PAY = fp2_from_fp(pa.y), PBX = fp2_from_fp(pb.x), PBY = fp2_from_fp(pb.y);
+  for (QuadSteps s = quad_steps_begin(); quad_step_type(s) != 4; quad_step_next(s)) {
+    const int ty = quad_step_type(s);
+    Fp2 l0, l1, l2;
+    if (ty == 0) { QuadDblTmp k; quad_dbl_line(l0, l1, l2, k, t, PAX, PAY); quad_dbl_update(t, k); }
+    else {
+      Fp2 qx = qa.x, qy = ty > 0 ? qa.y : qa_yneg;
+      if (ty == 2) { qx = fp2_mul(fp2_conj(qa.x), fp2_load_const(C_TW_FROB_X1)); qy = fp2_mul(fp2_conj(qa.y), fp2_load_const(C_TW_FROB_Y1)); }
+      if (ty == 3) { qx = fp2_mul(qa.x, fp2_load_const(C_TW_FROB_X2)); qy = qa.y; }
+      QuadAddTmp k; quad_add_line(l0, l1, l2, k, t, qx, qy, PAX, PAY); quad_add_squares(k); quad_add_update(t, k);
+    }
+    TrioLineProduct L;
+    quad_line_product(L, l0, l1, l2, s.k, quad_table_m1(s.k, PBX), PBY, skip_a, skip_b, any_skip);
+    Fp6 g0 = f.c0, g1 = f.c1;
+    if (ty == 0) { Fp6 ab, u; quad_sqr_ab(ab, f.c0, f.c1); quad_sqr_u(u, f.c0, f.c1); quad_sqr_g1(g1, ab); quad_sqr_g0(g0, u, ab); }
+    Fp6 t0, uu, t1;
+    quad_mul_t0(t0, g0, L.b0); quad_mul_uu(uu, g0, g1, L); quad_mul_t1(t1, g1, L.b10, L.b11);
+    quad_mul_r0(f.c0, t0, t1); quad_mul_r1(f.c1, uu, t0, t1);
+  }
+}
+#endif
 #endif
 
 // f <- f * lineA(pa) * lineC(pc) for two variable lines: 6 Fq2 products for the line product (Karatsuba over

@@ -19,6 +19,7 @@ OPT_PAIR_LANES = 4
 OPT_RAND_MIN_BATCH = 5
 OPT_TRIO_MAX_BATCH = 6
 OPT_HASH_DIRECT_WIDTH = 7
+OPT_TRIO_WAVE_ROLES = 8
 
 
 class NativeError(RuntimeError):

@@ -231,6 +231,9 @@ int bn254_ctx_set_profiling(bn254_ctx *ctx, int enabled);
                                      three Fq6 products of every Fq12 operation in three lane pairs) — fewer instructions per lane, i.e. lower
                                      latency when the batch cannot fill the chip anyway; same status bytes.  Default 8192 (one wave on each of the
                                      1024 SIMDs: 3.2 ms for 1 verify, 4.1 ms for 8192, against 6.6 / 7.4 ms on lane pairs); 0 = never */
+#define BN254_OPT_TRIO_WAVE_ROLES 8 /* octet layout: 1 (default) = the Miller loop's four lane pairs of a verify are the four WAVES of a workgroup, each
+                                     with its own instruction stream (twist point / line product / the two halves of f), exchanging values
+                                     through LDS between barriers; 0 = four lane pairs of one wave (every pair runs all the linear work) */
 #define BN254_OPT_HASH_DIRECT_WIDTH 7 /* hash-to-G1 of batches of up to 4096 messages: this many counters of every message are tried at once, in
                                        lanes of one wave, with the square root itself (latency 0.17 ms instead of 0.25); a power of two <= 32,
                                        default 32; 0 = always the filter rounds.  Same points and try counts either way. */

@@ -59,6 +59,11 @@ int hp_verify_decoded(const uint8_t* h64, const uint8_t* sig64, const uint8_t* p
     const Fp2* a[6] = {&d1.c0.c0, &d1.c0.c1, &d1.c0.c2, &d1.c1.c0, &d1.c1.c1, &d1.c1.c2};
     const Fp2* b[6] = {&d2.c0.c0, &d2.c0.c1, &d2.c0.c2, &d2.c1.c0, &d2.c1.c1, &d2.c1.c2};
     for (int k = 0; k < 6; ++k) if (!fp2_eq(*a[k], *b[k])) return 254;
+    Fp12 f3, d3;                                     // the same loop as wave roles (k_miller_verify_quad), in barrier order
+    miller_verify_quad_model(f3, h, pk, sig);
+    final_exponentiation(d3, f3, acc);
+    const Fp2* c[6] = {&d3.c0.c0, &d3.c0.c1, &d3.c0.c2, &d3.c1.c0, &d3.c1.c1, &d3.c1.c2};
+    for (int k = 0; k < 6; ++k) if (!fp2_eq(*c[k], *b[k])) return 253;
   }
 #else
   miller_loop<true, true>(f, h, pk, sig);

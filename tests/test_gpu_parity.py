@@ -396,10 +396,11 @@ def test_pair_lanes_and_single_lane_agree(eng, derived):
 
 
 def test_octet_and_pair_layouts_agree_with_oracle(eng, c, derived, kats):
-    """small batches run in the OCTET layout (eight lanes per verify, bn254_trio.hip; default up to 8192 items), larger
-    ones on lane pairs: both against the golden cases, the oracle on ragged sizes with faults of every class, and
+    """small batches run in the OCTET layout (eight lanes per verify, bn254_trio.hip; default up to 8192 items; the Miller loop
+    with the four lane pairs of a verify as four waves with their own roles, or as lane groups of one wave), larger ones on
+    lane pairs: all against the golden cases, the oracle on ragged sizes with faults of every class, and
     check_public_keys; the threshold itself (8192 octet, 8193 pairs) gives the same bytes on either side"""
-    from bn254_amd.engine import OPT_TRIO_MAX_BATCH
+    from bn254_amd.engine import OPT_TRIO_MAX_BATCH, OPT_TRIO_WAVE_ROLES
     from tests.datagen import make_verify_batch
     cs = derived["verify_cases"]
     args = ([H(v["message_hex"]) for v in cs], b"".join(H(v["sig"]) for v in cs), b"".join(H(v["pk"]) for v in cs))
@@ -424,8 +425,10 @@ def test_octet_and_pair_layouts_agree_with_oracle(eng, c, derived, kats):
     cpk_want = bytes(v["status"] for v in cpk) * 3
     edge = make_verify_batch(eng, 8193, corrupt_every=11)
     try:
-        for lim in (1 << 20, 0, 8192):
+        # the octet path's Miller loop as wave roles (default) and as lane groups of one wave; lane pairs; the default threshold
+        for lim, roles in ((1 << 20, 1), (1 << 20, 0), (0, 1), (8192, 1)):
             eng.set_option(OPT_TRIO_MAX_BATCH, lim)
+            eng.set_option(OPT_TRIO_WAVE_ROLES, roles)
             assert list(eng.batch_verify(*args, flags=1)) == want, lim
             for msgs, sigs, pks, oracle in batches:
                 assert eng.batch_verify(msgs, sigs, pks, flags=1) == oracle, (lim, len(msgs))
@@ -434,6 +437,7 @@ def test_octet_and_pair_layouts_agree_with_oracle(eng, c, derived, kats):
             assert eng.batch_verify(edge[0][:8192], edge[1][:8192 * 64], edge[2][:8192 * 128]) == edge[3][:8192], lim
     finally:
         eng.set_option(OPT_TRIO_MAX_BATCH, 8192)
+        eng.set_option(OPT_TRIO_WAVE_ROLES, 1)
 
 
 def test_malformed_inputs_fuzz_vs_oracle(eng, c, derived):

@@ -8,7 +8,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: F401,E402  (one HIP runtime per process: torch first)
 import bn254_amd  # noqa: E402
-from bn254_amd.engine import OPT_TRIO_MAX_BATCH  # noqa: E402
+from bn254_amd.engine import OPT_TRIO_MAX_BATCH, OPT_TRIO_WAVE_ROLES  # noqa: E402
 from oracle import c_oracle as c  # noqa: E402
 from tests.datagen import make_verify_batch  # noqa: E402
 
@@ -24,8 +24,9 @@ for n in SIZES:
     sigs = bytes(sigs)
     want, _ = c.batch_verify(msgs, sigs, pks, flags=0, nthreads=16)
     res = {"n": n}
-    for name, lim in (("pair", 0), ("octet", 1 << 20)):
+    for name, lim, roles in (("pair", 0, 0), ("octet", 1 << 20, 0), ("roles", 1 << 20, 1)):
         eng.set_option(OPT_TRIO_MAX_BATCH, lim)
+        eng.set_option(OPT_TRIO_WAVE_ROLES, roles)
         got = eng.batch_verify(msgs, sigs, pks, flags=0)
         res[name + "_ok"] = got == want
         if got != want:

@@ -4,7 +4,7 @@ import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bn254_amd
-from bn254_amd.engine import OPT_TRIO_MAX_BATCH
+from bn254_amd.engine import OPT_TRIO_MAX_BATCH, OPT_TRIO_WAVE_ROLES
 from tests.datagen import make_verify_batch
 eng = bn254_amd.Engine(0)
 dev = torch.device("cuda", 0)
@@ -16,8 +16,9 @@ for n in [int(x) for x in os.environ.get("TRIO_SIZES", "64,1024,8192").split(","
     d_st = torch.zeros(n, dtype=torch.uint8, device=dev)
     stream = torch.cuda.Stream(device=dev)
     eng.set_profiling(True)
-    for name, lim in (("pair", 0), ("octet", 1 << 20)):
+    for name, lim, roles in (("pair", 0, 0), ("octet", 1 << 20, 0), ("roles", 1 << 20, 1)):
         eng.set_option(OPT_TRIO_MAX_BATCH, lim)
+        eng.set_option(OPT_TRIO_WAVE_ROLES, roles)
         best = None
         for _ in range(4):
             with torch.cuda.stream(stream):
