@@ -341,8 +341,9 @@ BN_DEVM void miller_verify_rounds(Fp12& f, const G1Affine& pa, const G2Affine& q
 //   wave 3  the twist point: the line of the NEXT step (8 products for a doubling, 6 for an addition) and T's update
 //           (4 / 9), one step ahead of the others — it depends on nothing they compute;
 //   wave 2  the product of that line with the table line (7 products), then t1 = g1 * (b10 + b11 v) (5);
-//   wave 0  ab = f0 f1 (6), g1 = 2ab, then t0 = g0 b0 (6) and the half r0 = t0 + v t1 of the new f;
-//   wave 1  u = (f0 + f1)(f0 + v f1) (6), g0 = u - ab - v ab, then (g0 + g1)(b0 + b1) (6) and r1.
+//   wave 0  ab = f0 f1 (6), then t0 = g0 b0 (6);
+//   wave 1  u = (f0 + f1)(f0 + v f1) (6), then uu = (g0 + g1)(b0 + b1) (6);
+//   the recombinations g0 = u - ab - v ab, g1 = 2ab and f0 <- t0 + v t1, f1 <- uu - t0 - t1 one coefficient per wave.
 // Every wave does ~12 products per doubling step and only ITS share of the linear work.  The functions below are the
 // roles' arithmetic — the same formulas and carry sites as the rounds above — as pure functions, so that the host
 // emulation can run them one after the other (miller_verify_quad_model) and prove values and bounds.
@@ -417,11 +418,18 @@ BN_DEV void quad_sqr_u(Fp6& u, const Fp6& f0, const Fp6& f1) {
   fp6_mul_v(w, f1); fp6_add(w, w, f0); fp6_site_n<403>(w, w);
   Fp2 p[6]; quad_kprod(p, s, w); fp6_kfin<410>(u, p);
 }
-BN_DEV void quad_sqr_g1(Fp6& g1, const Fp6& ab) { Fp6 s; fp6_add(s, ab, ab); fp6_site_r<417>(g1, s); }
+// the recombinations one COEFFICIENT at a time (the six coefficients of g and of the new f are spread over the four waves):
+// coefficient K of v x is x_{K-1}, or xi x_2 for K = 0 — the caller passes that neighbour as `below`
+template <int K> BN_DEV Fp2 quad_v_coef(const Fp2& below) { if constexpr (K == 0) return fp2_mul_xi(below); else return below; }
+template <int K> BN_DEV Fp2 quad_g1_coef(const Fp2& ab_k) { return NR(417 + K, fp2_add(ab_k, ab_k)); }
+template <int K> BN_DEV Fp2 quad_g0_coef(const Fp2& u_k, const Fp2& ab_k, const Fp2& ab_below) {
+  return NR(414 + K, fp2_sub(fp2_sub(u_k, ab_k), quad_v_coef<K>(ab_below)));
+}
+template <int K> BN_DEV Fp2 quad_r0_coef(const Fp2& t0_k, const Fp2& t1_below) { return NR(437 + K, fp2_add(t0_k, quad_v_coef<K>(t1_below))); }
+template <int K> BN_DEV Fp2 quad_r1_coef(const Fp2& uu_k, const Fp2& t0_k, const Fp2& t1_k) { return NR(440 + K, fp2_sub(fp2_sub(uu_k, t0_k), t1_k)); }
+BN_DEV void quad_sqr_g1(Fp6& g1, const Fp6& ab) { g1.c0 = quad_g1_coef<0>(ab.c0); g1.c1 = quad_g1_coef<1>(ab.c1); g1.c2 = quad_g1_coef<2>(ab.c2); }
 BN_DEV void quad_sqr_g0(Fp6& g0, const Fp6& u, const Fp6& ab) {
-  Fp6 s, t;
-  fp6_sub(t, u, ab); fp6_mul_v(s, ab); fp6_sub(t, t, s);
-  fp6_site_r<414>(g0, t);
+  g0.c0 = quad_g0_coef<0>(u.c0, ab.c0, ab.c2); g0.c1 = quad_g0_coef<1>(u.c1, ab.c1, ab.c0); g0.c2 = quad_g0_coef<2>(u.c2, ab.c2, ab.c1);
 }
 // waves 0 / 1 / 2, g * (b0 + (b10 + b11 v) w) (sites 420 .. 445 as in trio_line_mul_prepare / _finish)
 BN_DEV void quad_mul_t0(Fp6& t0, const Fp6& g0, const Fp6& b0) { Fp2 p[6]; quad_kprod(p, g0, b0); fp6_kfin<426>(t0, p); }
@@ -442,8 +450,12 @@ BN_DEV void quad_mul_t1(Fp6& t1, const Fp6& g1, const Fp2& b10, const Fp2& b11) 
   p[3] = fp2_mul(fp2_add(g1.c0, g1.c1), fp2_add(b10, b11)); p[4] = fp2_mul(g1.c2, b10);
   quad_t1_from_products(t1, p);
 }
-BN_DEV void quad_mul_r0(Fp6& r0, const Fp6& t0, const Fp6& t1) { Fp6 s; fp6_mul_v(s, t1); fp6_add(s, t0, s); fp6_site_r<437>(r0, s); }
-BN_DEV void quad_mul_r1(Fp6& r1, const Fp6& uu, const Fp6& t0, const Fp6& t1) { Fp6 u; fp6_sub(u, uu, t0); fp6_sub(u, u, t1); fp6_site_r<440>(r1, u); }
+BN_DEV void quad_mul_r0(Fp6& r0, const Fp6& t0, const Fp6& t1) {
+  r0.c0 = quad_r0_coef<0>(t0.c0, t1.c2); r0.c1 = quad_r0_coef<1>(t0.c1, t1.c0); r0.c2 = quad_r0_coef<2>(t0.c2, t1.c1);
+}
+BN_DEV void quad_mul_r1(Fp6& r1, const Fp6& uu, const Fp6& t0, const Fp6& t1) {
+  r1.c0 = quad_r1_coef<0>(uu.c0, t0.c0, t1.c0); r1.c1 = quad_r1_coef<1>(uu.c1, t0.c1, t1.c1); r1.c2 = quad_r1_coef<2>(uu.c2, t0.c2, t1.c2);
+}
 // the sequence of steps of the loop: 64 doublings, an addition of +-Q after those with a non-zero digit, then + pi(Q), - pi^2(Q)
 struct QuadSteps { int d, sub, k; };                      // digit index, 0 = doubling / 1 = its addition, step counter
 BN_DEV QuadSteps quad_steps_begin() { QuadSteps s; s.d = 0; s.sub = 0; s.k = 0; return s; }

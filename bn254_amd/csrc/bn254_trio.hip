@@ -71,20 +71,27 @@ KERNEL_TRIO void k_final_exp_trio(size_t n, Ws ws, int use_hash, uint8_t* status
 
 // ---- the Miller loop of a verify as WAVE ROLES (bn254_pairing.h: quad_*): the four lane pairs of a verify in the four waves
 // of a workgroup (pair p of every wave = verify 32 * blockIdx + p), Fq2 values handed over through LDS mailboxes between
-// workgroup barriers — four per loop step, the same in every wave.  Mailbox layout: [slot][limb][lane of the wave]
-// (consecutive lanes, consecutive words).
-enum { QS_LINE = 0, QS_LP = 6, QS_AB = 11, QS_G0 = 14, QS_G1 = 17, QS_T0 = 20, QS_T1 = 23, QS_F0 = 26, QS_F1 = 29, QS_SLOTS = 32 };
-#define BN_QUAD_LDS_WORDS (QS_SLOTS * BN_LIMBS * BN_WAVE)
+// workgroup barriers — four per loop step, the same in every wave.
+enum { QS_LINE = 0, QS_LP = 6, QS_AB = 11, QS_U = 14, QS_G0 = 17, QS_G1 = 20, QS_T0 = 23, QS_UU = 26, QS_T1 = 29, QS_F0 = 32, QS_F1 = 35, QS_SLOTS = 38 };
+// a mailbox: [slot][lane of the wave][12 words] — nine limbs in three 16-byte-aligned accesses (b128, b128, b32); the stride of
+// 12 words keeps the 16 lanes of a b128 pass on distinct banks
+#define BN_QUAD_STRIDE 12
+#define BN_QUAD_LDS_WORDS (QS_SLOTS * BN_QUAD_STRIDE * BN_WAVE)
+static_assert(BN_LIMBS == 9, "mailbox accessors move 4 + 4 + 1 limbs");
+typedef int32_t bn_i4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void qbox_put(int slot, const Fp2& x) {
-  const unsigned at = (unsigned)slot * BN_LIMBS * BN_WAVE + (threadIdx.x & 63u);
-#pragma unroll
-  for (int k = 0; k < BN_LIMBS; ++k) bn_trio_lds[at + k * BN_WAVE] = x.c[0].v[k];
+  int32_t* at = bn_trio_lds + ((unsigned)slot * BN_WAVE + (threadIdx.x & 63u)) * BN_QUAD_STRIDE;
+  const int32_t* v = x.c[0].v;
+  *(bn_i4*)at = bn_i4{v[0], v[1], v[2], v[3]};
+  *(bn_i4*)(at + 4) = bn_i4{v[4], v[5], v[6], v[7]};
+  at[8] = v[8];
 }
 __device__ __forceinline__ Fp2 qbox_get(int slot) {
-  const unsigned at = (unsigned)slot * BN_LIMBS * BN_WAVE + (threadIdx.x & 63u);
+  const int32_t* at = bn_trio_lds + ((unsigned)slot * BN_WAVE + (threadIdx.x & 63u)) * BN_QUAD_STRIDE;
+  const bn_i4 lo = *(const bn_i4*)at, hi = *(const bn_i4*)(at + 4);
   Fp2 x;
-#pragma unroll
-  for (int k = 0; k < BN_LIMBS; ++k) x.c[0].v[k] = bn_trio_lds[at + k * BN_WAVE];
+  int32_t* v = x.c[0].v;
+  v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w; v[8] = at[8];
   return x;
 }
 __device__ __forceinline__ void qbox_put6(int slot, const Fp6& x) { qbox_put(slot, x.c0); qbox_put(slot + 1, x.c1); qbox_put(slot + 2, x.c2); }
@@ -94,14 +101,17 @@ __device__ __forceinline__ void qbox_get6(Fp6& x, int slot) { x.c0 = qbox_get(sl
 // the register allocation of a role then covers that role's values only.
 struct QuadIn { Fp2 PAX, PAY, PBX, PBY; G2Affine pk; bool skip_a, skip_b, any_skip; };
 #define QUAD_BARRIER() __syncthreads()
-// wave 0: ab = f0 f1, g1 = 2ab; t0 = g0 b0; f0 <- t0 + v t1
+// The recombinations are spread one coefficient per wave (interval after barriers 1 and 3):
+//   g1 = 2ab: wave 0;  g0_0: wave 1, g0_1: wave 2, g0_2: wave 3;   f0_0, f0_1: wave 0, f0_2: wave 3;  f1_0, f1_1: wave 1, f1_2: wave 2.
+// wave 0: ab = f0 f1; t0 = g0 b0
 __device__ __noinline__ void quad_role0(Fp6& f0) {
   f0.c0 = fp2_one(); f0.c1 = fp2_zero(); f0.c2 = fp2_zero();
   qbox_put6(QS_F0, f0);
   QUAD_BARRIER();
   for (QuadSteps s = quad_steps_begin(); quad_step_type(s) != 4; quad_step_next(s)) {
     const bool dbl = quad_step_type(s) == 0;
-    Fp6 ab, g0, t0, t1, x;
+    Fp6 ab, g0, t0, x;
+    f0.c2 = qbox_get(QS_F0 + 2);
     if (dbl) { qbox_get6(x, QS_F1); quad_sqr_ab(ab, f0, x); qbox_put6(QS_AB, ab); }
     QUAD_BARRIER();
     if (dbl) { quad_sqr_g1(x, ab); qbox_put6(QS_G1, x); }
@@ -111,34 +121,39 @@ __device__ __noinline__ void quad_role0(Fp6& f0) {
     quad_mul_t0(t0, g0, x);
     qbox_put6(QS_T0, t0);
     QUAD_BARRIER();
-    qbox_get6(t1, QS_T1);
-    quad_mul_r0(f0, t0, t1);
-    qbox_put6(QS_F0, f0);
+    f0.c0 = quad_r0_coef<0>(t0.c0, qbox_get(QS_T1 + 2));
+    f0.c1 = quad_r0_coef<1>(t0.c1, qbox_get(QS_T1));
+    qbox_put(QS_F0, f0.c0); qbox_put(QS_F0 + 1, f0.c1);
     QUAD_BARRIER();
   }
+  f0.c2 = qbox_get(QS_F0 + 2);
 }
-// wave 1: u = (f0 + f1)(f0 + v f1), g0 = u - ab - v ab; uu = (g0 + g1)(b0 + b1); f1 <- uu - t0 - t1
+// wave 1: u = (f0 + f1)(f0 + v f1); uu = (g0 + g1)(b0 + b1)
 __device__ __noinline__ void quad_role1(Fp6& f1) {
   f1.c0 = fp2_zero(); f1.c1 = fp2_zero(); f1.c2 = fp2_zero();
   qbox_put6(QS_F1, f1);
   QUAD_BARRIER();
   for (QuadSteps s = quad_steps_begin(); quad_step_type(s) != 4; quad_step_next(s)) {
     const bool dbl = quad_step_type(s) == 0;
-    Fp6 u, g0, g1, uu, x, y;
-    if (dbl) { qbox_get6(x, QS_F0); quad_sqr_u(u, x, f1); }
+    Fp6 u, g0, g1, uu, x;
+    f1.c2 = qbox_get(QS_F1 + 2);
+    if (dbl) { qbox_get6(x, QS_F0); quad_sqr_u(u, x, f1); qbox_put(QS_U + 1, u.c1); qbox_put(QS_U + 2, u.c2); }
     QUAD_BARRIER();
-    if (dbl) { qbox_get6(x, QS_AB); quad_sqr_g0(g0, u, x); qbox_put6(QS_G0, g0); }
+    if (dbl) { g0.c0 = quad_g0_coef<0>(u.c0, qbox_get(QS_AB), qbox_get(QS_AB + 2)); qbox_put(QS_G0, g0.c0); }
     QUAD_BARRIER();
-    if (dbl) qbox_get6(g1, QS_G1); else { qbox_get6(g0, QS_F0); g1 = f1; }
+    if (dbl) { g0.c1 = qbox_get(QS_G0 + 1); g0.c2 = qbox_get(QS_G0 + 2); qbox_get6(g1, QS_G1); }
+    else { qbox_get6(g0, QS_F0); g1 = f1; }
     TrioLineProduct L;
     qbox_get6(L.b0, QS_LP); L.b10 = qbox_get(QS_LP + 3); L.b11 = qbox_get(QS_LP + 4);
     quad_mul_uu(uu, g0, g1, L);
+    qbox_put(QS_UU + 2, uu.c2);
     QUAD_BARRIER();
-    qbox_get6(x, QS_T0); qbox_get6(y, QS_T1);
-    quad_mul_r1(f1, uu, x, y);
-    qbox_put6(QS_F1, f1);
+    f1.c0 = quad_r1_coef<0>(uu.c0, qbox_get(QS_T0), qbox_get(QS_T1));
+    f1.c1 = quad_r1_coef<1>(uu.c1, qbox_get(QS_T0 + 1), qbox_get(QS_T1 + 1));
+    qbox_put(QS_F1, f1.c0); qbox_put(QS_F1 + 1, f1.c1);
     QUAD_BARRIER();
   }
+  f1.c2 = qbox_get(QS_F1 + 2);
 }
 // wave 2: the product of the step's line with the table line; t1 = g1 (b10 + b11 v)
 __device__ __noinline__ void quad_role2(const QuadIn& in) {
@@ -154,6 +169,7 @@ __device__ __noinline__ void quad_role2(const QuadIn& in) {
       qbox_put6(QS_LP, L.b0); qbox_put(QS_LP + 3, L.b10); qbox_put(QS_LP + 4, L.b11);
     }
     QUAD_BARRIER();
+    if (dbl) qbox_put(QS_G0 + 1, quad_g0_coef<1>(qbox_get(QS_U + 1), qbox_get(QS_AB + 1), qbox_get(QS_AB)));
     QUAD_BARRIER();
     Fp6 g1, t1;
     qbox_get6(g1, dbl ? QS_G1 : QS_F1);
@@ -161,6 +177,7 @@ __device__ __noinline__ void quad_role2(const QuadIn& in) {
     qbox_put6(QS_T1, t1);
     if (s.k + 1 < BN_N_FIXED_LINES) m1 = quad_table_m1(s.k + 1, in.PBX);   // for the next step
     QUAD_BARRIER();
+    qbox_put(QS_F1 + 2, quad_r1_coef<2>(qbox_get(QS_UU + 2), qbox_get(QS_T0 + 2), t1.c2));
     QUAD_BARRIER();
   }
 }
@@ -195,10 +212,12 @@ __device__ __noinline__ void quad_role3(const QuadIn& in) {
   for (QuadSteps s = quad_steps_begin(); quad_step_type(s) != 4; quad_step_next(s), quad_step_next(ahead)) {
     quad_t_line(ahead, in, t, qa_yneg, kd, ka);
     QUAD_BARRIER();
+    if (quad_step_type(s) == 0) qbox_put(QS_G0 + 2, quad_g0_coef<2>(qbox_get(QS_U + 2), qbox_get(QS_AB + 2), qbox_get(QS_AB + 1)));
     QUAD_BARRIER();
     const int ty = quad_step_type(ahead);
     if (ty == 0) quad_dbl_update(t, kd); else if (ty != 4) quad_add_update(t, ka);
     QUAD_BARRIER();
+    qbox_put(QS_F0 + 2, quad_r0_coef<2>(qbox_get(QS_T0 + 2), qbox_get(QS_T1 + 1)));
     QUAD_BARRIER();
   }
 }
