@@ -34,7 +34,7 @@ def build(force=False, verbose=False):
         subprocess.check_call(["python3", gen], stdout=None if verbose else subprocess.DEVNULL)
     if force or _stale():
         hipcc = os.environ.get("HIPCC", "hipcc")
-        cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB_PATH, os.path.join(_CSRC, "bn254_hip.hip"), os.path.join(_CSRC, "bn254_pair.hip"), os.path.join(_CSRC, "bn254_trio.hip")]
+        cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB_PATH, os.path.join(_CSRC, "bn254_hip.hip"), os.path.join(_CSRC, "bn254_pair.hip"), os.path.join(_CSRC, "bn254_trio.hip"), os.path.join(_CSRC, "bn254_quad.hip")]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

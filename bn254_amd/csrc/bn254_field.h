@@ -956,6 +956,40 @@ BN_DEVF void fp12_mul_hot(Fp12& r, const Fp12& a, const Fp12& b) { fp12_mul_body
 // Values are exchanged through LDS.  BN_TRIO_FORMULAS selects the FORMULAS of that layout in any build — the host
 // emulations use it to run the same arithmetic, bound tracker included, with the products of a group computed one after
 // the other; BN_TRIO_DEVICE adds the lane-group machinery.
+#if defined(BN_QUAD_DEVICE)
+// ---- wave roles (bn254_quad.hip): the four lane pairs of a verify are the four WAVES of a workgroup; Fq2 values cross
+// waves through LDS mailboxes between workgroup barriers.  A mailbox: [slot][lane of the wave][12 words] — nine limbs in
+// three 16-byte-aligned accesses (b128, b128, b32); the stride of 12 words keeps the 16 lanes of a b128 pass on distinct banks.
+}  // namespace bn254
+extern __shared__ int32_t bn_trio_lds[];
+namespace bn254 {
+#define BN_QUAD_WG 256
+#define BN_QUAD_STRIDE 12
+#define BN_QUAD_SLOT_WORDS (BN_QUAD_STRIDE * 64)
+static_assert(BN_LIMBS == 9, "mailbox accessors move 4 + 4 + 1 limbs");
+typedef int32_t bn_i4 __attribute__((ext_vector_type(4)));
+BN_DEV int quad_wave() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }     // the wave's role, 0..3 (scalar)
+BN_DEV void qbox_put(int slot, const Fp2& x) {
+  int32_t* at = bn_trio_lds + ((unsigned)slot * 64 + (threadIdx.x & 63u)) * BN_QUAD_STRIDE;
+  const int32_t* v = x.c[0].v;
+  *(bn_i4*)at = bn_i4{v[0], v[1], v[2], v[3]};
+  *(bn_i4*)(at + 4) = bn_i4{v[4], v[5], v[6], v[7]};
+  at[8] = v[8];
+}
+BN_DEV Fp2 qbox_get(int slot) {
+  const int32_t* at = bn_trio_lds + ((unsigned)slot * 64 + (threadIdx.x & 63u)) * BN_QUAD_STRIDE;
+  const bn_i4 lo = *(const bn_i4*)at, hi = *(const bn_i4*)(at + 4);
+  Fp2 x;
+  int32_t* v = x.c[0].v;
+  v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w; v[8] = at[8];
+  return x;
+}
+BN_DEV void qbox_put6(int slot, const Fp6& x) { qbox_put(slot, x.c0); qbox_put(slot + 1, x.c1); qbox_put(slot + 2, x.c2); }
+BN_DEV void qbox_get6(Fp6& x, int slot) { x.c0 = qbox_get(slot); x.c1 = qbox_get(slot + 1); x.c2 = qbox_get(slot + 2); }
+// workgroup barrier for the mailboxes: only LDS traffic has to be complete (lgkmcnt) — __syncthreads() also waits for every
+// outstanding scratch / global store (vmcnt(0)), ~0.5 us per barrier here, several hundred barriers per verify
+#define QUAD_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
 #if defined(BN_TRIO_DEVICE)
 }  // namespace bn254
 extern __shared__ int32_t bn_trio_lds[];          // dynamic LDS of the octet kernels: [accumulator slots | Fq6 exchange | Fq2 exchange]

@@ -100,5 +100,6 @@ __attribute__((visibility("hidden"))) int bn254_pair_decompress_g2(const uint8_t
 
 // entry points of bn254_trio.hip (octet layout for small batches)
 __attribute__((visibility("hidden"))) int bn254_trio_miller_verify(size_t n, Ws ws, hipStream_t s, int mode = 0);
-__attribute__((visibility("hidden"))) int bn254_quad_miller_verify(size_t n, Ws ws, hipStream_t s, int mode = 0);   // wave roles instead of lane groups
+// entry points of bn254_quad.hip (the same with the four lane pairs of a verify as four waves with roles)
+__attribute__((visibility("hidden"))) int bn254_quad_miller_verify(size_t n, Ws ws, hipStream_t s, int mode = 0);
 __attribute__((visibility("hidden"))) int bn254_trio_final_exp(size_t n, Ws ws, int use_hash, uint8_t* status_out, hipStream_t s);
