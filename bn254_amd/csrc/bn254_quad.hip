@@ -5,7 +5,7 @@
 // runs its own instruction stream and the waves exchange Fq2 values through LDS mailboxes between workgroup barriers
 // (bn254_field.h: BN_QUAD_DEVICE; roles of the Miller loop: bn254_pairing.h quad_*).  One workgroup per CU, one wave per
 // SIMD; same formulas and carry sites as the octet layout (BN_TRIO_FORMULAS), proven on the host by
-// tests/hostsim/libhostsim_trio*.so (miller_verify_quad_model).  The final exponentiation stays in the octet layout
+// the emulation builds of tests/hostsim (miller_verify_quad_model).  The final exponentiation stays in the octet layout
 // (bn254_trio.hip): measured as wave roles too — an Fq12 product as four Fq6 products in four waves, a cyclotomic squaring as
 // three Fq4 squares in three — 1.23 ms against 1.12 ms: per operation the two barriers with an LDS round trip between
 // them cost what the replicated linear work costs inside one wave.
