@@ -4,7 +4,7 @@
 
 #define BN_WAVE 64
 #define BN_SPLIT_MAX_N ((size_t)98304)   // <= 1.5 waves per SIMD with one lane per verify
-#define TRIO_MAX_BATCH_DEFAULT 8192                // octet layout up to one wave per SIMD (1024 SIMDs x 8 verifies per wave): 4.1 ms vs 7.4 ms at 8192
+#define TRIO_MAX_BATCH_DEFAULT 16384               // octet layout up to TWO passes of one wave per SIMD (1024 SIMDs x 8 verifies): 3.5 ms at 8192, 6.5 ms at 16384 (lane pairs: 7.1 / 7.9 ms)
 #define TRIO_WAVE_ROLES_DEFAULT 1                  // ... with the Miller loop as wave roles (k_miller_verify_quad)
 #define RAND_MIN_BATCH_DEFAULT 131072              // randomised verify pays off from about here
 #define RAND_TWO_PER_LANE_MIN_N ((size_t)131072)   // randomised verify: two items per lane once that still fills 1024 SIMDs

@@ -396,7 +396,7 @@ def test_pair_lanes_and_single_lane_agree(eng, derived):
 
 
 def test_octet_and_pair_layouts_agree_with_oracle(eng, c, derived, kats):
-    """small batches run in the OCTET layout (eight lanes per verify, bn254_trio.hip; default up to 8192 items; the Miller loop
+    """small batches run in the OCTET layout (eight lanes per verify, bn254_trio.hip; default up to 16384 items; the Miller loop
     with the four lane pairs of a verify as four waves with their own roles, or as lane groups of one wave), larger ones on
     lane pairs: all against the golden cases, the oracle on ragged sizes with faults of every class, and
     check_public_keys; the threshold itself (8192 octet, 8193 pairs) gives the same bytes on either side"""
@@ -426,7 +426,7 @@ def test_octet_and_pair_layouts_agree_with_oracle(eng, c, derived, kats):
     edge = make_verify_batch(eng, 8193, corrupt_every=11)
     try:
         # the octet path's Miller loop as wave roles (default) and as lane groups of one wave; lane pairs; the default threshold
-        for lim, roles in ((1 << 20, 1), (1 << 20, 0), (0, 1), (8192, 1)):
+        for lim, roles in ((1 << 20, 1), (1 << 20, 0), (0, 1), (8192, 1)):      # 8192: the edge batch of 8193 on lane pairs, its first 8192 in octets
             eng.set_option(OPT_TRIO_MAX_BATCH, lim)
             eng.set_option(OPT_TRIO_WAVE_ROLES, roles)
             assert list(eng.batch_verify(*args, flags=1)) == want, lim
@@ -436,7 +436,7 @@ def test_octet_and_pair_layouts_agree_with_oracle(eng, c, derived, kats):
             assert eng.batch_verify(edge[0], edge[1], edge[2]) == edge[3], lim
             assert eng.batch_verify(edge[0][:8192], edge[1][:8192 * 64], edge[2][:8192 * 128]) == edge[3][:8192], lim
     finally:
-        eng.set_option(OPT_TRIO_MAX_BATCH, 8192)
+        eng.set_option(OPT_TRIO_MAX_BATCH, 16384)                     # the defaults
         eng.set_option(OPT_TRIO_WAVE_ROLES, 1)
 
 
