@@ -946,7 +946,7 @@ static int launch_hash_rounds(bn254_ctx* c, hipStream_t s, const uint8_t* d_msgs
 
 extern "C" {
 
-const char* bn254_version(void) { return "bn254-mi355x 0.4 (gfx950; 9x29-bit balanced Montgomery limbs; verify on lane pairs)"; }
+const char* bn254_version(void) { return "bn254-mi355x 0.5 (gfx950; 9x29-bit balanced Montgomery limbs; verify on lane pairs, batches <= 16384 on lane octets with wave roles)"; }
 
 int bn254_ctx_create(int hip_device, bn254_ctx** out) {
   if (!out) return BN254_E_BAD_ARGUMENT;
