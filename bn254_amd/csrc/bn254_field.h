@@ -1055,11 +1055,16 @@ template <int K> BN_DEV Fp2 fp6_kop(const Fp6& x) {
   else if constexpr (K == 4) return fp2_add(x.c0, x.c1);
   else return fp2_add(x.c0, x.c2);
 }
+// coefficient K of that result from the four products it depends on: p0, p1, p2 and pk = p[3 + K]
+template <int S, int K> BN_DEV Fp2 fp6_kfin_coef(const Fp2& p0, const Fp2& p1, const Fp2& p2, const Fp2& pk) {
+  if constexpr (K == 0) return NS(S + 1, fp2_add(fp2_mul_xi(NS(S, fp2_sub(fp2_sub(pk, p1), p2))), p0));
+  else if constexpr (K == 1) return NS(S + 2, fp2_add(fp2_sub(fp2_sub(pk, p0), p1), fp2_mul_xi(p2)));
+  else return NS(S + 3, fp2_add(fp2_sub(fp2_sub(pk, p0), p2), p1));
+}
 template <int S> BN_DEV void fp6_kfin(Fp6& r, const Fp2 (&p)[6]) {   // p: x0y0, x1y1, x2y2, (x1+x2)(y1+y2), (x0+x1)(y0+y1), (x0+x2)(y0+y2)
-  Fp2 c0 = fp2_add(fp2_mul_xi(NS(S, fp2_sub(fp2_sub(p[3], p[1]), p[2]))), p[0]);
-  Fp2 c1 = fp2_add(fp2_sub(fp2_sub(p[4], p[0]), p[1]), fp2_mul_xi(p[2]));
-  Fp2 c2 = fp2_add(fp2_sub(fp2_sub(p[5], p[0]), p[2]), p[1]);
-  r.c0 = NS(S + 1, c0); r.c1 = NS(S + 2, c1); r.c2 = NS(S + 3, c2);
+  r.c0 = fp6_kfin_coef<S, 0>(p[0], p[1], p[2], p[3]);
+  r.c1 = fp6_kfin_coef<S, 1>(p[0], p[1], p[2], p[4]);
+  r.c2 = fp6_kfin_coef<S, 2>(p[0], p[1], p[2], p[5]);
 }
 // an Fq scalar as an Fq2 value (k + 0 i), so that a scaling by it can ride in a round as an ordinary Fq2 product
 BN_DEV Fp2 fp2_from_fp(const Fp& k) { return fp2_make(k, fp_zero()); }

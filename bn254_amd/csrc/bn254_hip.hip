@@ -1017,7 +1017,7 @@ int bn254_ctx_set_option(bn254_ctx* c, int option, int value) {
   if (option == BN254_OPT_RAND_MIN_BATCH) { if (value < 0) return BN254_E_BAD_ARGUMENT; c->rand_min_batch = value; return 0; }
   if (option == BN254_OPT_RAND_ITEMS_PER_LANE) { if (value < 0 || value > 2) return BN254_E_BAD_ARGUMENT; c->rand_items_per_lane = value; return 0; }
   if (option == BN254_OPT_TRIO_MAX_BATCH) { if (value < 0) return BN254_E_BAD_ARGUMENT; c->trio_max_batch = value; return 0; }
-  if (option == BN254_OPT_TRIO_WAVE_ROLES) { c->trio_wave_roles = value != 0; return 0; }
+  if (option == BN254_OPT_TRIO_WAVE_ROLES) { if (value < 0 || value > 2) return BN254_E_BAD_ARGUMENT; c->trio_wave_roles = value; return 0; }
   if (option == BN254_OPT_HASH_DIRECT_WIDTH) {
     if (value < 0 || value > 32 || (value & (value - 1))) return BN254_E_BAD_ARGUMENT;
     c->hash_direct_width = value;
@@ -1041,7 +1041,8 @@ int bn254_ctx_last_kernel_ms(bn254_ctx* c, float ms[4]) {
 static int launch_pair_or_trio(bn254_ctx* c, hipStream_t s, size_t n, int use_hash, uint8_t* d_status, int mode, bool mark) {
   int rc;
   if (c->trio_max_batch > 0 && n <= (size_t)c->trio_max_batch) {
-    if ((rc = c->trio_wave_roles ? bn254_quad_miller_verify(n, c->ws, s, mode) : bn254_trio_miller_verify(n, c->ws, s, mode))) return rc;
+    if ((rc = c->trio_wave_roles == 2 ? bn254_w8_miller_verify(n, c->ws, s, mode)
+              : c->trio_wave_roles ? bn254_quad_miller_verify(n, c->ws, s, mode) : bn254_trio_miller_verify(n, c->ws, s, mode))) return rc;
     if (mark) PROF_MARK(3);
     return bn254_trio_final_exp(n, c->ws, use_hash, d_status, s);
   }

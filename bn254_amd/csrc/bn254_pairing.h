@@ -498,6 +498,287 @@ BN_DEVM void miller_verify_quad_model(Fp12& f, const G1Affine& pa, const G2Affin
   }
 }
 #endif
+
+// ---- EIGHT wave roles (bn254_quad.hip: k_miller_verify_w8) ------------------------------------------------------------------
+// With four waves every wave carries ~12 products per doubling step, one after the other.  Eight waves (two per SIMD of a
+// CU, each still at the lone-wave issue rate) halve that: every Karatsuba Fq6 product of the f-chain is split over two
+// waves (products K = 0, 1, 2 / K = 3, 4, 5), its coefficients are formed one per wave in a short phase after a barrier,
+// the product of the lines and the twist-point step are split over two waves each:
+//   A0, A1  ab = f0 f1, then t0 = g0 b0            B0, B1  u = (f0 + f1)(f0 + v f1), then uu = (g0 + g1)(b0 + b1)
+//   L0, L1  (l0 + l1 w + l2 w^3)(m0 + m1 w + w^3) with b10 = l0 m1 + l1 m0 as two products (no cross dependency), then
+//           t1 = g1 (b10 + b11 v)
+//   T0, T1  the twist point, one step ahead: T0 the y / z side (b, c, e; theta), T1 the x side (y z, x^2; mu); h = 2 y z
+// Phases of a step, each closed by a workgroup barrier: I1 (products) | C1 (coefficients of ab, u, the line product) |
+// G (g0, g1; doubling steps only) | I2 (products) | C2 (coefficients of t0, uu, t1) | F (the new f).
+// The functions are templates over the mailbox (`Box`: get(slot) / put(slot, value)): the kernel passes LDS, the host
+// model an array — the same source runs in both, the model executing the eight roles of a phase one after the other.
+enum { W8_F0 = 0, W8_F1 = 3, W8_P = 6, W8_C = 23, W8_LP = 32, W8_LINE = 37, W8_TC = 45, W8_TA = 48, W8_M0 = 51, W8_SLOTS = 52 };
+// W8_P: 17 products (stage 1: ab 0..5, u 6..11; stage 2: t0 0..5, uu 6..11, t1 12..16).  W8_C: ab 0..2 | g0 3..5 | g1 6..8, in
+// stage 2 t0 0..2 | t1 3..5; the six products of the line product use 3..8 between I1 and C1.  W8_LINE: 2 x (l0, l1, l2 | ca, cb).
+// W8_M0: C0 * y_B of the next step's table line, computed by T1 (two products in its I2 against L0's three) for L0.
+enum { W8_A0 = 0, W8_A1, W8_B0, W8_B1, W8_L0, W8_L1, W8_T0, W8_T1 };
+struct W8In { Fp2 PAX, PAY, PBX, PBY; G2Affine pk; Fp2 pk_yneg; bool skip_a, skip_b, any_skip; };
+struct W8Regs {                    // what a role keeps in registers between phases (each role uses its own subset)
+  Fp2 p0, p1, p2;                  // A / B: own products of the current stage;  L: own products
+  Fp2 c;                           // own coefficient (ab_k / u_k, later t0_k / uu_k)
+  Fp2 l0, l1, l2, m;               // L: the step's line (after the skip selects), own table-line scaling m0 / m1
+  Fp2 b10, b11;                    // L
+  G2Proj t;                        // T
+  Fp2 a0, a1, a2;                  // T: values of the step in flight (b, e | yz-side; theta, c | mu, d, e)
+  Fp2 qx, qy;                      // T: the point added in the step in flight
+};
+template <class Box> BN_DEV void w8_get6(Fp6& x, Box& bx, int slot) { x.c0 = bx.get(slot); x.c1 = bx.get(slot + 1); x.c2 = bx.get(slot + 2); }
+// operand K of a Karatsuba Fq6 product for K = 0..2 (h = 0) or 3..5 (h = 1), j = 0, 1, 2
+template <int H, int J> BN_DEV Fp2 w8_kop(const Fp6& x) { return fp6_kop<3 * H + J>(x); }
+template <int H> BN_DEV void w8_half_products(W8Regs& r, const Fp6& x, const Fp6& y) {
+  r.p0 = fp2_mul(w8_kop<H, 0>(x), w8_kop<H, 0>(y)); r.p1 = fp2_mul(w8_kop<H, 1>(x), w8_kop<H, 1>(y)); r.p2 = fp2_mul(w8_kop<H, 2>(x), w8_kop<H, 2>(y));
+}
+// ---- phase I1
+template <int ROLE, class Box> BN_DEV void w8_phase_i1(W8Regs& r, Box& bx, const W8In& in, int ty, int k, int ty_next) {
+  if constexpr (ROLE == W8_A0 || ROLE == W8_A1 || ROLE == W8_B0 || ROLE == W8_B1) {
+    if (ty != 0) return;                                        // no squaring in an addition step
+    Fp6 f0, f1;
+    w8_get6(f0, bx, W8_F0); w8_get6(f1, bx, W8_F1);
+    constexpr int H = (ROLE == W8_A1 || ROLE == W8_B1) ? 1 : 0;
+    if constexpr (ROLE == W8_A0 || ROLE == W8_A1) {
+      w8_half_products<H>(r, f0, f1);
+      bx.put(W8_P + 3 * H, r.p0); bx.put(W8_P + 3 * H + 1, r.p1); bx.put(W8_P + 3 * H + 2, r.p2);
+    } else {
+      Fp6 s, w;
+      fp6_add(s, f0, f1); fp6_site_n<400>(s, s);
+      fp6_mul_v(w, f1); fp6_add(w, w, f0); fp6_site_n<403>(w, w);
+      w8_half_products<H>(r, s, w);
+      bx.put(W8_P + 6 + 3 * H, r.p0); bx.put(W8_P + 6 + 3 * H + 1, r.p1); bx.put(W8_P + 6 + 3 * H + 2, r.p2);
+    }
+  } else if constexpr (ROLE == W8_L0 || ROLE == W8_L1) {
+    const int at = W8_LINE + 4 * (k & 1);
+    r.l0 = bx.get(at); r.l1 = bx.get(at + 1);
+    if (ty == 0) r.l2 = bx.get(at + 2);
+    else r.l2 = NS(223, fp2_sub(bx.get(at + 2), bx.get(at + 3)));        // theta x_Q - mu y_Q
+    if (in.any_skip) {
+      r.l2 = fp2_select(in.skip_a, fp2_zero(), r.l2);
+      r.l0 = fp2_select(in.skip_a, fp2_one(), r.l0);
+      r.l1 = fp2_select(in.skip_a, fp2_zero(), r.l1);
+    }
+    if constexpr (ROLE == W8_L0) {                               // m = m0 (from T1): w3p = l2 m0, v0 = l0 m0, l1 m0
+      r.m = bx.get(W8_M0);
+      r.p0 = fp2_mul(r.l2, r.m); r.p1 = fp2_mul(r.l0, r.m); r.p2 = fp2_mul(r.l1, r.m);
+      bx.put(W8_C + 3, r.p0); bx.put(W8_C + 4, r.p1); bx.put(W8_C + 5, r.p2);
+    } else {                                                     // m = m1: w4p = l2 m1, v1 = l1 m1, l0 m1
+      r.p0 = fp2_mul(r.l2, r.m); r.p1 = fp2_mul(r.l1, r.m); r.p2 = fp2_mul(r.l0, r.m);
+      bx.put(W8_C + 6, r.p0); bx.put(W8_C + 7, r.p1); bx.put(W8_C + 8, r.p2);
+    }
+  } else {                                                       // T0 / T1: the line of the NEXT step (type ty_next, index k + 1)
+    if (ty_next == 4) return;
+    r.t.x = bx.get(W8_TC); r.t.y = bx.get(W8_TC + 1); r.t.z = bx.get(W8_TC + 2);
+    const int at = W8_LINE + 4 * ((k + 1) & 1);
+    if (ty_next == 0) {
+      if constexpr (ROLE == W8_T0) {
+        const Fp2 b = fp2_mul(r.t.y, r.t.y), c = fp2_sqr(r.t.z);
+        const Fp2 e = fp2_mul(c, fp2_load_const(C_TWIST_3B));
+        bx.put(at + 2, NS(223, fp2_sub(b, e)));
+        r.a0 = b; r.a1 = e;
+        bx.put(W8_TA, b); bx.put(W8_TA + 1, e);
+      } else {
+        const Fp2 yz = fp2_mul(r.t.y, r.t.z), x2 = fp2_sqr(r.t.x);
+        const Fp2 h = NS(207, fp2_dbl(yz));                     // (y + z)^2 - y^2 - z^2
+        bx.put(at, fp2_mul(h, in.PAY));
+        bx.put(at + 1, fp2_mul(fp2_neg(fp2_add(fp2_dbl(x2), x2)), in.PAX));
+        r.a0 = h;
+        bx.put(W8_TA + 2, h);
+      }
+    } else {
+      r.qx = in.pk.x; r.qy = ty_next > 0 ? in.pk.y : in.pk_yneg;
+      if (ty_next == 2) { r.qx = fp2_mul(fp2_conj(in.pk.x), fp2_load_const(C_TW_FROB_X1)); r.qy = fp2_mul(fp2_conj(in.pk.y), fp2_load_const(C_TW_FROB_Y1)); }
+      if (ty_next == 3) { r.qx = fp2_mul(in.pk.x, fp2_load_const(C_TW_FROB_X2)); r.qy = in.pk.y; }
+      if constexpr (ROLE == W8_T0) {                             // theta side
+        const Fp2 theta = NS(210, fp2_sub(r.t.y, fp2_mul(r.qy, r.t.z)));
+        bx.put(at + 2, fp2_mul(theta, r.qx));
+        bx.put(at + 1, fp2_mul(fp2_neg(theta), in.PAX));
+        const Fp2 c = fp2_sqr(theta);
+        r.a0 = theta;
+        bx.put(W8_TA, fp2_mul(r.t.z, c));                        // F = Z theta^2
+      } else {                                                   // mu side
+        const Fp2 mu = NS(211, fp2_sub(r.t.x, fp2_mul(r.qx, r.t.z)));
+        bx.put(at + 3, fp2_mul(mu, r.qy));
+        bx.put(at, fp2_mul(mu, in.PAY));
+        const Fp2 d = fp2_sqr(mu);
+        const Fp2 e = fp2_mul(mu, d), g = fp2_mul(r.t.x, d);
+        r.a0 = mu; r.a1 = e;
+        bx.put(W8_TA + 1, e); bx.put(W8_TA + 2, g);
+      }
+    }
+  }
+}
+// ---- phase C1: coefficients of ab and u (doubling steps), the line product
+template <int ROLE, class Box> BN_DEV void w8_phase_c1(W8Regs& r, Box& bx, const W8In& in, int ty) {
+  if constexpr (ROLE == W8_A0) { if (ty == 0) { r.c = fp6_kfin_coef<406, 0>(r.p0, r.p1, r.p2, bx.get(W8_P + 3)); bx.put(W8_C, r.c); } }
+  else if constexpr (ROLE == W8_A1) { if (ty == 0) { r.c = fp6_kfin_coef<406, 1>(bx.get(W8_P), bx.get(W8_P + 1), bx.get(W8_P + 2), r.p1); bx.put(W8_C + 1, r.c); } }
+  else if constexpr (ROLE == W8_T0) { if (ty == 0) { r.a2 = fp6_kfin_coef<406, 2>(bx.get(W8_P), bx.get(W8_P + 1), bx.get(W8_P + 2), bx.get(W8_P + 5)); bx.put(W8_C + 2, r.a2); } }
+  else if constexpr (ROLE == W8_B0) { if (ty == 0) r.c = fp6_kfin_coef<410, 0>(r.p0, r.p1, r.p2, bx.get(W8_P + 9)); }
+  else if constexpr (ROLE == W8_B1) { if (ty == 0) r.c = fp6_kfin_coef<410, 1>(bx.get(W8_P + 6), bx.get(W8_P + 7), bx.get(W8_P + 8), r.p1); }
+  else if constexpr (ROLE == W8_T1) { if (ty == 0) r.a2 = fp6_kfin_coef<410, 2>(bx.get(W8_P + 6), bx.get(W8_P + 7), bx.get(W8_P + 8), bx.get(W8_P + 11)); }
+  else if constexpr (ROLE == W8_L0) {                            // own: w3p, v0, l1 m0
+    Fp2 b00 = NS(224, fp2_add(r.p1, fp2_mul_xi(r.l2)));
+    r.b11 = NS(227, fp2_add(r.l0, r.p0));
+    if (in.any_skip) { b00 = fp2_select(in.skip_b, r.l0, b00); r.b11 = fp2_select(in.skip_b, r.l2, r.b11); }
+    bx.put(W8_LP, b00); bx.put(W8_LP + 4, r.b11);
+  } else {                                                       // L1, own: w4p, v1, l0 m1
+    Fp2 b01 = r.p1, b02 = NS(225, fp2_add(r.l1, r.p0));
+    r.b10 = NS(226, fp2_add(r.p2, bx.get(W8_C + 5)));            // l0 m1 + l1 m0
+    if (in.any_skip) {
+      b01 = fp2_select(in.skip_b, fp2_zero(), b01); b02 = fp2_select(in.skip_b, fp2_zero(), b02);
+      r.b10 = fp2_select(in.skip_b, r.l1, r.b10);
+    }
+    bx.put(W8_LP + 1, b01); bx.put(W8_LP + 2, b02); bx.put(W8_LP + 3, r.b10);
+  }
+}
+// ---- phase G (doubling steps): g1_k = 2 ab_k, g0_k = u_k - ab_k - (v ab)_k
+template <int ROLE, class Box> BN_DEV void w8_phase_g(W8Regs& r, Box& bx) {
+  if constexpr (ROLE == W8_A0) bx.put(W8_C + 6, quad_g1_coef<0>(r.c));
+  else if constexpr (ROLE == W8_A1) bx.put(W8_C + 7, quad_g1_coef<1>(r.c));
+  else if constexpr (ROLE == W8_T0) bx.put(W8_C + 8, quad_g1_coef<2>(r.a2));
+  else if constexpr (ROLE == W8_B0) bx.put(W8_C + 3, quad_g0_coef<0>(r.c, bx.get(W8_C), bx.get(W8_C + 2)));
+  else if constexpr (ROLE == W8_B1) bx.put(W8_C + 4, quad_g0_coef<1>(r.c, bx.get(W8_C + 1), bx.get(W8_C)));
+  else if constexpr (ROLE == W8_T1) bx.put(W8_C + 5, quad_g0_coef<2>(r.a2, bx.get(W8_C + 2), bx.get(W8_C + 1)));
+}
+// ---- phase I2: products of g * (line product); the twist point's update; the table-line scaling of the next step
+template <int ROLE, class Box> BN_DEV void w8_phase_i2(W8Regs& r, Box& bx, const W8In& in, int ty, int k, int ty_next) {
+  const int g0_at = ty == 0 ? W8_C + 3 : W8_F0, g1_at = ty == 0 ? W8_C + 6 : W8_F1;
+  if constexpr (ROLE == W8_A0 || ROLE == W8_A1) {
+    constexpr int H = ROLE == W8_A1 ? 1 : 0;
+    Fp6 g0, b0;
+    w8_get6(g0, bx, g0_at); w8_get6(b0, bx, W8_LP);
+    w8_half_products<H>(r, g0, b0);
+    bx.put(W8_P + 3 * H, r.p0); bx.put(W8_P + 3 * H + 1, r.p1); bx.put(W8_P + 3 * H + 2, r.p2);
+  } else if constexpr (ROLE == W8_B0 || ROLE == W8_B1) {
+    constexpr int H = ROLE == W8_B1 ? 1 : 0;
+    Fp12 g;
+    TrioLineProduct L;
+    w8_get6(g.c0, bx, g0_at); w8_get6(g.c1, bx, g1_at);
+    w8_get6(L.b0, bx, W8_LP); L.b10 = bx.get(W8_LP + 3); L.b11 = bx.get(W8_LP + 4);
+    TrioLineMul M;
+    trio_line_mul_prepare(M, g, L);
+    w8_half_products<H>(r, M.sg, M.bs);
+    bx.put(W8_P + 6 + 3 * H, r.p0); bx.put(W8_P + 6 + 3 * H + 1, r.p1); bx.put(W8_P + 6 + 3 * H + 2, r.p2);
+  } else if constexpr (ROLE == W8_L0) {
+    Fp6 g1;
+    w8_get6(g1, bx, g1_at);
+    const Fp2 b10 = bx.get(W8_LP + 3);
+    r.p0 = fp2_mul(g1.c0, b10); r.p1 = fp2_mul(g1.c1, r.b11); r.p2 = fp2_mul(g1.c2, r.b11);
+    bx.put(W8_P + 12, r.p0); bx.put(W8_P + 13, r.p1); bx.put(W8_P + 14, r.p2);
+  } else if constexpr (ROLE == W8_L1) {
+    Fp6 g1;
+    w8_get6(g1, bx, g1_at);
+    const Fp2 b11 = bx.get(W8_LP + 4);
+    r.p0 = fp2_mul(fp2_add(g1.c0, g1.c1), fp2_add(r.b10, b11)); r.p1 = fp2_mul(g1.c2, r.b10);
+    bx.put(W8_P + 15, r.p0); bx.put(W8_P + 16, r.p1);
+    if (k + 1 < BN_N_FIXED_LINES) r.m = fp2_mul(fp2_load_const(C_NEG_G2_LINES[k + 1][1]), in.PBX);
+  } else {                                                       // T0 / T1: update for the step whose line went out in I1
+    if constexpr (ROLE == W8_T1) { if (k + 1 < BN_N_FIXED_LINES) bx.put(W8_M0, fp2_mul(fp2_load_const(C_NEG_G2_LINES[k + 1][0]), in.PBY)); }
+    if (ty_next == 4) return;
+    if (ty_next == 0) {
+      if constexpr (ROLE == W8_T0) {                             // y, z of 2T: has b, e; h from T1
+        const Fp2 h = bx.get(W8_TA + 2);
+        const Fp2 e2 = fp2_sqr(r.a1), f3 = fp2_add(fp2_dbl(r.a1), r.a1);
+        const Fp2 bf = NS(204, fp2_add(r.a0, f3));
+        const Fp2 oz = fp2_mul(r.a0, h), oy2 = fp2_sqr(bf);
+        const Fp2 e2x4 = NS(201, fp2_dbl(fp2_dbl(e2)));
+        bx.put(W8_TC + 1, NS(205, fp2_sub(oy2, fp2_add(fp2_dbl(e2x4), e2x4))));
+        bx.put(W8_TC + 2, NS(206, fp2_dbl(fp2_dbl(oz))));
+      } else {                                                   // x of 2T: b, e from T0
+        const Fp2 b = bx.get(W8_TA), e = bx.get(W8_TA + 1);
+        const Fp2 f3 = fp2_add(fp2_dbl(e), e);
+        const Fp2 xy = fp2_mul(r.t.x, r.t.y);
+        bx.put(W8_TC, NS(203, fp2_mul(fp2_dbl(xy), NS(202, fp2_sub(b, f3)))));
+      }
+    } else {
+      const Fp2 ff = bx.get(W8_TA), e = bx.get(W8_TA + 1), g = bx.get(W8_TA + 2);
+      const Fp2 h = NS(212, fp2_sub(fp2_sub(fp2_add(e, ff), g), g));
+      if constexpr (ROLE == W8_T0) {                             // Y3 = theta (G - H) - E Y
+        const Fp2 oy1 = fp2_mul(r.a0, NS(213, fp2_sub(g, h))), oy2 = fp2_mul(e, r.t.y);
+        bx.put(W8_TC + 1, NS(214, fp2_sub(oy1, oy2)));
+      } else {                                                   // X3 = mu H, Z3 = Z E
+        bx.put(W8_TC, fp2_mul(r.a0, h));
+        bx.put(W8_TC + 2, fp2_mul(r.t.z, e));
+      }
+    }
+  }
+}
+// ---- phase C2: coefficients of t0, uu, t1
+template <int ROLE, class Box> BN_DEV void w8_phase_c2(W8Regs& r, Box& bx) {
+  if constexpr (ROLE == W8_A0) { r.c = fp6_kfin_coef<426, 0>(r.p0, r.p1, r.p2, bx.get(W8_P + 3)); bx.put(W8_C, r.c); }
+  else if constexpr (ROLE == W8_A1) { r.c = fp6_kfin_coef<426, 1>(bx.get(W8_P), bx.get(W8_P + 1), bx.get(W8_P + 2), r.p1); bx.put(W8_C + 1, r.c); }
+  else if constexpr (ROLE == W8_T0) { r.a2 = fp6_kfin_coef<426, 2>(bx.get(W8_P), bx.get(W8_P + 1), bx.get(W8_P + 2), bx.get(W8_P + 5)); bx.put(W8_C + 2, r.a2); }
+  else if constexpr (ROLE == W8_B0) r.c = fp6_kfin_coef<430, 0>(r.p0, r.p1, r.p2, bx.get(W8_P + 9));
+  else if constexpr (ROLE == W8_B1) r.c = fp6_kfin_coef<430, 1>(bx.get(W8_P + 6), bx.get(W8_P + 7), bx.get(W8_P + 8), r.p1);
+  else if constexpr (ROLE == W8_T1) r.a2 = fp6_kfin_coef<430, 2>(bx.get(W8_P + 6), bx.get(W8_P + 7), bx.get(W8_P + 8), bx.get(W8_P + 11));
+  else if constexpr (ROLE == W8_L0) {                            // t1_0 = xi p2 + p0, t1_2 = p4 + p1
+    bx.put(W8_C + 3, NS(434, fp2_add(fp2_mul_xi(r.p2), r.p0)));
+    bx.put(W8_C + 5, NS(436, fp2_add(bx.get(W8_P + 16), r.p1)));
+  } else bx.put(W8_C + 4, NS(435, fp2_sub(fp2_sub(r.p0, bx.get(W8_P + 12)), bx.get(W8_P + 13))));    // L1: t1_1 = p3 - p0 - p1
+}
+// ---- phase F: f0_k = t0_k + (v t1)_k, f1_k = uu_k - t0_k - t1_k
+template <int ROLE, class Box> BN_DEV void w8_phase_f(W8Regs& r, Box& bx) {
+  if constexpr (ROLE == W8_A0) bx.put(W8_F0, quad_r0_coef<0>(r.c, bx.get(W8_C + 5)));
+  else if constexpr (ROLE == W8_A1) bx.put(W8_F0 + 1, quad_r0_coef<1>(r.c, bx.get(W8_C + 3)));
+  else if constexpr (ROLE == W8_T0) bx.put(W8_F0 + 2, quad_r0_coef<2>(r.a2, bx.get(W8_C + 4)));
+  else if constexpr (ROLE == W8_B0) bx.put(W8_F1, quad_r1_coef<0>(r.c, bx.get(W8_C), bx.get(W8_C + 3)));
+  else if constexpr (ROLE == W8_B1) bx.put(W8_F1 + 1, quad_r1_coef<1>(r.c, bx.get(W8_C + 1), bx.get(W8_C + 4)));
+  else if constexpr (ROLE == W8_T1) bx.put(W8_F1 + 2, quad_r1_coef<2>(r.a2, bx.get(W8_C + 2), bx.get(W8_C + 5)));
+}
+// before the loop: f = 1, T = Q, the table-line scalings of step 0; then the T waves run I1 / I2 once for step 0 (k = -1)
+template <int ROLE, class Box> BN_DEV void w8_init(W8Regs& r, Box& bx, const W8In& in) {
+  if constexpr (ROLE == W8_A0) { bx.put(W8_F0, fp2_one()); bx.put(W8_F0 + 1, fp2_zero()); bx.put(W8_F0 + 2, fp2_zero()); }
+  else if constexpr (ROLE == W8_B0) { bx.put(W8_F1, fp2_zero()); bx.put(W8_F1 + 1, fp2_zero()); bx.put(W8_F1 + 2, fp2_zero()); }
+  else if constexpr (ROLE == W8_L1) r.m = fp2_mul(fp2_load_const(C_NEG_G2_LINES[0][1]), in.PBX);
+  else if constexpr (ROLE == W8_T0) { bx.put(W8_TC + 1, in.pk.y); bx.put(W8_TC + 2, fp2_one()); }
+  else if constexpr (ROLE == W8_T1) bx.put(W8_TC, in.pk.x);
+}
+#if !defined(BN_TRIO_DEVICE) && !defined(BN_QUAD_DEVICE)
+// host model of k_miller_verify_w8: the same role / phase functions over an array mailbox, the eight roles of a phase one
+// after the other, the phases in barrier order
+struct W8HostBox { Fp2 v[W8_SLOTS]; Fp2 get(int s) const { return v[s]; } void put(int s, const Fp2& x) { v[s] = x; } };
+#define W8_ALL_ROLES(CALL) CALL(W8_A0) CALL(W8_A1) CALL(W8_B0) CALL(W8_B1) CALL(W8_L0) CALL(W8_L1) CALL(W8_T0) CALL(W8_T1)
+BN_DEVM void miller_verify_w8_model(Fp12& f, const G1Affine& pa, const G2Affine& qa, const G1Affine& pb) {
+  W8In in;
+  in.skip_a = pa.inf || qa.inf; in.skip_b = pb.inf; in.any_skip = in.skip_a || in.skip_b;
+  in.pk = qa; in.pk_yneg = fp2_neg(qa.y);
+  in.PAX = fp2_from_fp(pa.x); in.PAY = fp2_from_fp(pa.y); in.PBX = fp2_from_fp(pb.x); in.PBY = fp2_from_fp(pb.y);
+  W8HostBox bx;
+  for (int i = 0; i < W8_SLOTS; ++i) bx.v[i] = fp2_zero();
+  W8Regs r[8];
+  for (int w = 0; w < 8; ++w) { r[w].p0 = r[w].p1 = r[w].p2 = r[w].c = r[w].l0 = r[w].l1 = r[w].l2 = r[w].m = r[w].b10 = r[w].b11 = fp2_zero();
+    r[w].a0 = r[w].a1 = r[w].a2 = r[w].qx = r[w].qy = fp2_zero(); r[w].t.x = r[w].t.y = r[w].t.z = fp2_zero(); }
+#define W8_INIT(R) w8_init<R>(r[R], bx, in);
+  W8_ALL_ROLES(W8_INIT)
+  QuadSteps s = quad_steps_begin();
+  {                                                              // the twist waves' head start: line and update of step 0
+    const int ty0 = quad_step_type(s);
+    w8_phase_i1<W8_T0>(r[W8_T0], bx, in, 4, -1, ty0); w8_phase_i1<W8_T1>(r[W8_T1], bx, in, 4, -1, ty0);
+    w8_phase_i2<W8_T0>(r[W8_T0], bx, in, 4, -1, ty0); w8_phase_i2<W8_T1>(r[W8_T1], bx, in, 4, -1, ty0);
+  }
+  for (; quad_step_type(s) != 4; quad_step_next(s)) {
+    const int ty = quad_step_type(s);
+    QuadSteps nx = s; quad_step_next(nx);
+    const int ty_next = quad_step_type(nx);
+#define W8_I1(R) w8_phase_i1<R>(r[R], bx, in, ty, s.k, ty_next);
+#define W8_C1(R) w8_phase_c1<R>(r[R], bx, in, ty);
+#define W8_G(R) w8_phase_g<R>(r[R], bx);
+#define W8_I2(R) w8_phase_i2<R>(r[R], bx, in, ty, s.k, ty_next);
+#define W8_C2(R) w8_phase_c2<R>(r[R], bx);
+#define W8_F(R) w8_phase_f<R>(r[R], bx);
+    W8_ALL_ROLES(W8_I1)
+    W8_ALL_ROLES(W8_C1)
+    if (ty == 0) { W8_ALL_ROLES(W8_G) }
+    W8_ALL_ROLES(W8_I2)
+    W8_ALL_ROLES(W8_C2)
+    W8_ALL_ROLES(W8_F)
+  }
+  f.c0.c0 = bx.v[W8_F0]; f.c0.c1 = bx.v[W8_F0 + 1]; f.c0.c2 = bx.v[W8_F0 + 2];
+  f.c1.c0 = bx.v[W8_F1]; f.c1.c1 = bx.v[W8_F1 + 1]; f.c1.c2 = bx.v[W8_F1 + 2];
+}
+#endif
 #endif
 
 // f <- f * lineA(pa) * lineC(pc) for two variable lines: 6 Fq2 products for the line product (Karatsuba over

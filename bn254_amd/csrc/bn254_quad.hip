@@ -193,4 +193,80 @@ int bn254_quad_miller_verify(size_t n, Ws ws, hipStream_t s, int mode) {
   return 0;
 }
 
-
+// ---- the same loop on EIGHT waves (bn254_pairing.h: w8_*): a 512-thread workgroup, two waves per SIMD, 32 verifies; every
+// Fq6 product of the f-chain, the product of the lines and the twist-point step are split over two waves each, six phases
+// per doubling step (five per addition step), each closed by a barrier.  One function per role.
+#define BN_W8_WG 512
+#define BN_W8_LDS_WORDS (W8_SLOTS * BN_QUAD_SLOT_WORDS)
+#define KERNEL_W8 __global__ __launch_bounds__(BN_W8_WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
+struct W8LdsBox {
+  __device__ __forceinline__ Fp2 get(int slot) const { return qbox_get(slot); }
+  __device__ __forceinline__ void put(int slot, const Fp2& x) const { qbox_put(slot, x); }
+};
+template <int ROLE> __device__ __noinline__ void w8_role(const W8In& in) {
+  W8Regs r;
+  W8LdsBox bx;
+  constexpr bool TWIST = ROLE == W8_T0 || ROLE == W8_T1;
+  w8_init<ROLE>(r, bx, in);
+  QUAD_BARRIER();
+  QuadSteps s = quad_steps_begin();
+  if constexpr (TWIST) w8_phase_i1<ROLE>(r, bx, in, 4, -1, quad_step_type(s));     // head start: line of step 0 ...
+  QUAD_BARRIER();
+  if constexpr (TWIST) w8_phase_i2<ROLE>(r, bx, in, 4, -1, quad_step_type(s));     // ... and its update
+  QUAD_BARRIER();
+  for (; quad_step_type(s) != 4; quad_step_next(s)) {
+    const int ty = quad_step_type(s);
+    QuadSteps nx = s;
+    quad_step_next(nx);
+    const int ty_next = quad_step_type(nx);
+    w8_phase_i1<ROLE>(r, bx, in, ty, s.k, ty_next);
+    QUAD_BARRIER();
+    w8_phase_c1<ROLE>(r, bx, in, ty);
+    QUAD_BARRIER();
+    if (ty == 0) { w8_phase_g<ROLE>(r, bx); QUAD_BARRIER(); }
+    w8_phase_i2<ROLE>(r, bx, in, ty, s.k, ty_next);
+    QUAD_BARRIER();
+    w8_phase_c2<ROLE>(r, bx);
+    QUAD_BARRIER();
+    w8_phase_f<ROLE>(r, bx);
+    QUAD_BARRIER();
+  }
+}
+KERNEL_W8 void k_miller_verify_w8(size_t n, Ws ws, int mode) {
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // the wave's role
+  size_t i = (size_t)blockIdx.x * 32 + ((threadIdx.x & 63u) >> 1);
+  const bool live = i < n;
+  if (!live) i = n - 1;                                 // no early exit: the barriers need all eight waves
+  {
+    G1Affine sig, h;
+    W8In in;
+    ws_load_g1(ws, PL_P1X, BY_P1_INF, i, sig);
+    if (mode == 1) { h.x = fp_load_const(C_G1_GEN[0]); h.y = fp_load_const(C_G1_GEN[1]); h.inf = false; }   // uniform
+    else ws_load_g1(ws, PL_P2X, BY_P2_INF, i, h);
+    in.pk.x = ws_load_fp2_role(ws, PL_QX0, i);
+    in.pk.y = ws_load_fp2_role(ws, PL_QY0, i);
+    in.pk.inf = ws_byte(ws, BY_Q_INF, i) != 0;
+    in.pk_yneg = fp2_neg(in.pk.y);
+    in.skip_a = h.inf || in.pk.inf; in.skip_b = sig.inf;
+    in.any_skip = __builtin_amdgcn_ballot_w64(in.skip_a || in.skip_b) != 0;
+    in.PAX = fp2_from_fp(h.x); in.PAY = fp2_from_fp(h.y); in.PBX = fp2_from_fp(sig.x); in.PBY = fp2_from_fp(sig.y);
+    switch (w) {
+      case W8_A0: w8_role<W8_A0>(in); break;
+      case W8_A1: w8_role<W8_A1>(in); break;
+      case W8_B0: w8_role<W8_B0>(in); break;
+      case W8_B1: w8_role<W8_B1>(in); break;
+      case W8_L0: w8_role<W8_L0>(in); break;
+      case W8_L1: w8_role<W8_L1>(in); break;
+      case W8_T0: w8_role<W8_T0>(in); break;
+      default: w8_role<W8_T1>(in); break;
+    }
+  }
+  if (!live || w > 1) return;                           // waves A0 / A1 write f0 / f1 out (complete behind the last barrier)
+#pragma unroll
+  for (int k = 0; k < 3; ++k) ws_store_fp(ws, PL_F0 + 6 * w + 2 * k + (int)(threadIdx.x & 1u), i, qbox_get((w == 0 ? W8_F0 : W8_F1) + k).c[0]);
+}
+int bn254_w8_miller_verify(size_t n, Ws ws, hipStream_t s, int mode) {
+  k_miller_verify_w8<<<(unsigned)((n + 31) / 32), BN_W8_WG, BN_W8_LDS_WORDS * sizeof(int32_t), s>>>(n, ws, mode);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}

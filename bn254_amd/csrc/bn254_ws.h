@@ -5,7 +5,7 @@
 #define BN_WAVE 64
 #define BN_SPLIT_MAX_N ((size_t)98304)   // <= 1.5 waves per SIMD with one lane per verify
 #define TRIO_MAX_BATCH_DEFAULT 16384               // octet layout up to TWO passes of one wave per SIMD (1024 SIMDs x 8 verifies): 3.5 ms at 8192, 6.5 ms at 16384 (lane pairs: 7.1 / 7.9 ms)
-#define TRIO_WAVE_ROLES_DEFAULT 1                  // ... with the Miller loop as wave roles (k_miller_verify_quad)
+#define TRIO_WAVE_ROLES_DEFAULT 2                  // ... with the Miller loop as wave roles: 2 = eight waves per 32 verifies (k_miller_verify_w8), 1 = four
 #define RAND_MIN_BATCH_DEFAULT 131072              // randomised verify pays off from about here
 #define RAND_TWO_PER_LANE_MIN_N ((size_t)131072)   // randomised verify: two items per lane once that still fills 1024 SIMDs
 // Register budget: amdgpu_waves_per_eu(W, W) on the kernels is propagated to every device function
@@ -102,4 +102,5 @@ __attribute__((visibility("hidden"))) int bn254_pair_decompress_g2(const uint8_t
 __attribute__((visibility("hidden"))) int bn254_trio_miller_verify(size_t n, Ws ws, hipStream_t s, int mode = 0);
 // entry points of bn254_quad.hip (the same with the four lane pairs of a verify as four waves with roles)
 __attribute__((visibility("hidden"))) int bn254_quad_miller_verify(size_t n, Ws ws, hipStream_t s, int mode = 0);
+__attribute__((visibility("hidden"))) int bn254_w8_miller_verify(size_t n, Ws ws, hipStream_t s, int mode = 0);      // eight waves per 32 verifies
 __attribute__((visibility("hidden"))) int bn254_trio_final_exp(size_t n, Ws ws, int use_hash, uint8_t* status_out, hipStream_t s);

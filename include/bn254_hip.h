@@ -232,9 +232,10 @@ int bn254_ctx_set_profiling(bn254_ctx *ctx, int enabled);
                                      latency when the batch cannot fill the chip anyway; same status bytes.  Default 16384 (two passes of one wave
                                      on each of the 1024 SIMDs: 2.5 ms for 1 verify, 3.5 ms for 8192, 6.5 ms for 16384, against 6.2 / 7.1 /
                                      7.9 ms on lane pairs); 0 = never */
-#define BN254_OPT_TRIO_WAVE_ROLES 8 /* octet layout: 1 (default) = the Miller loop's four lane pairs of a verify are the four WAVES of a workgroup, each
-                                     with its own instruction stream (twist point / line product / the two halves of f), exchanging values
-                                     through LDS between barriers; 0 = four lane pairs of one wave (every pair runs all the linear work) */
+#define BN254_OPT_TRIO_WAVE_ROLES 8 /* octet path, Miller loop: the lane pairs of a verify as WAVES of a workgroup, each with its own instruction
+                                     stream (twist point / line product / the halves of f), values exchanged through LDS between barriers:
+                                     2 (default) = eight waves per 32 verifies (every Fq6 product split over two waves), 1 = four waves,
+                                     0 = four lane pairs of one wave (every pair runs all the linear work).  Same status bytes. */
 #define BN254_OPT_HASH_DIRECT_WIDTH 7 /* hash-to-G1 of batches of up to 4096 messages: this many counters of every message are tried at once, in
                                        lanes of one wave, with the square root itself (latency 0.17 ms instead of 0.25); a power of two <= 32,
                                        default 32; 0 = always the filter rounds.  Same points and try counts either way. */

@@ -64,6 +64,11 @@ int hp_verify_decoded(const uint8_t* h64, const uint8_t* sig64, const uint8_t* p
     final_exponentiation(d3, f3, acc);
     const Fp2* c[6] = {&d3.c0.c0, &d3.c0.c1, &d3.c0.c2, &d3.c1.c0, &d3.c1.c1, &d3.c1.c2};
     for (int k = 0; k < 6; ++k) if (!fp2_eq(*c[k], *b[k])) return 253;
+    Fp12 f4, d4;                                     // ... and as eight wave roles (k_miller_verify_w8), phase by phase
+    miller_verify_w8_model(f4, h, pk, sig);
+    final_exponentiation(d4, f4, acc);
+    const Fp2* e[6] = {&d4.c0.c0, &d4.c0.c1, &d4.c0.c2, &d4.c1.c0, &d4.c1.c1, &d4.c1.c2};
+    for (int k = 0; k < 6; ++k) if (!fp2_eq(*e[k], *b[k])) return 252;
   }
 #else
   miller_loop<true, true>(f, h, pk, sig);

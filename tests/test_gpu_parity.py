@@ -425,8 +425,8 @@ def test_octet_and_pair_layouts_agree_with_oracle(eng, c, derived, kats):
     cpk_want = bytes(v["status"] for v in cpk) * 3
     edge = make_verify_batch(eng, 8193, corrupt_every=11)
     try:
-        # the octet path's Miller loop as wave roles (default) and as lane groups of one wave; lane pairs; the default threshold
-        for lim, roles in ((1 << 20, 1), (1 << 20, 0), (0, 1), (8192, 1)):      # 8192: the edge batch of 8193 on lane pairs, its first 8192 in octets
+        # the octet path's Miller loop as eight (default) / four wave roles and as lane groups of one wave; lane pairs; the default threshold
+        for lim, roles in ((1 << 20, 2), (1 << 20, 1), (1 << 20, 0), (0, 2), (8192, 2)):   # 8192: the edge batch of 8193 on lane pairs, its first 8192 in octets
             eng.set_option(OPT_TRIO_MAX_BATCH, lim)
             eng.set_option(OPT_TRIO_WAVE_ROLES, roles)
             assert list(eng.batch_verify(*args, flags=1)) == want, lim
@@ -437,7 +437,7 @@ def test_octet_and_pair_layouts_agree_with_oracle(eng, c, derived, kats):
             assert eng.batch_verify(edge[0][:8192], edge[1][:8192 * 64], edge[2][:8192 * 128]) == edge[3][:8192], lim
     finally:
         eng.set_option(OPT_TRIO_MAX_BATCH, 16384)                     # the defaults
-        eng.set_option(OPT_TRIO_WAVE_ROLES, 1)
+        eng.set_option(OPT_TRIO_WAVE_ROLES, 2)
 
 
 def test_malformed_inputs_fuzz_vs_oracle(eng, c, derived):

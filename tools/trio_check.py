@@ -24,7 +24,7 @@ for n in SIZES:
     sigs = bytes(sigs)
     want, _ = c.batch_verify(msgs, sigs, pks, flags=0, nthreads=16)
     res = {"n": n}
-    for name, lim, roles in (("pair", 0, 0), ("octet", 1 << 20, 0), ("roles", 1 << 20, 1)):
+    for name, lim, roles in (("pair", 0, 0), ("octet", 1 << 20, 0), ("roles", 1 << 20, 1), ("roles8", 1 << 20, 2)):
         eng.set_option(OPT_TRIO_MAX_BATCH, lim)
         eng.set_option(OPT_TRIO_WAVE_ROLES, roles)
         got = eng.batch_verify(msgs, sigs, pks, flags=0)

@@ -16,7 +16,7 @@ for n in [int(x) for x in os.environ.get("TRIO_SIZES", "64,1024,8192").split(","
     d_st = torch.zeros(n, dtype=torch.uint8, device=dev)
     stream = torch.cuda.Stream(device=dev)
     eng.set_profiling(True)
-    for name, lim, roles in (("pair", 0, 0), ("octet", 1 << 20, 0), ("roles", 1 << 20, 1)):
+    for name, lim, roles in (("pair", 0, 0), ("octet", 1 << 20, 0), ("roles", 1 << 20, 1), ("roles8", 1 << 20, 2)):
         eng.set_option(OPT_TRIO_MAX_BATCH, lim)
         eng.set_option(OPT_TRIO_WAVE_ROLES, roles)
         best = None
