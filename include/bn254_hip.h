@@ -230,7 +230,7 @@ int bn254_ctx_set_profiling(bn254_ctx *ctx, int enabled);
 #define BN254_OPT_TRIO_MAX_BATCH 6 /* verify / check_public_keys batches of up to this many items run in the OCTET layout (eight lanes per item: the
                                      three Fq6 products of every Fq12 operation in three lane pairs) — fewer instructions per lane, i.e. lower
                                      latency when the batch cannot fill the chip anyway; same status bytes.  Default 16384 (two passes of one wave
-                                     on each of the 1024 SIMDs: 2.5 ms for 1 verify, 3.5 ms for 8192, 6.5 ms for 16384, against 6.2 / 7.1 /
+                                     on each of the 1024 SIMDs: 2.3 ms for 1 verify, 3.3 ms for 8192, 6.3 ms for 16384, against 6.4 / 7.1 /
                                      7.9 ms on lane pairs); 0 = never */
 #define BN254_OPT_TRIO_WAVE_ROLES 8 /* octet path, Miller loop: the lane pairs of a verify as WAVES of a workgroup, each with its own instruction
                                      stream (twist point / line product / the halves of f), values exchanged through LDS between barriers:
