@@ -44,7 +44,7 @@ def soak(args):
     """run the differential for args.seconds with args.seed; returns the summary, raises SoakMismatch on a difference
     (tests/test_gpu_fullsize.py runs a slice of it in the driver-run suite)"""
     import bn254_amd
-    from bn254_amd.engine import OPT_PAIR_LANES, OPT_RAND_MIN_BATCH
+    from bn254_amd.engine import OPT_PAIR_LANES, OPT_RAND_MIN_BATCH, OPT_TRIO_MAX_BATCH, OPT_TRIO_WAVE_ROLES
     from oracle import c_oracle as c
     from tests.datagen import sk_bytes
     eng = bn254_amd.Engine(0)
@@ -94,7 +94,15 @@ def soak(args):
         seed = rnd.randbytes(32)
         for flags in (0, 1):
             want, _ = c.batch_verify(msgs, sigs, pks, flags=flags, nthreads=cores)
-            got = {"pair": eng.batch_verify(msgs, sigs, pks, flags=flags)}
+            # the small-batch layouts (defaults: eight wave roles up to 16384 items), then the lane pairs for the same batch
+            got = {"roles8": eng.batch_verify(msgs, sigs, pks, flags=flags)}
+            for name, roles in (("roles4", 1), ("octet", 0)):
+                eng.set_option(OPT_TRIO_WAVE_ROLES, roles)
+                got[name] = eng.batch_verify(msgs, sigs, pks, flags=flags)
+            eng.set_option(OPT_TRIO_WAVE_ROLES, 2)
+            eng.set_option(OPT_TRIO_MAX_BATCH, 0)
+            got["pair"] = eng.batch_verify(msgs, sigs, pks, flags=flags)
+            eng.set_option(OPT_TRIO_MAX_BATCH, 16384)
             eng.set_option(OPT_PAIR_LANES, 0)
             got["single"] = eng.batch_verify(msgs, sigs, pks, flags=flags)
             eng.set_option(OPT_PAIR_LANES, 1)
