@@ -164,9 +164,9 @@ def soak(args):
         if time.time() - last_note > 60:          # a progress line a minute (a silent GPU command is taken to be hung)
             last_note = time.time()
             print("soak: %d s, %d rounds, %d tuples, no mismatch" % (last_note - t0, rounds, items), flush=True)
-    res = {"rounds": rounds, "tuples": items, "comparisons": items * 2 * 5, "seconds": round(time.time() - t0, 1), "oracle_threads": cores,
+    res = {"rounds": rounds, "tuples": items, "comparisons": items * 2 * 8, "seconds": round(time.time() - t0, 1), "oracle_threads": cores,
            "status_histogram": {str(k): v for k, v in sorted(codes.items())}, "mismatches": 0, "seed": args.seed, "also_compared": extra,
-           "modes": ["exact on lane pairs", "exact, one lane per verify", "randomised 128-bit", "randomised GLV", "randomised 64-bit"],
+           "modes": ["exact, eight wave roles", "exact, four wave roles", "exact, lane groups of one wave (octet)", "exact on lane pairs", "exact, one lane per verify", "randomised 128-bit", "randomised GLV", "randomised 64-bit"],
            "flags": [0, 1]}
     return res
 
