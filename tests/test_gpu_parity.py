@@ -438,6 +438,10 @@ def test_octet_and_pair_layouts_agree_with_oracle(eng, c, derived, kats):
     finally:
         eng.set_option(OPT_TRIO_MAX_BATCH, 16384)                     # the defaults
         eng.set_option(OPT_TRIO_WAVE_ROLES, 2)
+    # the default threshold itself: 16384 verifies in two passes of the small-batch kernels, 16385 on lane pairs
+    big = make_verify_batch(eng, 16385, corrupt_every=13)
+    assert eng.batch_verify(big[0], big[1], big[2]) == big[3]
+    assert eng.batch_verify(big[0][:16384], big[1][:16384 * 64], big[2][:16384 * 128]) == big[3][:16384]
 
 
 def test_malformed_inputs_fuzz_vs_oracle(eng, c, derived):
