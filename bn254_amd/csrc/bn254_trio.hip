@@ -1,12 +1,13 @@
 // Third device translation unit of libbn254hip.so: ECDSA::verify (/root/reference/src/ecdsa.rs:49-64) for SMALL batches,
-// one verify per OCTET of lanes.  Same tower / pairing source as bn254_pair.hip in the pair layout of the Fq2 values, but
-// the three Fq6 products of every Karatsuba Fq12 operation (fp12_kmul: Fq12 squaring, the two-line multiplication, the
-// multiplications of the final exponentiation) and the three Fq4 squarings of a cyclotomic squaring run in three lane
-// pairs at once, and the twist-point steps with the line preparation run as rounds of FOUR independent Fq2 products, one
-// per lane pair (bn254_pairing.h: miller_verify_rounds); results are exchanged through LDS (bn254_field.h:
-// BN_TRIO_DEVICE).  Everything else is replicated in the pairs.  A wave that has its SIMD to itself issues a multiply-add only every ~4.4 ns, so for a batch that cannot fill
-// the chip latency is instructions per LANE; this layout has ~2 times fewer of them than the pair layout.  256-thread
-// workgroups (32 verifies), 91 KB of LDS -> one workgroup per CU, one wave per SIMD.
+// one verify per OCTET of lanes (four lane pairs of one wave).  Same tower / pairing source as bn254_pair.hip in the pair
+// layout of the Fq2 values, but an Fq12 product runs as its four Fq6 products, one per lane pair (fp12_kmul4), a cyclotomic
+// squaring as three Fq4 squarings in three pairs, each also forming the outputs that come from its square, and every Fq2
+// product of a Miller-loop step in rounds of FOUR independent products, one per pair (bn254_pairing.h:
+// miller_verify_rounds); results are exchanged through LDS (bn254_field.h: BN_TRIO_DEVICE); everything linear is replicated
+// in the pairs.  A wave that has its SIMD to itself issues a multiply-add only every ~4.4 ns, so for a batch that cannot
+// fill the chip latency is instructions per LANE.  256-thread workgroups (32 verifies), 91 KB of LDS -> one workgroup per
+// CU, one wave per SIMD.  The final exponentiation of every small batch runs here; the Miller loop runs here only with
+// BN254_OPT_TRIO_WAVE_ROLES = 0 — by default it runs as wave roles (bn254_quad.hip).  DESIGN.md section 4d.
 #include <hip/hip_runtime.h>
 
 #define BN_SPLIT_FP2 1
