@@ -544,6 +544,26 @@ def run_verify(args, R):
             "hbm": {"algorithmic_bytes_per_step": io_bytes, "achieved_GBps": io_bytes / (1e-3 * 1e3 * elapsed / args.steps) / 1e9,
                     "peak_GBps": HBM_PEAK_GBPS, "note": "evidence that the path is not memory-bound"},
         }
+        if world == 1 and n >= 1024:
+            # informational, outside the timed region: latency of a SMALL call through the host-pointer entry point (H2D, kernels,
+            # D2H, sync) — batches of up to 16 384 verifies take the small-batch kernels
+            try:
+                lat = {}
+                last = args.warmup + args.steps - 1
+                for m in (1, 1024):
+                    best = None
+                    for _ in range(5):
+                        t1 = time.perf_counter()
+                        got = eng.batch_verify(msgs[:m], sig_sets[last & 1][:64 * m], pks[:128 * m], flags=0)
+                        dt = time.perf_counter() - t1
+                        best = dt if best is None or dt < best else best
+                    assert got == expected_for(0, last, m), "small-batch statuses differ from the expected pattern"
+                    lat["verifies_%d_ms" % m] = 1e3 * best
+                result["small_batch_latency"] = lat
+            except AssertionError:
+                raise
+            except Exception as exc:                             # never lose the bench line over the extra
+                result["small_batch_latency"] = {"error": repr(exc)}
         if world == 1 and not args.no_cpu_baseline:
             from oracle import c_oracle
             cores = effective_cores()
