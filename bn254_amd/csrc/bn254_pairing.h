@@ -588,20 +588,24 @@ template <int ROLE, class Box> BN_DEV void w8_phase_i1(W8Regs& r, Box& bx, const
         bx.put(W8_TA + 2, h);
       }
     } else {
-      r.qx = in.pk.x; r.qy = ty_next > 0 ? in.pk.y : in.pk_yneg;
-      if (ty_next == 2) { r.qx = fp2_mul(fp2_conj(in.pk.x), fp2_load_const(C_TW_FROB_X1)); r.qy = fp2_mul(fp2_conj(in.pk.y), fp2_load_const(C_TW_FROB_Y1)); }
-      if (ty_next == 3) { r.qx = fp2_mul(in.pk.x, fp2_load_const(C_TW_FROB_X2)); r.qy = in.pk.y; }
-      if constexpr (ROLE == W8_T0) {                             // theta side
+      // theta = Y - y_Q Z and mu = X - x_Q Z go out with y_Q / x_Q (mailbox slots of the t1 products, idle until I2): the four
+      // products with them that make up the line — l1 = -theta x_A, theta x_Q, l0 = mu y_A, mu y_Q — are computed by the four
+      // f waves in the C1 phase of this step (w8_phase_c1), which have nothing else to do there in an addition step's
+      // neighbourhood; the twist waves keep the chains theta -> theta^2 -> Z theta^2 and mu -> mu^2 -> mu^3, X mu^2.
+      if constexpr (ROLE == W8_T0) {                             // theta side, y_Q
+        r.qy = ty_next == -1 ? in.pk_yneg : in.pk.y;
+        if (ty_next == 2) r.qy = fp2_mul(fp2_conj(in.pk.y), fp2_load_const(C_TW_FROB_Y1));
         const Fp2 theta = NS(210, fp2_sub(r.t.y, fp2_mul(r.qy, r.t.z)));
-        bx.put(at + 2, fp2_mul(theta, r.qx));
-        bx.put(at + 1, fp2_mul(fp2_neg(theta), in.PAX));
+        bx.put(W8_P + 12, theta); bx.put(W8_P + 15, r.qy);
         const Fp2 c = fp2_sqr(theta);
         r.a0 = theta;
         bx.put(W8_TA, fp2_mul(r.t.z, c));                        // F = Z theta^2
-      } else {                                                   // mu side
+      } else {                                                   // mu side, x_Q
+        r.qx = in.pk.x;
+        if (ty_next == 2) r.qx = fp2_mul(fp2_conj(in.pk.x), fp2_load_const(C_TW_FROB_X1));
+        if (ty_next == 3) r.qx = fp2_mul(in.pk.x, fp2_load_const(C_TW_FROB_X2));
         const Fp2 mu = NS(211, fp2_sub(r.t.x, fp2_mul(r.qx, r.t.z)));
-        bx.put(at + 3, fp2_mul(mu, r.qy));
-        bx.put(at, fp2_mul(mu, in.PAY));
+        bx.put(W8_P + 13, mu); bx.put(W8_P + 14, r.qx);
         const Fp2 d = fp2_sqr(mu);
         const Fp2 e = fp2_mul(mu, d), g = fp2_mul(r.t.x, d);
         r.a0 = mu; r.a1 = e;
@@ -611,7 +615,16 @@ template <int ROLE, class Box> BN_DEV void w8_phase_i1(W8Regs& r, Box& bx, const
   }
 }
 // ---- phase C1: coefficients of ab and u (doubling steps), the line product
-template <int ROLE, class Box> BN_DEV void w8_phase_c1(W8Regs& r, Box& bx, const W8In& in, int ty) {
+template <int ROLE, class Box> BN_DEV void w8_phase_c1(W8Regs& r, Box& bx, const W8In& in, int ty, int k, int ty_next) {
+  if constexpr (ROLE == W8_A0 || ROLE == W8_A1 || ROLE == W8_B0 || ROLE == W8_B1) {
+    if (ty_next != 0 && ty_next != 4) {                          // the next step adds a point: its line from theta, mu (see w8_phase_i1)
+      const int at = W8_LINE + 4 * ((k + 1) & 1);
+      if constexpr (ROLE == W8_A0) bx.put(at, fp2_mul(bx.get(W8_P + 13), in.PAY));                    // l0 = mu y_A
+      else if constexpr (ROLE == W8_A1) bx.put(at + 3, fp2_mul(bx.get(W8_P + 13), bx.get(W8_P + 15)));  // mu y_Q
+      else if constexpr (ROLE == W8_B0) bx.put(at + 1, fp2_mul(fp2_neg(bx.get(W8_P + 12)), in.PAX));   // l1 = -theta x_A
+      else bx.put(at + 2, fp2_mul(bx.get(W8_P + 12), bx.get(W8_P + 14)));                              // theta x_Q
+    }
+  }
   if constexpr (ROLE == W8_A0) { if (ty == 0) { r.c = fp6_kfin_coef<406, 0>(r.p0, r.p1, r.p2, bx.get(W8_P + 3)); bx.put(W8_C, r.c); } }
   else if constexpr (ROLE == W8_A1) { if (ty == 0) { r.c = fp6_kfin_coef<406, 1>(bx.get(W8_P), bx.get(W8_P + 1), bx.get(W8_P + 2), r.p1); bx.put(W8_C + 1, r.c); } }
   else if constexpr (ROLE == W8_T0) { if (ty == 0) { r.a2 = fp6_kfin_coef<406, 2>(bx.get(W8_P), bx.get(W8_P + 1), bx.get(W8_P + 2), bx.get(W8_P + 5)); bx.put(W8_C + 2, r.a2); } }
@@ -763,7 +776,7 @@ BN_DEVM void miller_verify_w8_model(Fp12& f, const G1Affine& pa, const G2Affine&
     QuadSteps nx = s; quad_step_next(nx);
     const int ty_next = quad_step_type(nx);
 #define W8_I1(R) w8_phase_i1<R>(r[R], bx, in, ty, s.k, ty_next);
-#define W8_C1(R) w8_phase_c1<R>(r[R], bx, in, ty);
+#define W8_C1(R) w8_phase_c1<R>(r[R], bx, in, ty, s.k, ty_next);
 #define W8_G(R) w8_phase_g<R>(r[R], bx);
 #define W8_I2(R) w8_phase_i2<R>(r[R], bx, in, ty, s.k, ty_next);
 #define W8_C2(R) w8_phase_c2<R>(r[R], bx);

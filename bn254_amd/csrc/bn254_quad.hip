@@ -221,7 +221,7 @@ template <int ROLE> __device__ __noinline__ void w8_role(const W8In& in) {
     const int ty_next = quad_step_type(nx);
     w8_phase_i1<ROLE>(r, bx, in, ty, s.k, ty_next);
     QUAD_BARRIER();
-    w8_phase_c1<ROLE>(r, bx, in, ty);
+    w8_phase_c1<ROLE>(r, bx, in, ty, s.k, ty_next);
     QUAD_BARRIER();
     if (ty == 0) { w8_phase_g<ROLE>(r, bx); QUAD_BARRIER(); }
     w8_phase_i2<ROLE>(r, bx, in, ty, s.k, ty_next);
