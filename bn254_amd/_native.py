@@ -10,7 +10,18 @@ import subprocess
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_PKG, "csrc")
 LIB_PATH = os.environ.get("BN254_LIB", os.path.join(_PKG, "libbn254hip.so"))   # BN254_LIB: A/B-test another build
-_SOURCES = ["bn254_hip.hip", "bn254_pair.hip", "bn254_trio.hip", "bn254_ws.h", "bn254_fp2_pair.h", "bn254_codec_g2.h", "bn254_norm_sites.h", "bn254_field.h", "bn254_curve.h", "bn254_pairing.h", "bn254_hash.h", "bn254_io.h", "gen_constants.py"]
+import glob
+
+
+def translation_units():
+    """Every .hip file of csrc/ is a translation unit of the library (the compile command and the staleness check both
+    come from this list, so they cannot drift apart)."""
+    return sorted(glob.glob(os.path.join(_CSRC, "*.hip")))
+
+
+def _dependencies():
+    return translation_units() + sorted(glob.glob(os.path.join(_CSRC, "*.h"))) + [
+        os.path.join(_CSRC, "gen_constants.py"), os.path.join(os.path.dirname(_PKG), "include", "bn254_hip.h")]
 
 # -Wl,--no-undefined: a missing translation unit fails at link time.  max-ilp: the AMDGPU machine scheduler's ILP-first
 # strategy — these kernels are VALU-issue bound at a fixed occupancy (amdgpu_waves_per_eu), so the default strategy's
@@ -22,8 +33,7 @@ def _stale():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    paths = [os.path.join(_CSRC, s) for s in _SOURCES] + [os.path.join(os.path.dirname(_PKG), "include", "bn254_hip.h")]
-    return any(os.path.exists(p) and os.path.getmtime(p) > t for p in paths)
+    return any(os.path.getmtime(p) > t for p in _dependencies())
 
 
 def build(force=False, verbose=False):
@@ -34,7 +44,7 @@ def build(force=False, verbose=False):
         subprocess.check_call(["python3", gen], stdout=None if verbose else subprocess.DEVNULL)
     if force or _stale():
         hipcc = os.environ.get("HIPCC", "hipcc")
-        cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB_PATH, os.path.join(_CSRC, "bn254_hip.hip"), os.path.join(_CSRC, "bn254_pair.hip"), os.path.join(_CSRC, "bn254_trio.hip"), os.path.join(_CSRC, "bn254_quad.hip")]
+        cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB_PATH] + translation_units()
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
@@ -61,6 +71,7 @@ def load():
     L.bn254_ctx_reserve.argtypes = [vp, sz]
     L.bn254_ctx_synchronize.argtypes = [vp]
     L.bn254_ctx_set_profiling.argtypes = [vp, i32]
+    L.bn254_ctx_expect_msgs_len.argtypes = [vp, ctypes.c_uint64]
     L.bn254_ctx_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
     L.bn254_ctx_set_option.argtypes = [vp, i32, i32]
     L.bn254_batch_verify.argtypes = [vp, vp, vp, vp, vp, sz, u32, vp]
@@ -105,5 +116,5 @@ EXPORTED_SYMBOLS = [
     "bn254_batch_pairing_check", "bn254_batch_pairing", "bn254_batch_pairing_device", "bn254_batch_check_public_keys",
     "bn254_batch_g1_add", "bn254_batch_g2_add", "bn254_batch_g1_mul", "bn254_batch_g2_mul", "bn254_batch_g1_mul_device",
     "bn254_batch_g2_mul_device", "bn254_batch_sign", "bn254_batch_sign_device", "bn254_batch_g1_sum", "bn254_batch_g2_sum",
-    "bn254_batch_aggregate_verify", "bn254_batch_aggregate_verify_device", "bn254_batch_g1_decompress", "bn254_batch_g2_decompress", "bn254_debug_fp_op", "bn254_debug_fp12_op", "bn254_debug_miller_loop", "bn254_debug_hash_candidate", "bn254_probe_issue_rate", "bn254_ctx_set_profiling", "bn254_ctx_last_kernel_ms", "bn254_ctx_set_option",
+    "bn254_batch_aggregate_verify", "bn254_batch_aggregate_verify_device", "bn254_batch_g1_decompress", "bn254_batch_g2_decompress", "bn254_debug_fp_op", "bn254_debug_fp12_op", "bn254_debug_miller_loop", "bn254_debug_hash_candidate", "bn254_probe_issue_rate", "bn254_ctx_set_profiling", "bn254_ctx_last_kernel_ms", "bn254_ctx_set_option", "bn254_ctx_expect_msgs_len",
 ]

@@ -28,9 +28,14 @@ BN_DEV void u512_divmod_q(U256& hi, U256& lo, bool& hi_overflow, const uint32_t*
 }
 // G2 (65 B): sign || BE64(x.im * q + x.re), sign 0x0b iff u512(y) > u512(-y), else 0x0a.
 // bn::G2::from_compressed as used at /root/reference/src/types.rs:92, in the order that decoder works: x.im >= q (the
-// U512 does not split) -> InvalidEncoding(3); no square root -> NotMemberError(6); a sign byte other than 0x0a / 0x0b
-// -> InvalidEncoding(3); not in the order-r subgroup -> NotMemberError(6) (the caller runs the wave-uniform subgroup
-// ladder).  An input with two faults reports the first in this order (oracle/bn254_model.py: g2_from_compressed).
+// U512 does not split into two field elements) -> NotMemberError(6); no square root -> NotMemberError(6); a sign byte
+// other than 0x0a / 0x0b -> InvalidEncoding(3); not in the order-r subgroup -> NotMemberError(6) (the caller runs the
+// wave-uniform subgroup ladder).  An input with two faults reports the first in this order (oracle/bn254_model.py:
+// g2_from_compressed).
+// The x.im >= q code is UNPINNED: the reference holds no vector for it and zeropool-bn 0.5.11 is not vendored.  Upstream's
+// Fq2::from_slice is recalled as `U512::from_slice(..).map_err(InvalidU512Encoding)` (a LENGTH fault, unreachable behind
+// the 65-byte check) followed by `divrem`, whose missing quotient goes through `ok_or(FieldError::NotMember)` — and
+// FieldError::NotMember is Error::NotMemberError at /root/reference/src/error.rs:44-51.  Rounds 1-2 reported 3 here.
 BN_DEV uint8_t decompress_g2(G2Affine& pt, const uint8_t* b) {
   uint8_t sign = b[0];
   uint32_t v[16];
@@ -52,7 +57,7 @@ BN_DEV uint8_t decompress_g2(G2Affine& pt, const uint8_t* b) {
   pt.x = x;
   pt.y = fp2_select(y_gt == want_gt, y, yn);
   pt.inf = false;
-  if (!split_ok) return ST_INVALID_ENCODING;
+  if (!split_ok) return ST_NOT_MEMBER;
   if (!has_root) return ST_NOT_MEMBER;
   if (!sign_ok) return ST_INVALID_ENCODING;
   return ST_OK;

@@ -105,12 +105,25 @@ KERNEL void k_decode_g2(const uint8_t* pts, size_t n, uint32_t flags, Ws ws, int
 //   * k_hash_finish then computes ONE square root per message, for the winning counter.
 // Lane w of a round: slot = w % n_act (message), j = w / n_act (counter offset) — consecutive lanes
 // work on consecutive messages with the same offset.
+// Message i of an offsets array: the bytes [off[i], off[i+1]) of a buffer of msgs_len bytes.  A pair that is reversed or
+// runs past the buffer — only a *_device caller can hand one over: the host entry points validate their arrays, Rust slices
+// cannot express one (/root/reference/src/ecdsa.rs:49) — is hashed as the EMPTY message, never dereferenced, and the item
+// reports InvalidLength (5) in its hash status.  msgs_len = UINT64_MAX when the caller did not declare the buffer size
+// (bn254_ctx_expect_msgs_len): then only reversed pairs can be caught.
+__device__ __forceinline__ bool msg_span(const uint64_t* off, size_t i, uint64_t msgs_len, uint64_t& lo, uint64_t& len) {
+  lo = off[i];
+  const uint64_t hi = off[i + 1];
+  const bool ok = lo <= hi && hi <= msgs_len;
+  len = ok ? hi - lo : 0;
+  if (!ok) lo = 0;
+  return ok;
+}
 KERNEL_SMALL void k_hash_init(size_t n, Ws ws) {
   size_t i = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
   if (i < n) { ws.h_best[i] = HASH_NONE; ws.h_next[i] = 0; }
   if (i <= HASH_MAX_ROUNDS) ws.h_cnt[i] = (i == 0) ? (uint32_t)n : 0u;
 }
-KERNEL_SMALL void k_hash_round(const uint8_t* msgs, const uint64_t* off, Ws ws, int round, uint32_t width, uint32_t max_ctr) {
+KERNEL_SMALL void k_hash_round(const uint8_t* msgs, const uint64_t* off, uint64_t msgs_len, Ws ws, int round, uint32_t width, uint32_t max_ctr) {
   const uint32_t n_act = ws.h_cnt[round];
   if (n_act == 0) return;
   const uint32_t* list = round == 0 ? nullptr : ws.h_list + (size_t)(round & 1) * ws.stride;
@@ -120,8 +133,9 @@ KERNEL_SMALL void k_hash_round(const uint8_t* msgs, const uint64_t* off, Ws ws, 
     uint32_t i = list ? list[slot] : slot;
     uint32_t ctr = (uint32_t)ws.h_next[i] + j;
     if (ctr >= max_ctr) continue;                                  // hash.rs:40: counters 0..=254
-    const uint8_t* msg = msgs + off[i];
-    uint64_t len = off[i + 1] - off[i];
+    uint64_t lo, len;
+    msg_span(off, i, msgs_len, lo, len);
+    const uint8_t* msg = msgs + lo;
     HashState hs;
     hash_state_init(hs, msg, len);
     if (hash_try_filter(hs, msg, len, ctr)) atomicMin(&ws.h_best[i], ctr);
@@ -148,7 +162,7 @@ KERNEL_SMALL void k_hash_resolve(Ws ws, int round, uint32_t width, uint32_t max_
 // first: SHA-256 + one exponentiation instead of SHA-256 + Jacobi symbol, then SHA-256 + exponentiation in a second
 // kernel), the lowest passing counter writes its point.  A message without one (p = 0.5274^32 = 1.3e-9) is queued as a
 // survivor of "round 0" for the ordinary rounds, which start at counter `width` (and cost it a second exponentiation).
-KERNEL_SMALL void k_hash_direct(const uint8_t* msgs, const uint64_t* off, size_t n, Ws ws, uint32_t width, uint32_t max_ctr, int px,
+KERNEL_SMALL void k_hash_direct(const uint8_t* msgs, const uint64_t* off, uint64_t msgs_len, size_t n, Ws ws, uint32_t width, uint32_t max_ctr, int px,
                                 int inf_plane, uint8_t* tries_out) {
   const size_t w = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
   const size_t i = w / width;
@@ -156,15 +170,27 @@ KERNEL_SMALL void k_hash_direct(const uint8_t* msgs, const uint64_t* off, size_t
   bool ok = false;
   G1Affine p;
   g1_set_generator(p);
+  bool span_ok = true;
   if (i < n && ctr < max_ctr) {
-    const uint8_t* msg = msgs + off[i];
-    const uint64_t len = off[i + 1] - off[i];
+    uint64_t lo, len;
+    span_ok = msg_span(off, i, msgs_len, lo, len);
+    const uint8_t* msg = msgs + lo;
     HashState hs;
     hash_state_init(hs, msg, len);
     ok = hash_try(p, hs, msg, len, ctr);
   }
   const uint64_t pass = __ballot(ok);
   if (i >= n) return;
+  if (!span_ok) {                                                   // the whole counter group of the message agrees
+    if (ctr == 0) {
+      g1_set_generator(p);
+      ws_store_g1(ws, px, inf_plane, i, p);
+      ws_byte(ws, BY_ST_HASH, i) = (uint8_t)ST_INVALID_LENGTH;
+      if (tries_out) tries_out[i] = 0;
+      ws.h_best[i] = HASH_DONE;
+    }
+    return;
+  }
   const uint32_t group = (uint32_t)(pass >> (threadIdx.x & ~(width - 1u))) & (uint32_t)((1ull << width) - 1u);
   if (group != 0) {
     if (ctr == (uint32_t)__builtin_ctz(group)) {                    // hash.rs:40-59: the first counter that yields a point
@@ -183,24 +209,25 @@ KERNEL_SMALL void k_hash_direct(const uint8_t* msgs, const uint64_t* off, size_t
   }
 }
 // the point of every message: the even root for its winning counter (or the error status)
-KERNEL_SMALL void k_hash_finish(const uint8_t* msgs, const uint64_t* off, size_t n, Ws ws, uint32_t max_ctr, int px, int inf_plane,
+KERNEL_SMALL void k_hash_finish(const uint8_t* msgs, const uint64_t* off, uint64_t msgs_len, size_t n, Ws ws, uint32_t max_ctr, int px, int inf_plane,
                                 uint8_t* tries_out) {
   size_t i = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
   if (i >= n) return;
   const uint32_t best = ws.h_best[i];
   if (best == HASH_DONE) return;                                   // k_hash_direct
-  const uint8_t* msg = msgs + off[i];
-  uint64_t len = off[i + 1] - off[i];
+  uint64_t lo, len;
+  const bool span_ok = msg_span(off, i, msgs_len, lo, len);
+  const uint8_t* msg = msgs + lo;
   HashState hs;
   hash_state_init(hs, msg, len);
   G1Affine p;
   // the filter and the exponentiation agree by construction (Euler's criterion); a disagreement would be
   // reported as an error status, never as a wrong point
-  bool ok = best != HASH_NONE && hash_try(p, hs, msg, len, best);
+  bool ok = span_ok && best != HASH_NONE && hash_try(p, hs, msg, len, best);
   if (!ok) g1_set_generator(p);
   ws_store_g1(ws, px, inf_plane, i, p);
-  ws_byte(ws, BY_ST_HASH, i) = ok ? (uint8_t)ST_OK : (uint8_t)ST_HASH_TO_POINT;
-  if (tries_out) tries_out[i] = ok ? (uint8_t)(best + 1) : (uint8_t)max_ctr;
+  ws_byte(ws, BY_ST_HASH, i) = ok ? (uint8_t)ST_OK : !span_ok ? (uint8_t)ST_INVALID_LENGTH : (uint8_t)ST_HASH_TO_POINT;
+  if (tries_out) tries_out[i] = ok ? (uint8_t)(best + 1) : !span_ok ? (uint8_t)0 : (uint8_t)max_ctr;
 }
 
 // ECDSA::verify Miller loop: f = miller(H(m), pk) * miller(sig, -G2)   (ecdsa.rs:53-57)
@@ -825,8 +852,12 @@ struct bn254_ctx {
   int trio_max_batch; // verify / check_public_keys batches up to this size run in the octet layout (bn254_trio.hip); 0 = never
   hipEvent_t ev[5];
   int ev_valid;
+  int ev_hash_first;   // the recorded intervals are hash, decode, ... (host-pointer verify) instead of decode, hash, ...
   hipStream_t copy_stream;   // host-pointer verify: signatures and keys cross PCIe here while the hash rounds run on `stream`
   hipEvent_t copy_done;
+  uint64_t msgs_len_next;    // bn254_ctx_expect_msgs_len: size of the d_msgs buffer of the NEXT call that hashes messages
+  int msgs_len_declared;
+  bool fits_w8, fits_quad, fits_trio;   // the device can hold a workgroup of the small-batch kernels (LDS), asked at creation
 };
 
 
@@ -911,13 +942,15 @@ static int launch_decode_g2(bn254_ctx* c, hipStream_t s, const uint8_t* d_pts, s
 static int launch_hash_rounds(bn254_ctx* c, hipStream_t s, const uint8_t* d_msgs, const uint64_t* d_off, size_t n, int px, int inf_plane,
                               uint8_t* d_tries) {
   const uint32_t max_ctr = c->hash_max_tries ? (uint32_t)c->hash_max_tries : 255u;
+  const uint64_t msgs_len = c->msgs_len_declared ? c->msgs_len_next : UINT64_MAX;   // bn254_ctx_expect_msgs_len: one call only
+  c->msgs_len_declared = 0;
   k_hash_init<<<grid_for(n > HASH_MAX_ROUNDS + 1 ? n : HASH_MAX_ROUNDS + 1), BN_WAVE, 0, s>>>(n, c->ws);
   if (n <= HASH_DIRECT_MAX_N && c->hash_direct_width > 0) {
     const uint32_t width = (uint32_t)c->hash_direct_width;
-    k_hash_direct<<<grid_for(n * width), BN_WAVE, 0, s>>>(d_msgs, d_off, n, c->ws, width, max_ctr, px, inf_plane, d_tries);
+    k_hash_direct<<<grid_for(n * width), BN_WAVE, 0, s>>>(d_msgs, d_off, msgs_len, n, c->ws, width, max_ctr, px, inf_plane, d_tries);
     if (max_ctr > width)                 // the (rare) survivors: every remaining counter at once (grid-stride beyond 64 of them)
-      k_hash_round<<<grid_for(64 * (max_ctr - width)), BN_WAVE, 0, s>>>(d_msgs, d_off, c->ws, 1, max_ctr - width, max_ctr);
-    k_hash_finish<<<grid_for(n), BN_WAVE, 0, s>>>(d_msgs, d_off, n, c->ws, max_ctr, px, inf_plane, d_tries);
+      k_hash_round<<<grid_for(64 * (max_ctr - width)), BN_WAVE, 0, s>>>(d_msgs, d_off, msgs_len, c->ws, 1, max_ctr - width, max_ctr);
+    k_hash_finish<<<grid_for(n), BN_WAVE, 0, s>>>(d_msgs, d_off, msgs_len, n, c->ws, max_ctr, px, inf_plane, d_tries);
     HIP_TRY(hipGetLastError());
     return 0;
   }
@@ -932,21 +965,21 @@ static int launch_hash_rounds(bn254_ctx* c, hipStream_t s, const uint8_t* d_msgs
     if (bound > (double)n) bound = (double)n;
     size_t lanes = (size_t)(bound * width);
     if (lanes > HASH_MAX_GRID_LANES) lanes = HASH_MAX_GRID_LANES;   // grid-stride loops cover the rest
-    k_hash_round<<<grid_for(lanes), BN_WAVE, 0, s>>>(d_msgs, d_off, c->ws, round, width, max_ctr);
+    k_hash_round<<<grid_for(lanes), BN_WAVE, 0, s>>>(d_msgs, d_off, msgs_len, c->ws, round, width, max_ctr);
     k_hash_resolve<<<grid_for((size_t)bound), BN_WAVE, 0, s>>>(c->ws, round, width, max_ctr);
     consumed += width;
     double pf = 1.0;
     for (uint32_t t = 0; t < width && pf > 1e-12; ++t) pf *= 0.5274;
     expect *= pf;
   }
-  k_hash_finish<<<grid_for(n), BN_WAVE, 0, s>>>(d_msgs, d_off, n, c->ws, max_ctr, px, inf_plane, d_tries);
+  k_hash_finish<<<grid_for(n), BN_WAVE, 0, s>>>(d_msgs, d_off, msgs_len, n, c->ws, max_ctr, px, inf_plane, d_tries);
   HIP_TRY(hipGetLastError());
   return 0;
 }
 
 extern "C" {
 
-const char* bn254_version(void) { return "bn254-mi355x 0.5 (gfx950; 9x29-bit balanced Montgomery limbs; verify on lane pairs, batches <= 16384 on lane octets with wave roles)"; }
+const char* bn254_version(void) { return "bn254-mi355x 0.6 (gfx950; 9x29-bit balanced Montgomery limbs; verify on lane pairs, batches <= 16384 on lane octets with wave roles)"; }
 
 int bn254_ctx_create(int hip_device, bn254_ctx** out) {
   if (!out) return BN254_E_BAD_ARGUMENT;
@@ -963,6 +996,12 @@ int bn254_ctx_create(int hip_device, bn254_ctx** out) {
   c->trio_max_batch = TRIO_MAX_BATCH_DEFAULT;
   c->hash_direct_width = HASH_DIRECT_WIDTH_DEFAULT;
   c->trio_wave_roles = TRIO_WAVE_ROLES_DEFAULT;
+  // the small-batch kernels ask for up to 156 KB of dynamic LDS per workgroup: on a part that cannot hold one, step down
+  // (eight wave roles -> four -> lane groups -> lane pairs only) instead of failing at the first launch
+  c->fits_w8 = bn254_quad_fits_device(1); c->fits_quad = bn254_quad_fits_device(0); c->fits_trio = bn254_trio_fits_device();
+  if (c->trio_wave_roles == 2 && !c->fits_w8) c->trio_wave_roles = 1;
+  if (c->trio_wave_roles == 1 && !c->fits_quad) c->trio_wave_roles = 0;
+  if (!c->fits_trio) c->trio_max_batch = 0;
   c->device = hip_device;
   hipError_t err = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (err == hipSuccess) err = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
@@ -1004,6 +1043,12 @@ int bn254_ctx_synchronize(bn254_ctx* c) {
   HIP_TRY(hipStreamSynchronize(c->stream));
   return 0;
 }
+int bn254_ctx_expect_msgs_len(bn254_ctx* c, uint64_t msgs_len) {
+  if (!c) return BN254_E_BAD_ARGUMENT;
+  c->msgs_len_next = msgs_len;
+  c->msgs_len_declared = 1;
+  return 0;
+}
 int bn254_ctx_set_profiling(bn254_ctx* c, int enabled) {
   if (!c) return BN254_E_BAD_ARGUMENT;
   c->profiling = enabled;
@@ -1016,8 +1061,16 @@ int bn254_ctx_set_option(bn254_ctx* c, int option, int value) {
   if (option == BN254_OPT_PAIR_LANES) { c->pair_lanes = value != 0; return 0; }
   if (option == BN254_OPT_RAND_MIN_BATCH) { if (value < 0) return BN254_E_BAD_ARGUMENT; c->rand_min_batch = value; return 0; }
   if (option == BN254_OPT_RAND_ITEMS_PER_LANE) { if (value < 0 || value > 2) return BN254_E_BAD_ARGUMENT; c->rand_items_per_lane = value; return 0; }
-  if (option == BN254_OPT_TRIO_MAX_BATCH) { if (value < 0) return BN254_E_BAD_ARGUMENT; c->trio_max_batch = value; return 0; }
-  if (option == BN254_OPT_TRIO_WAVE_ROLES) { if (value < 0 || value > 2) return BN254_E_BAD_ARGUMENT; c->trio_wave_roles = value; return 0; }
+  if (option == BN254_OPT_TRIO_MAX_BATCH) {
+    if (value < 0 || (value > 0 && !c->fits_trio)) return BN254_E_BAD_ARGUMENT;
+    c->trio_max_batch = value;
+    return 0;
+  }
+  if (option == BN254_OPT_TRIO_WAVE_ROLES) {
+    if (value < 0 || value > 2 || (value == 2 && !c->fits_w8) || (value == 1 && !c->fits_quad)) return BN254_E_BAD_ARGUMENT;
+    c->trio_wave_roles = value;
+    return 0;
+  }
   if (option == BN254_OPT_HASH_DIRECT_WIDTH) {
     if (value < 0 || value > 32 || (value & (value - 1))) return BN254_E_BAD_ARGUMENT;
     c->hash_direct_width = value;
@@ -1030,6 +1083,9 @@ int bn254_ctx_last_kernel_ms(bn254_ctx* c, float ms[4]) {
   if (!c || !ms || !c->ev_valid) return BN254_E_BAD_ARGUMENT;
   HIP_TRY(hipEventSynchronize(c->ev[4]));
   for (int i = 0; i < 4; ++i) HIP_TRY(hipEventElapsedTime(&ms[i], c->ev[i], c->ev[i + 1]));
+  // the host-pointer verify hashes FIRST (the messages cross PCIe first) and decodes second: keep the documented slots
+  // (ms[0] decode, ms[1] hash-to-G1 — there including the transfer of the messages)
+  if (c->ev_hash_first) { float t = ms[0]; ms[0] = ms[1]; ms[1] = t; }
   return 0;
 }
 
@@ -1070,7 +1126,7 @@ static int verify_after_decode(bn254_ctx* c, hipStream_t s, const uint8_t* d_msg
     k_final_exp<<<g, BN_WAVE, 0, s>>>(n, 1, 1, 1, c->ws, 1, nullptr, d_status, 0, 0, nullptr, nullptr);
   }
   PROF_MARK(4);
-  if (c->profiling) c->ev_valid = 1;
+  if (c->profiling) { c->ev_valid = 1; c->ev_hash_first = 0; }
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -1129,31 +1185,9 @@ int bn254_batch_verify_compressed(bn254_ctx* c, const uint8_t* msgs, const uint6
   return 0;
 }
 
-// Host-buffer entry point.  The hash-to-G1 rounds need only the messages, so those cross PCIe first and the hash
-// kernels start at once; signatures and public keys (5/6 of the bytes) follow on a second stream while the hash runs,
-// and the decode kernels wait for them on an event.  What is left exposed of the transfer is the message copy and the
-// status bytes coming back.
-int bn254_batch_verify(bn254_ctx* c, const uint8_t* msgs, const uint64_t* off, const uint8_t* sigs, const uint8_t* pks, size_t n,
-                       uint32_t flags, uint8_t* status) {
-  if (!c || (n && (!off || !sigs || !pks || !status))) return BN254_E_BAD_ARGUMENT;
-  if (n == 0) return 0;
-  HIP_TRY(hipSetDevice(c->device));
-  if (!offsets_ok(off, n)) return BN254_E_BAD_ARGUMENT;
-  size_t msg_bytes = (size_t)off[n];
-  if (msg_bytes && !msgs) return BN254_E_BAD_ARGUMENT;
+static int verify_host_overlapped(bn254_ctx* c, const uint8_t* msgs, const uint64_t* off, const uint8_t* sigs, const uint8_t* pks, size_t n,
+                                  uint32_t flags, uint8_t* status, size_t msg_bytes) {
   int rc;
-  bool split = c->split_miller && n <= BN_SPLIT_MAX_N;
-  if (split) {                                       // A/B layout: plain staging, then the device entry point
-    if ((rc = stage_in(c, 0, msgs, msg_bytes))) return rc;
-    if ((rc = stage_in(c, 1, off, (n + 1) * sizeof(uint64_t)))) return rc;
-    if ((rc = stage_in(c, 2, sigs, n * 64))) return rc;
-    if ((rc = stage_in(c, 3, pks, n * 128))) return rc;
-    if ((rc = stage_reserve(c, 4, n))) return rc;
-    if ((rc = bn254_batch_verify_device(c, c->stage[0], (const uint64_t*)c->stage[1], c->stage[2], c->stage[3], n, flags, c->stage[4], nullptr))) return rc;
-    if ((rc = stage_out(c, 4, status, n))) return rc;
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    return 0;
-  }
   if ((rc = ws_reserve(c, n))) return rc;
   for (int slot = 0; slot < 5; ++slot) {
     const size_t need[5] = {msg_bytes ? msg_bytes : 1, (n + 1) * sizeof(uint64_t), n * 64, n * 128, n};
@@ -1180,11 +1214,46 @@ int bn254_batch_verify(bn254_ctx* c, const uint8_t* msgs, const uint64_t* off, c
     k_final_exp<<<grid_for(n), BN_WAVE, 0, s>>>(n, 1, 1, 1, c->ws, 1, nullptr, c->stage[4], 0, 0, nullptr, nullptr);
   }
   PROF_MARK(4);
-  if (c->profiling) c->ev_valid = 1;                 // host path: ms[0] = transfer + hash, ms[1] = decode
+  if (c->profiling) { c->ev_valid = 1; c->ev_hash_first = 1; }   // intervals: transfer + hash, decode, Miller, final exp.
   HIP_TRY(hipGetLastError());
   if ((rc = stage_out(c, 4, status, n))) return rc;
   HIP_TRY(hipStreamSynchronize(c->stream));
   return 0;
+}
+
+// Host-buffer entry point.  The hash-to-G1 rounds need only the messages, so those cross PCIe first and the hash
+// kernels start at once; signatures and public keys (5/6 of the bytes) follow on a second stream while the hash runs,
+// and the decode kernels wait for them on an event.  What is left exposed of the transfer is the message copy and the
+// status bytes coming back.
+int bn254_batch_verify(bn254_ctx* c, const uint8_t* msgs, const uint64_t* off, const uint8_t* sigs, const uint8_t* pks, size_t n,
+                       uint32_t flags, uint8_t* status) {
+  if (!c || (n && (!off || !sigs || !pks || !status))) return BN254_E_BAD_ARGUMENT;
+  if (n == 0) return 0;
+  HIP_TRY(hipSetDevice(c->device));
+  if (!offsets_ok(off, n)) return BN254_E_BAD_ARGUMENT;
+  size_t msg_bytes = (size_t)off[n];
+  if (msg_bytes && !msgs) return BN254_E_BAD_ARGUMENT;
+  int rc;
+  bool split = c->split_miller && n <= BN_SPLIT_MAX_N;
+  if (split) {                                       // A/B layout: plain staging, then the device entry point
+    if ((rc = stage_in(c, 0, msgs, msg_bytes))) return rc;
+    if ((rc = stage_in(c, 1, off, (n + 1) * sizeof(uint64_t)))) return rc;
+    if ((rc = stage_in(c, 2, sigs, n * 64))) return rc;
+    if ((rc = stage_in(c, 3, pks, n * 128))) return rc;
+    if ((rc = stage_reserve(c, 4, n))) return rc;
+    if ((rc = bn254_batch_verify_device(c, c->stage[0], (const uint64_t*)c->stage[1], c->stage[2], c->stage[3], n, flags, c->stage[4], nullptr))) return rc;
+    if ((rc = stage_out(c, 4, status, n))) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+  }
+  rc = verify_host_overlapped(c, msgs, off, sigs, pks, n, flags, status, msg_bytes);
+  if (rc) {
+    // a failure after the first asynchronous enqueue: the copies and kernels already in flight still read the caller's
+    // buffers — wait for both streams before handing them back
+    (void)hipStreamSynchronize(c->copy_stream);
+    (void)hipStreamSynchronize(c->stream);
+  }
+  return rc;
 }
 
 int bn254_batch_verify_randomized_device(bn254_ctx* c, const uint8_t* d_msgs, const uint64_t* d_off, const uint8_t* d_sigs,
@@ -1249,7 +1318,7 @@ int bn254_batch_verify_randomized_device(bn254_ctx* c, const uint8_t* d_msgs, co
     k_final_exp<<<g, BN_WAVE, 0, s>>>(n, 1, 1, 1, c->ws, 1, nullptr, d_status, 0, 0, c->ws.h_list, c->ws.h_cnt);
   }
   PROF_MARK(4);
-  if (c->profiling) c->ev_valid = 1;
+  if (c->profiling) { c->ev_valid = 1; c->ev_hash_first = 0; }
   HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -187,6 +187,8 @@ KERNEL_QUAD void k_miller_verify_quad(size_t n, Ws ws, int mode) {
 #pragma unroll
   for (int k = 0; k < 3; ++k) ws_store_fp(ws, PL_F0 + 6 * w + 2 * k + (int)(threadIdx.x & 1u), i, c[k]->c[0]);
 }
+#define BN_GFX950_LDS_BYTES (160 * 1024)
+static_assert(BN_QUAD_LDS_WORDS * sizeof(int32_t) <= BN_GFX950_LDS_BYTES, "mailboxes of the four-wave kernel exceed the 160 KB of LDS of a gfx950 CU");
 int bn254_quad_miller_verify(size_t n, Ws ws, hipStream_t s, int mode) {
   k_miller_verify_quad<<<(unsigned)((n + BN_QUAD_WG / 8 - 1) / (BN_QUAD_WG / 8)), BN_QUAD_WG, BN_QUAD_LDS_WORDS * sizeof(int32_t), s>>>(n, ws, mode);
   HIP_TRY(hipGetLastError());
@@ -264,6 +266,14 @@ KERNEL_W8 void k_miller_verify_w8(size_t n, Ws ws, int mode) {
   if (!live || w > 1) return;                           // waves A0 / A1 write f0 / f1 out (complete behind the last barrier)
 #pragma unroll
   for (int k = 0; k < 3; ++k) ws_store_fp(ws, PL_F0 + 6 * w + 2 * k + (int)(threadIdx.x & 1u), i, qbox_get((w == 0 ? W8_F0 : W8_F1) + k).c[0]);
+}
+static_assert(BN_W8_LDS_WORDS * sizeof(int32_t) <= BN_GFX950_LDS_BYTES, "mailboxes of the eight-wave kernel exceed the 160 KB of LDS of a gfx950 CU");
+bool bn254_quad_fits_device(int eight_waves) {
+  int blocks = 0;
+  hipError_t e = eight_waves ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_miller_verify_w8, BN_W8_WG, BN_W8_LDS_WORDS * sizeof(int32_t))
+                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_miller_verify_quad, BN_QUAD_WG, BN_QUAD_LDS_WORDS * sizeof(int32_t));
+  if (e != hipSuccess) { (void)hipGetLastError(); return true; }
+  return blocks > 0;
 }
 int bn254_w8_miller_verify(size_t n, Ws ws, hipStream_t s, int mode) {
   k_miller_verify_w8<<<(unsigned)((n + 31) / 32), BN_W8_WG, BN_W8_LDS_WORDS * sizeof(int32_t), s>>>(n, ws, mode);

@@ -70,6 +70,13 @@ KERNEL_TRIO void k_final_exp_trio(size_t n, Ws ws, int use_hash, uint8_t* status
   if ((threadIdx.x & 7u) == 0) status_out[i] = st != ST_OK ? st : (one ? (uint8_t)ST_OK : (uint8_t)ST_VERIFICATION_FAILED);
 }
 
+static_assert(BN_TRIO_LDS_WORDS * sizeof(int32_t) <= 160 * 1024, "octet kernels: accumulators + exchange areas exceed the 160 KB of LDS of a gfx950 CU");
+bool bn254_trio_fits_device() {
+  int blocks = 0;
+  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_final_exp_trio, BN_TRIO_WG, BN_TRIO_LDS_WORDS * sizeof(int32_t));
+  if (e != hipSuccess) { (void)hipGetLastError(); return true; }
+  return blocks > 0;
+}
 int bn254_trio_miller_verify(size_t n, Ws ws, hipStream_t s, int mode) {
   k_miller_verify_trio<<<(unsigned)((8 * n + BN_TRIO_WG - 1) / BN_TRIO_WG), BN_TRIO_WG, BN_TRIO_LDS_WORDS * sizeof(int32_t), s>>>(n, ws, mode);
   HIP_TRY(hipGetLastError());

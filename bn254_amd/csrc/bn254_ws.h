@@ -103,4 +103,8 @@ __attribute__((visibility("hidden"))) int bn254_trio_miller_verify(size_t n, Ws 
 // entry points of bn254_quad.hip (the same with the four lane pairs of a verify as four waves with roles)
 __attribute__((visibility("hidden"))) int bn254_quad_miller_verify(size_t n, Ws ws, hipStream_t s, int mode = 0);
 __attribute__((visibility("hidden"))) int bn254_w8_miller_verify(size_t n, Ws ws, hipStream_t s, int mode = 0);      // eight waves per 32 verifies
+// can the current device hold one workgroup of the small-batch kernels with the dynamic LDS they ask for (up to 156 KB)?
+// Asked of the runtime's occupancy calculator at context creation; a runtime that cannot answer counts as "yes".
+__attribute__((visibility("hidden"))) bool bn254_trio_fits_device();
+__attribute__((visibility("hidden"))) bool bn254_quad_fits_device(int eight_waves);
 __attribute__((visibility("hidden"))) int bn254_trio_final_exp(size_t n, Ws ws, int use_hash, uint8_t* status_out, hipStream_t s);

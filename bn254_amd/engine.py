@@ -80,6 +80,11 @@ class Engine:
     def set_profiling(self, on):
         _check("bn254_ctx_set_profiling", self._lib.bn254_ctx_set_profiling(self._h, 1 if on else 0))
 
+    def expect_msgs_len(self, msgs_len):
+        """size in bytes of the d_msgs buffer of the NEXT *_device call that hashes messages: its spans get bounds-checked on the
+        device (status 5 for a span outside the buffer) — include/bn254_hip.h: bn254_ctx_expect_msgs_len"""
+        _check("bn254_ctx_expect_msgs_len", self._lib.bn254_ctx_expect_msgs_len(self._h, int(msgs_len)))
+
     def set_option(self, option, value):
         _check("bn254_ctx_set_option", self._lib.bn254_ctx_set_option(self._h, option, value))
 

@@ -39,7 +39,10 @@
  * so a second *_device call may be enqueued only on the same stream as the first (stream order then keeps them
  * apart) — for concurrent calls on several streams create one context per stream.
  * Offsets arrays (n + 1 entries) must be non-decreasing: the host-pointer entry points check it and return
- * BN254_E_BAD_ARGUMENT, for the *_device variants it is a precondition (the arrays live in device memory).
+ * BN254_E_BAD_ARGUMENT.  The *_device variants cannot read their arrays on the host; the kernels check every pair
+ * themselves: a message whose offsets are reversed — or, when the caller has declared the size of the message buffer
+ * with bn254_ctx_expect_msgs_len, run past it — is never dereferenced and its item reports 5 (InvalidLength); the other
+ * items of the batch are unaffected.
  */
 #ifndef BN254_HIP_H
 #define BN254_HIP_H
@@ -83,6 +86,11 @@ void bn254_ctx_destroy(bn254_ctx *ctx);
  * hipMalloc inside a later *_device call) */
 int bn254_ctx_reserve(bn254_ctx *ctx, size_t n_items);
 int bn254_ctx_synchronize(bn254_ctx *ctx);
+/* Declares the size in bytes of the d_msgs buffer of the NEXT call on this context that hashes messages (verify, verify_compressed,
+ * verify_randomized, hash_to_g1, sign, aggregate_verify and their *_device forms); the declaration is consumed by that call.
+ * With it every message span is bounds-checked on the device (offsets non-decreasing and <= msgs_len), without it only
+ * reversed offset pairs can be detected.  No counterpart in the reference: a Rust slice (src/ecdsa.rs:49) carries its length. */
+int bn254_ctx_expect_msgs_len(bn254_ctx *ctx, uint64_t msgs_len);
 
 /* status[i] = what ECDSA::verify(msg_i, sig_i, pk_i) returns (src/ecdsa.rs:49-64):
  * e(H(m), pk) * e(sig, -G2::one()) == 1.  Decoding errors of sig (first) or pk are reported with
@@ -189,10 +197,11 @@ int bn254_batch_aggregate_verify_device(bn254_ctx *ctx, const uint8_t *d_msgs, c
  * bn::G1::from_compressed / bn::G2::from_compressed report through src/types.rs:91-93, :233-237, checked in the order
  * those decoders work (an input with several faults reports the first):
  *   G1: x >= q -> 6 NotMemberError; no square root -> 6; prefix byte not 0x02 / 0x03 -> 3 InvalidEncoding.
- *   G2: x.im >= q (the U512 does not split) -> 3 InvalidEncoding; no square root -> 6; sign byte not 0x0a / 0x0b -> 3;
- *       not in the order-r subgroup -> 6.
- * (x.im >= q is InvalidU512Encoding upstream as recalled in SURVEY.md Appendix B; the zeropool-bn source is not
- * available here to confirm whether it surfaces as InvalidEncoding or NotMember through src/error.rs:31-55.) */
+ *   G2: x.im >= q (the U512 does not split into two field elements) -> 6 NotMemberError; no square root -> 6; sign
+ *       byte not 0x0a / 0x0b -> 3; not in the order-r subgroup -> 6.
+ * (The x.im >= q code is UNPINNED: no reference vector exists and zeropool-bn is not vendored.  Upstream's
+ * Fq2::from_slice is recalled as mapping a missing `divrem` quotient through `ok_or(FieldError::NotMember)`, which
+ * src/error.rs:44-51 turns into NotMemberError; library versions before 0.6 returned 3 here.) */
 int bn254_batch_g1_decompress(bn254_ctx *ctx, const uint8_t *in /* n*33 */, size_t n, uint8_t *out /* n*64 */, uint8_t *status);
 int bn254_batch_g2_decompress(bn254_ctx *ctx, const uint8_t *in /* n*65 */, size_t n, uint8_t *out /* n*128 */, uint8_t *status);
 
@@ -241,6 +250,9 @@ int bn254_ctx_set_profiling(bn254_ctx *ctx, int enabled);
                                        default 32; 0 = always the filter rounds.  Same points and try counts either way. */
 #define BN254_OPT_HASH_MAX_TRIES 2 /* test knob: counters tried before HashToPointError; 0 = 255 as in src/hash.rs:40 */
 int bn254_ctx_set_option(bn254_ctx *ctx, int option, int value);
+/* per-kernel times of the last verify-shaped call with profiling on (HIP events on the call's stream):
+ * ms[0] decode, ms[1] hash-to-G1, ms[2] Miller loop, ms[3] final exponentiation.  The host-pointer bn254_batch_verify runs
+ * the hash first and its ms[1] includes the transfer of the messages. */
 int bn254_ctx_last_kernel_ms(bn254_ctx *ctx, float ms[4]);
 
 #ifdef __cplusplus

@@ -432,7 +432,10 @@ def g2_from_compressed(data):
     v = int.from_bytes(data[1:], "big")
     c1, c0 = divmod(v, Q)
     if c1 >= Q:
-        raise Bn254Error(ERR_INVALID_ENCODING)        # FieldError::InvalidU512Encoding
+        # unpinned (no reference vector; the dependency is not vendored): upstream's Fq2::from_slice is recalled as
+        # divrem(..).0.ok_or(FieldError::NotMember) -> Error::NotMemberError (/root/reference/src/error.rs:44-51);
+        # InvalidU512Encoding is the wrong-LENGTH fault of U512::from_slice, unreachable behind the 65-byte check
+        raise Bn254Error(ERR_NOT_MEMBER)
     x = (c0, c1)
     y = f2_sqrt(f2_add(f2_mul(f2_mul(x, x), x), B2))
     if y is None:

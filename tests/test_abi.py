@@ -48,3 +48,22 @@ def test_product_does_not_import_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
                 assert "libbn254_oracle" not in src and "hostsim" not in src.replace("tests/hostsim", ""), f
+
+
+def test_every_source_makes_the_library_stale(monkeypatch):
+    """The staleness check covers every translation unit and header the compile command reads (a forgotten file would let
+    tests and bench run against an old libbn254hip.so): with each dependency's mtime pushed past the library's, in turn,
+    `_stale()` must say so; with none newer it must not."""
+    deps = _native._dependencies()
+    names = {os.path.basename(p) for p in deps}
+    csrc = os.path.join(ROOT, "bn254_amd", "csrc")
+    on_disk = {f for f in os.listdir(csrc) if f.endswith((".hip", ".h"))}
+    assert on_disk <= names and {"bn254_quad.hip", "bn254_constants.h", "bn254_hip.h", "gen_constants.py"} <= names
+    assert set(_native.translation_units()) == {os.path.join(csrc, f) for f in on_disk if f.endswith(".hip")}
+    real = os.path.getmtime
+    lib_t = 1000.0
+    for newer in [None] + deps:
+        monkeypatch.setattr(os.path, "getmtime", lambda p, newer=newer: lib_t + 1 if p == newer else (lib_t if p == _native.LIB_PATH else lib_t - 1))
+        monkeypatch.setattr(os.path, "exists", lambda p: True)
+        assert _native._stale() == (newer is not None), newer
+    monkeypatch.setattr(os.path, "getmtime", real)

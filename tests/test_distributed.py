@@ -58,7 +58,8 @@ def _worker(rank, world, port, q):
                                   b"".join(bytes.fromhex(v["pk"]) for v in mine))
     local = torch.zeros(per, dtype=torch.uint8)
     local[: hi - lo] = torch.tensor(list(st), dtype=torch.uint8)
-    allst = gather_status(local, n_total=n)
+    padded = gather_status(local)                                   # rank-major, every shard padded to `per`
+    allst = torch.cat([padded[r * per: r * per + (shard_range(n, r, world)[1] - shard_range(n, r, world)[0])] for r in range(world)])
     fails = failure_count(local[: hi - lo])
     # the 8-byte checksum all-reduce of the pairing workload: each rank sums the words of "its" bytes, wrapping mod 2^64
     blob = torch.frombuffer(bytearray(hashlib.sha256(b"gt-%d" % rank).digest() * 12), dtype=torch.uint8)   # 384 B
@@ -70,11 +71,14 @@ def _worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_gather_gloo(derived):
+@pytest.mark.parametrize("world", [2, 8])
+def test_n_rank_gather_gloo(derived, world):
+    """world size 2 and the full node's 8: contiguous shards, rank-major gather (the last shard is short: 8 does not divide
+    the case count), failure count and wrapping checksum all-reduce"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     got, fails, total = q.get(timeout=120)
@@ -85,7 +89,7 @@ def test_two_rank_gather_gloo(derived):
     assert got == want
     assert fails == sum(1 for s in want if s)
     ref = 0
-    for r in range(2):
+    for r in range(world):
         b = hashlib.sha256(b"gt-%d" % r).digest() * 12
         ref += sum(int.from_bytes(b[i:i + 8], "little") for i in range(0, 384, 8)) + 0x7FFFFFFFFFFFFF00 + r
     assert total == ref % (1 << 64)
@@ -115,6 +119,36 @@ def test_bench_launcher_starts_ranks_and_fails_loudly_without_gpu():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env={**env_clean, "WORLD_SIZE": "2", "RANK": "0"},
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert p.returncode != 0 and "WORLD_SIZE=2" in p.stderr
+
+
+def test_rank_selects_its_own_device_for_local_ranks_0_to_7(monkeypatch):
+    """bench.py's Rank on an 8-GPU node, without the single-device test knob: LOCAL_RANK r -> torch.cuda.set_device(r), the
+    RCCL process group is created with device_id cuda:r, and the rank's stream lives on that device (torch.cuda mocked:
+    no GPU here; world size 8 has never run on hardware, so this pins the selection logic)."""
+    import importlib.util
+    import types
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    calls = {}
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: calls.setdefault("set_device", []).append(d))
+    monkeypatch.setattr(torch.cuda, "Stream", lambda device=None: types.SimpleNamespace(device=device))
+    monkeypatch.setattr(dist, "init_process_group", lambda backend=None, device_id=None, **kw: calls.setdefault("init", []).append((backend, device_id)))
+    monkeypatch.setattr(dist, "get_world_size", lambda: 8)
+    for k in ("BN254_BENCH_BACKEND", "BN254_BENCH_SINGLE_DEVICE", "BN254_BENCH_FORCE_DIST"):
+        monkeypatch.delenv(k, raising=False)
+    for r in range(8):
+        monkeypatch.setenv("RANK", str(r)); monkeypatch.setenv("LOCAL_RANK", str(r)); monkeypatch.setenv("WORLD_SIZE", "8")
+        R = bench.Rank(types.SimpleNamespace(gpus=8))
+        assert R.rank == r and R.local_rank == r and R.world == 8 and R.dist_on and R.backend == "nccl"
+        assert R.dev == torch.device("cuda", r) and R.stream.device == torch.device("cuda", r)
+    assert calls["set_device"] == list(range(8))
+    assert calls["init"] == [("nccl", torch.device("cuda", r)) for r in range(8)]
+    # a launcher whose world size disagrees with --gpus is refused
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    with pytest.raises(SystemExit):
+        bench.Rank(types.SimpleNamespace(gpus=8))
 
 
 def _two_rank_env():
@@ -166,6 +200,48 @@ def test_bench_gpus2_pairing_command_line_checksum_vs_oracle():
     Qs = [c.g2_mul(g2, red(k)) for k in sc[pool:]]
     total = 0
     for rank in range(2):
+        pi, qi = bench.pairing_indices(np, rank * n, n, pool)
+        gt, st = c.batch_pairing(b"".join(P[i] for i in pi), b"".join(Qs[i] for i in qi), n, 1, nthreads=8)
+        assert st == bytes([9]) * n
+        total += int(np.frombuffer(gt, dtype="<u8").sum(dtype=np.uint64))
+    assert "%016x" % (total % (1 << 64)) == r["config"]["gt_checksum_u64"]
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_bench_gpus4_both_workloads_all_shards_checked():
+    """more ranks than two on the one GPU of the box: `bench.py --gpus 4` for both sharded workloads (gloo, single-device
+    knobs).  FOUR, not the node's eight: the GPU pool allows at most six processes on a card at once and this test process
+    is one of them (world size 8 itself: test_n_rank_gather_gloo[8] and test_rank_selects_its_own_device... on the CPU).
+    Every rank checks every gathered shard; the all-reduced Gt checksum equals the oracle's over all four shards."""
+    import numpy as np
+    from oracle import c_oracle as c
+    W = 4
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(W), "--steps", "2", "--warmup", "1", "--batch", "2048"],
+                       env=_two_rank_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=840)
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert r["n_gpus"] == W and r["config"]["bit_exact_vs_expected"] is True and r["config"]["batch_per_gpu"] == 2048
+    assert r["config"]["status_vectors_checked"] == 2 * (1 + W)              # 2 checks x (own shard + W gathered shards)
+    assert abs(r["value"] - 2 * W * 2048 * 2 / (r["ms_per_step"] * 2e-3)) / r["value"] < 1e-6
+    n = 512
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(W), "--workload", "pairing", "--steps", "2", "--warmup", "1",
+                        "--batch", str(n)], env=_two_rank_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=840)
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert r["n_gpus"] == W and r["config"]["batch_per_gpu"] == n
+    spec = __import__("importlib.util").util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = __import__("importlib.util").util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    pool = min(4096, n)
+    sc = [hashlib.sha256(b"cfg4-%d" % j).digest() for j in range(2 * pool)]
+    R = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+    red = lambda k: (int.from_bytes(k, "big") % R).to_bytes(32, "big")   # noqa: E731
+    g1, g2 = c.g1_generator(), c.g2_generator()
+    P = [c.g1_mul(g1, red(k)) for k in sc[:pool]]
+    Qs = [c.g2_mul(g2, red(k)) for k in sc[pool:]]
+    total = 0
+    for rank in range(W):
         pi, qi = bench.pairing_indices(np, rank * n, n, pool)
         gt, st = c.batch_pairing(b"".join(P[i] for i in pi), b"".join(Qs[i] for i in qi), n, 1, nthreads=8)
         assert st == bytes([9]) * n

@@ -129,7 +129,7 @@ def test_config4_pairings_512k(env):
     negP = np.stack([np.frombuffer(P[64 * j:64 * j + 32] + (Q - int.from_bytes(P[64 * j + 32:64 * j + 64], "big")).to_bytes(32, "big"), dtype=np.uint8)
                      for j in range(pool)])
     i = np.arange(n)
-    pi, qi = (i * 7 + 3) % pool, (i * 13 + 5) % pool
+    pi, qi = i % pool, (i // pool + 5 * i) % pool            # (pi, qi) distinct for i < pool^2 = 262 144: two copies of each pair
     # k = 2: (P, Q), (-P, Q) -> 1
     g1s = np.stack([Pn[pi], negP[pi]], axis=1).reshape(-1)
     g2s = np.stack([Qn[qi], Qn[qi]], axis=1).reshape(-1)
@@ -149,16 +149,19 @@ def test_config4_pairings_512k(env):
     gt = d_gt.view(n, 384)
     for k in list(range(16)) + [n - 1, n // 2 + 17]:
         assert gt[k].cpu().numpy().tobytes() == c.pairing(Pn[pi[k]].tobytes(), Qn[qi[k]].tobytes())
-    # 4 096 Gt values spread over the shard vs the oracle, byte for byte, and the additive 64-bit checksum over them
-    # (the quantity bench.py all-reduces) computed on the device bytes and on the oracle's
+    # 64 Ki Gt values of DISTINCT pairs spread over the shard vs the oracle (">= 64 Ki subsample per
+    # GPU"), byte for byte, and the additive 64-bit checksum over them (the quantity bench.py all-reduces) computed on the
+    # device bytes and on the oracle's
     from bn254_amd.sharding import gt_checksum
-    sel = np.unique(np.concatenate([np.arange(0, n, n // 3072)[:3072], np.random.default_rng(4).integers(0, n, 1024)]))[:4096]
+    sel = np.unique(np.concatenate([np.arange(0, pool * pool, 4), np.random.default_rng(4).integers(0, n, 1024)]))
+    sel = np.concatenate([sel[:65535], [n - 1]])
+    assert len(sel) == 65536 and len(np.unique(pi[sel[:-1]] * pool + qi[sel[:-1]])) >= 65000
     want_gt, want_st = c.batch_pairing(Pn[pi[sel]].tobytes(), Qn[qi[sel]].tobytes(), len(sel), 1, nthreads=_cores())
     got_sel = gt[torch.from_numpy(sel).to(dev)].contiguous()
     assert got_sel.cpu().numpy().tobytes() == want_gt and want_st == bytes([9]) * len(sel)
     assert int(gt_checksum(got_sel.view(-1)).item()) & (2**64 - 1) == int(np.frombuffer(want_gt, dtype="<u8").sum(dtype=np.uint64))
-    # items with the same (P,Q) indices produce identical bytes: period lcm(512,512) = 512
-    assert bool((gt[:1024] == gt[512 * 100:512 * 100 + 1024]).all())
+    # items with the same (P,Q) indices produce identical bytes: period pool^2
+    assert bool((gt[:pool * pool] == gt[pool * pool:]).all())
 
 
 def test_config3_aggregate_1m(env):

@@ -734,15 +734,87 @@ def test_aggregate_verify_index_validation_device_and_host(eng, c):
         d_moff = t([0, len(msgs[0]), len(msgs[0]) + len(msgs[1])], torch.int64)
         d_pk = torch.frombuffer(bytearray(pk_pool), dtype=torch.uint8).to(dev)
         d_sig = torch.frombuffer(bytearray(sig_pool), dtype=torch.uint8).to(dev)
-        d_tm, d_to, d_si = t([0, 1, 1], torch.int32), t([0, 5, 2, 4], torch.int64), t([0, 1, 2, 3, 4, 0], torch.int32)
-        d_st = torch.full((3,), 255, dtype=torch.uint8, device=dev)
+        # ... and a message index >= n_msgs (tuple 3) through the same entry point
+        d_tm, d_to, d_si = t([0, 1, 1, 9], torch.int32), t([0, 5, 2, 4, 6], torch.int64), t([0, 1, 2, 3, 4, 0], torch.int32)
+        d_st = torch.full((4,), 255, dtype=torch.uint8, device=dev)
         stream = torch.cuda.Stream(device=dev)
         with torch.cuda.stream(stream):
             eng.batch_aggregate_verify_device(d_msgs.data_ptr(), d_moff.data_ptr(), M, d_pk.data_ptr(), S, d_sig.data_ptr(), d_tm.data_ptr(),
-                                              d_to.data_ptr(), d_si.data_ptr(), 3, d_st.data_ptr(), stream=stream.cuda_stream)
+                                              d_to.data_ptr(), d_si.data_ptr(), 4, d_st.data_ptr(), stream=stream.cuda_stream)
         stream.synchronize()
-        assert d_st.cpu().tolist() == [0, 2, 0]
+        assert d_st.cpu().tolist() == [0, 2, 0, 2]
     eng.set_option(OPT_PAIR_LANES, 1)
+
+
+def test_device_entry_points_bound_check_message_offsets(eng, c):
+    """*_device entry points read their offsets array on the device: a reversed pair, or — once the caller has declared the
+    buffer size (bn254_ctx_expect_msgs_len) — a span past the buffer, is never dereferenced; its item reports 5
+    (InvalidLength), every other item what the oracle says.  Small batch (direct hash + wave roles) and lane-pair sizes;
+    verify, hash_to_g1 and sign."""
+    import torch
+    from tests.datagen import make_verify_batch
+    dev = torch.device("cuda", 0)
+    for n in (70, 20000):
+        msgs, sigs, pks, expected = make_verify_batch(eng, n, corrupt_every=9)          # 32-byte messages, status 9 at 8, 17, ...
+        blob = b"".join(msgs)
+        off = [32 * i for i in range(n + 1)]
+        want = c.batch_verify(msgs, sigs, pks, flags=0, nthreads=8)[0]
+        assert want == expected
+        d_msgs = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+        d_sigs = torch.frombuffer(bytearray(sigs), dtype=torch.uint8).to(dev)
+        d_pks = torch.frombuffer(bytearray(pks), dtype=torch.uint8).to(dev)
+        stream = torch.cuda.Stream(device=dev)
+        for declare in (True, False):
+            bad = list(off)
+            bad[4] = off[3] - 1            # item 3 reversed -> 5; item 4 = [off[3] - 1, off[5]) is another message: not compared
+            exp = bytearray(want)
+            exp[3] = 5
+            if declare:
+                bad[n - 1] = len(blob) + (1 << 40)        # item n-2 runs past the buffer, item n-1 = [huge, off[n]) is reversed
+                exp[n - 2] = exp[n - 1] = 5
+                eng.expect_msgs_len(len(blob))
+            else:
+                bad[n] = off[n - 1] - 1                   # undeclared size: only reversed pairs can be seen — item n-1
+                exp[n - 1] = 5
+            d_off = torch.tensor(bad, dtype=torch.int64, device=dev)
+            d_st = torch.full((n,), 255, dtype=torch.uint8, device=dev)
+            eng.batch_verify_device(d_msgs.data_ptr(), d_off.data_ptr(), d_sigs.data_ptr(), d_pks.data_ptr(), n, d_st.data_ptr(), flags=0,
+                                    stream=stream.cuda_stream)
+            stream.synchronize()
+            got = d_st.cpu().numpy().tobytes()
+            diff = [(i, got[i], exp[i]) for i in range(n) if i != 4 and got[i] != exp[i]]
+            assert not diff, (n, declare, diff[:10])
+            assert got[4] in (5, 9)
+    # hash_to_g1 and sign see the same check (status 5, tries 0)
+    n = 40
+    msgs = [b"span-%d" % i for i in range(n)]
+    blob = b"".join(msgs)
+    off = [0]
+    for m in msgs:
+        off.append(off[-1] + len(m))
+    off[n] = len(blob) + 1000
+    d_msgs = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+    d_off = torch.tensor(off, dtype=torch.int64, device=dev)
+    d_pts = torch.zeros(64 * n, dtype=torch.uint8, device=dev)
+    d_st = torch.full((n,), 255, dtype=torch.uint8, device=dev)
+    d_tr = torch.full((n,), 255, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    eng.expect_msgs_len(len(blob))
+    eng.batch_hash_to_g1_device(d_msgs.data_ptr(), d_off.data_ptr(), n, d_pts.data_ptr(), d_st.data_ptr(), d_tr.data_ptr(), stream=stream)
+    torch.cuda.synchronize()
+    st, tr, pts = d_st.cpu().tolist(), d_tr.cpu().tolist(), d_pts.cpu().numpy().tobytes()
+    assert st == [0] * (n - 1) + [5] and tr[n - 1] == 0
+    for i in range(n - 1):
+        assert (0, pts[64 * i:64 * i + 64], tr[i]) == c.hash_to_g1(msgs[i])
+    # the declaration is consumed by ONE call: the same arrays again without it -> the last span is taken at face value
+    # only if it lies inside the allocation; do not run that (it would read past the buffer) — instead check that a
+    # declaration larger than the span accepts it
+    off[n] = len(blob)
+    d_off = torch.tensor(off, dtype=torch.int64, device=dev)
+    eng.expect_msgs_len(len(blob))
+    eng.batch_hash_to_g1_device(d_msgs.data_ptr(), d_off.data_ptr(), n, d_pts.data_ptr(), d_st.data_ptr(), d_tr.data_ptr(), stream=stream)
+    torch.cuda.synchronize()
+    assert d_st.cpu().tolist() == [0] * n
 
 
 def test_cpp_host_mirror_example(eng):
