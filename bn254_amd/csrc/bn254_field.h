@@ -88,6 +88,11 @@ extern "C" unsigned long long bn_fp_dual_counter;   // of those, dual-accumulate
 // count of the long loops.  The issue arbiter otherwise favours the older wave of a SIMD and the pair drifts 3 ms
 // apart; with the cycle, whichever wave falls a few steps behind is in a higher-priority part of the cycle and
 // catches up.  A no-op everywhere else.
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__) && defined(BN_USE_RELOAD_FENCE)
+#define BN_RELOAD_FENCE() asm volatile("" ::: "memory")
+#else
+#define BN_RELOAD_FENCE() do { } while (0)
+#endif
 #ifndef BN_SET_STEP_PRIORITY
 #define BN_SET_STEP_PRIORITY(step) do { } while (0)
 #endif
@@ -929,13 +934,20 @@ BN_DEV void fp12_mul_body(Fp12& r, const Fp12& a, const Fp12& b) {  // sites 20 
   // VGPRs): the Karatsuba product of the sums first, while nothing else is alive, then one Fq6 product at a time.
   // t0 = a0 b0 is parked in r.c0 (memory) while a1 b1 is computed: r may be a or b themselves (acc = acc * x), and by
   // then a.c0 / b.c0 have had their last use.
+  // BN_RELOAD_FENCE between the three Fq6 products (opt-in, -DBN_USE_RELOAD_FENCE): a and b are memory operands (LDS
+  // accumulator, private-segment slot); without the fence the compiler keeps the halves it loaded for the sums alive across
+  // the first product and spills 28 words (reloading 42); with it each product re-reads the two halves it needs and the
+  // multiplication has no spill at all — but the re-reads sit right in front of their use: measured 4.08 against 4.05 ms
+  // per 65 536 (profiles/r03_b_ab_fe_machine.log), so it is off.
   Fp6 s, t, u;
   fp6_add(s, a.c0, a.c1); fp6_site_n<28>(s, s);
   fp6_add(t, b.c0, b.c1); fp6_site_n<31>(t, t);
   fp6_mul<34>(u, s, t);
+  BN_RELOAD_FENCE();
   fp6_mul<20>(s, a.c0, b.c0);                      // t0
   fp6_sub(u, u, s);
   r.c0 = s;
+  BN_RELOAD_FENCE();
   fp6_mul<24>(t, a.c1, b.c1);                      // t1
   fp6_sub(u, u, t);
   fp6_site_r<41>(r.c1, u);
@@ -1218,7 +1230,7 @@ BN_DEV Fp2& fp12_coef(Fp12& a, int k) {
   return (k >> 1) == 0 ? h.c0 : (k >> 1) == 1 ? h.c1 : h.c2;
 }
 // q^power Frobenius, power in {1,2,3}
-BN_DEVN void fp12_frob(Fp12& r, const Fp12& a, int power) {
+BN_DEV void fp12_frob_body(Fp12& r, const Fp12& a, int power) {
   Fp12 t = a;
   for (int k = 0; k < 6; ++k) {
     Fp2& c = fp12_coef(t, k);
@@ -1228,6 +1240,7 @@ BN_DEVN void fp12_frob(Fp12& r, const Fp12& a, int power) {
   }
   r = t;
 }
+BN_DEVN void fp12_frob(Fp12& r, const Fp12& a, int power) { fp12_frob_body(r, a, power); }
 // (a + b s)^2 in Fq4 = Fq2[s]/(s^2 - xi): r0 = a^2 + xi b^2, r1 = 2ab; a, b tight.  Sites S .. S+2.
 template <int S> BN_DEV void fp4_sqr(Fp2& r0, Fp2& r1, const Fp2& a, const Fp2& b) {
   Fp2 a2 = fp2_sqr(a), b2 = fp2_sqr(b);

@@ -53,6 +53,8 @@ __device__ __forceinline__ void ws_load_g2(const Ws& ws, size_t i, G2Affine& q) 
 // every wave stays convergent; its status byte keeps the decode error.
 __device__ __forceinline__ void g1_set_generator(G1Affine& p) { p.x = fp_load_const(C_G1_GEN[0]); p.y = fp_load_const(C_G1_GEN[1]); p.inf = false; }
 __device__ __forceinline__ void g2_set_generator(G2Affine& q) { q.x = fp2_load_const(C_G2_GEN[0]); q.y = fp2_load_const(C_G2_GEN[1]); q.inf = false; }
+// the coordinates of the generator with the identity flag untouched (a stand-in for arithmetic that must not meet (0, 0))
+__device__ __forceinline__ void g2_set_generator_keep_inf(G2Affine& q) { q.x = fp2_load_const(C_G2_GEN[0]); q.y = fp2_load_const(C_G2_GEN[1]); }
 
 // The Miller accumulator f (12 field elements = 432 B per lane) is the hottest per-lane state: every
 // Fq12 squaring / line multiplication reads and rewrites it.  It is staged in LDS, one padded slot per
@@ -89,6 +91,34 @@ KERNEL void k_decode_g2(const uint8_t* pts, size_t n, uint32_t flags, Ws ws, int
   ws_store_g2(ws, i, q);
   uint8_t prev = accumulate ? ws_byte(ws, BY_ST_DECODE, i) : (uint8_t)ST_OK;
   ws_byte(ws, BY_ST_DECODE, i) = prev != ST_OK ? prev : st;
+}
+
+// Keyed verify, registration: key j is decoded like PublicKey::from_uncompressed does (/root/reference/src/types.rs:96-99
+// -> src/utils.rs:107-116; the subgroup check of AffineG2::new ALWAYS runs here, whatever the caller's flags: the table form
+// below relies on it) and the 87 lines of its Miller loop are written in the c2 = 1 form (bn254_pairing.h: g2_line_table).
+// One key per lane; a refused key walks on with the generator so that the wave stays convergent.  One-time work per key
+// set (87 Fq2 inversions per key: ~15 ms for 256 keys), not part of any verify.
+KERNEL void k_register_keys(const uint8_t* pks, size_t n_keys, uint32_t flags, int32_t* lines, uint8_t* key_st, uint8_t* key_inf) {
+  const size_t j = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
+  const bool live = j < n_keys;
+  G2Affine q;
+  uint8_t st = decode_g2(q, pks + 128 * (live ? j : n_keys - 1), flags);
+  if (st != ST_OK || q.inf) g2_set_generator_keep_inf(q);
+  const bool in = g2_in_subgroup(q);
+  if (st == ST_OK && !q.inf && !in) { st = ST_INVALID_GROUP_POINT; g2_set_generator_keep_inf(q); }
+  int32_t* out = lines + (live ? j : 0) * (size_t)BN_N_FIXED_LINES * BN_KEY_LINE_WORDS;
+  const bool ok = g2_line_table(q, [&](int idx, const KeyLine& kl) {
+    if (!live) return;
+    const Fp c[4] = {fp_canon(kl.c0.c0), fp_canon(kl.c0.c1), fp_canon(kl.c1.c0), fp_canon(kl.c1.c1)};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int k = 0; k < BN_LIMBS; ++k) out[((size_t)idx * 4 + e) * BN_LIMBS + k] = c[e].v[k];
+  });
+  if (!live) return;
+  if (st == ST_OK && !q.inf && !ok) st = ST_INVALID_GROUP_POINT;   // a line with c2 = 0: not reachable from the order-r subgroup (~2^-250)
+  key_st[j] = st;
+  key_inf[j] = q.inf;
 }
 
 // hash_to_try_and_increment (hash.rs:29-63) in ROUNDS.  The reference tries counters 0,1,2,... per
@@ -857,6 +887,10 @@ struct bn254_ctx {
   hipEvent_t copy_done;
   uint64_t msgs_len_next;    // bn254_ctx_expect_msgs_len: size of the d_msgs buffer of the NEXT call that hashes messages
   int msgs_len_declared;
+  int32_t* key_lines;        // keyed verify: registered keys (bn254_ctx_register_keys), see KeyTable in bn254_ws.h
+  uint8_t* key_st;
+  uint8_t* key_inf;
+  size_t n_keys, key_cap;
   bool fits_w8, fits_quad, fits_trio;   // the device can hold a workgroup of the small-batch kernels (LDS), asked at creation
 };
 
@@ -1030,6 +1064,9 @@ void bn254_ctx_destroy(bn254_ctx* c) {
   if (c->ws.h_cnt) (void)hipFree(c->ws.h_cnt);
   for (int i = 0; i < 3; ++i) { if (c->pool[i].planes) (void)hipFree(c->pool[i].planes); if (c->pool[i].st) (void)hipFree(c->pool[i].st); }
   for (int i = 0; i < 8; ++i) if (c->stage[i]) (void)hipFree(c->stage[i]);
+  if (c->key_lines) (void)hipFree(c->key_lines);
+  if (c->key_st) (void)hipFree(c->key_st);
+  if (c->key_inf) (void)hipFree(c->key_inf);
   for (int i = 0; i < 5; ++i) (void)hipEventDestroy(c->ev[i]);
   (void)hipEventDestroy(c->copy_done);
   (void)hipStreamSynchronize(c->copy_stream);
@@ -1254,6 +1291,74 @@ int bn254_batch_verify(bn254_ctx* c, const uint8_t* msgs, const uint64_t* off, c
     (void)hipStreamSynchronize(c->stream);
   }
   return rc;
+}
+
+// ---- keyed verify (include/bn254_hip.h) ---------------------------------------------------------------------------------
+int bn254_ctx_register_keys(bn254_ctx* c, const uint8_t* pks, size_t n_keys, uint32_t flags, uint8_t* key_status) {
+  if (!c || (n_keys && !pks) || n_keys > 0xFFFFFFFFu) return BN254_E_BAD_ARGUMENT;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));           // no verify may still be reading the previous table
+  c->n_keys = 0;
+  if (n_keys == 0) return 0;
+  if (n_keys > c->key_cap) {
+    if (c->key_lines) { HIP_TRY(hipFree(c->key_lines)); c->key_lines = nullptr; }
+    if (c->key_st) { HIP_TRY(hipFree(c->key_st)); c->key_st = nullptr; }
+    if (c->key_inf) { HIP_TRY(hipFree(c->key_inf)); c->key_inf = nullptr; }
+    c->key_cap = 0;
+    HIP_TRY(hipMalloc((void**)&c->key_lines, n_keys * (size_t)BN_N_FIXED_LINES * BN_KEY_LINE_WORDS * sizeof(int32_t)));
+    HIP_TRY(hipMalloc((void**)&c->key_st, n_keys));
+    HIP_TRY(hipMalloc((void**)&c->key_inf, n_keys));
+    c->key_cap = n_keys;
+  }
+  int rc;
+  if ((rc = stage_in(c, 3, pks, n_keys * 128))) return rc;
+  k_register_keys<<<grid_for(n_keys), BN_WAVE, 0, c->stream>>>(c->stage[3], n_keys, flags & FLAG_REJECT_IDENTITY, c->key_lines, c->key_st, c->key_inf);
+  HIP_TRY(hipGetLastError());
+  if (key_status) HIP_TRY(hipMemcpyAsync(key_status, c->key_st, n_keys, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->n_keys = n_keys;
+  return 0;
+}
+int bn254_batch_verify_keyed_device(bn254_ctx* c, const uint8_t* d_msgs, const uint64_t* d_off, const uint8_t* d_sigs, const uint32_t* d_key_idx,
+                                    size_t n, uint32_t flags, uint8_t* d_status, void* stream) {
+  if (!c || (n && (!d_msgs || !d_off || !d_sigs || !d_key_idx || !d_status))) return BN254_E_BAD_ARGUMENT;
+  if (n == 0) return 0;
+  if (misaligned(d_sigs) || misaligned(d_key_idx) || ((uintptr_t)d_off & 7u)) return BN254_E_MISALIGNED;
+  HIP_TRY(hipSetDevice(c->device));
+  int rc = ws_reserve(c, n);
+  if (rc) return rc;
+  hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  KeyTable kt = {c->key_lines, c->key_st, c->key_inf, (uint32_t)c->n_keys};
+  PROF_MARK(0);
+  k_decode_g1<<<grid_for(n), BN_WAVE, 0, s>>>(d_sigs, n, flags, c->ws, PL_P1X, BY_P1_INF, 0);
+  PROF_MARK(1);
+  if ((rc = launch_hash_rounds(c, s, d_msgs, d_off, n, PL_P2X, BY_P2_INF, nullptr))) return rc;
+  PROF_MARK(2);
+  if ((rc = bn254_pair_miller_verify_keyed(n, c->ws, d_key_idx, kt, s))) return rc;
+  PROF_MARK(3);
+  if ((rc = bn254_pair_final_exp(n, c->ws, 1, d_status, nullptr, nullptr, s))) return rc;
+  PROF_MARK(4);
+  if (c->profiling) { c->ev_valid = 1; c->ev_hash_first = 0; }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+int bn254_batch_verify_keyed(bn254_ctx* c, const uint8_t* msgs, const uint64_t* off, const uint8_t* sigs, const uint32_t* key_idx, size_t n,
+                             uint32_t flags, uint8_t* status) {
+  if (!c || (n && (!off || !sigs || !key_idx || !status))) return BN254_E_BAD_ARGUMENT;
+  if (n == 0) return 0;
+  HIP_TRY(hipSetDevice(c->device));
+  if (!offsets_ok(off, n)) return BN254_E_BAD_ARGUMENT;
+  if (off[n] && !msgs) return BN254_E_BAD_ARGUMENT;
+  int rc;
+  if ((rc = stage_in(c, 0, msgs, (size_t)off[n]))) return rc;
+  if ((rc = stage_in(c, 1, off, (n + 1) * sizeof(uint64_t)))) return rc;
+  if ((rc = stage_in(c, 2, sigs, n * 64))) return rc;
+  if ((rc = stage_in(c, 3, key_idx, n * sizeof(uint32_t)))) return rc;
+  if ((rc = stage_reserve(c, 4, n))) return rc;
+  rc = bn254_batch_verify_keyed_device(c, c->stage[0], (const uint64_t*)c->stage[1], c->stage[2], (const uint32_t*)c->stage[3], n, flags, c->stage[4], nullptr);
+  if (!rc) rc = stage_out(c, 4, status, n);
+  hipError_t e = hipStreamSynchronize(c->stream);     // also on failure: the staged copies read the caller's buffers
+  return rc ? rc : -(int)e;
 }
 
 int bn254_batch_verify_randomized_device(bn254_ctx* c, const uint8_t* d_msgs, const uint64_t* d_off, const uint8_t* d_sigs,

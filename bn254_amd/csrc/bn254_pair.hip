@@ -167,6 +167,37 @@ KERNEL_PAIR void k_miller_verify_pair(size_t n, Ws ws, const uint32_t* map, cons
   miller_loop<true, true, true>(f, h, pk, sig);
   ws_store_f12_own(ws, i, f);
 }
+// Keyed verify: f = miller(H(m), pk[key_idx[i]]) * miller(sig, -G2) with BOTH line sequences read from tables — pair A from
+// the registered key's 87 lines in HBM (each lane loads the 2 x 9 words of its role per line: 12.5 KB per verify, L2-resident
+// for a validator set), pair B from the constant table.  No twist-point arithmetic: 36 product slots per doubling step
+// against 48 (bn254_pairing.h: miller_loop_keyed).  Status: the signature's decode status stays first; then the key's
+// (index >= n_keys -> IndexOutOfBounds, else what registration found), written back for k_final_exp_pair.
+KERNEL_PAIR void k_miller_verify_keyed_pair(size_t n, Ws ws, const uint32_t* key_idx, KeyTable kt) {
+  const size_t i = ((size_t)blockIdx.x * BN_PAIR_WG + threadIdx.x) >> 1;
+  if (i >= n) return;
+  uint32_t key = key_idx[i];
+  uint8_t kst = ST_OK;
+  if (key >= kt.n_keys) { kst = ST_INDEX_OOB; key = 0; }
+  else kst = kt.st[key];
+  const bool key_inf = kst != ST_OK || kt.inf[key] != 0;      // a refused key walks the loop as a skipped pair
+  if ((threadIdx.x & 1u) == 0) {
+    const uint8_t prev = ws_byte(ws, BY_ST_DECODE, i);
+    ws_byte(ws, BY_ST_DECODE, i) = prev != ST_OK ? prev : kst;
+  }
+  G1Affine sig, h;
+  ws_load_g1(ws, PL_P1X, BY_P1_INF, i, sig);
+  ws_load_g1(ws, PL_P2X, BY_P2_INF, i, h);
+  __shared__ Fp12PairSlot lds_f[BN_PAIR_WG];
+  Fp12& f = lds_f[threadIdx.x].v;
+  typedef const int32_t (*LinePtr)[2][2][BN_LIMBS];
+  miller_loop_keyed<true>(f, h, key_inf, (LinePtr)(kt.lines + (size_t)key * BN_N_FIXED_LINES * BN_KEY_LINE_WORDS), sig);
+  ws_store_f12_own(ws, i, f);
+}
+int bn254_pair_miller_verify_keyed(size_t n, Ws ws, const uint32_t* key_idx, KeyTable kt, hipStream_t s) {
+  k_miller_verify_keyed_pair<<<(unsigned)((2 * n + BN_PAIR_WG - 1) / BN_PAIR_WG), BN_PAIR_WG, 0, s>>>(n, ws, key_idx, kt);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
 // generic single pair per lane pair: f = miller(P1, Q)   (bn254_batch_pairing*)
 KERNEL_PAIR void k_miller_var_pair(size_t n, Ws ws) {
   size_t i = ((size_t)blockIdx.x * BN_PAIR_WG + threadIdx.x) >> 1;
@@ -182,47 +213,6 @@ KERNEL_PAIR void k_miller_var_pair(size_t n, Ws ws) {
   miller_loop<true, false, true>(f, p, q, p);
   ws_store_f12_own(ws, i, f);
 }
-// 32 big-endian bytes of the canonical value (4-byte aligned destination)
-__device__ __forceinline__ void store_fp_be(uint8_t* b, const Fp& a) {
-  U256 x = fp_to_u256(a);
-  uint32_t* w = (uint32_t*)b;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) w[k] = __builtin_bswap32(x.w[7 - k]);
-}
-// item i: product of the k Miller values at workspace indices base + i*item_stride + j*pair_stride, final
-// exponentiation, comparison with one (status) and / or the canonical Gt bytes (each lane writes the 32-byte halves
-// of its role).  Same contract as k_final_exp of bn254_hip.hip.
-KERNEL_PAIR void k_final_exp_pair(size_t n, size_t k, size_t item_stride, size_t pair_stride, Ws ws, int use_hash, uint8_t* gt_out,
-                                  uint8_t* status_out, int raw_only, size_t base, const uint32_t* map, const uint32_t* count) {
-  size_t i = ((size_t)blockIdx.x * BN_PAIR_WG + threadIdx.x) >> 1;
-  if (i >= n) return;
-  if (map) { if (i >= *count) return; i = map[i]; }
-  Fp12 f, g;
-  ws_load_f12_own(ws, base + i * item_stride, f);
-  uint8_t st = ws_byte(ws, BY_ST_DECODE, base + i * item_stride);
-  for (size_t j = 1; j < k; ++j) {
-    size_t idx = base + i * item_stride + j * pair_stride;
-    ws_load_f12_own(ws, idx, g);
-    fp12_mul(f, f, g);
-    uint8_t sj = ws_byte(ws, BY_ST_DECODE, idx);
-    if (st == ST_OK) st = sj;
-  }
-  if (st == ST_OK && use_hash) st = ws_byte(ws, BY_ST_HASH, i);
-  __shared__ Fp12PairSlot lds_acc[BN_PAIR_WG];
-  if (!raw_only) {
-    // canonical Gt bytes need the exact exponent; the == one test alone takes the shorter chain (wave-uniform branch)
-    if (gt_out) final_exponentiation<true>(f, f, lds_acc[threadIdx.x].v);
-    else final_exponentiation_check<true>(f, f, lds_acc[threadIdx.x].v);
-  }
-  const unsigned role = threadIdx.x & 1u;
-  if (gt_out) {
-    const Fp2* c[6] = {&f.c0.c0, &f.c0.c1, &f.c0.c2, &f.c1.c0, &f.c1.c1, &f.c1.c2};
-    for (int e = 0; e < 6; ++e) store_fp_be(gt_out + 384 * i + 64 * e + 32 * role, c[e]->c[0]);
-  }
-  const bool one = fp12_is_one(f);   // combined over the pair
-  if (status_out && role == 0) status_out[i] = st != ST_OK ? st : (one ? (uint8_t)ST_OK : (uint8_t)ST_VERIFICATION_FAILED);
-}
-
 // ---- randomised batch verification (see bn254_hip.hip) on lane pairs -------------------------------------------
 // A 256-lane workgroup = 128 lane pairs.  k_miller_rand_pair: one item per pair -> 2 groups of 64 items per
 // workgroup; k_miller_rand2_pair: two items per pair (shared f^2, merged lines) -> 4 groups per workgroup.
@@ -379,16 +369,6 @@ int bn254_pair_miller_verify(size_t n, Ws ws, const uint32_t* map, const uint32_
 }
 int bn254_pair_miller_var(size_t n, Ws ws, hipStream_t s) {
   k_miller_var_pair<<<(unsigned)((2 * n + BN_PAIR_WG - 1) / BN_PAIR_WG), BN_PAIR_WG, 0, s>>>(n, ws);
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-int bn254_pair_final_exp(size_t n, Ws ws, int use_hash, uint8_t* status_out, const uint32_t* map, const uint32_t* count, hipStream_t s, size_t base) {
-  k_final_exp_pair<<<(unsigned)((2 * n + BN_PAIR_WG - 1) / BN_PAIR_WG), BN_PAIR_WG, 0, s>>>(n, 1, 1, 1, ws, use_hash, nullptr, status_out, 0, base, map, count);
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-int bn254_pair_final_exp_product(size_t n, size_t k, Ws ws, uint8_t* gt_out, uint8_t* status_out, int raw_only, hipStream_t s) {
-  k_final_exp_pair<<<(unsigned)((2 * n + BN_PAIR_WG - 1) / BN_PAIR_WG), BN_PAIR_WG, 0, s>>>(n, k, k, 1, ws, 0, gt_out, status_out, raw_only, 0, nullptr, nullptr);
   HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -160,6 +160,95 @@ BN_DEVM void miller_loop(Fp12& f, const G1Affine& pa, const G2Affine& qa, const 
   else if constexpr (HAS_B) { fixed_line(l, idx++); mul_by_line(f, l, pb.x, pb.y, skip_b); }
 }
 
+// ---- keyed verify: the line functions of a REGISTERED public key ----------------------------------------------------------
+// The twist-point arithmetic of pair A = (H(m), pk) — 64 doublings and 23 additions, ~2.5 k of the 11.1 k Fq products of a
+// verify's Miller loop — depends on pk alone.  For a key that verifies many messages (a validator set; the reference's
+// PublicKey is Copy and validated once at construction, /root/reference/src/types.rs:80-99) the 87 lines are computed
+// once (g2_line_table) in the shape of the constant table of -G2::one(): scaled so that c2 = 1, (c0, c1) stored.  A verify
+// then multiplies two table lines per step:
+//   (l0 + l1 w + w^3)(m0 + m1 w + w^3) = (l0 m0 + xi) + (l0 m1 + l1 m0) w + l1 m1 w^2 + (l0 + m0) w^3 + (l1 + m1) w^4
+// 3 Fq2 products (Karatsuba for the w term) + the four scalings by the G1 coordinates, against 10 for the step of T, 4
+// scalings and 5 for the line product: 36 product slots per doubling step instead of 48.
+// c2 = Y^2 - 3b'Z^2 (tangent) or theta x_Q - mu y_Q (chord) vanishes only on a handful of algebraic points, none of
+// which lies in the order-r subgroup except with probability ~2^-250 (keys are subgroup-checked at registration, so an
+// adversarial key cannot aim for one); g2_line_table reports it and the key is refused.
+struct KeyLine { Fp2 c0, c1; };
+template <class Store>
+BN_DEV bool g2_line_table(const G2Affine& q, Store&& store) {            // sites 290 .. 293
+  G2Proj t;
+  LineCoef l;
+  t.x = q.x; t.y = q.y; t.z = fp2_one();
+  const Fp2 q_yneg = fp2_neg(q.y);
+  bool ok = true;
+  int idx = 0;
+  auto emit = [&]() {
+    const Fp2 c2 = NR(290, l.c2);
+    ok = !fp2_is_zero(c2) && ok;
+    const Fp2 inv = NS(291, fp2_inv(c2));
+    KeyLine kl;
+    kl.c0 = fp2_mul(NS(292, l.c0), inv);
+    kl.c1 = fp2_mul(NS(293, l.c1), inv);
+    store(idx++, kl);
+  };
+  for (int d = 0; d < 64; ++d) {
+    dbl_step(t, l); emit();
+    const int digit = C_ATE_NAF[d];
+    if (digit != 0) { add_step(t, l, q.x, fp2_select(digit > 0, q.y, q_yneg)); emit(); }
+  }
+  add_step(t, l, fp2_mul(fp2_conj(q.x), fp2_load_const(C_TW_FROB_X1)), fp2_mul(fp2_conj(q.y), fp2_load_const(C_TW_FROB_Y1))); emit();
+  add_step(t, l, fp2_mul(q.x, fp2_load_const(C_TW_FROB_X2)), q.y); emit();
+  return ok;
+}
+// f <- f * lineA(pa) * lineB(pb): lineA = (la.c0, la.c1, 1) of the registered key, lineB = entry idx of the -G2 table
+BN_DEV void mul_by_two_table_lines(Fp12& f, const KeyLine& la, const Fp& pax, const Fp& pay, bool skip_a, int idx, const Fp& pbx, const Fp& pby,
+                                   bool skip_b, bool any_skip) {   // sites 280 .. 284
+  const Fp2 l0 = fp2_mul_fp(la.c0, pay), l1 = fp2_mul_fp(la.c1, pax);
+  const Fp2 m0 = fp2_mul_fp(fp2_load_const(C_NEG_G2_LINES[idx][0]), pby), m1 = fp2_mul_fp(fp2_load_const(C_NEG_G2_LINES[idx][1]), pbx);
+  const Fp2 v0 = fp2_mul(l0, m0), v1 = fp2_mul(l1, m1);
+  const Fp2 x01 = fp2_sub(fp2_sub(fp2_mul(NS(280, fp2_add(l0, l1)), NS(281, fp2_add(m0, m1))), v0), v1);
+  Fp6 b0;
+  b0.c0 = NS(282, fp2_add(v0, fp2_load_const(C_XI_MONT))); b0.c1 = v1; b0.c2 = NS(283, fp2_add(l1, m1));
+  Fp2 b10 = NS(284, x01), b11 = NS(285, fp2_add(l0, m0));
+  if (any_skip) {
+    // a skipped pair contributes the line 1: both skipped -> 1; A skipped -> lineB = m0 + m1 w + w^3; B skipped -> lineA
+    const Fp2 one = fp2_one(), zero = fp2_zero();
+    const bool both = skip_a && skip_b, only_a = skip_a && !skip_b, only_b = skip_b && !skip_a;
+    b0.c0 = fp2_select(both, one, fp2_select(only_a, m0, fp2_select(only_b, l0, b0.c0)));
+    b0.c1 = fp2_select(skip_a || skip_b, zero, b0.c1);
+    b0.c2 = fp2_select(skip_a || skip_b, zero, b0.c2);
+    b10 = fp2_select(both, zero, fp2_select(only_a, m1, fp2_select(only_b, l1, b10)));
+    b11 = fp2_select(both, zero, fp2_select(skip_a || skip_b, one, b11));
+  }
+  fp12_mul_line2(f, f, b0, b10, b11);
+}
+// f = miller(pa, key) * miller(pb, -G2): `tab` = the key's 87 x (c0, c1) as [line][coefficient][re / im][limb]
+template <bool F_LDS = false>
+BN_DEVM void miller_loop_keyed(Fp12& f, const G1Affine& pa, bool key_inf, const int32_t (*tab)[2][2][BN_LIMBS], const G1Affine& pb) {
+  if constexpr (F_LDS) BN_ASSUME_LDS(&f);
+  fp12_set_one(f);
+  const bool skip_a = pa.inf || key_inf, skip_b = pb.inf;
+#if defined(__HIPCC__)
+  const bool any_skip = __builtin_amdgcn_ballot_w64(skip_a || skip_b) != 0;   // wave-uniform
+#else
+  const bool any_skip = skip_a || skip_b;
+#endif
+  int idx = 0;
+  auto step = [&]() {
+    KeyLine la;
+    la.c0 = fp2_load_const(tab[idx][0]); la.c1 = fp2_load_const(tab[idx][1]);
+    mul_by_two_table_lines(f, la, pa.x, pa.y, skip_a, idx, pb.x, pb.y, skip_b, any_skip);
+    ++idx;
+  };
+  for (int d = 0; d < 64; ++d) {
+    BN_SET_STEP_PRIORITY(d);
+    fp12_sqr(f, f);
+    step();
+    if (C_ATE_NAF[d] != 0) step();      // wave-uniform
+  }
+  step();
+  step();
+}
+
 #if defined(BN_TRIO_FORMULAS)
 // ---- ECDSA::verify's Miller loop in ROUNDS (octet layout, bn254_trio.hip) ------------------------------------------
 // f = miller(pa, qa) * miller(pb, -G2), the same values as miller_loop<true, true>, with EVERY Fq2 product of a loop step
@@ -957,5 +1046,40 @@ BN_DEVN void final_exponentiation_check(Fp12& r, const Fp12& fin, Fp12& acc) {
   fp12_frob(a, t, 3);
   fp12_mul(r, a, y11);
 }
+
+// ---- the final exponentiation as an ACCUMULATOR MACHINE (the lane-pair kernels, bn254_pair.hip) ---------------------------
+// The chains above call ~26 Fq12 routines outside the loop of fp12_pow_u; as real functions each of them saves and restores
+// the callee-saved VGPRs it touches (fp12_mul: all 112 -> 224 private-segment dwords per call) and takes its Fq12 arguments
+// through memory.  Here the same chains are PROGRAMS (bn254_constants.h: C_FE_CHECK, C_FE_EXACT, written and proved by
+// gen_constants.py, which tracks the exponent every value carries) for a machine with ONE Fq12 accumulator — an LDS slot
+// in the kernels — and a file of Fq12 slots in the lane's private segment (coalesced dword-interleaved like any private
+// array).  The interpreter loop has one switch; every Fq12 routine is inlined at its ONE case, no value lives across
+// iterations, and the only memory traffic left is what the chain itself needs: a slot read per multiplication (54 words per
+// lane), a slot written per stored intermediate.  Instruction = (opcode, slot or Frobenius power), wave-uniform.
+enum FeOpcode : int { FE_END = 0, FE_LOAD = 1, FE_STORE = 2, FE_CSQR = 3, FE_MUL = 4, FE_CONJ = 5, FE_FROB = 6, FE_INV = 7 };
+template <int NSLOTS>
+BN_DEV void fe_machine(Fp12& acc, Fp12 (&slot)[NSLOTS], const unsigned char (*prog)[2]) {
+#if defined(__HIPCC__)
+#pragma clang loop unroll(disable)
+#endif
+  for (int pc = 0;; ++pc) {
+    const int op = prog[pc][0], arg = prog[pc][1];
+    if (op == FE_END) break;
+    BN_SET_STEP_PRIORITY(pc >> 1);
+    switch (op) {
+      case FE_LOAD: acc = slot[arg]; break;
+      case FE_STORE: slot[arg] = acc; break;
+      case FE_CSQR: fp12_cyclotomic_sqr_body<170>(acc, acc); break;
+      case FE_MUL: fp12_mul_body(acc, acc, slot[arg]); break;
+      case FE_CONJ: fp6_neg(acc.c1, acc.c1); break;        // balanced digits stay balanced: no carry
+      case FE_FROB: fp12_frob_body(acc, acc, arg); break;
+      default: fp12_inv(acc, acc); break;                   // FE_INV: once per program, a real call
+    }
+  }
+}
+// f^(m (q^12-1)/r), one exactly when the pairing product is one: what final_exponentiation_check computes
+BN_DEV void fe_machine_check(Fp12& acc) { Fp12 slot[BN_FE_CHECK_SLOTS]; fe_machine(acc, slot, C_FE_CHECK); }
+// the canonical Gt value f^((q^12-1)/r): what final_exponentiation computes
+BN_DEV void fe_machine_exact(Fp12& acc) { Fp12 slot[BN_FE_EXACT_SLOTS]; fe_machine(acc, slot, C_FE_EXACT); }
 
 }  // namespace bn254

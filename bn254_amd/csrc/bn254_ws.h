@@ -98,6 +98,12 @@ __attribute__((visibility("hidden"))) int bn254_pair_aggregate(const uint32_t* t
 __attribute__((visibility("hidden"))) int bn254_pair_decode_g2(const uint8_t* pts, size_t n, uint32_t flags, Ws ws, int accumulate, hipStream_t s);
 __attribute__((visibility("hidden"))) int bn254_pair_decompress_g2(const uint8_t* in, size_t n, Ws ws, hipStream_t s);
 
+// keyed verify: the registered keys of a context — per key the 87 lines of its Miller loop in the c2 = 1 form,
+// lines[key][line][coefficient c0 / c1][re / im][limb] (canonical limbs; 12.5 KB per key), its decode status and identity flag
+#define BN_KEY_LINE_WORDS (2 * 2 * BN_LIMBS)
+struct KeyTable { const int32_t* lines; const uint8_t* st; const uint8_t* inf; uint32_t n_keys; };
+__attribute__((visibility("hidden"))) int bn254_pair_miller_verify_keyed(size_t n, Ws ws, const uint32_t* key_idx, KeyTable kt, hipStream_t s);
+
 // entry points of bn254_trio.hip (octet layout for small batches)
 __attribute__((visibility("hidden"))) int bn254_trio_miller_verify(size_t n, Ws ws, hipStream_t s, int mode = 0);
 // entry points of bn254_quad.hip (the same with the four lane pairs of a verify as four waves with roles)

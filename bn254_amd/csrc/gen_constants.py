@@ -54,6 +54,123 @@ def fpow(a, e):
     return out
 
 
+# ---- final exponentiation as an ACCUMULATOR-MACHINE program (bn254_pairing.h: fe_machine) ---------------------------------
+# One Fq12 accumulator (an LDS slot in the kernels) and a small file of Fq12 slots in the lane's private segment; every
+# Fq12 routine then has ONE inlined call site in the kernel (a switch inside the interpreter loop) instead of ~26 out-of-loop
+# calls that each save and restore up to 112 VGPRs.  Instructions are (opcode, slot) byte pairs:
+FE_END, FE_LOAD, FE_STORE, FE_CSQR, FE_MUL, FE_CONJ, FE_FROB, FE_INV = range(8)
+FE_OPNAMES = ["END", "LOAD", "STORE", "CSQR", "MUL", "CONJ", "FROB", "INV"]
+
+
+class FeProgram:
+    """builds a program and, alongside, the EXPONENT every value carries: after the easy part all values are powers of
+    g = f^((q^6-1)(q^2+1)), an element of the cyclotomic subgroup of order Phi12(q) = q^4 - q^2 + 1, where conjugation
+    is inversion and Frobenius is the q-th power — so a program is correct iff the exponent left in the accumulator is the
+    wanted one modulo Phi12(q).  (The easy part itself is checked symbolically: see fe_easy.)"""
+
+    def __init__(self):
+        self.code = []
+        self.slots = {}
+        self.phi = Q**4 - Q**2 + 1
+        self.acc = None               # exponent of the accumulator (None before the easy part)
+        self.exp = {}                 # slot -> exponent
+
+    def slot(self, name):
+        return self.slots.setdefault(name, len(self.slots))
+
+    def emit(self, op, name=None, arg=0):
+        self.code.append((op, self.slot(name) if name is not None else arg))
+
+    def load(self, n): self.emit(FE_LOAD, n); self.acc = self.exp[n]
+    def store(self, n): self.emit(FE_STORE, n); self.exp[n] = self.acc
+    def csqr(self): self.emit(FE_CSQR); self.acc = self.acc * 2 % self.phi
+    def mul(self, n): self.emit(FE_MUL, n); self.acc = (self.acc + self.exp[n]) % self.phi
+    def conj(self): self.emit(FE_CONJ); self.acc = -self.acc % self.phi
+    def frob(self, k): self.emit(FE_FROB, None, k); self.acc = self.acc * pow(Q, k, self.phi) % self.phi
+
+    def mulc(self, n):
+        """acc * conj(slot) = conj(conj(acc) * slot): the conjugations run on the accumulator (27 negations in LDS) so that
+        the multiplication keeps its one site and reads its second operand straight from the slot"""
+        self.conj(); self.mul(n); self.conj()
+
+    def easy(self):
+        """f^((q^6-1)(q^2+1)) with one inversion: f1 = conj(f) * f^-1 = f^(q^6-1); then frob2(f1) * f1"""
+        self.emit(FE_STORE, "F")      # fin
+        self.emit(FE_INV)
+        self.emit(FE_CONJ); self.emit(FE_MUL, "F"); self.emit(FE_CONJ)   # conj(conj(inv) * fin) = inv * conj(fin)  [conj is a ring automorphism]
+        self.emit(FE_STORE, "F")      # f1
+        self.emit(FE_FROB, None, 2)
+        self.emit(FE_MUL, "F")
+        self.acc = 1                  # g
+
+    def pow_u(self, w4):
+        """acc <- acc^u over the signed digits {1, 15, 19}: table a (T0), a^15 (T1), a^19 (T2)"""
+        self.store("T0")
+        self.csqr(); self.csqr(); self.store("T2")          # a^4
+        self.csqr(); self.csqr()                              # a^16
+        self.mulc("T0"); self.store("T1")                    # a^15
+        self.mul("T2"); self.store("T2")                     # a^19
+        tab = {1: "T0", 15: "T1", 19: "T2"}
+        base = self.exp["T0"]
+        assert self.exp["T1"] == 15 * base % self.phi and self.exp["T2"] == 19 * base % self.phi
+        self.load(tab[w4[0]])
+        for d in w4[1:]:
+            self.csqr()
+            if d > 0:
+                self.mul(tab[d])
+            elif d < 0:
+                self.mulc(tab[-d])
+        assert self.acc == base * U % self.phi
+
+    def finish(self, want):
+        assert self.acc == want % self.phi, "final exponentiation program computes the wrong power"
+        self.code.append((FE_END, 0))
+        assert len(self.slots) <= 16 and all(0 <= a < 256 for _, a in self.code)
+        return self.code
+
+
+def fe_program_check(w4):
+    """the == one test of verify: Fuentes-Castaneda et al. hard part, g^(m h) with h = Phi12(q)/r, m = 2u(6u^2+3u+1)
+    (10 multiplications, 3 squarings, 3 Frobenius maps beside the three exponentiations by u)"""
+    P = FeProgram()
+    P.easy()
+    P.store("F")
+    P.pow_u(w4); P.conj(); P.csqr(); P.store("Y1")          # g^-2u
+    P.csqr(); P.mul("Y1"); P.store("Y3")                    # g^-6u
+    P.pow_u(w4); P.conj(); P.store("Y4")                    # g^(6u^2)
+    P.csqr(); P.pow_u(w4)                                   # g^(12u^3)
+    P.mul("Y4"); P.mulc("Y3"); P.store("Y8")                # g^(12u^3+6u^2+6u)
+    P.mul("Y1"); P.store("Y9")                              # g^(12u^3+6u^2+4u)
+    P.load("Y8"); P.mul("Y4"); P.mul("F"); P.store("Y11")   # g^(12u^3+12u^2+6u+1)
+    P.load("Y9"); P.frob(1); P.mul("Y11"); P.store("Y11")
+    P.load("Y8"); P.frob(2); P.mul("Y11"); P.store("Y11")
+    P.load("Y9"); P.mulc("F"); P.frob(3); P.mul("Y11")
+    lam = (12 * U**3 + 12 * U**2 + 6 * U + 1) + (12 * U**3 + 6 * U**2 + 4 * U) * Q + (12 * U**3 + 6 * U**2 + 6 * U) * Q**2 + \
+          (12 * U**3 + 6 * U**2 + 4 * U - 1) * Q**3
+    m = 2 * U * (6 * U**2 + 3 * U + 1)
+    h = (Q**4 - Q**2 + 1) // R_ORDER
+    assert (Q**4 - Q**2 + 1) % R_ORDER == 0 and lam % P.phi == m * h % P.phi and 0 < m < R_ORDER and R_ORDER % m != 0
+    return P.finish(m * h), P.slots
+
+
+def fe_program_exact(w4):
+    """the canonical Gt of the pairing API: the exact hard part Phi12(q)/r by the vectorial addition chain
+    y0 y1^2 y2^6 y3^12 y4^18 y5^30 y6^36 (13 multiplications, 4 squarings, 6 Frobenius maps)"""
+    P = FeProgram()
+    P.easy()
+    P.store("F"); P.pow_u(w4); P.store("FU"); P.pow_u(w4); P.store("FU2"); P.pow_u(w4); P.store("FU3")
+    P.load("FU2"); P.frob(1); P.mul("FU"); P.conj(); P.store("Y4")                  # y4 = conj(frob(fu2) fu)
+    P.load("FU3"); P.frob(1); P.mul("FU3"); P.conj()                                  # y6 = conj(frob(fu3) fu3)
+    P.csqr(); P.mul("Y4"); P.mulc("FU2"); P.store("A")                              # t0 = y6^2 y4 y5,  y5 = conj(fu2)
+    P.load("FU"); P.frob(1); P.conj(); P.mulc("FU2"); P.mul("A"); P.store("B")     # t1 = y3 y5 t0,  y3 = conj(frob(fu))
+    P.load("FU2"); P.frob(2); P.mul("A"); P.store("A")                              # t0 = t0 y2,  y2 = frob2(fu2)
+    P.load("B"); P.csqr(); P.mul("A"); P.csqr(); P.store("B")                      # t1 = (t1^2 t0)^2
+    P.mulc("F"); P.csqr(); P.store("A")                                              # t0 = (t1 y1)^2,  y1 = conj(f)
+    P.load("F"); P.frob(1); P.store("Y4"); P.load("F"); P.frob(2); P.mul("Y4"); P.store("Y4"); P.load("F"); P.frob(3); P.mul("Y4")   # y0
+    P.mul("B"); P.mul("A")
+    return P.finish((Q**4 - Q**2 + 1) // R_ORDER), P.slots
+
+
 TWIST_B = smul(inv(XI), 3)
 TWIST_3B = smul(TWIST_B, 3)
 
@@ -298,6 +415,7 @@ def main():
     o.append("BN_CONST int32_t C_THREE[BN_LIMBS] = %s;        /* curve b = 3 */" % c_fp(3))
     o.append("BN_CONST int32_t C_TWIST_B[2][BN_LIMBS] = %s;   /* 3/xi */" % c_fp2(TWIST_B))
     o.append("BN_CONST int32_t C_TWIST_3B[2][BN_LIMBS] = %s;  /* 9/xi */" % c_fp2(TWIST_3B))
+    o.append("BN_CONST int32_t C_XI_MONT[2][BN_LIMBS] = %s;  /* xi = 9 + i (w^6; the product of two table lines with c2 = 1) */" % c_fp2(XI))
     for j in (1, 2, 3):
         o.append("BN_CONST int32_t C_FROB%d[6][2][BN_LIMBS] = {%s};  /* xi^(k(q^%d-1)/6), k=0..5 */" % (j, ", ".join(c_fp2(t) for t in frob[j]), j))
     o.append("BN_CONST int32_t C_TW_FROB_X1[2][BN_LIMBS] = %s;" % c_fp2(g_x1))
@@ -348,6 +466,12 @@ def main():
     o.append("#define BN_U_W4_LEN %d" % len(w4))
     o.append("BN_CONST signed char C_U_W4[BN_U_W4_LEN] = {%s};  /* signed digits of u from {0, +-1, +-15, +-19}, MSB first, %d non-zero */" %
              (", ".join(str(d) for d in w4), sum(1 for d in w4 if d)))
+    for name, (code, slots) in (("CHECK", fe_program_check(w4)), ("EXACT", fe_program_exact(w4))):
+        o.append("#define BN_FE_%s_LEN %d" % (name, len(code)))
+        o.append("#define BN_FE_%s_SLOTS %d" % (name, len(slots)))
+        o.append("BN_CONST unsigned char C_FE_%s[BN_FE_%s_LEN][2] = {%s};  /* accumulator-machine program of the final exponentiation (gen_constants.py: fe_program_%s; %s) */" %
+                 (name, name, ", ".join("{%d, %d}" % ins for ins in code), name.lower(),
+                  ", ".join("%d %s" % (sum(1 for op, _ in code if op == k), FE_OPNAMES[k]) for k in range(1, 8))))
     o.append("/* line coefficients (c0 -> *yP, c1 -> *xP, c2 == 1) for Q = -G2::one(), in order of use */")
     o.append("BN_CONST int32_t C_NEG_G2_LINES[BN_N_FIXED_LINES][3][2][BN_LIMBS] = {")
     for ln in lines:

@@ -261,6 +261,28 @@ class Engine:
         return out.raw[:n * G1_BYTES], status.raw[:n]
 
     # ---- device-pointer entry points (inputs resident in HBM; enqueue only) ---------------
+    def register_keys(self, pks, flags=0):
+        """replace the context's registered key set (uncompressed G2, 128 B each); returns the per-key status bytes
+        (what PublicKey::from_uncompressed reports, subgroup check included)"""
+        n = len(pks) // G2_BYTES
+        assert len(pks) == n * G2_BYTES
+        st = ctypes.create_string_buffer(max(n, 1))
+        _check("bn254_ctx_register_keys", self._lib.bn254_ctx_register_keys(self._h, bytes(pks), n, flags, st))
+        return st.raw[:n]
+
+    def batch_verify_keyed(self, messages, sigs, key_idx, flags=0):
+        n = len(messages)
+        assert len(sigs) == n * G1_BYTES and len(key_idx) == n
+        msgs, off = pack_messages(messages)
+        idx = (ctypes.c_uint32 * max(n, 1))(*key_idx)
+        status = ctypes.create_string_buffer(max(n, 1))
+        _check("bn254_batch_verify_keyed", self._lib.bn254_batch_verify_keyed(self._h, msgs, off, bytes(sigs), idx, n, flags, status))
+        return status.raw[:n]
+
+    def batch_verify_keyed_device(self, d_msgs, d_off, d_sigs, d_key_idx, n, d_status, flags=0, stream=None):
+        _check("bn254_batch_verify_keyed_device",
+               self._lib.bn254_batch_verify_keyed_device(self._h, d_msgs, d_off, d_sigs, d_key_idx, n, flags, d_status, stream))
+
     def batch_verify_device(self, d_msgs, d_off, d_sigs, d_pks, n, d_status, flags=0, stream=None):
         _check("bn254_batch_verify_device",
                self._lib.bn254_batch_verify_device(self._h, d_msgs, d_off, d_sigs, d_pks, n, flags, d_status, stream))

@@ -112,6 +112,28 @@ int bn254_batch_verify_compressed_device(bn254_ctx *ctx, const uint8_t *d_msgs, 
                                          const uint8_t *d_sigs33, const uint8_t *d_pks65, size_t n, uint8_t *d_status,
                                          void *stream);
 
+/* Keyed verify — the same check for public keys REGISTERED with the context beforehand (a validator set).
+ * The reference validates a PublicKey once, at construction (PublicKey::from_uncompressed, src/types.rs:96-99 ->
+ * src/utils.rs:107-116), and every ECDSA::verify (src/ecdsa.rs:49-64) then repeats the key-dependent half of the Miller
+ * loop; here registration also tabulates that half (the 87 line functions of the key, 12.5 KB per key in HBM) and a keyed
+ * verify reads it back instead of recomputing it: about a quarter of the Miller loop's field products disappear.
+ *
+ * bn254_ctx_register_keys replaces the context's key set with `n_keys` uncompressed G2 points (n_keys * 128 bytes, host
+ * memory).  key_status[j] (may be NULL) = what PublicKey::from_uncompressed reports for key j: 0, 6 (a coordinate >= q) or 4
+ * (not on the curve / not in the order-r subgroup — the subgroup check ALWAYS runs here, as in AffineG2::new; flags: only
+ * BN254_FLAG_REJECT_IDENTITY is looked at).  An all-zero key is the identity (its pair contributes 1).  The call
+ * synchronises the context's stream; it must not overlap a keyed verify of the same context.
+ *
+ * bn254_batch_verify_keyed[_device]: as bn254_batch_verify with key_idx[i] (uint32) in place of the i-th public key.
+ * status[i] = the signature's decode error, else 2 (IndexOutOfBounds) if key_idx[i] >= n_keys, else the key's registration
+ * status, else what verify gives.  Same result bytes as bn254_batch_verify(flags | BN254_FLAG_G2_SUBGROUP_CHECK) on the
+ * expanded keys.  Always runs the lane-pair kernels (no small-batch layout). */
+int bn254_ctx_register_keys(bn254_ctx *ctx, const uint8_t *pks /* n_keys*128 */, size_t n_keys, uint32_t flags, uint8_t *key_status /* n_keys or NULL */);
+int bn254_batch_verify_keyed(bn254_ctx *ctx, const uint8_t *msgs, const uint64_t *msg_off /* n+1 */, const uint8_t *sigs /* n*64 */,
+                             const uint32_t *key_idx /* n */, size_t n, uint32_t flags, uint8_t *status /* n */);
+int bn254_batch_verify_keyed_device(bn254_ctx *ctx, const uint8_t *d_msgs, const uint64_t *d_msg_off, const uint8_t *d_sigs,
+                                    const uint32_t *d_key_idx, size_t n, uint32_t flags, uint8_t *d_status, void *stream);
+
 /* Randomised batch verification — OPT-IN, probabilistic.  No counterpart in the
  * reference, which verifies one tuple at a time (src/ecdsa.rs:49-64); same inputs and status bytes as
  * bn254_batch_verify.  Items are taken 64 at a time; with r_i = the first 16 bytes (BN254_FLAG_RAND64: 8) of

@@ -44,6 +44,28 @@ static uint8_t dec_g2(G2Affine& q, const uint8_t* b, uint32_t flags) {
   }
   return st;
 }
+extern "C" {
+// mirrors k_register_keys (one lane per key): decode with the subgroup check always on, then the 87 lines of the key in the
+// c2 = 1 form, canonical limbs.  Returns the registration status; *inf_out = identity key.  tab: 87 x 2 x 2 x 9 words.
+int hs_register_key(const uint8_t* pk128, uint32_t flags, int32_t* tab, int* inf_out) {
+  G2Affine q;
+  alignas(4) uint8_t tmp[128];
+  memcpy(tmp, pk128, 128);
+  uint8_t st = decode_g2(q, tmp, flags & FLAG_REJECT_IDENTITY);
+  const bool inf = q.inf;
+  if (st != ST_OK || q.inf) { set_g2_gen(q); q.inf = inf; }
+  const bool in = g2_in_subgroup(q);
+  if (st == ST_OK && !q.inf && !in) { st = ST_INVALID_GROUP_POINT; set_g2_gen(q); q.inf = inf; }
+  const bool ok = g2_line_table(q, [&](int idx, const KeyLine& kl) {
+    const Fp c[4] = {fp_canon(kl.c0.c0), fp_canon(kl.c0.c1), fp_canon(kl.c1.c0), fp_canon(kl.c1.c1)};
+    for (int e = 0; e < 4; ++e)
+      for (int k = 0; k < BN_LIMBS; ++k) tab[(idx * 4 + e) * BN_LIMBS + k] = c[e].v[k];
+  });
+  if (st == ST_OK && !q.inf && !ok) st = ST_INVALID_GROUP_POINT;
+  *inf_out = q.inf;
+  return st;
+}
+}
 // mirrors k_hash_round (filter: candidate + Jacobi symbol) and k_hash_finish (one square root, for the winner)
 static uint8_t hash_item(G1Affine& p, const uint8_t* msg, uint64_t len, int* tries) {
   HashState hs;

@@ -73,12 +73,46 @@ int hp_verify_decoded(const uint8_t* h64, const uint8_t* sig64, const uint8_t* p
 #else
   miller_loop<true, true>(f, h, pk, sig);
 #endif
-  Fp12 g;
-  final_exponentiation_check(g, f, acc);            // what k_final_exp_pair runs for a status
+  Fp12 g, m1 = f, m2 = f;
+  final_exponentiation_check(g, f, acc);            // the chain as straight-line code (octet / one-lane kernels)
   final_exponentiation(f, f, acc);                   // the exact value must agree on "is one"
+  fe_machine_check(m1);                              // what k_final_exp_pair runs for a status: the same chains as programs of the
+  fe_machine_exact(m2);                              // accumulator machine -> the very same values, coefficient by coefficient
+  {
+    const Fp2* a[6] = {&g.c0.c0, &g.c0.c1, &g.c0.c2, &g.c1.c0, &g.c1.c1, &g.c1.c2};
+    const Fp2* b[6] = {&m1.c0.c0, &m1.c0.c1, &m1.c0.c2, &m1.c1.c0, &m1.c1.c1, &m1.c1.c2};
+    const Fp2* c[6] = {&f.c0.c0, &f.c0.c1, &f.c0.c2, &f.c1.c0, &f.c1.c1, &f.c1.c2};
+    const Fp2* d[6] = {&m2.c0.c0, &m2.c0.c1, &m2.c0.c2, &m2.c1.c0, &m2.c1.c1, &m2.c1.c2};
+    for (int k = 0; k < 6; ++k) if (!fp2_eq(*a[k], *b[k]) || !fp2_eq(*c[k], *d[k])) return 251;
+  }
   const bool one_check = fp12_is_one(g), one_exact = fp12_is_one(f);
   if (one_check != one_exact) return 255;
   return one_check ? 0 : 9;
+}
+// The keyed verify (k_register_keys + k_miller_verify_keyed_pair): the key's 87 lines tabulated once (c2 = 1 form, canonical
+// limbs as the kernel stores them), then the table-driven loop; returns 0 / 9 as hp_verify_decoded, 250 if its Gt value
+// differs from the generic loop's, 249 if the table could not be built.  tab_out (may be null): 87 x 2 x 2 x 9 words.
+int hp_verify_keyed_decoded(const uint8_t* h64, const uint8_t* sig64, const uint8_t* pk128, int32_t* tab_out) {
+  G1Affine h, sig;
+  G2Affine pk;
+  load_g1(h, h64); load_g1(sig, sig64); load_g2(pk, pk128);
+  static int32_t tab[BN_N_FIXED_LINES][2][2][BN_LIMBS];
+  const bool ok = g2_line_table(pk, [&](int idx, const KeyLine& kl) {
+    const Fp2* c[2] = {&kl.c0, &kl.c1};
+    for (int e = 0; e < 2; ++e)
+      for (int r = 0; r < 2; ++r) { Fp x = fp_canon(c[e]->c[r]); for (int k = 0; k < BN_LIMBS; ++k) tab[idx][e][r][k] = x.v[k]; }
+  });
+  if (!ok) return 249;
+  if (tab_out) memcpy(tab_out, tab, sizeof tab);
+  Fp12 f, g;
+  miller_loop_keyed(f, h, pk.inf, tab, sig);
+  miller_loop<true, true>(g, h, pk, sig);
+  fe_machine_exact(f);
+  fe_machine_exact(g);
+  const Fp2* a[6] = {&f.c0.c0, &f.c0.c1, &f.c0.c2, &f.c1.c0, &f.c1.c1, &f.c1.c2};
+  const Fp2* b[6] = {&g.c0.c0, &g.c0.c1, &g.c0.c2, &g.c1.c0, &g.c1.c1, &g.c1.c2};
+  for (int k = 0; k < 6; ++k) if (!fp2_eq(*a[k], *b[k])) return 250;
+  return fp12_is_one(f) ? 0 : 9;
 }
 // Products per LANE of the pair kernels for one verify / one pairing (both roles run here in sequence, so totals / 2):
 // out = {miller_verify dual, single, final_exp dual, single, miller_var dual, single}.  "single" includes squares.
@@ -92,13 +126,25 @@ void hp_lane_counts(const uint8_t* h64, const uint8_t* sig64, const uint8_t* pk1
   miller_loop<true, true>(f, h, pk, sig);
   out6[0] = (bn_fp_dual_counter - d0) / 2; out6[1] = ((bn_fp_mul_counter - m0) - (bn_fp_dual_counter - d0)) / 2;
   m0 = bn_fp_mul_counter; d0 = bn_fp_dual_counter;
-  final_exponentiation_check(g, f, acc);
+  g = f;
+  fe_machine_check(g);
   bool one = fp12_is_one(g);
   (void)one;
   out6[2] = (bn_fp_dual_counter - d0) / 2; out6[3] = ((bn_fp_mul_counter - m0) - (bn_fp_dual_counter - d0)) / 2;
   m0 = bn_fp_mul_counter; d0 = bn_fp_dual_counter;
   miller_loop<true, false>(f, h, pk, h);
   out6[4] = (bn_fp_dual_counter - d0) / 2; out6[5] = ((bn_fp_mul_counter - m0) - (bn_fp_dual_counter - d0)) / 2;
+}
+// the same for the keyed Miller loop: out2 = {dual, single} per lane
+void hp_lane_counts_keyed(const uint8_t* h64, const uint8_t* sig64, const uint8_t* pk128, unsigned long long* out2) {
+  static int32_t tab[BN_N_FIXED_LINES][2][2][BN_LIMBS];
+  if (hp_verify_keyed_decoded(h64, sig64, pk128, &tab[0][0][0][0]) > 9) { out2[0] = out2[1] = 0; return; }
+  G1Affine h, sig;
+  load_g1(h, h64); load_g1(sig, sig64);
+  Fp12 f;
+  unsigned long long m0 = bn_fp_mul_counter, d0 = bn_fp_dual_counter;
+  miller_loop_keyed(f, h, false, tab, sig);
+  out2[0] = (bn_fp_dual_counter - d0) / 2; out2[1] = ((bn_fp_mul_counter - m0) - (bn_fp_dual_counter - d0)) / 2;
 }
 // canonical Gt of one pairing through the pair layout
 void hp_pairing(const uint8_t* g1, const uint8_t* g2, uint8_t* gt384) {
@@ -107,7 +153,8 @@ void hp_pairing(const uint8_t* g1, const uint8_t* g2, uint8_t* gt384) {
   load_g1(p, g1); load_g2(q, g2);
   Fp12 f, acc;
   miller_loop<true, false>(f, p, q, p);
-  final_exponentiation(f, f, acc);
+  (void)acc;
+  fe_machine_exact(f);
   const Fp2* c[6] = {&f.c0.c0, &f.c0.c1, &f.c0.c2, &f.c1.c0, &f.c1.c1, &f.c1.c2};
   for (int k = 0; k < 6; ++k) { fp_to_be32(gt384 + 64 * k, c[k]->c[0]); fp_to_be32(gt384 + 64 * k + 32, c[k]->c[1]); }
 }

@@ -32,6 +32,7 @@ hp = ctypes.CDLL(root + '/tests/hostsim/libhostsim_pair_san.so')
 g1 = (1).to_bytes(32, 'big') + (2).to_bytes(32, 'big')
 for v in cs[:4]:
     if v['status'] in (0, 9): hp.hp_verify_decoded(g1, H(v['sig']), H(v['pk']))
+assert hp.hp_verify_keyed_decoded(g1, H(cs[0]['sig']), H(cs[0]['pk']), None) <= 9     # keyed verify: line table + table-driven loop
 v = d['pairing_gt'][1]; o = buf(384); hp.hp_pairing(H(v['g1']), H(v['g2']), o); assert o.raw.hex() == v['gt']
 o = buf(128); assert hp.hp_g2_decompress(H(k['g2_compressed_roundtrip']['hex']), o) == 0
 g2b = H(d['g2_generator']); hp.hp_g2_sum_and_subgroup(g2b + g2b + bytes(128) + g2b, 4, o)

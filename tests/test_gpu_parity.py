@@ -817,6 +817,71 @@ def test_device_entry_points_bound_check_message_offsets(eng, c):
     assert d_st.cpu().tolist() == [0] * n
 
 
+def test_keyed_verify_vs_oracle(eng, c, derived):
+    """bn254_ctx_register_keys + bn254_batch_verify_keyed[_device]: per-key registration statuses equal what the oracle's decoder
+    (subgroup check on) reports, and the keyed statuses equal bn254o_batch_verify on the EXPANDED keys — valid and failing
+    tuples, a key outside G2, a key with a coordinate >= q, an off-curve key, the identity key (pair contributes 1), an index
+    >= n_keys (IndexOutOfBounds, 2), malformed signatures (their status comes first), at a size inside one wave and one
+    past the small-batch threshold."""
+    import random
+    import torch
+    from tests.datagen import D, sk_bytes
+    rnd = random.Random(31)
+    K = 37
+    sks = [sk_bytes(500 + j) for j in range(K)]
+    pk_pool, st = eng.batch_g2_mul(None, b"".join(sks), K, reduce_scalar=True)
+    assert st == bytes(K)
+    keys = [bytearray(pk_pool[128 * j:128 * j + 128]) for j in range(K)]
+    keys[5] = bytearray(H(derived["g2_not_in_subgroup"]))                   # on the twist, outside the order-r subgroup -> 4
+    keys[6][0:32] = Q.to_bytes(32, "big")                                    # x.re = q -> 6
+    keys[7][127] ^= 1                                                        # off the curve -> 4
+    keys[8] = bytearray(128)                                                 # identity
+    key_bytes = b"".join(bytes(k) for k in keys)
+    kst = eng.register_keys(key_bytes)
+    want_kst = bytes(c.batch_verify([b""], bytes(64), bytes(k), flags=1)[0][0] for k in keys)   # sig = identity: status = the key's decode status, or 0 / 9
+    for j in range(K):
+        assert kst[j] == (want_kst[j] if want_kst[j] in (3, 4, 6) else 0), (j, kst[j], want_kst[j])
+    assert kst[5] == 4 and kst[6] == 6 and kst[7] == 4 and kst[8] == 0
+    for n in (50, 20011):
+        msgs = [D("keyed", i) for i in range(n)]
+        kidx = [rnd.randrange(K) for _ in range(n)]
+        sigs, st = eng.batch_sign(msgs, b"".join(sks[k] for k in kidx))
+        assert st == bytes(n)
+        sigs = bytearray(sigs)
+        for i in range(3, n, 11):
+            sigs[64 * i:64 * i + 64] = sigs[64 * (i - 1):64 * i]             # wrong signature -> 9
+        for i in range(7, n, 97):
+            sigs[64 * i + 63] ^= 1                                            # off the curve -> 4 (comes before the key's status)
+        for i in range(9, n, 131):
+            sigs[64 * i:64 * i + 64] = bytes(64)                              # identity signature
+        oob = set(range(13, n, 173))
+        idx_call = [K + 5 if i in oob else kidx[i] for i in range(n)]
+        idx_call[1 % n] = 0xFFFFFFFF
+        oob.add(1 % n)
+        want = bytearray(c.batch_verify(msgs, bytes(sigs), b"".join(bytes(keys[k]) for k in kidx), flags=1, nthreads=8)[0])
+        sig_only = c.batch_verify(msgs, bytes(sigs), bytes(128) * n, flags=1, nthreads=8)[0]    # identity key: status = the signature's decode status or 0 / 9
+        for i in oob:
+            want[i] = sig_only[i] if sig_only[i] in (3, 4, 6) else 2
+        got = eng.batch_verify_keyed(msgs, bytes(sigs), idx_call)
+        diff = [(i, got[i], want[i], kidx[i]) for i in range(n) if got[i] != want[i]]
+        assert not diff, diff[:10]
+        assert n < 1000 or {0, 2, 4, 6, 9} <= set(got)
+        # the device entry point on the caller's stream
+        dev = torch.device("cuda", 0)
+        t8 = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)   # noqa: E731
+        d_msgs, d_sigs = t8(b"".join(msgs)), t8(bytes(sigs))
+        d_off = torch.arange(0, 32 * (n + 1), 32, dtype=torch.int64, device=dev)
+        d_idx = torch.tensor([x if x < 2**31 else x - 2**32 for x in idx_call], dtype=torch.int32, device=dev)
+        d_st = torch.full((n,), 255, dtype=torch.uint8, device=dev)
+        stream = torch.cuda.Stream(device=dev)
+        eng.batch_verify_keyed_device(d_msgs.data_ptr(), d_off.data_ptr(), d_sigs.data_ptr(), d_idx.data_ptr(), n, d_st.data_ptr(), stream=stream.cuda_stream)
+        stream.synchronize()
+        assert d_st.cpu().numpy().tobytes() == bytes(want)
+    # an empty key set: every index is out of range
+    assert eng.register_keys(b"") == b""
+    assert eng.batch_verify_keyed(msgs[:3], bytes(sigs[:192]), [0, 1, 2]) == bytes([2, 2, 2])
+
+
 def test_cpp_host_mirror_example(eng):
     """the C++ mirror of the reference API (bn254_amd/host/bn254.hpp) runs the reference's example scenario
     (/root/reference/examples/bn254.rs:3-34) end to end on the GPU"""

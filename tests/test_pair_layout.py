@@ -46,6 +46,44 @@ def test_pair_layout_verify_and_gt_match_oracle(pair_lib, derived, kats):
         assert out.raw == c.pairing(p, q)
 
 
+def test_keyed_verify_line_tables(pair_lib, derived):
+    """keyed verify on the host: the key's 87 lines in the c2 = 1 form (g2_line_table) give, through the table-driven loop
+    (miller_loop_keyed), the very Gt value of the generic loop on every verify case; the table built by the one-lane source
+    (k_register_keys) and by the pair-layout source are the same words; registration statuses for keys outside G2 / off the
+    curve / out of range; and the products per lane of the keyed loop (2 508 dual + 348 single against 3 194 + 778)."""
+    from tests import hostsim_binding as hs
+    one = hs.lib()
+    one.hs_register_key.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int)]
+    W = 87 * 2 * 2 * 9
+    n = 0
+    for v in derived["verify_cases"]:
+        if v["status"] not in (0, 9):
+            continue
+        st, h, _ = c.hash_to_g1(H(v["message_hex"]))
+        tab_pair = (ctypes.c_int32 * W)()
+        assert pair_lib.hp_verify_keyed_decoded(h, H(v["sig"]), H(v["pk"]), tab_pair) == v["status"], v["name"]
+        tab_one, inf = (ctypes.c_int32 * W)(), ctypes.c_int(0)
+        assert one.hs_register_key(H(v["pk"]), 0, tab_one, ctypes.byref(inf)) == 0
+        assert inf.value == (1 if H(v["pk"]) == bytes(128) else 0)
+        if not inf.value:
+            assert list(tab_one) == list(tab_pair), v["name"]
+        n += 1
+    assert n >= 10
+    tab, inf = (ctypes.c_int32 * W)(), ctypes.c_int(0)
+    g2 = bytearray(c.g2_generator())
+    assert one.hs_register_key(H(derived["g2_not_in_subgroup"]), 0, tab, ctypes.byref(inf)) == 4
+    bad = bytearray(g2); bad[127] ^= 1
+    assert one.hs_register_key(bytes(bad), 0, tab, ctypes.byref(inf)) == 4
+    Qm = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47
+    bad = bytearray(g2); bad[32:64] = Qm.to_bytes(32, "big")
+    assert one.hs_register_key(bytes(bad), 0, tab, ctypes.byref(inf)) == 6
+    assert one.hs_register_key(bytes(128), 2, tab, ctypes.byref(inf)) == 4          # BN254_FLAG_REJECT_IDENTITY
+    out = (ctypes.c_ulonglong * 2)()
+    v = derived["verify_cases"][0]
+    pair_lib.hp_lane_counts_keyed(c.hash_to_g1(H(v["message_hex"]))[1], H(v["sig"]), H(v["pk"]), out)
+    assert list(out) == [64 * 12 + 87 * 20, 87 * 4]
+
+
 def test_pair_layout_multi_pair_and_g2_sums(pair_lib, derived):
     import hashlib
     g1, g2 = c.g1_generator(), c.g2_generator()
@@ -109,6 +147,7 @@ g1 = (1).to_bytes(32, "big") + (2).to_bytes(32, "big")
 for v in d["verify_cases"]:
     if v["status"] in (0, 9):
         L.hp_verify_decoded(g1, H(v["sig"]), H(v["pk"]))      # any G1 point exercises the same operation sequence
+        assert L.hp_verify_keyed_decoded(g1, H(v["sig"]), H(v["pk"]), None) <= 9      # keyed verify: line table + table-driven loop
 g2 = H(d["g2_generator"]); o = ctypes.create_string_buffer(384)
 L.hp_pairing_product4(g1 * 4, g2 * 4, o)
 o = ctypes.create_string_buffer(128)
