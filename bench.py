@@ -172,6 +172,25 @@ def other_workloads(args, torch, eng, dev, stream):
         assert st.raw == expected
         out.update(metric="BN254 pairings/sec (batch verify, host buffers: H2D + kernels + D2H + sync)", value=2 * n / dt, unit="pairings/s",
                    ms_per_step=1e3 * dt, batch=n)
+    elif args.workload == "verify-keyed":
+        # configs[1] tuples whose public keys are REGISTERED with the context (the batch draws from a pool of 256 keys): the keyed
+        # verify reads the keys' line tables instead of recomputing the twist-point arithmetic (include/bn254_hip.h)
+        from tests.datagen import KEY_POOL
+        n = args.batch or BATCH
+        msgs, sigs, pks, expected = make_verify_batch(eng, n)
+        pool = min(KEY_POOL, n)
+        assert eng.register_keys(pks[:128 * pool]) == bytes(pool)
+        d_msgs, d_sigs = dev_bytes(b"".join(msgs)), dev_bytes(sigs)
+        d_off = torch.arange(0, 32 * (n + 1), 32, dtype=torch.int64, device=dev)
+        d_idx = (torch.arange(n, dtype=torch.int64, device=dev) % pool).to(torch.int32)
+        d_st = torch.full((n,), 255, dtype=torch.uint8, device=dev)
+        eng.reserve(n)
+        eng.set_profiling(True)
+        dt = timed(lambda: eng.batch_verify_keyed_device(d_msgs.data_ptr(), d_off.data_ptr(), d_sigs.data_ptr(), d_idx.data_ptr(), n, d_st.data_ptr(),
+                                                         stream=sh), args.steps, args.warmup)
+        assert bytes(d_st.cpu().numpy()) == expected
+        out.update(metric="BN254 pairings/sec (batch verify, registered keys: line tables from HBM)", value=2 * n / dt, unit="pairings/s",
+                   ms_per_step=1e3 * dt, batch=n, registered_keys=pool, kernel_ms=eng.last_kernel_ms())
     elif args.workload == "verify-compressed":
         # configs[1] tuples given as the compressed wire encodings (33-byte signatures, 65-byte public keys), device resident
         from bn254_amd import PublicKey, Signature
@@ -268,8 +287,15 @@ def other_workloads(args, torch, eng, dev, stream):
                                                              tuple_msg.data_ptr(), tuple_off.data_ptr(), signer_idx.data_ptr(), n, d_st.data_ptr(),
                                                              stream=sh), args.steps, args.warmup)
         assert int(d_st.max()) == 0
+        eng.set_option(9, 0)                                       # BN254_OPT_AGG_SUBSET_MIN_TUPLES = 0: every key added one by one (rounds 1-2)
+        dt_direct = timed(lambda: eng.batch_aggregate_verify_device(d_msgs.data_ptr(), d_moff.data_ptr(), M, d_pk.data_ptr(), S, d_sig.data_ptr(),
+                                                                    tuple_msg.data_ptr(), tuple_off.data_ptr(), signer_idx.data_ptr(), n, d_st.data_ptr(),
+                                                                    stream=sh), max(1, args.steps // 2), 1)
+        assert int(d_st.max()) == 0
+        eng.set_option(9, 4096)
         out.update(metric="aggregate verifies/sec (1024 signers, ~512 per tuple, pools decoded per step)", value=n / dt, unit="verifies/s",
-                   ms_per_step=1e3 * dt, batch=n, mean_signers_per_tuple=float(signer_idx.numel()) / n)
+                   ms_per_step=1e3 * dt, batch=n, mean_signers_per_tuple=float(signer_idx.numel()) / n,
+                   without_subset_sum_table={"verifies_per_s": n / dt_direct, "ms_per_step": 1e3 * dt_direct})
     print(json.dumps(out))
 
 
@@ -702,7 +728,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pair-lanes", action="store_true", help="one lane per verify instead of lane pairs (A/B)")
     ap.add_argument("--split-miller", action="store_true", help="one pairing per lane instead of the fused 2-pair Miller loop (A/B)")
-    ap.add_argument("--workload", default="verify", choices=["verify", "pairing", "verify-host", "verify-compressed", "verify-randomized", "hash", "aggregate"],
+    ap.add_argument("--workload", default="verify", choices=["verify", "pairing", "verify-host", "verify-keyed", "verify-compressed", "verify-randomized", "hash", "aggregate"],
                     help="verify = the headline (configs[1]) and pairing = configs[3]: both run on N ranks; the others time configs 2, 4 or "
                          "other entry points on one GPU (informational — see DESIGN.md §4b)")
     args = ap.parse_args()

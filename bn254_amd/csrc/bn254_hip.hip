@@ -681,6 +681,35 @@ KERNEL void k_pool_decode_g2(const uint8_t* pts, size_t n, uint32_t flags, Pool 
   pool_store_fp(pool, 2, i, q.y.c0); pool_store_fp(pool, 3, i, q.y.c1);
   pool.st[i] = st | (q.inf ? 0x80 : 0);
 }
+// Subset sums of the public-key pool ("four Russians"): every tuple of an aggregate verify adds up a subset of the SAME n_signers
+// keys, so the sums of all 255 non-empty subsets of every group of 8 consecutive keys are tabulated once per call (n_signers / 8
+// x 256 affine points, 4.7 MB for 1024 signers; ~4 additions + one inversion per entry) and a tuple adds ONE table entry per
+// group — 128 additions instead of the ~512 of a dense list (k_aggregate_pair).  Entry j = group * 256 + mask; a pool entry
+// that failed to decode counts as the identity here (the tuples that name it carry its status anyway).
+KERNEL void k_pool_subsets_g2(Pool pk_pool, size_t n_signers, size_t n_groups, Pool sub) {
+  const size_t j = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
+  const bool live = j < n_groups * 256;
+  const size_t g = (live ? j : 0) >> 8;
+  const unsigned mask = (unsigned)(j & 255u);
+  G2Jac acc;
+  jac_set_identity(acc);
+  for (int b = 0; b < 8; ++b) {                      // wave-uniform: jac_accumulate votes across the wave
+    const size_t sgn = g * 8 + b;
+    const size_t ss = sgn < n_signers ? sgn : 0;
+    const uint8_t st = pk_pool.st[ss];
+    G2Affine p;
+    p.x.c0 = pool_load_fp(pk_pool, 0, ss); p.x.c1 = pool_load_fp(pk_pool, 1, ss);
+    p.y.c0 = pool_load_fp(pk_pool, 2, ss); p.y.c1 = pool_load_fp(pk_pool, 3, ss);
+    p.inf = !live || !((mask >> b) & 1u) || sgn >= n_signers || st != 0;       // st: 0x80 = identity entry, low bits = decode error
+    jac_accumulate(acc, p);
+  }
+  G2Affine a;
+  jac_to_affine(a, acc);
+  if (!live) return;
+  pool_store_fp(sub, 0, j, a.x.c0); pool_store_fp(sub, 1, j, a.x.c1);
+  pool_store_fp(sub, 2, j, a.y.c0); pool_store_fp(sub, 3, j, a.y.c1);
+  sub.st[j] = a.inf ? 0x80 : 0;
+}
 // tuple i: agg_sig = sum_s sig_pool[msg_i * S + s], agg_pk = sum_s pk_pool[s] over its signer list
 // (Add for Signature / PublicKey, types.rs:264-270, :126-132); results + H(msg_i) go to the verify planes.
 // A wave walks its lanes' lists in lockstep until the longest is exhausted.
@@ -871,8 +900,9 @@ struct bn254_ctx {
   size_t stage_cap[8];
   int profiling;
   int split_miller;  // A/B knob: one pairing per lane (k_miller_verify_split) instead of the fused 2-pair loop
-  Pool pool[3];       // aggregate verify: pk pool, sig pool, H(m) pool (grown on demand)
-  size_t pool_fp[3];  // coordinates per entry: 4, 2, 2
+  Pool pool[4];       // aggregate verify: pk pool, sig pool, H(m) pool, subset sums of the pk pool (grown on demand)
+  size_t pool_fp[4];  // coordinates per entry: 4, 2, 2, 4
+  int agg_subset_min_tuples;  // aggregate verify: tabulate subset sums of the pk pool for batches of at least this many tuples (0 = never)
   int pair_lanes;    // verify: Miller loop + final exponentiation on lane pairs (bn254_pair.hip); default on
   int rand_min_batch;      // randomised verify: batches below this size run the exact kernels (default RAND_MIN_BATCH_DEFAULT)
   int rand_items_per_lane; // randomised verify: 0 = by batch size, 1 or 2 forced (A/B and tests)
@@ -1030,6 +1060,7 @@ int bn254_ctx_create(int hip_device, bn254_ctx** out) {
   c->trio_max_batch = TRIO_MAX_BATCH_DEFAULT;
   c->hash_direct_width = HASH_DIRECT_WIDTH_DEFAULT;
   c->trio_wave_roles = TRIO_WAVE_ROLES_DEFAULT;
+  c->agg_subset_min_tuples = AGG_SUBSET_MIN_TUPLES_DEFAULT;
   // the small-batch kernels ask for up to 156 KB of dynamic LDS per workgroup: on a part that cannot hold one, step down
   // (eight wave roles -> four -> lane groups -> lane pairs only) instead of failing at the first launch
   c->fits_w8 = bn254_quad_fits_device(1); c->fits_quad = bn254_quad_fits_device(0); c->fits_trio = bn254_trio_fits_device();
@@ -1062,7 +1093,7 @@ void bn254_ctx_destroy(bn254_ctx* c) {
   if (c->ws.h_next) (void)hipFree(c->ws.h_next);
   if (c->ws.h_list) (void)hipFree(c->ws.h_list);
   if (c->ws.h_cnt) (void)hipFree(c->ws.h_cnt);
-  for (int i = 0; i < 3; ++i) { if (c->pool[i].planes) (void)hipFree(c->pool[i].planes); if (c->pool[i].st) (void)hipFree(c->pool[i].st); }
+  for (int i = 0; i < 4; ++i) { if (c->pool[i].planes) (void)hipFree(c->pool[i].planes); if (c->pool[i].st) (void)hipFree(c->pool[i].st); }
   for (int i = 0; i < 8; ++i) if (c->stage[i]) (void)hipFree(c->stage[i]);
   if (c->key_lines) (void)hipFree(c->key_lines);
   if (c->key_st) (void)hipFree(c->key_st);
@@ -1098,6 +1129,7 @@ int bn254_ctx_set_option(bn254_ctx* c, int option, int value) {
   if (option == BN254_OPT_PAIR_LANES) { c->pair_lanes = value != 0; return 0; }
   if (option == BN254_OPT_RAND_MIN_BATCH) { if (value < 0) return BN254_E_BAD_ARGUMENT; c->rand_min_batch = value; return 0; }
   if (option == BN254_OPT_RAND_ITEMS_PER_LANE) { if (value < 0 || value > 2) return BN254_E_BAD_ARGUMENT; c->rand_items_per_lane = value; return 0; }
+  if (option == BN254_OPT_AGG_SUBSET_MIN_TUPLES) { if (value < 0) return BN254_E_BAD_ARGUMENT; c->agg_subset_min_tuples = value; return 0; }
   if (option == BN254_OPT_TRIO_MAX_BATCH) {
     if (value < 0 || (value > 0 && !c->fits_trio)) return BN254_E_BAD_ARGUMENT;
     c->trio_max_batch = value;
@@ -1704,7 +1736,16 @@ int bn254_batch_aggregate_verify_device(bn254_ctx* c, const uint8_t* d_msgs, con
   if ((rc = launch_hash_rounds(c, s, d_msgs, d_msg_off, n_msgs, PL_P2X, BY_P2_INF, nullptr))) return rc;
   k_hash_to_pool<<<grid_for(n_msgs), BN_WAVE, 0, s>>>(n_msgs, c->ws, c->pool[2]);
   if (c->pair_lanes) {
-    if ((rc = bn254_pair_aggregate(d_tuple_msg, d_tuple_off, d_signer_idx, n, n_signers, n_msgs, c->pool[0], c->pool[1], c->pool[2], c->ws, s))) return rc;
+    // subset sums of the key pool for batches large enough to repay the table (n_groups x 256 entries of ~4 additions + an
+    // inversion each); the kernel uses it for the waves whose longest signer list has more entries than there are groups
+    size_t n_groups = 0;
+    if (c->agg_subset_min_tuples > 0 && n >= (size_t)c->agg_subset_min_tuples && n_signers <= AGG_SUBSET_MAX_SIGNERS) {
+      n_groups = (n_signers + 7) / 8;
+      if ((rc = pool_reserve(c, 3, 4, n_groups * 256))) return rc;
+      k_pool_subsets_g2<<<grid_for(n_groups * 256), BN_WAVE, 0, s>>>(c->pool[0], n_signers, n_groups, c->pool[3]);
+    }
+    if ((rc = bn254_pair_aggregate(d_tuple_msg, d_tuple_off, d_signer_idx, n, n_signers, n_msgs, c->pool[0], c->pool[1], c->pool[2], c->pool[3], n_groups,
+                                   c->ws, s))) return rc;
   } else {
     k_aggregate<<<grid_for(n), BN_WAVE, 0, s>>>(d_tuple_msg, d_tuple_off, d_signer_idx, n, n_signers, n_msgs, c->pool[0], c->pool[1], c->pool[2], c->ws);
   }

@@ -282,10 +282,16 @@ int bn254_pair_rand_tail(size_t n_groups, Ws ws, size_t gbase, hipStream_t s) {
 }
 
 // Aggregation for config 3 on lane pairs (see k_aggregate in bn254_hip.hip): a pair walks the signer list of its
-// tuple two entries per iteration — both public keys are added to the G2 sum in the pair layout, and each lane adds
-// the signature of "its" entry (2t + role) to its own partial G1 sum; the two partial sums are added at the end.
+// tuple two entries per iteration; each lane adds the signature of "its" entry (2t + role) to its own partial G1 sum and the
+// two partial sums are added at the end.  The public keys take one of two routes, chosen per wave:
+//   * direct: both keys of the iteration are added to the G2 sum in the pair layout (lists shorter than n_groups);
+//   * subset sums (k_pool_subsets_g2): the walk only sets bit (signer mod 8) in the tuple's mask byte of group signer / 8 (LDS,
+//     atomic OR: the two lanes of a pair may meet in one word), then ONE table entry per group is added — n_signers / 8
+//     additions whatever the list length.  A tuple that names a signer twice (the OR would swallow the second copy) is
+//     detected by the bit already being set and takes the direct route afterwards; sums are commutative, so order is free.
+extern __shared__ uint32_t bn_agg_masks[];     // [BN_PAIR_WG / 2 tuples][mask_stride words], mask_stride odd
 KERNEL_PAIR void k_aggregate_pair(const uint32_t* tuple_msg, const uint64_t* tuple_off, const uint32_t* signer_idx, size_t n, size_t n_signers,
-                                  size_t n_msgs, Pool pk_pool, Pool sig_pool, Pool h_pool, Ws ws) {
+                                  size_t n_msgs, Pool pk_pool, Pool sig_pool, Pool h_pool, Pool sub_pool, unsigned n_groups, unsigned mask_stride, Ws ws) {
   const unsigned role = threadIdx.x & 1u;
   size_t i = ((size_t)blockIdx.x * BN_PAIR_WG + threadIdx.x) >> 1;
   const bool live = i < n;                 // no early return: the wave-level votes and shuffles below need every lane
@@ -305,6 +311,13 @@ KERNEL_PAIR void k_aggregate_pair(const uint32_t* tuple_msg, const uint64_t* tup
     uint64_t other = __shfl_xor((unsigned long long)longest, off, BN_WAVE);
     longest = other > longest ? other : longest;
   }
+  const bool use_sub = n_groups != 0 && longest > n_groups;             // wave-uniform
+  uint32_t* my_masks = bn_agg_masks + (threadIdx.x >> 1) * mask_stride;
+  bool dup = false;
+  if (use_sub) {
+    for (unsigned w = role; w < mask_stride; w += 2) my_masks[w] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  }
   for (uint64_t t = 0; t < longest; t += 2) {
     G2Affine pp[2];
     G1Affine sp;
@@ -320,17 +333,58 @@ KERNEL_PAIR void k_aggregate_pair(const uint32_t* tuple_msg, const uint64_t* tup
       uint8_t s1 = sig_pool.st[sj], s2 = pk_pool.st[sgn];
       if (valid && st == ST_OK && (s1 & 0x7f)) st = s1 & 0x7f;
       if (valid && st == ST_OK && (s2 & 0x7f)) st = s2 & 0x7f;
-      pp[e].x.c[0] = pool_load_fp(pk_pool, 0 + (int)role, sgn);
-      pp[e].y.c[0] = pool_load_fp(pk_pool, 2 + (int)role, sgn);
-      pp[e].inf = !valid || (s2 & 0x80);
-      if ((unsigned)e == role) {            // this lane's signature of the iteration
+      if (!use_sub) {
+        pp[e].x.c[0] = pool_load_fp(pk_pool, 0 + (int)role, sgn);
+        pp[e].y.c[0] = pool_load_fp(pk_pool, 2 + (int)role, sgn);
+        pp[e].inf = !valid || (s2 & 0x80);
+      }
+      if ((unsigned)e == role) {            // this lane's entry of the iteration: its signature, and its bit of the key masks
         sp.x = pool_load_fp(sig_pool, 0, sj); sp.y = pool_load_fp(sig_pool, 1, sj);
         sp.inf = !valid || (s1 & 0x80);
+        if (use_sub && valid) {
+          const uint32_t bit = 1u << (8u * ((sgn >> 3) & 3u) + (sgn & 7u));
+          const uint32_t old = atomicOr(&my_masks[sgn >> 5], bit);
+          dup = dup || (old & bit) != 0;
+        }
       }
     }
-    jac_accumulate(acc2, pp[0]);
-    jac_accumulate(acc2, pp[1]);
+    if (!use_sub) {
+      jac_accumulate(acc2, pp[0]);
+      jac_accumulate(acc2, pp[1]);
+    }
     jac_accumulate(acc1, sp);
+  }
+  if (use_sub) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const int32_t partner_dup = bn_partner_word((int32_t)dup);           // unconditionally: a DPP fetch must not sit behind a short-circuit
+    dup = dup || partner_dup != 0;                                       // either lane of the pair saw a repeated signer
+    for (unsigned g = 0; g < n_groups; ++g) {                            // wave-uniform
+      const uint32_t mask = dup ? 0u : (my_masks[g >> 2] >> (8u * (g & 3u))) & 255u;
+      const size_t j = (size_t)g * 256 + mask;
+      G2Affine p;
+      p.x.c[0] = pool_load_fp(sub_pool, 0 + (int)role, j);
+      p.y.c[0] = pool_load_fp(sub_pool, 2 + (int)role, j);
+      p.inf = mask == 0 || (sub_pool.st[j] & 0x80);
+      jac_accumulate(acc2, p);
+    }
+    if (__builtin_amdgcn_ballot_w64(dup) != 0) {                          // rare: the tuples with a repeated signer add their keys one by one
+      uint64_t longest2 = dup ? hi - lo : 0;
+      for (int off = 32; off > 0; off >>= 1) {
+        uint64_t other = __shfl_xor((unsigned long long)longest2, off, BN_WAVE);
+        longest2 = other > longest2 ? other : longest2;
+      }
+      for (uint64_t t = 0; t < longest2; ++t) {
+        const bool active = dup && lo + t < hi;
+        uint32_t sgn = active ? signer_idx[lo + t] : 0u;
+        const bool valid = active && sgn < n_signers;
+        if (!valid) sgn = 0;
+        G2Affine p;
+        p.x.c[0] = pool_load_fp(pk_pool, 0 + (int)role, sgn);
+        p.y.c[0] = pool_load_fp(pk_pool, 2 + (int)role, sgn);
+        p.inf = !valid || pk_pool.st[sgn] != 0;                            // decode errors are in `st` already; identity entries add nothing
+        jac_accumulate(acc2, p);
+      }
+    }
   }
   // G1: own partial sum + the partner's
   G1Jac other;
@@ -356,9 +410,12 @@ KERNEL_PAIR void k_aggregate_pair(const uint32_t* tuple_msg, const uint64_t* tup
   }
 }
 int bn254_pair_aggregate(const uint32_t* tuple_msg, const uint64_t* tuple_off, const uint32_t* signer_idx, size_t n, size_t n_signers, size_t n_msgs,
-                         Pool pk_pool, Pool sig_pool, Pool h_pool, Ws ws, hipStream_t s) {
-  k_aggregate_pair<<<(unsigned)((2 * n + BN_PAIR_WG - 1) / BN_PAIR_WG), BN_PAIR_WG, 0, s>>>(tuple_msg, tuple_off, signer_idx, n, n_signers, n_msgs,
-                                                                                            pk_pool, sig_pool, h_pool, ws);
+                         Pool pk_pool, Pool sig_pool, Pool h_pool, Pool sub_pool, size_t n_groups, Ws ws, hipStream_t s) {
+  const unsigned mask_stride = n_groups ? (unsigned)(((n_groups + 3) / 4) | 1u) : 1u;     // words per tuple, odd: the tuples of a wave hit different banks
+  const size_t lds = n_groups ? (size_t)(BN_PAIR_WG / 2) * mask_stride * sizeof(uint32_t) : 0;
+  k_aggregate_pair<<<(unsigned)((2 * n + BN_PAIR_WG - 1) / BN_PAIR_WG), BN_PAIR_WG, lds, s>>>(tuple_msg, tuple_off, signer_idx, n, n_signers, n_msgs,
+                                                                                              pk_pool, sig_pool, h_pool, sub_pool, (unsigned)n_groups,
+                                                                                              mask_stride, ws);
   HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -6,6 +6,8 @@
 #define BN_SPLIT_MAX_N ((size_t)98304)   // <= 1.5 waves per SIMD with one lane per verify
 #define TRIO_MAX_BATCH_DEFAULT 16384               // octet layout up to TWO passes of one wave per SIMD (1024 SIMDs x 8 verifies): 3.5 ms at 8192, 6.5 ms at 16384 (lane pairs: 7.1 / 7.9 ms)
 #define TRIO_WAVE_ROLES_DEFAULT 2                  // ... with the Miller loop as wave roles: 2 = eight waves per 32 verifies (k_miller_verify_w8), 1 = four
+#define AGG_SUBSET_MIN_TUPLES_DEFAULT 4096       // aggregate verify: subset-sum table of the key pool from this many tuples on (the table costs ~0.3 ms)
+#define AGG_SUBSET_MAX_SIGNERS ((size_t)2048)     // ... one mask byte per group of 8 keys and tuple in LDS: 256 groups at most
 #define RAND_MIN_BATCH_DEFAULT 131072              // randomised verify pays off from about here
 #define RAND_TWO_PER_LANE_MIN_N ((size_t)131072)   // randomised verify: two items per lane once that still fills 1024 SIMDs
 // Register budget: amdgpu_waves_per_eu(W, W) on the kernels is propagated to every device function
@@ -94,7 +96,8 @@ __attribute__((visibility("hidden"))) int bn254_pair_final_exp(size_t n, Ws ws, 
 __attribute__((visibility("hidden"))) int bn254_pair_miller_rand(size_t n, size_t n_groups, int items_per_pair, Ws ws, size_t gbase, hipStream_t s);
 __attribute__((visibility("hidden"))) int bn254_pair_rand_tail(size_t n_groups, Ws ws, size_t gbase, hipStream_t s);
 __attribute__((visibility("hidden"))) int bn254_pair_aggregate(const uint32_t* tuple_msg, const uint64_t* tuple_off, const uint32_t* signer_idx, size_t n,
-                                                               size_t n_signers, size_t n_msgs, Pool pk_pool, Pool sig_pool, Pool h_pool, Ws ws, hipStream_t s);
+                                                               size_t n_signers, size_t n_msgs, Pool pk_pool, Pool sig_pool, Pool h_pool, Pool sub_pool,
+                                                               size_t n_groups, Ws ws, hipStream_t s);
 __attribute__((visibility("hidden"))) int bn254_pair_decode_g2(const uint8_t* pts, size_t n, uint32_t flags, Ws ws, int accumulate, hipStream_t s);
 __attribute__((visibility("hidden"))) int bn254_pair_decompress_g2(const uint8_t* in, size_t n, Ws ws, hipStream_t s);
 

@@ -20,6 +20,7 @@ OPT_RAND_MIN_BATCH = 5
 OPT_TRIO_MAX_BATCH = 6
 OPT_HASH_DIRECT_WIDTH = 7
 OPT_TRIO_WAVE_ROLES = 8
+OPT_AGG_SUBSET_MIN_TUPLES = 9
 
 
 class NativeError(RuntimeError):

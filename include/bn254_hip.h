@@ -270,6 +270,9 @@ int bn254_ctx_set_profiling(bn254_ctx *ctx, int enabled);
 #define BN254_OPT_HASH_DIRECT_WIDTH 7 /* hash-to-G1 of batches of up to 4096 messages: this many counters of every message are tried at once, in
                                        lanes of one wave, with the square root itself (latency 0.17 ms instead of 0.25); a power of two <= 32,
                                        default 32; 0 = always the filter rounds.  Same points and try counts either way. */
+#define BN254_OPT_AGG_SUBSET_MIN_TUPLES 9 /* aggregate verify: from this many tuples on (default 4096) the sums of all subsets of every 8 consecutive
+                                            keys of the pool are tabulated once per call and a tuple adds one table entry per group instead of one
+                                            key per signer (pools of up to 2048 signers, lists longer than n_signers / 8); 0 = never.  Same statuses. */
 #define BN254_OPT_HASH_MAX_TRIES 2 /* test knob: counters tried before HashToPointError; 0 = 255 as in src/hash.rs:40 */
 int bn254_ctx_set_option(bn254_ctx *ctx, int option, int value);
 /* per-kernel times of the last verify-shaped call with profiling on (HIP events on the call's stream):

@@ -571,6 +571,56 @@ def test_aggregate_verify_vs_oracle(eng, c):
     assert got == bytes([4, 0])
 
 
+def test_aggregate_verify_subset_sum_table_vs_oracle(eng, c):
+    """the subset-sum route of the aggregate kernel (k_pool_subsets_g2 + mask bytes in LDS, forced on by
+    BN254_OPT_AGG_SUBSET_MIN_TUPLES = 1) gives the oracle's statuses: dense lists (longer than the number of groups), a pool
+    size that is not a multiple of 8, lists in descending and shuffled order, a signer named twice / three times (direct
+    route for that tuple), an out-of-range signer, an identity and an undecodable pool entry, empty lists, a wave with only
+    short lists (direct route), and the same inputs with the table switched off."""
+    import random
+    from bn254_amd.engine import OPT_AGG_SUBSET_MIN_TUPLES
+    from tests.datagen import sk_bytes
+    rnd = random.Random(77)
+    M, S = 3, 43                                                           # 6 groups, the last one with 3 keys
+    msgs = [b"sub-msg-%d" % m for m in range(M)]
+    sks = [sk_bytes(700 + s) for s in range(S)]
+    pk_pool, st = eng.batch_g2_mul(None, b"".join(sks), S, reduce_scalar=True)
+    sig_pool, st2 = eng.batch_sign([msgs[m] for m in range(M) for _ in range(S)], b"".join(sks * M))
+    assert st == bytes(S) and st2 == bytes(M * S)
+    pk_pool, sig_pool = bytearray(pk_pool), bytearray(sig_pool)
+    pk_pool[128 * 11:128 * 12] = bytes(128)                                 # identity key 11 ...
+    for m in range(M):
+        sig_pool[64 * (m * S + 11):64 * (m * S + 12)] = bytes(64)           # ... with identity signatures: tuples using it still verify
+    pk_pool[128 * 20 + 127] ^= 1                                            # key 20 does not decode -> status 4 for its tuples
+    pk_pool, sig_pool = bytes(pk_pool), bytes(sig_pool)
+    tuples = []
+    for i in range(150):
+        k = rnd.choice([0, 1, 5, 7, 12, 25, 40, S])
+        lst = rnd.sample(range(S), k)
+        if i % 7 == 0:
+            lst = sorted(lst, reverse=True)
+        if i % 13 == 5 and lst:
+            lst = lst + [lst[0]]                                             # a signer twice
+        if i % 29 == 9 and lst:
+            lst = [lst[-1]] * 3 + lst                                        # ... and four times
+        if i % 31 == 3:
+            lst = lst + [S + 2]                                              # out of range
+        tuples.append((rnd.randrange(M), lst))
+    tuples += [(1, [2, 3])] * 70                                             # a whole wave of short lists at the end
+    off, flat = [0], []
+    for _, lst in tuples:
+        flat += lst
+        off.append(len(flat))
+    want = c.batch_aggregate_verify(msgs, pk_pool, sig_pool, [t[0] for t in tuples], off, flat)
+    assert {0, 2, 4} <= set(want)
+    for knob in (1, 0):
+        eng.set_option(OPT_AGG_SUBSET_MIN_TUPLES, knob)
+        got = eng.batch_aggregate_verify(msgs, pk_pool, sig_pool, [t[0] for t in tuples], [t[1] for t in tuples])
+        diff = [(i, got[i], want[i], tuples[i]) for i in range(len(tuples)) if got[i] != want[i]]
+        assert not diff, (knob, diff[:5])
+    eng.set_option(OPT_AGG_SUBSET_MIN_TUPLES, 4096)
+
+
 def test_full_size_batch_properties(eng):
     """config-2 size (65 536): expected-status pattern (valid except every 64th), and
     permutation-equivariance of the result — size-independent properties, no oracle needed."""
