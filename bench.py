@@ -82,14 +82,39 @@ def effective_cores():
     return n
 
 
+PMC_WORKLOAD = "verify"            # which section of profiles/pmc_latest.json the roofline helpers read (set by main from --workload)
+
+
 def _pmc(kernel):
     """the committed rocprofv3 PMC summary of this same command for `kernel` (profiles/pmc_latest.json, produced by
-    tests/pmc_profile.sh + tests/pmc_to_json.py; separate --pmc passes), or None"""
+    tests/pmc_profile.sh + tests/pmc_to_json.py; separate --pmc passes; one section per bench workload), or None"""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
-            return json.load(f)["kernels"][kernel]
+            d = json.load(f)
+        return (d["kernels"] if PMC_WORKLOAD == "verify" else d["workloads"][PMC_WORKLOAD]["kernels"])[kernel]
     except Exception:
         return None
+
+
+def lib_sha16():
+    import bn254_amd._native as nat
+    try:
+        return hashlib.sha256(open(nat.LIB_PATH, "rb").read()).hexdigest()[:16]
+    except Exception:
+        return None
+
+
+def pmc_as_of():
+    """which binary the committed counter summary (profiles/pmc_latest.json) was measured on, and whether that is the library
+    loaded now: `traffic` and the instruction counts of a roofline object are static numbers from that file"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
+            d = json.load(f)
+    except Exception:
+        return None
+    cur = lib_sha16()
+    return {"file": "profiles/pmc_latest.json", "lib_sha256_16": d.get("lib_sha256_16"), "current_lib_sha256_16": cur,
+            "stale": d.get("lib_sha256_16") != cur, "note": "traffic / instruction counts are read from the file, not measured in this run"}
 
 
 def measured_traffic(kernel):
@@ -125,8 +150,12 @@ def measured_valu_issue(kernel, lane_products, probe, kernel_seconds):
             "ns_per_wave_inst_per_simd": {"multiplier_class": 1e9 * t_mul, "other": 1e9 * t_other},
             "kernel_ms_this_run": 1e3 * kernel_seconds, "utilisation": priced / kernel_seconds,
             "utilisation_flat_4_cycles": 4.0 * k["SQ_INSTS_VALU"] / (probe["n_simd"] * k["GRBM_GUI_ACTIVE"] / 8.0) if "GRBM_GUI_ACTIVE" in k else None,
-            "note": "cost-weighted, wall-clock on both sides; instruction counts from profiles/pmc_latest.json (same command, PMC pass), "
-                    "issue costs from bn254_probe_issue_rate in this process"}
+            "sq_wait_any_over_wave_cycles": k["SQ_WAIT_ANY"] / k["SQ_WAVE_CYCLES"] if "SQ_WAIT_ANY" in k and k.get("SQ_WAVE_CYCLES") else None,
+            "sq_wait_inst_any_over_wave_cycles": k["SQ_WAIT_INST_ANY"] / k["SQ_WAVE_CYCLES"] if "SQ_WAIT_INST_ANY" in k and k.get("SQ_WAVE_CYCLES") else None,
+            "note": "a CONSISTENCY figure, not a measure of slack: the instruction mix priced with single-instruction probes (two waves per "
+                    "SIMD) against the kernel's duration; values above 1 mean the probes over-price the mix.  Stall evidence is the wait "
+                    "share next to it (SQ_WAIT_ANY / SQ_WAVE_CYCLES from the PMC pass).  Instruction counts come from "
+                    "profiles/pmc_latest.json (see pmc_as_of), issue costs from bn254_probe_issue_rate in this process"}
 
 
 def issue_probe(eng):
@@ -141,26 +170,59 @@ def issue_probe(eng):
             "cycles_per_wave_inst_at_2p4GHz": {"mad_u64_u32": simds * 2.4e9 / mad, "add_u32": simds * 2.4e9 / add, "mul_lo_u32": simds * 2.4e9 / mul_lo}}
 
 
+# Algorithmic Fq products of the other workloads' kernels (tests/test_workcount.py keeps them in sync with the device source):
+FP_MUL_MILLER_KEYED = 8220         # keyed verify: two table lines per step, no twist-point arithmetic (2 508 dual + 348 single per lane)
+FP_MUL_G1_MADD, FP_MUL_G2_MADD = 13, 26            # mixed additions of k_aggregate_pair (per tuple: both lanes of the pair together)
+FP_MUL_AGG_TAIL = 7 + 18 + 27                      # G1 / G2 to affine, the final G1 addition of the two partial sums
+HASH_MEAN_TRIES = 2.116                            # counters tested per message on average (p = 0.4726 per try)
+
+
+def kernel_roofline(kernel, fp_mul_per_launch, kernel_ms, note=None):
+    """roofline object of one kernel: algorithmic MAC32 per launch / its HIP-event duration in THIS run, against the
+    VALU integer-multiply peak; `traffic` from the committed PMC pass of the same command when there is one"""
+    achieved = fp_mul_per_launch * MAC32_PER_FP_MUL / (kernel_ms * 1e-3) / 1e12
+    t = measured_traffic(kernel)
+    r = {"bound": "valu", "kernel": kernel, "achieved": achieved, "peak": PEAK_MAC32_THEORETICAL / 1e12, "unit": "TMAC32/s",
+         "frac": achieved / (PEAK_MAC32_THEORETICAL / 1e12), "traffic": (t or {}).get("bytes_per_launch"), "traffic_detail": t,
+         "kernel_ms": kernel_ms, "fp_products_per_launch": fp_mul_per_launch}
+    if note:
+        r["note"] = note
+    return r
+
+
 def other_workloads(args, torch, eng, dev, stream):
-    """informational timings of configs 2 (aggregate) and 4 (hash) and of the host-buffer (PCIe-inclusive) verify;
-    one JSON line, single GPU"""
+    """configs[2] (aggregate), configs[4] (hash) and the other entry points of the verify path on one GPU; one JSON line
+    with a `roofline` for the dominant kernel (HIP events in this run) and a `cpu_baseline` (the oracle on a bounded sample
+    of the same inputs, results compared)"""
     from tests.datagen import make_verify_batch, sk_bytes
     sh = stream.cuda_stream
 
-    def timed(fn, steps, warmup):
+    def timed(fn, steps, warmup, per_step=None):
         for _ in range(warmup):
             fn()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
             fn()
+            if per_step:
+                per_step()
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / steps
 
     def dev_bytes(b):
         return torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
 
-    out = {"workload": args.workload, "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "data": "synthetic"}
+    kms = {"decode": 0.0, "hash_to_g1": 0.0, "miller_loop": 0.0, "final_exp": 0.0}
+
+    def collect():
+        ms = eng.last_kernel_ms()
+        for key in kms:
+            kms[key] += ms[key] / args.steps
+
+    cpu = not args.no_cpu_baseline
+    cores = effective_cores()
+    out = {"workload": args.workload, "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "data": "synthetic", "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "u32"}
     if args.workload == "verify-host":
         n = args.batch or BATCH
         msgs, sigs, pks, expected = make_verify_batch(eng, n)
@@ -168,10 +230,21 @@ def other_workloads(args, torch, eng, dev, stream):
         packed = bn254_pack(msgs)
         st = __import__("ctypes").create_string_buffer(n)
         lib, h = eng._lib, eng._h
-        dt = timed(lambda: lib.bn254_batch_verify(h, packed[0], packed[1], sigs, pks, n, 0, st), args.steps, args.warmup)
+        eng.set_profiling(True)
+        dt = timed(lambda: lib.bn254_batch_verify(h, packed[0], packed[1], sigs, pks, n, 0, st), args.steps, args.warmup, collect)
         assert st.raw == expected
         out.update(metric="BN254 pairings/sec (batch verify, host buffers: H2D + kernels + D2H + sync)", value=2 * n / dt, unit="pairings/s",
-                   ms_per_step=1e3 * dt, batch=n)
+                   ms_per_step=1e3 * dt, config={"workload": "configs[1] through the host-pointer entry point (PCIe-inclusive)", "batch": n},
+                   roofline=kernel_roofline("k_miller_verify_pair", FP_MUL_MILLER * n, kms["miller_loop"]), kernel_ms=dict(kms))
+        if cpu:
+            from oracle import c_oracle
+            sample = min(n, 8192)
+            t1 = time.perf_counter()
+            st_cpu, _ = c_oracle.batch_verify(msgs[:sample], sigs[:64 * sample], pks[:128 * sample], flags=0, nthreads=cores)
+            dtc = time.perf_counter() - t1
+            assert st_cpu == expected[:sample]
+            out["cpu_baseline"] = {"value": 2.0 * sample / dtc, "unit": "pairings/s", "cores": cores, "kind": "port",
+                                   "sample": "first %d tuples of the batch, oracle/bn254_oracle.c; statuses equal the GPU's" % sample}
     elif args.workload == "verify-keyed":
         # configs[1] tuples whose public keys are REGISTERED with the context (the batch draws from a pool of 256 keys): the keyed
         # verify reads the keys' line tables instead of recomputing the twist-point arithmetic (include/bn254_hip.h)
@@ -179,7 +252,9 @@ def other_workloads(args, torch, eng, dev, stream):
         n = args.batch or BATCH
         msgs, sigs, pks, expected = make_verify_batch(eng, n)
         pool = min(KEY_POOL, n)
+        t1 = time.perf_counter()
         assert eng.register_keys(pks[:128 * pool]) == bytes(pool)
+        t_reg = time.perf_counter() - t1
         d_msgs, d_sigs = dev_bytes(b"".join(msgs)), dev_bytes(sigs)
         d_off = torch.arange(0, 32 * (n + 1), 32, dtype=torch.int64, device=dev)
         d_idx = (torch.arange(n, dtype=torch.int64, device=dev) % pool).to(torch.int32)
@@ -187,10 +262,24 @@ def other_workloads(args, torch, eng, dev, stream):
         eng.reserve(n)
         eng.set_profiling(True)
         dt = timed(lambda: eng.batch_verify_keyed_device(d_msgs.data_ptr(), d_off.data_ptr(), d_sigs.data_ptr(), d_idx.data_ptr(), n, d_st.data_ptr(),
-                                                         stream=sh), args.steps, args.warmup)
+                                                         stream=sh), args.steps, args.warmup, collect)
         assert bytes(d_st.cpu().numpy()) == expected
         out.update(metric="BN254 pairings/sec (batch verify, registered keys: line tables from HBM)", value=2 * n / dt, unit="pairings/s",
-                   ms_per_step=1e3 * dt, batch=n, registered_keys=pool, kernel_ms=eng.last_kernel_ms())
+                   ms_per_step=1e3 * dt, kernel_ms=dict(kms),
+                   config={"workload": "configs[1] with the public keys registered beforehand (bn254_ctx_register_keys): %d keys, 12.5 KB of line "
+                                       "coefficients each, read per verify" % pool, "batch": n, "registered_keys": pool,
+                           "registration_ms": 1e3 * t_reg, "line_table_bytes_read_per_step": 87 * 2 * 2 * 9 * 4 * n},
+                   roofline=kernel_roofline("k_miller_verify_keyed_pair", FP_MUL_MILLER_KEYED * n, kms["miller_loop"]))
+        if cpu:
+            from oracle import c_oracle
+            sample = min(n, 8192)
+            t1 = time.perf_counter()
+            st_cpu, _ = c_oracle.batch_verify(msgs[:sample], sigs[:64 * sample], pks[:128 * sample], flags=1, nthreads=cores)
+            dtc = time.perf_counter() - t1
+            assert st_cpu == expected[:sample]
+            out["cpu_baseline"] = {"value": 2.0 * sample / dtc, "unit": "pairings/s", "cores": cores, "kind": "port",
+                                   "sample": "first %d tuples with their keys expanded, oracle/bn254_oracle.c (subgroup check on, as registration "
+                                             "does); statuses equal the GPU's" % sample}
     elif args.workload == "verify-compressed":
         # configs[1] tuples given as the compressed wire encodings (33-byte signatures, 65-byte public keys), device resident
         from bn254_amd import PublicKey, Signature
@@ -209,11 +298,24 @@ def other_workloads(args, torch, eng, dev, stream):
         d_st = torch.full((n,), 255, dtype=torch.uint8, device=dev)
         eng.reserve(n)
         lib, h = eng._lib, eng._h
+        eng.set_profiling(True)
         dt = timed(lambda: lib.bn254_batch_verify_compressed_device(h, d_msgs.data_ptr(), d_off.data_ptr(), d_sc.data_ptr(), d_pc.data_ptr(), n,
-                                                                    d_st.data_ptr(), sh), args.steps, args.warmup)
+                                                                    d_st.data_ptr(), sh), args.steps, args.warmup, collect)
         assert bytes(d_st.cpu().numpy()) == expected
         out.update(metric="BN254 pairings/sec (batch verify from compressed encodings: square roots + subgroup test on decode)", value=2 * n / dt,
-                   unit="pairings/s", ms_per_step=1e3 * dt, batch=n)
+                   unit="pairings/s", ms_per_step=1e3 * dt, kernel_ms=dict(kms),
+                   config={"workload": "configs[1] from the 33- / 65-byte compressed encodings, device resident", "batch": n},
+                   roofline=kernel_roofline("k_miller_verify_pair", FP_MUL_MILLER * n, kms["miller_loop"]))
+        if cpu:
+            from oracle import c_oracle
+            sample = min(n, 8192)
+            t1 = time.perf_counter()
+            st_cpu, _ = c_oracle.batch_verify(msgs[:sample], sigs[:64 * sample], pks[:128 * sample], flags=1, nthreads=cores)
+            dtc = time.perf_counter() - t1
+            assert st_cpu == expected[:sample]
+            out["cpu_baseline"] = {"value": 2.0 * sample / dtc, "unit": "pairings/s", "cores": cores, "kind": "port",
+                                   "sample": "first %d tuples (uncompressed forms of the same points, subgroup check on), oracle/bn254_oracle.c; "
+                                             "statuses equal the GPU's" % sample}
     elif args.workload == "verify-randomized":
         # opt-in randomised batch verification against the exact path on the same inputs;
         # generated in chunks so that the message list stays small on the host
@@ -247,7 +349,8 @@ def other_workloads(args, torch, eng, dev, stream):
         sig_view[63::64] = saved
         res["rand128_every_group_fails"] = {"verifies_per_s": n / dt, "ms_per_step": 1e3 * dt}
         out.update(metric="BN254 verifies/sec, randomised batch verification (groups of 64) vs exact, all-valid batch", unit="verifies/s",
-                   value=res["rand128"]["verifies_per_s"], ms_per_step=res["rand128"]["ms_per_step"], batch=n, modes=res,
+                   value=res["rand128"]["verifies_per_s"], ms_per_step=res["rand128"]["ms_per_step"], modes=res,
+                   config={"workload": "configs[1]-shaped tuples, opt-in randomised batch verification", "batch": n},
                    speedup_vs_exact=res["rand128"]["verifies_per_s"] / res["exact"]["verifies_per_s"])
     elif args.workload == "hash":
         n = args.batch or (1 << 24)                                 # config 4: 16 Mi messages
@@ -258,10 +361,38 @@ def other_workloads(args, torch, eng, dev, stream):
         d_pts = torch.empty(n * 64, dtype=torch.uint8, device=dev)
         d_st = torch.empty(n, dtype=torch.uint8, device=dev)
         eng.reserve(n)
+        eng.set_profiling(True)
         dt = timed(lambda: eng.batch_hash_to_g1_device(d_msgs.data_ptr(), d_off.data_ptr(), n, d_pts.data_ptr(), d_st.data_ptr(), None, stream=sh),
-                   args.steps, args.warmup)
+                   args.steps, args.warmup, collect)
         assert int(d_st.max()) == 0
-        out.update(metric="hash_to_try_and_increment messages/sec", value=n / dt, unit="messages/s", ms_per_step=1e3 * dt, batch=n)
+        fp_mul = (FP_MUL_HASH_FILTER * HASH_MEAN_TRIES + FP_MUL_HASH_FINISH) * n
+        io = (32 + 8 + 64 + 1) * n
+        out.update(metric="hash_to_try_and_increment messages/sec", value=n / dt, unit="messages/s", ms_per_step=1e3 * dt, kernel_ms=dict(kms),
+                   config={"workload": "configs[4]: %d 32-byte messages -> G1 points (SHA-256 try-and-increment in rounds: Jacobi filter, then one "
+                                       "square root per message)" % n, "batch": n},
+                   roofline=kernel_roofline("k_hash_finish", FP_MUL_HASH_FINISH * n, kms["hash_to_g1"],
+                                            note="kernel_ms is the whole round sequence (k_hash_init / round / resolve / finish: HIP events around it); the "
+                                                 "products counted are those of k_hash_finish, the square roots — SHA-256 and the Jacobi symbols of the "
+                                                 "filter rounds are 32-bit integer work outside the MAC32 unit, so `frac` understates the utilisation"))
+        out["roofline"]["hbm"] = {"algorithmic_bytes_per_step": io, "achieved_GBps": io / dt / 1e9, "peak_GBps": HBM_PEAK_GBPS}
+        out["roofline"]["fp_products_incl_filter_per_launch"] = fp_mul
+        if cpu:
+            from concurrent.futures import ThreadPoolExecutor
+            from oracle import c_oracle
+            sample = min(n, 65536)
+            m_host = d_msgs[:32 * sample].cpu().numpy().tobytes()
+            p_host = d_pts[:64 * sample].cpu().numpy().tobytes()
+
+            def chunk(lo):
+                return [c_oracle.hash_to_g1(m_host[32 * i:32 * i + 32])[1] for i in range(lo, min(lo + 1024, sample))]
+            t1 = time.perf_counter()
+            with ThreadPoolExecutor(cores) as ex:                     # the oracle call releases the GIL
+                pts = b"".join(b"".join(c) for c in ex.map(chunk, range(0, sample, 1024)))
+            dtc = time.perf_counter() - t1
+            assert pts == p_host, "oracle points differ from the GPU's"
+            out["cpu_baseline"] = {"value": sample / dtc, "unit": "messages/s", "cores": cores, "kind": "port",
+                                   "sample": "first %d messages, oracle/bn254_oracle.c hash_to_try_and_increment called per message from %d Python "
+                                             "threads; points equal the GPU's byte for byte" % (sample, cores)}
     else:
         n = args.batch or (1 << 20)                                 # config 2: 1 Mi tuples, 1024 signers
         M = S = 1024
@@ -283,19 +414,45 @@ def other_workloads(args, torch, eng, dev, stream):
         d_msgs, d_pk, d_sig = dev_bytes(b"".join(msgs)), dev_bytes(pk_pool), dev_bytes(sig_pool)
         d_moff = torch.arange(0, 32 * (M + 1), 32, dtype=torch.int64, device=dev)
         d_st = torch.empty(n, dtype=torch.uint8, device=dev)
-        dt = timed(lambda: eng.batch_aggregate_verify_device(d_msgs.data_ptr(), d_moff.data_ptr(), M, d_pk.data_ptr(), S, d_sig.data_ptr(),
-                                                             tuple_msg.data_ptr(), tuple_off.data_ptr(), signer_idx.data_ptr(), n, d_st.data_ptr(),
-                                                             stream=sh), args.steps, args.warmup)
+
+        def call():
+            eng.batch_aggregate_verify_device(d_msgs.data_ptr(), d_moff.data_ptr(), M, d_pk.data_ptr(), S, d_sig.data_ptr(), tuple_msg.data_ptr(),
+                                              tuple_off.data_ptr(), signer_idx.data_ptr(), n, d_st.data_ptr(), stream=sh)
+        eng.set_profiling(True)
+        dt = timed(call, args.steps, args.warmup, collect)
         assert int(d_st.max()) == 0
+        k_table = dict(kms)
         eng.set_option(9, 0)                                       # BN254_OPT_AGG_SUBSET_MIN_TUPLES = 0: every key added one by one (rounds 1-2)
-        dt_direct = timed(lambda: eng.batch_aggregate_verify_device(d_msgs.data_ptr(), d_moff.data_ptr(), M, d_pk.data_ptr(), S, d_sig.data_ptr(),
-                                                                    tuple_msg.data_ptr(), tuple_off.data_ptr(), signer_idx.data_ptr(), n, d_st.data_ptr(),
-                                                                    stream=sh), max(1, args.steps // 2), 1)
+        dt_direct = timed(call, max(1, args.steps // 2), 1)
         assert int(d_st.max()) == 0
         eng.set_option(9, 4096)
-        out.update(metric="aggregate verifies/sec (1024 signers, ~512 per tuple, pools decoded per step)", value=n / dt, unit="verifies/s",
-                   ms_per_step=1e3 * dt, batch=n, mean_signers_per_tuple=float(signer_idx.numel()) / n,
-                   without_subset_sum_table={"verifies_per_s": n / dt_direct, "ms_per_step": 1e3 * dt_direct})
+        total_signers = int(signer_idx.numel())
+        groups = (S + 7) // 8
+        agg_products = FP_MUL_G1_MADD * total_signers + (FP_MUL_G2_MADD * groups + FP_MUL_AGG_TAIL) * n
+        out.update(metric="aggregate verifies/sec (1024 signers, ~512 per tuple)", value=n / dt, unit="verifies/s",
+                   ms_per_step=1e3 * dt, kernel_ms={"pools_hash_table": k_table["decode"], "aggregate": k_table["hash_to_g1"],
+                                                    "miller_loop": k_table["miller_loop"], "final_exp": k_table["final_exp"]},
+                   config={"workload": "configs[2]: %d aggregate verifies over pools of %d signers x %d messages (random subsets, %.1f signers per "
+                                       "tuple): G1 / G2 sums, then one verify each" % (n, S, M, total_signers / n), "batch": n,
+                           "mean_signers_per_tuple": total_signers / n, "key_route": "subset sums of the key pool: %d table additions per tuple" % groups},
+                   without_subset_sum_table={"verifies_per_s": n / dt_direct, "ms_per_step": 1e3 * dt_direct},
+                   roofline=kernel_roofline("k_aggregate_pair", agg_products, k_table["hash_to_g1"],
+                                            note="products per tuple: 13 per signature added + 26 per group of 8 keys (one table entry) + 52"))
+        out["roofline"]["whole_step"] = {"fp_products_per_tuple": agg_products / n + FP_MUL_MILLER + FP_MUL_FINAL_EXP,
+                                         "frac": (agg_products / n + FP_MUL_MILLER + FP_MUL_FINAL_EXP) * MAC32_PER_FP_MUL * n / dt / PEAK_MAC32_THEORETICAL}
+        if cpu:
+            from oracle import c_oracle
+            sample = min(n, 2048)
+            hi = int(tuple_off[sample].item())
+            t1 = time.perf_counter()
+            st_cpu = c_oracle.batch_aggregate_verify(msgs, pk_pool, sig_pool, tuple_msg[:sample].cpu().numpy(), tuple_off[:sample + 1].cpu().numpy(),
+                                                     signer_idx[:hi].cpu().numpy(), nthreads=cores)
+            dtc = time.perf_counter() - t1
+            assert st_cpu == bytes(d_st[:sample].cpu().numpy()), "oracle statuses differ from the GPU's"
+            out["cpu_baseline"] = {"value": sample / dtc, "unit": "verifies/s", "cores": cores, "kind": "port",
+                                   "sample": "first %d tuples (%d signer entries), oracle/bn254_oracle.c: Add of src/types.rs per signer, then verify; "
+                                             "statuses equal the GPU's" % (sample, hi)}
+    out["pmc_as_of"] = pmc_as_of()
     print(json.dumps(out))
 
 
@@ -609,6 +766,7 @@ def run_verify(args, R):
                           "4x64-bit Montgomery limbs, pthreads, gcc -O2); statuses equal the GPU's" % sample,
                 "single_thread_value": 2.0 * one / dt_one,
             }
+        result["pmc_as_of"] = pmc_as_of()
         print(json.dumps(result))
     R.finish()
 
@@ -700,8 +858,11 @@ def run_pairing(args, R):
         ms = 1e3 * elapsed / args.steps
         fp_mul = FP_MUL_MILLER_SINGLE + FP_MUL_FINAL_EXP_EXACT
         achieved = fp_mul * MAC32_PER_FP_MUL * n / (ms * 1e-3) / 1e12
+        tr_m, tr_f = measured_traffic("k_miller_var_pair"), measured_traffic("k_final_exp_pair")
         result["roofline"] = {"bound": "valu", "kernel": "k_miller_var_pair + k_final_exp_pair (whole step)", "achieved": achieved,
-                              "peak": PEAK_MAC32_THEORETICAL / 1e12, "unit": "TMAC32/s", "frac": achieved / (PEAK_MAC32_THEORETICAL / 1e12), "traffic": None,
+                              "peak": PEAK_MAC32_THEORETICAL / 1e12, "unit": "TMAC32/s", "frac": achieved / (PEAK_MAC32_THEORETICAL / 1e12),
+                              "traffic": (tr_m["bytes_per_launch"] + tr_f["bytes_per_launch"]) if tr_m and tr_f else None,
+                              "traffic_detail": {"k_miller_var_pair": tr_m, "k_final_exp_pair": tr_f},
                               "hbm": {"algorithmic_bytes_per_step": BYTES_PER_PAIRING_IO * n, "achieved_GBps": BYTES_PER_PAIRING_IO * n / (ms * 1e-3) / 1e9,
                                       "peak_GBps": HBM_PEAK_GBPS}}
         if world == 1 and not args.no_cpu_baseline:
@@ -715,6 +876,7 @@ def run_pairing(args, R):
             assert same_bytes, "oracle Gt bytes differ from the GPU's"
             result["cpu_baseline"] = {"value": sample / dt, "unit": "pairings/s", "cores": cores, "kind": "port",
                                       "sample": "first %d pairings of the shard, oracle/bn254_oracle.c; canonical Gt bytes equal the GPU's" % sample}
+        result["pmc_as_of"] = pmc_as_of()
         print(json.dumps(result))
     R.finish()
 
@@ -732,6 +894,8 @@ def main():
                     help="verify = the headline (configs[1]) and pairing = configs[3]: both run on N ranks; the others time configs 2, 4 or "
                          "other entry points on one GPU (informational — see DESIGN.md §4b)")
     args = ap.parse_args()
+    global PMC_WORKLOAD
+    PMC_WORKLOAD = args.workload
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

@@ -1492,8 +1492,14 @@ int bn254_batch_hash_to_g1_device(bn254_ctx* c, const uint8_t* d_msgs, const uin
   if (rc) return rc;
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
   unsigned g = grid_for(n);
+  PROF_MARK(0);
+  PROF_MARK(1);                                        // ms[0] = 0, ms[1] = the hash rounds, ms[2] = encoding the points, ms[3] = 0
   if ((rc = launch_hash_rounds(c, s, d_msgs, d_off, n, PL_P1X, BY_P1_INF, d_tries))) return rc;
+  PROF_MARK(2);
   k_encode_g1<<<g, BN_WAVE, 0, s>>>(n, c->ws, PL_P1X, BY_P1_INF, d_points, d_status);
+  PROF_MARK(3);
+  PROF_MARK(4);
+  if (c->profiling) { c->ev_valid = 1; c->ev_hash_first = 0; }
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -1527,15 +1533,22 @@ static int pairing_device(bn254_ctx* c, const uint8_t* d_g1, const uint8_t* d_g2
   int rc = ws_reserve(c, lanes);
   if (rc) return rc;
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  PROF_MARK(0);
   k_decode_g1<<<grid_for(lanes), BN_WAVE, 0, s>>>(d_g1, lanes, flags, c->ws, PL_P1X, BY_P1_INF, 0);
   if ((rc = launch_decode_g2(c, s, d_g2, lanes, flags, 1))) return rc;
+  PROF_MARK(1);
+  PROF_MARK(2);                                      // no hash in a pairing: ms[1] = 0
   if (c->pair_lanes) {
     if ((rc = bn254_pair_miller_var(lanes, c->ws, s))) return rc;
+    PROF_MARK(3);
     if ((rc = bn254_pair_final_exp_product(n, k, c->ws, d_gt, d_status, raw_only, s))) return rc;
   } else {
     k_miller_var<<<grid_for(lanes), BN_WAVE, 0, s>>>(lanes, c->ws);
+    PROF_MARK(3);
     k_final_exp<<<grid_for(n), BN_WAVE, 0, s>>>(n, k, k, 1, c->ws, 0, d_gt, d_status, raw_only, 0, nullptr, nullptr);
   }
+  PROF_MARK(4);
+  if (c->profiling) { c->ev_valid = 1; c->ev_hash_first = 0; }
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -1731,6 +1744,7 @@ int bn254_batch_aggregate_verify_device(bn254_ctx* c, const uint8_t* d_msgs, con
   if ((rc = pool_reserve(c, 1, 2, n_msgs * n_signers))) return rc;
   if ((rc = pool_reserve(c, 2, 2, n_msgs))) return rc;
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  PROF_MARK(0);                                        // ms[0] = pools (decode, hash of the messages, subset-sum table), ms[1] = the aggregation kernel
   k_pool_decode_g2<<<grid_for(n_signers), BN_WAVE, 0, s>>>(d_pk_pool, n_signers, flags, c->pool[0]);
   k_pool_decode_g1<<<grid_for(n_msgs * n_signers), BN_WAVE, 0, s>>>(d_sig_pool, n_msgs * n_signers, flags, c->pool[1]);
   if ((rc = launch_hash_rounds(c, s, d_msgs, d_msg_off, n_msgs, PL_P2X, BY_P2_INF, nullptr))) return rc;
@@ -1744,18 +1758,25 @@ int bn254_batch_aggregate_verify_device(bn254_ctx* c, const uint8_t* d_msgs, con
       if ((rc = pool_reserve(c, 3, 4, n_groups * 256))) return rc;
       k_pool_subsets_g2<<<grid_for(n_groups * 256), BN_WAVE, 0, s>>>(c->pool[0], n_signers, n_groups, c->pool[3]);
     }
+    PROF_MARK(1);
     if ((rc = bn254_pair_aggregate(d_tuple_msg, d_tuple_off, d_signer_idx, n, n_signers, n_msgs, c->pool[0], c->pool[1], c->pool[2], c->pool[3], n_groups,
                                    c->ws, s))) return rc;
   } else {
+    PROF_MARK(1);
     k_aggregate<<<grid_for(n), BN_WAVE, 0, s>>>(d_tuple_msg, d_tuple_off, d_signer_idx, n, n_signers, n_msgs, c->pool[0], c->pool[1], c->pool[2], c->ws);
   }
+  PROF_MARK(2);
   if (c->pair_lanes) {
     if ((rc = bn254_pair_miller_verify(n, c->ws, nullptr, nullptr, s))) return rc;
+    PROF_MARK(3);
     if ((rc = bn254_pair_final_exp(n, c->ws, 1, d_status, nullptr, nullptr, s))) return rc;
   } else {
     k_miller_verify<<<grid_for(n), BN_WAVE, 0, s>>>(n, c->ws, nullptr, nullptr);
+    PROF_MARK(3);
     k_final_exp<<<grid_for(n), BN_WAVE, 0, s>>>(n, 1, 1, 1, c->ws, 1, nullptr, d_status, 0, 0, nullptr, nullptr);
   }
+  PROF_MARK(4);
+  if (c->profiling) { c->ev_valid = 1; c->ev_hash_first = 0; }
   HIP_TRY(hipGetLastError());
   return 0;
 }

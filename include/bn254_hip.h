@@ -277,7 +277,9 @@ int bn254_ctx_set_profiling(bn254_ctx *ctx, int enabled);
 int bn254_ctx_set_option(bn254_ctx *ctx, int option, int value);
 /* per-kernel times of the last verify-shaped call with profiling on (HIP events on the call's stream):
  * ms[0] decode, ms[1] hash-to-G1, ms[2] Miller loop, ms[3] final exponentiation.  The host-pointer bn254_batch_verify runs
- * the hash first and its ms[1] includes the transfer of the messages. */
+ * the hash first and its ms[1] includes the transfer of the messages.  Other *_device calls reuse the slots: pairing ms[1] = 0;
+ * hash_to_g1 ms[1] = the hash rounds, ms[2] = encoding the points, ms[0] = ms[3] = 0; aggregate_verify ms[0] = the pools
+ * (decoding, hashing the messages, the subset-sum table), ms[1] = the aggregation kernel. */
 int bn254_ctx_last_kernel_ms(bn254_ctx *ctx, float ms[4]);
 
 #ifdef __cplusplus

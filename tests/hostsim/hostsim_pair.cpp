@@ -146,6 +146,25 @@ void hp_lane_counts_keyed(const uint8_t* h64, const uint8_t* sig64, const uint8_
   miller_loop_keyed(f, h, false, tab, sig);
   out2[0] = (bn_fp_dual_counter - d0) / 2; out2[1] = ((bn_fp_mul_counter - m0) - (bn_fp_dual_counter - d0)) / 2;
 }
+// Fq products (both lanes of the pair together, i.e. per tuple) of the group operations of k_aggregate_pair:
+// out = {G1 mixed addition, G2 mixed addition, G1 to affine, G2 to affine, G1 full addition}
+void hp_group_op_counts(unsigned long long* out5) {
+  G1Affine p1; p1.x = fp_load_const(C_G1_GEN[0]); p1.y = fp_load_const(C_G1_GEN[1]); p1.inf = false;
+  G2Affine p2; p2.x = fp2_load_const(C_G2_GEN[0]); p2.y = fp2_load_const(C_G2_GEN[1]); p2.inf = false;
+  G1Jac a1, b1; G2Jac a2;
+  jac_set_identity(a1); jac_set_identity(a2);
+  jac_accumulate(a1, p1); jac_accumulate(a1, p1);        // 2 P (second call: the doubling case)
+  jac_accumulate(a2, p2); jac_accumulate(a2, p2);
+  b1 = a1;
+  unsigned long long m0 = bn_fp_mul_counter;
+  jac_accumulate(a1, p1); out5[0] = bn_fp_mul_counter - m0; m0 = bn_fp_mul_counter;      // 3 P: the common case
+  jac_accumulate(a2, p2); out5[1] = bn_fp_mul_counter - m0; m0 = bn_fp_mul_counter;
+  G1Affine r1; G2Affine r2;
+  jac_to_affine(r1, a1); out5[2] = bn_fp_mul_counter - m0; m0 = bn_fp_mul_counter;
+  jac_to_affine(r2, a2); out5[3] = bn_fp_mul_counter - m0; m0 = bn_fp_mul_counter;
+  jac_add(a1, a1, b1); out5[4] = bn_fp_mul_counter - m0;
+  (void)r1; (void)r2;
+}
 // canonical Gt of one pairing through the pair layout
 void hp_pairing(const uint8_t* g1, const uint8_t* g2, uint8_t* gt384) {
   G1Affine p;

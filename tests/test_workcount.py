@@ -59,6 +59,23 @@ def test_lane_product_counts_for_bench(derived):
     assert _bench().lane_product_counts() == counts
 
 
+def test_other_workload_product_counts_for_bench(derived):
+    """the product counts bench.py prices the other workloads' rooflines with: keyed Miller loop (per verify) and the group
+    operations of the aggregation kernel (per tuple), from the instrumented host compilation of the device source"""
+    from oracle import c_oracle as c
+    from tests import hostsim_binding
+    hostsim_binding.build_all()
+    L = ctypes.CDLL(os.path.join(ROOT, "tests", "hostsim", "libhostsim_pair.so"))
+    b = _bench()
+    v = [v for v in derived["verify_cases"] if v["status"] == 0][0]
+    out = (ctypes.c_ulonglong * 2)()
+    L.hp_lane_counts_keyed(c.hash_to_g1(bytes.fromhex(v["message_hex"]))[1], bytes.fromhex(v["sig"]), bytes.fromhex(v["pk"]), out)
+    assert 3 * out[0] + 2 * out[1] == b.FP_MUL_MILLER_KEYED          # a dual product = 3 Fq products (Karatsuba), a square / scaling = 2
+    o5 = (ctypes.c_ulonglong * 5)()
+    L.hp_group_op_counts(o5)
+    assert (o5[0], o5[1]) == (b.FP_MUL_G1_MADD, b.FP_MUL_G2_MADD) and o5[2] + o5[3] + o5[4] == b.FP_MUL_AGG_TAIL
+
+
 def test_host_example_compiles():
     """the C++ host mirror (bn254_amd/host/bn254.hpp) compiles and links against the C ABI"""
     import subprocess

@@ -1,12 +1,29 @@
 #!/bin/bash
-# final-binary measurements for profiles/r02_<tag>_*: bench line, kernel stats, PMC, other workloads, batch sweep
-tag=$1
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02_$tag; mkdir -p $O
-python $R/bench.py > $O/bench.json 2> $O/bench.err; echo bench done
-python $R/bench.py --workload pairing --steps 3 --warmup 1 > $O/bench_pairing.json 2>> $O/bench.err; echo pairing done
-for w in verify-host verify-compressed hash aggregate; do python $R/bench.py --workload $w --steps 3 --warmup 1 2>/dev/null | tail -1 >> $O/other_workloads.jsonl; echo $w done; done
-python $R/bench.py --workload verify-randomized --steps 3 --warmup 1 --batch 1048576 2>/dev/null | tail -1 > $O/randomized_1m.json; echo rand1m done
-for b in 1 64 1024 4096 8192 16384 32768 65536 131072 262144 1048576; do python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --batch $b 2>/dev/null | python -c "
+# measurements behind profiles/r03_<tag>_*: usage profile_round.sh <tag> <part>   (parts keep every gpurun call under its limit)
+#   part a: bench lines of every workload (roofline + cpu_baseline each), batch sweep
+#   part b: PMC passes of the headline command (all counter groups) + kernel-trace stats
+#   part c: PMC passes (traffic + SQ group) and kernel-trace stats of the other workloads
+tag=$1; part=$2
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03_$tag; mkdir -p $O
+SHORT="FETCH_SIZE;WRITE_SIZE;SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM SQ_WAIT_INST_ANY SQ_WAIT_ANY"
+if [ "$part" = a ]; then
+  python $R/bench.py > $O/bench.json 2> $O/bench.err; echo bench done
+  python $R/bench.py --workload pairing --steps 3 --warmup 1 > $O/bench_pairing.json 2>> $O/bench.err; echo pairing done
+  rm -f $O/other_workloads.jsonl
+  for w in verify-host verify-keyed verify-compressed hash aggregate; do python $R/bench.py --workload $w --steps 3 --warmup 1 2>>$O/bench.err | tail -1 >> $O/other_workloads.jsonl; echo $w done; done
+  python $R/bench.py --workload verify-randomized --steps 3 --warmup 1 --batch 1048576 2>/dev/null | tail -1 > $O/randomized_1m.json; echo rand1m done
+  rm -f $O/batch_sweep.jsonl
+  for b in 1 64 1024 4096 8192 16384 32768 65536 131072 262144 1048576; do python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --batch $b 2>/dev/null | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); print(json.dumps({'batch': $b, 'pairings_per_s': d['value'], 'ms_per_step': d['ms_per_step'], 'kernel_ms': d['roofline']['kernel_ms']}))" >> $O/batch_sweep.jsonl; done; echo sweep done
-bash $R/tests/pmc_profile.sh r02_$tag "" > $O/pmc.log 2>&1; echo pmc done
-cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/stats.log 2>&1; echo stats done
+elif [ "$part" = b ]; then
+  bash $R/tests/pmc_profile.sh r03_$tag "" verify 65536 > $O/pmc_verify.log 2>&1; cp $R/gpurun_out/pmc_r03_$tag.json $O/pmc.json; echo pmc verify done
+  cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_verify -- python3 $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats_verify.err; echo stats done
+elif [ "$part" = c ]; then
+  cp $O/pmc.json $R/gpurun_out/pmc_r03_$tag.json 2>/dev/null
+  for spec in "verify-keyed:65536" "pairing:524288" "hash:16777216" "aggregate:1048576"; do
+    w=${spec%%:*}; b=${spec##*:}
+    OUTJ=$R/gpurun_out/pmc_r03_${tag}_$w.json; cp $O/pmc.json $OUTJ
+    bash $R/tests/pmc_profile.sh r03_${tag}_$w "--workload $w" $w $b "$SHORT" > $O/pmc_$w.log 2>&1; cp $OUTJ $O/pmc.json; echo pmc $w done
+    cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$w -- python3 $R/bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_${w}_under_rocprof.json 2> $O/stats_$w.err; echo stats $w done
+  done
+fi
