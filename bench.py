@@ -428,16 +428,21 @@ def other_workloads(args, torch, eng, dev, stream):
         eng.set_option(9, 4096)
         total_signers = int(signer_idx.numel())
         groups = (S + 7) // 8
-        agg_products = FP_MUL_G1_MADD * total_signers + (FP_MUL_G2_MADD * groups + FP_MUL_AGG_TAIL) * n
+        # route of this batch (bn254_hip.hip: bn254_batch_aggregate_verify_device): key sums from the 8-bit subset table, and — a message
+        # being shared by >= 64 tuples on average — signature sums from the per-message 4-bit tables
+        sig_tables = n >= 64 * M
+        agg_products = (FP_MUL_G1_MADD * 2 * groups * n if sig_tables else FP_MUL_G1_MADD * total_signers) + (FP_MUL_G2_MADD * groups + FP_MUL_AGG_TAIL) * n
         out.update(metric="aggregate verifies/sec (1024 signers, ~512 per tuple)", value=n / dt, unit="verifies/s",
                    ms_per_step=1e3 * dt, kernel_ms={"pools_hash_table": k_table["decode"], "aggregate": k_table["hash_to_g1"],
                                                     "miller_loop": k_table["miller_loop"], "final_exp": k_table["final_exp"]},
                    config={"workload": "configs[2]: %d aggregate verifies over pools of %d signers x %d messages (random subsets, %.1f signers per "
                                        "tuple): G1 / G2 sums, then one verify each" % (n, S, M, total_signers / n), "batch": n,
-                           "mean_signers_per_tuple": total_signers / n, "key_route": "subset sums of the key pool: %d table additions per tuple" % groups},
+                           "mean_signers_per_tuple": total_signers / n, "key_route": "subset sums of the key pool: %d table additions per tuple" % groups,
+                           "signature_route": ("per-message subset tables: %d table additions per tuple" % (2 * groups)) if sig_tables else "one addition per signer"},
                    without_subset_sum_table={"verifies_per_s": n / dt_direct, "ms_per_step": 1e3 * dt_direct},
                    roofline=kernel_roofline("k_aggregate_pair", agg_products, k_table["hash_to_g1"],
-                                            note="products per tuple: 13 per signature added + 26 per group of 8 keys (one table entry) + 52"))
+                                            note="products per tuple: 13 per signature-table entry (group of 4 signers) or signature added + 26 per key-table entry "
+                                                 "(group of 8 keys) + 52; the walk over the signer list (status checks, mask bits) is not MAC32 work"))
         out["roofline"]["whole_step"] = {"fp_products_per_tuple": agg_products / n + FP_MUL_MILLER + FP_MUL_FINAL_EXP,
                                          "frac": (agg_products / n + FP_MUL_MILLER + FP_MUL_FINAL_EXP) * MAC32_PER_FP_MUL * n / dt / PEAK_MAC32_THEORETICAL}
         if cpu:

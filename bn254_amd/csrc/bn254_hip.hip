@@ -710,6 +710,33 @@ KERNEL void k_pool_subsets_g2(Pool pk_pool, size_t n_signers, size_t n_groups, P
   pool_store_fp(sub, 2, j, a.y.c0); pool_store_fp(sub, 3, j, a.y.c1);
   sub.st[j] = a.inf ? 0x80 : 0;
 }
+// The same for the signatures, per message: the sums of the 15 non-empty subsets of every group of 4 consecutive signers of
+// message m (entry j = (m * groups4 + group) * 16 + mask; 302 MB for 1024 x 1024 — HBM is what this machine has), so that a
+// tuple adds one table entry per group of 4 signers (256 instead of ~512 additions; 4 bits, not 8: an entry costs two additions
+// and an inversion to build and is used by ~n / n_msgs tuples only).
+KERNEL_SMALL void k_pool_subsets_g1(Pool sig_pool, size_t n_signers, size_t groups4, size_t n_msgs, Pool sub) {
+  const size_t j = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
+  const bool live = j < n_msgs * groups4 * 16;
+  const size_t jj = live ? j : 0;
+  const unsigned mask = (unsigned)(jj & 15u);
+  const size_t g = (jj >> 4) % groups4, m = (jj >> 4) / groups4;
+  G1Jac acc;
+  jac_set_identity(acc);
+  for (int b = 0; b < 4; ++b) {                      // wave-uniform
+    const size_t sgn = g * 4 + b;
+    const size_t sj = m * n_signers + (sgn < n_signers ? sgn : 0);
+    const uint8_t st = sig_pool.st[sj];
+    G1Affine p;
+    p.x = pool_load_fp(sig_pool, 0, sj); p.y = pool_load_fp(sig_pool, 1, sj);
+    p.inf = !live || !((mask >> b) & 1u) || sgn >= n_signers || st != 0;
+    jac_accumulate(acc, p);
+  }
+  G1Affine a;
+  jac_to_affine(a, acc);
+  if (!live) return;
+  pool_store_fp(sub, 0, j, a.x); pool_store_fp(sub, 1, j, a.y);
+  sub.st[j] = a.inf ? 0x80 : 0;
+}
 // tuple i: agg_sig = sum_s sig_pool[msg_i * S + s], agg_pk = sum_s pk_pool[s] over its signer list
 // (Add for Signature / PublicKey, types.rs:264-270, :126-132); results + H(msg_i) go to the verify planes.
 // A wave walks its lanes' lists in lockstep until the longest is exhausted.
@@ -900,8 +927,8 @@ struct bn254_ctx {
   size_t stage_cap[8];
   int profiling;
   int split_miller;  // A/B knob: one pairing per lane (k_miller_verify_split) instead of the fused 2-pair loop
-  Pool pool[4];       // aggregate verify: pk pool, sig pool, H(m) pool, subset sums of the pk pool (grown on demand)
-  size_t pool_fp[4];  // coordinates per entry: 4, 2, 2, 4
+  Pool pool[5];       // aggregate verify: pk pool, sig pool, H(m) pool, subset sums of the pk pool and of the signature pool (grown on demand)
+  size_t pool_fp[5];  // coordinates per entry: 4, 2, 2, 4, 2
   int agg_subset_min_tuples;  // aggregate verify: tabulate subset sums of the pk pool for batches of at least this many tuples (0 = never)
   int pair_lanes;    // verify: Miller loop + final exponentiation on lane pairs (bn254_pair.hip); default on
   int rand_min_batch;      // randomised verify: batches below this size run the exact kernels (default RAND_MIN_BATCH_DEFAULT)
@@ -985,7 +1012,8 @@ static int pool_reserve(bn254_ctx* c, int which, size_t n_fp, size_t entries) {
   if (p.st) { HIP_TRY(hipFree(p.st)); p.st = nullptr; }
   p.stride = 0;
   size_t cap = (entries + 255) & ~(size_t)255;
-  HIP_TRY(hipMalloc((void**)&p.planes, n_fp * BN_LIMBS * sizeof(int32_t) * cap));
+  p.g2 = n_fp == 4 ? 1u : 0u;                       // record layout: bn254_ws.h
+  HIP_TRY(hipMalloc((void**)&p.planes, (n_fp / 2) * BN_POOL_HALF_WORDS * sizeof(int32_t) * cap));
   HIP_TRY(hipMalloc((void**)&p.st, cap));
   p.stride = cap;
   c->pool_fp[which] = n_fp;
@@ -1093,7 +1121,7 @@ void bn254_ctx_destroy(bn254_ctx* c) {
   if (c->ws.h_next) (void)hipFree(c->ws.h_next);
   if (c->ws.h_list) (void)hipFree(c->ws.h_list);
   if (c->ws.h_cnt) (void)hipFree(c->ws.h_cnt);
-  for (int i = 0; i < 4; ++i) { if (c->pool[i].planes) (void)hipFree(c->pool[i].planes); if (c->pool[i].st) (void)hipFree(c->pool[i].st); }
+  for (int i = 0; i < 5; ++i) { if (c->pool[i].planes) (void)hipFree(c->pool[i].planes); if (c->pool[i].st) (void)hipFree(c->pool[i].st); }
   for (int i = 0; i < 8; ++i) if (c->stage[i]) (void)hipFree(c->stage[i]);
   if (c->key_lines) (void)hipFree(c->key_lines);
   if (c->key_st) (void)hipFree(c->key_st);
@@ -1752,15 +1780,23 @@ int bn254_batch_aggregate_verify_device(bn254_ctx* c, const uint8_t* d_msgs, con
   if (c->pair_lanes) {
     // subset sums of the key pool for batches large enough to repay the table (n_groups x 256 entries of ~4 additions + an
     // inversion each); the kernel uses it for the waves whose longest signer list has more entries than there are groups
-    size_t n_groups = 0;
+    size_t n_groups = 0, groups4 = 0;
     if (c->agg_subset_min_tuples > 0 && n >= (size_t)c->agg_subset_min_tuples && n_signers <= AGG_SUBSET_MAX_SIGNERS) {
       n_groups = (n_signers + 7) / 8;
       if ((rc = pool_reserve(c, 3, 4, n_groups * 256))) return rc;
       k_pool_subsets_g2<<<grid_for(n_groups * 256), BN_WAVE, 0, s>>>(c->pool[0], n_signers, n_groups, c->pool[3]);
+      // the signature tables are per message: worth it when a message's table (4 n_signers entries of ~2 additions + an inversion)
+      // is shared by enough tuples, and only while it fits a budget of HBM
+      const size_t entries = n_msgs * 2 * n_groups * 16;
+      if (n >= AGG_SUBSET_G1_TUPLES_PER_MSG * n_msgs && entries * (2 * BN_LIMBS * sizeof(int32_t) + 1) <= AGG_SUBSET_G1_MAX_BYTES) {
+        groups4 = 2 * n_groups;
+        if ((rc = pool_reserve(c, 4, 2, entries))) return rc;
+        k_pool_subsets_g1<<<grid_for(entries), BN_WAVE, 0, s>>>(c->pool[1], n_signers, groups4, n_msgs, c->pool[4]);
+      }
     }
     PROF_MARK(1);
     if ((rc = bn254_pair_aggregate(d_tuple_msg, d_tuple_off, d_signer_idx, n, n_signers, n_msgs, c->pool[0], c->pool[1], c->pool[2], c->pool[3], n_groups,
-                                   c->ws, s))) return rc;
+                                   c->pool[4], groups4, c->ws, s))) return rc;
   } else {
     PROF_MARK(1);
     k_aggregate<<<grid_for(n), BN_WAVE, 0, s>>>(d_tuple_msg, d_tuple_off, d_signer_idx, n, n_signers, n_msgs, c->pool[0], c->pool[1], c->pool[2], c->ws);

@@ -289,9 +289,13 @@ int bn254_pair_rand_tail(size_t n_groups, Ws ws, size_t gbase, hipStream_t s) {
 //     atomic OR: the two lanes of a pair may meet in one word), then ONE table entry per group is added — n_signers / 8
 //     additions whatever the list length.  A tuple that names a signer twice (the OR would swallow the second copy) is
 //     detected by the bit already being set and takes the direct route afterwards; sums are commutative, so order is free.
+//     With the per-message signature tables (k_pool_subsets_g1, groups4 != 0) the walk adds no signature either: the same
+//     mask bytes, read as two nibbles, select one table entry per group of 4 signers — the real-part lane takes the low
+//     nibbles, the imaginary-part lane the high ones, one G1 and one G2 addition per lane and group of 8.
 extern __shared__ uint32_t bn_agg_masks[];     // [BN_PAIR_WG / 2 tuples][mask_stride words], mask_stride odd
 KERNEL_PAIR void k_aggregate_pair(const uint32_t* tuple_msg, const uint64_t* tuple_off, const uint32_t* signer_idx, size_t n, size_t n_signers,
-                                  size_t n_msgs, Pool pk_pool, Pool sig_pool, Pool h_pool, Pool sub_pool, unsigned n_groups, unsigned mask_stride, Ws ws) {
+                                  size_t n_msgs, Pool pk_pool, Pool sig_pool, Pool h_pool, Pool sub_pool, unsigned n_groups, Pool sub1_pool, unsigned groups4,
+                                  unsigned mask_stride, Ws ws) {
   const unsigned role = threadIdx.x & 1u;
   size_t i = ((size_t)blockIdx.x * BN_PAIR_WG + threadIdx.x) >> 1;
   const bool live = i < n;                 // no early return: the wave-level votes and shuffles below need every lane
@@ -312,6 +316,7 @@ KERNEL_PAIR void k_aggregate_pair(const uint32_t* tuple_msg, const uint64_t* tup
     longest = other > longest ? other : longest;
   }
   const bool use_sub = n_groups != 0 && longest > n_groups;             // wave-uniform
+  const bool use_sub1 = use_sub && groups4 != 0;                        // ... signatures from the per-message tables as well
   uint32_t* my_masks = bn_agg_masks + (threadIdx.x >> 1) * mask_stride;
   bool dup = false;
   if (use_sub) {
@@ -339,8 +344,10 @@ KERNEL_PAIR void k_aggregate_pair(const uint32_t* tuple_msg, const uint64_t* tup
         pp[e].inf = !valid || (s2 & 0x80);
       }
       if ((unsigned)e == role) {            // this lane's entry of the iteration: its signature, and its bit of the key masks
-        sp.x = pool_load_fp(sig_pool, 0, sj); sp.y = pool_load_fp(sig_pool, 1, sj);
-        sp.inf = !valid || (s1 & 0x80);
+        if (!use_sub1) {
+          sp.x = pool_load_fp(sig_pool, 0, sj); sp.y = pool_load_fp(sig_pool, 1, sj);
+          sp.inf = !valid || (s1 & 0x80);
+        }
         if (use_sub && valid) {
           const uint32_t bit = 1u << (8u * ((sgn >> 3) & 3u) + (sgn & 7u));
           const uint32_t old = atomicOr(&my_masks[sgn >> 5], bit);
@@ -352,7 +359,7 @@ KERNEL_PAIR void k_aggregate_pair(const uint32_t* tuple_msg, const uint64_t* tup
       jac_accumulate(acc2, pp[0]);
       jac_accumulate(acc2, pp[1]);
     }
-    jac_accumulate(acc1, sp);
+    if (!use_sub1) jac_accumulate(acc1, sp);
   }
   if (use_sub) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -366,6 +373,14 @@ KERNEL_PAIR void k_aggregate_pair(const uint32_t* tuple_msg, const uint64_t* tup
       p.y.c[0] = pool_load_fp(sub_pool, 2 + (int)role, j);
       p.inf = mask == 0 || (sub_pool.st[j] & 0x80);
       jac_accumulate(acc2, p);
+      if (use_sub1) {                                                      // wave-uniform
+        const uint32_t nib = (mask >> (4u * role)) & 15u;
+        const size_t j1 = (((size_t)m * groups4) + 2u * g + role) * 16 + nib;
+        G1Affine q;
+        q.x = pool_load_fp(sub1_pool, 0, j1); q.y = pool_load_fp(sub1_pool, 1, j1);
+        q.inf = nib == 0 || (sub1_pool.st[j1] & 0x80);
+        jac_accumulate(acc1, q);
+      }
     }
     if (__builtin_amdgcn_ballot_w64(dup) != 0) {                          // rare: the tuples with a repeated signer add their keys one by one
       uint64_t longest2 = dup ? hi - lo : 0;
@@ -383,6 +398,13 @@ KERNEL_PAIR void k_aggregate_pair(const uint32_t* tuple_msg, const uint64_t* tup
         p.y.c[0] = pool_load_fp(pk_pool, 2 + (int)role, sgn);
         p.inf = !valid || pk_pool.st[sgn] != 0;                            // decode errors are in `st` already; identity entries add nothing
         jac_accumulate(acc2, p);
+        if (use_sub1) {                                                    // their signatures too: entry t goes to the lane of parity t
+          const size_t sj = (size_t)m * n_signers + sgn;
+          G1Affine q;
+          q.x = pool_load_fp(sig_pool, 0, sj); q.y = pool_load_fp(sig_pool, 1, sj);
+          q.inf = !valid || sig_pool.st[sj] != 0 || (unsigned)(t & 1u) != role;
+          jac_accumulate(acc1, q);
+        }
       }
     }
   }
@@ -410,12 +432,12 @@ KERNEL_PAIR void k_aggregate_pair(const uint32_t* tuple_msg, const uint64_t* tup
   }
 }
 int bn254_pair_aggregate(const uint32_t* tuple_msg, const uint64_t* tuple_off, const uint32_t* signer_idx, size_t n, size_t n_signers, size_t n_msgs,
-                         Pool pk_pool, Pool sig_pool, Pool h_pool, Pool sub_pool, size_t n_groups, Ws ws, hipStream_t s) {
+                         Pool pk_pool, Pool sig_pool, Pool h_pool, Pool sub_pool, size_t n_groups, Pool sub1_pool, size_t groups4, Ws ws, hipStream_t s) {
   const unsigned mask_stride = n_groups ? (unsigned)(((n_groups + 3) / 4) | 1u) : 1u;     // words per tuple, odd: the tuples of a wave hit different banks
   const size_t lds = n_groups ? (size_t)(BN_PAIR_WG / 2) * mask_stride * sizeof(uint32_t) : 0;
   k_aggregate_pair<<<(unsigned)((2 * n + BN_PAIR_WG - 1) / BN_PAIR_WG), BN_PAIR_WG, lds, s>>>(tuple_msg, tuple_off, signer_idx, n, n_signers, n_msgs,
                                                                                               pk_pool, sig_pool, h_pool, sub_pool, (unsigned)n_groups,
-                                                                                              mask_stride, ws);
+                                                                                              sub1_pool, (unsigned)groups4, mask_stride, ws);
   HIP_TRY(hipGetLastError());
   return 0;
 }

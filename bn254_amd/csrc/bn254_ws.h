@@ -8,6 +8,8 @@
 #define TRIO_WAVE_ROLES_DEFAULT 2                  // ... with the Miller loop as wave roles: 2 = eight waves per 32 verifies (k_miller_verify_w8), 1 = four
 #define AGG_SUBSET_MIN_TUPLES_DEFAULT 4096       // aggregate verify: subset-sum table of the key pool from this many tuples on (the table costs ~0.3 ms)
 #define AGG_SUBSET_MAX_SIGNERS ((size_t)2048)     // ... one mask byte per group of 8 keys and tuple in LDS: 256 groups at most
+#define AGG_SUBSET_G1_TUPLES_PER_MSG ((size_t)64)  // ... signature tables (per message) once a message is shared by this many tuples on average
+#define AGG_SUBSET_G1_MAX_BYTES ((size_t)8 << 30)  // ... and while they stay below 8 GB of HBM
 #define RAND_MIN_BATCH_DEFAULT 131072              // randomised verify pays off from about here
 #define RAND_TWO_PER_LANE_MIN_N ((size_t)131072)   // randomised verify: two items per lane once that still fills 1024 SIMDs
 // Register budget: amdgpu_waves_per_eu(W, W) on the kernels is propagated to every device function
@@ -66,18 +68,29 @@ __device__ __forceinline__ void ws_load_g1(const Ws& ws, int px, int inf_plane, 
   p.x = ws_load_fp(ws, px, i); p.y = ws_load_fp(ws, px + 1, i); p.inf = ws_byte(ws, inf_plane, i) != 0;
 }
 
-// Pools are decoded once into limb-major planes of their own: word k of coordinate e of entry j at
-// pool[(e*BN_LIMBS + k) * stride + j]; status byte per entry.
-struct Pool { int32_t* planes; uint8_t* st; size_t stride; };
+// Pools (aggregate verify) are decoded once into RECORDS: everything one lane reads of an entry is contiguous, because the
+// aggregation kernels GATHER entries by index — with the limb-major planes of the workspace a point cost 18 cache lines per
+// lane (1 152 distinct lines per wave-load, more than the L1 holds), with records it costs one or two.
+//   G1 entry (2 coordinates):  [x (9 words) | y (9) | 2 pad]                                   = 20 words (80 B, 16-byte aligned)
+//   G2 entry (4 coordinates):  [x.re (9) | y.re (9) | 2 pad] [x.im (9) | y.im (9) | 2 pad]     = 40 words: a lane of the pair
+//                              layout reads the half of its role
+// coordinate index e as before: G1 0 = x, 1 = y; G2 0 = x.re, 1 = x.im, 2 = y.re, 3 = y.im.  Status byte per entry.
+#define BN_POOL_HALF_WORDS 20
+struct Pool { int32_t* planes; uint8_t* st; size_t stride; uint32_t g2; };
+__device__ __forceinline__ size_t pool_word(const Pool& p, int e, size_t j) {
+  return p.g2 ? j * (2 * BN_POOL_HALF_WORDS) + (size_t)((e & 1) * BN_POOL_HALF_WORDS + (e >> 1) * BN_LIMBS) : j * BN_POOL_HALF_WORDS + (size_t)(e * BN_LIMBS);
+}
 __device__ __forceinline__ Fp pool_load_fp(const Pool& p, int e, size_t j) {
   Fp r;
+  const int32_t* w = p.planes + pool_word(p, e, j);
 #pragma unroll
-  for (int k = 0; k < BN_LIMBS; ++k) r.v[k] = p.planes[((size_t)e * BN_LIMBS + k) * p.stride + j];
+  for (int k = 0; k < BN_LIMBS; ++k) r.v[k] = w[k];
   return r;
 }
 __device__ __forceinline__ void pool_store_fp(const Pool& p, int e, size_t j, const Fp& a) {
+  int32_t* w = p.planes + pool_word(p, e, j);
 #pragma unroll
-  for (int k = 0; k < BN_LIMBS; ++k) p.planes[((size_t)e * BN_LIMBS + k) * p.stride + j] = a.v[k];
+  for (int k = 0; k < BN_LIMBS; ++k) w[k] = a.v[k];
 }
 #define HIP_TRY(expr)                                      \
   do {                                                     \
@@ -97,7 +110,7 @@ __attribute__((visibility("hidden"))) int bn254_pair_miller_rand(size_t n, size_
 __attribute__((visibility("hidden"))) int bn254_pair_rand_tail(size_t n_groups, Ws ws, size_t gbase, hipStream_t s);
 __attribute__((visibility("hidden"))) int bn254_pair_aggregate(const uint32_t* tuple_msg, const uint64_t* tuple_off, const uint32_t* signer_idx, size_t n,
                                                                size_t n_signers, size_t n_msgs, Pool pk_pool, Pool sig_pool, Pool h_pool, Pool sub_pool,
-                                                               size_t n_groups, Ws ws, hipStream_t s);
+                                                               size_t n_groups, Pool sub1_pool, size_t groups4, Ws ws, hipStream_t s);
 __attribute__((visibility("hidden"))) int bn254_pair_decode_g2(const uint8_t* pts, size_t n, uint32_t flags, Ws ws, int accumulate, hipStream_t s);
 __attribute__((visibility("hidden"))) int bn254_pair_decompress_g2(const uint8_t* in, size_t n, Ws ws, hipStream_t s);
 
