@@ -262,6 +262,26 @@ class ECDSA:
 
 
     @staticmethod
+    def register_keys(public_keys, engine=None):
+        """Register a validator set with the engine for `batch_verify_keyed` (replaces the previous set): result[j] is None,
+        or the Error PublicKey.from_uncompressed would raise for key j (types.rs:96-99; the subgroup check always runs)."""
+        eng = engine or _eng()
+        st = eng.register_keys(b"".join(p.raw for p in public_keys))
+        return [None if s == 0 else Error(s) for s in st]
+
+    @staticmethod
+    def batch_verify_keyed(messages, signatures, key_indices, engine=None):
+        """batch_verify with public_keys[i] named by its index in the registered set: result[i] is None iff
+        ECDSA.verify(messages[i], signatures[i], registered[key_indices[i]]) succeeds, Error(IndexOutOfBounds) for an index
+        outside the set, else the Error verify would raise."""
+        n = len(messages)
+        if not (len(signatures) == n and len(key_indices) == n):
+            raise Error(ErrorKind.InvalidLength)
+        eng = engine or _eng()
+        st = eng.batch_verify_keyed([bytes(m) for m in messages], b"".join(s.raw for s in signatures), [int(k) for k in key_indices])
+        return [None if s == 0 else Error(s) for s in st]
+
+    @staticmethod
     def batch_verify_compressed(messages, signatures33, public_keys65, engine=None):
         """batch_verify straight from the compressed wire encodings (33-byte signatures, 65-byte public keys):
         result[i] is None, or the Error that Signature/PublicKey.from_compressed or verify would raise."""

@@ -136,7 +136,7 @@ template <class F> BN_DEVN void jac_madd(Jac<F>& r, const Jac<F>& p, const Affin
 // Mixed addition for running sums (aggregation): the common case without the doubling that jac_madd computes for
 // every call just to be able to select it (40 % of its cost), and a flag for the rare lanes that did hit
 // P = +-Q; the caller redoes the step with jac_madd when any lane of the wave raised it.
-template <class F> BN_DEVN void jac_madd_common(Jac<F>& r, bool& exceptional, const Jac<F>& p, const Affine<F>& q) {
+template <class F> BN_DEV void jac_madd_common_body(Jac<F>& r, bool& exceptional, const Jac<F>& p, const Affine<F>& q) {
   F z1z1 = f_sqr(p.z);
   F u2 = f_mul(q.x, z1z1);
   F s2 = f_mul(f_mul(q.y, p.z), z1z1);
@@ -155,6 +155,7 @@ template <class F> BN_DEVN void jac_madd_common(Jac<F>& r, bool& exceptional, co
   jac_select(o, q.inf, p, o);
   r = o;
 }
+template <class F> BN_DEVN void jac_madd_common(Jac<F>& r, bool& exceptional, const Jac<F>& p, const Affine<F>& q) { jac_madd_common_body(r, exceptional, p, q); }
 #if defined(__HIPCC__)
 #define BN_WAVE_ANY(x) (__any((int)(x)) != 0)
 #else
@@ -167,6 +168,26 @@ template <class F> BN_DEV void jac_accumulate(Jac<F>& acc, const Affine<F>& q) {
   jac_madd_common(t, ex, acc, q);
   if (BN_WAVE_ANY(ex)) jac_madd(acc, acc, q);   // some lane met P = +-Q: the complete formula for the whole wave (rare)
   else acc = t;
+}
+
+// acc += q IN PLACE in the lanes of the common case; returns true in the lanes that met P = +-Q, whose accumulator is left as
+// it was.  For accumulators the caller keeps in LDS: as a real function the addition takes its operands through memory, and
+// with the accumulator in the private segment that memory is HBM — in the aggregation kernel, whose loops are nothing but
+// accumulations, 700 GB per 1 Mi tuples (7 TB/s: the kernel ran at the HBM roofline of its own argument passing,
+// profiles/r03_h_pmc.json); inlining the formula instead made it spill more than the calls moved (114 vs 102 ms).
+template <class F> BN_DEVN bool jac_madd_inplace(Jac<F>& acc, const Affine<F>& q) {
+  Jac<F> o;
+  bool ex;
+  jac_madd_common_body(o, ex, acc, q);
+  if (!ex) acc = o;
+  return ex;
+}
+template <class F> BN_DEV void jac_accumulate_mem(Jac<F>& acc, Affine<F> q) {
+  const bool ex = jac_madd_inplace(acc, q);
+  if (BN_WAVE_ANY(ex)) {                            // rare: the complete formula for the lanes that need it, nothing for the others
+    q.inf = q.inf || !ex;
+    jac_madd(acc, acc, q);
+  }
 }
 
 // P + Q for operands known to satisfy P != +-Q unless one of them is the identity (add-2007-bl without

