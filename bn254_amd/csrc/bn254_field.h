@@ -1196,7 +1196,11 @@ BN_DEVN void fp12_inv(Fp12& r, const Fp12& a) {                       // sites 8
   fp6_neg(r.c1, t0);
 }
 // f * (l0 + (l1 + l2 v) w): the sparse shape of a D-twist line (l0 at w^0, l1 at w^1, l2 at w^3); l0, l1, l2 tight
-BN_DEVN void fp12_mul_line(Fp12& r, const Fp12& f, const Fp2& l0, const Fp2& l1, const Fp2& l2) {   // sites 110 .. 139
+#if defined(BN_INLINE_MUL_LINE)       // bn254_pair.hip: one copy per call site of the single-pair loops instead of a call with its operands in memory
+BN_DEVH void fp12_mul_line(Fp12& r, const Fp12& f, const Fp2& l0, const Fp2& l1, const Fp2& l2) {   // sites 110 .. 139
+#else
+BN_DEVN void fp12_mul_line(Fp12& r, const Fp12& f, const Fp2& l0, const Fp2& l1, const Fp2& l2) {
+#endif
   Fp6 t0, t1, s, u;
   fp6_mul_fp2(t0, f.c0, l0);
   fp6_mul_01<110>(t1, f.c1, l1, l2);

@@ -45,7 +45,9 @@ struct Ws {
 #define HASH_DIRECT_MAX_N ((size_t)4096)         // ... for batches that leave the chip mostly idle: 32 n lanes <= two waves per SIMD
 #define HASH_MAX_ROUNDS 64
 #define HASH_MAX_GRID_LANES ((size_t)1 << 24)   // lanes launched per round at most (grid-stride beyond)
+#ifndef HASH_TARGET_LANES
 #define HASH_TARGET_LANES ((size_t)1 << 17)    // ~2 waves per SIMD
+#endif
 enum { PL_P1X = 0, PL_P1Y, PL_QX0, PL_QX1, PL_QY0, PL_QY1, PL_P2X, PL_P2Y, PL_HASHX, PL_HASHY, PL_F0, N_PLANES = PL_F0 + 12 };
 enum { BY_ST_DECODE = 0, BY_ST_HASH, BY_P1_INF, BY_Q_INF, BY_P2_INF, BY_A_INF, N_BYTE_PLANES };
 

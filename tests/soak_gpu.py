@@ -44,7 +44,7 @@ def soak(args):
     """run the differential for args.seconds with args.seed; returns the summary, raises SoakMismatch on a difference
     (tests/test_gpu_fullsize.py runs a slice of it in the driver-run suite)"""
     import bn254_amd
-    from bn254_amd.engine import OPT_PAIR_LANES, OPT_RAND_MIN_BATCH, OPT_TRIO_MAX_BATCH, OPT_TRIO_WAVE_ROLES
+    from bn254_amd.engine import OPT_AGG_SUBSET_MIN_TUPLES, OPT_PAIR_LANES, OPT_RAND_MIN_BATCH, OPT_TRIO_MAX_BATCH, OPT_TRIO_WAVE_ROLES
     from oracle import c_oracle as c
     from tests.datagen import sk_bytes
     eng = bn254_amd.Engine(0)
@@ -92,6 +92,22 @@ def soak(args):
                 s[:] = sigs[64 * (i - 1):64 * i]              # a valid signature of another message / key
         sigs, pks = bytes(sigs), bytes(pks)
         seed = rnd.randbytes(32)
+        # keyed verify: the distinct (mutated) keys of this batch registered as a set, every item names its key by index;
+        # a few indices point outside the set
+        distinct = {}
+        kidx = [distinct.setdefault(pks[128 * i:128 * i + 128], len(distinct)) for i in range(n)]
+        key_set = b"".join(distinct.keys())
+        oob = {i for i in range(n) if rnd.randrange(40) == 0}
+        kidx_call = [len(distinct) + rnd.randrange(3) if i in oob else kidx[i] for i in range(n)]
+        eng.register_keys(key_set)
+        got_keyed = eng.batch_verify_keyed(msgs, sigs, kidx_call)
+        want1, _ = c.batch_verify(msgs, sigs, pks, flags=1, nthreads=cores)
+        sig_only, _ = c.batch_verify(msgs, sigs, bytes(128) * n, flags=1, nthreads=cores) if oob else (want1, None)
+        for i in range(n):
+            w = (sig_only[i] if sig_only[i] in (3, 4, 6) else 2) if i in oob else want1[i]
+            if got_keyed[i] != w:
+                raise SoakMismatch("MISMATCH keyed round %d n %d item %d got %d want %d" % (rounds, n, i, got_keyed[i], w))
+        extra["keyed_tuples"] = extra.get("keyed_tuples", 0) + n
         for flags in (0, 1):
             want, _ = c.batch_verify(msgs, sigs, pks, flags=flags, nthreads=cores)
             # the small-batch layouts (defaults: eight wave roles up to 16384 items), then the lane pairs for the same batch
@@ -147,7 +163,17 @@ def soak(args):
                 if lst and rnd.randrange(4) == 0:
                     lst.append(lst[0])                       # duplicate signer
                 tuples.append((rnd.randrange(M), lst))
+            for _ in range(170):                             # dense lists, and enough tuples per message for the signature tables too
+                lst = rnd.sample(range(S), rnd.randrange(3, S + 1))
+                if rnd.randrange(5) == 0:
+                    lst.append(lst[-1])
+                tuples.append((rnd.randrange(M), lst))
             got_a = eng.batch_aggregate_verify(amsgs, apk_pool, asig_pool, [t[0] for t in tuples], [t[1] for t in tuples])
+            eng.set_option(OPT_AGG_SUBSET_MIN_TUPLES, 1)     # ... forced on for this small batch: both routes must agree with the oracle
+            got_b = eng.batch_aggregate_verify(amsgs, apk_pool, asig_pool, [t[0] for t in tuples], [t[1] for t in tuples])
+            eng.set_option(OPT_AGG_SUBSET_MIN_TUPLES, 4096)
+            if got_b != got_a:
+                raise SoakMismatch("MISMATCH aggregate routes round %d %r %r" % (rounds, list(got_a), list(got_b)))
             for j, (mi, lst) in enumerate(tuples):
                 asig, apk = bytes(64), bytes(128)
                 for sg in lst:
@@ -166,7 +192,7 @@ def soak(args):
             print("soak: %d s, %d rounds, %d tuples, no mismatch" % (last_note - t0, rounds, items), flush=True)
     res = {"rounds": rounds, "tuples": items, "comparisons": items * 2 * 8, "seconds": round(time.time() - t0, 1), "oracle_threads": cores,
            "status_histogram": {str(k): v for k, v in sorted(codes.items())}, "mismatches": 0, "seed": args.seed, "also_compared": extra,
-           "modes": ["exact, eight wave roles", "exact, four wave roles", "exact, lane groups of one wave (octet)", "exact on lane pairs", "exact, one lane per verify", "randomised 128-bit", "randomised GLV", "randomised 64-bit"],
+           "modes": ["keyed (registered keys, once per round with the subgroup check)", "exact, eight wave roles", "exact, four wave roles", "exact, lane groups of one wave (octet)", "exact on lane pairs", "exact, one lane per verify", "randomised 128-bit", "randomised GLV", "randomised 64-bit"],
            "flags": [0, 1]}
     return res
 
