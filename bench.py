@@ -352,6 +352,49 @@ def other_workloads(args, torch, eng, dev, stream):
                    value=res["rand128"]["verifies_per_s"], ms_per_step=res["rand128"]["ms_per_step"], modes=res,
                    config={"workload": "configs[1]-shaped tuples, opt-in randomised batch verification", "batch": n},
                    speedup_vs_exact=res["rand128"]["verifies_per_s"] / res["exact"]["verifies_per_s"])
+    elif args.workload == "verify-keyed-randomized":
+        # opt-in: registered keys + the combined check of items that share a key (64 per pairing product), against the exact keyed path
+        from tests.datagen import KEY_POOL
+        n = args.batch or (1 << 20)
+        seed = hashlib.sha256(b"bench-seed").digest()
+        eng.set_option(5, 0)                                  # BN254_OPT_RAND_MIN_BATCH: the randomised kernels at every size
+        chunk = 1 << 16
+        parts = [make_verify_batch(eng, min(chunk, n - lo), corrupt_every=0, tag="bn254/msgK%d" % lo) for lo in range(0, n, chunk)]
+        pool = min(KEY_POOL, n)
+        assert eng.register_keys(parts[0][2][:128 * pool]) == bytes(pool)
+        d_msgs, d_sigs = dev_bytes(b"".join(b"".join(p[0]) for p in parts)), dev_bytes(b"".join(p[1] for p in parts))
+        d_off = torch.arange(0, 32 * (n + 1), 32, dtype=torch.int64, device=dev)
+        d_idx = ((torch.arange(n, dtype=torch.int64, device=dev) % chunk) % pool).to(torch.int32)
+        d_st = torch.full((n,), 255, dtype=torch.uint8, device=dev)
+        eng.reserve(n + n // 64 + pool + 512)
+        ptrs = (d_msgs.data_ptr(), d_off.data_ptr(), d_sigs.data_ptr(), d_idx.data_ptr(), n)
+        res = {}
+        eng.set_profiling(True)
+        for name, flags in (("rand128", 0), ("rand128_glv", 0x200), ("rand64", 0x100)):
+            for key in kms:
+                kms[key] = 0.0
+            dt = timed(lambda: eng.batch_verify_keyed_randomized_device(*ptrs, seed, d_st.data_ptr(), flags=flags, stream=sh), args.steps, args.warmup, collect)
+            assert int(d_st.max()) == 0
+            res[name] = {"verifies_per_s": n / dt, "ms_per_step": 1e3 * dt,
+                         "kernel_ms": {"decode": kms["decode"], "hash_to_g1": kms["hash_to_g1"], "grouping_and_scalar_muls": kms["miller_loop"],
+                                       "group_checks_and_rechecks": kms["final_exp"]}}
+        dt = timed(lambda: eng.batch_verify_keyed_device(*ptrs, d_st.data_ptr(), stream=sh), args.steps, args.warmup)
+        assert int(d_st.max()) == 0
+        res["exact_keyed"] = {"verifies_per_s": n / dt, "ms_per_step": 1e3 * dt}
+        # one corrupted item in every 64: (nearly) every group fails and its items are re-verified exactly
+        sig_view = d_sigs.view(n, 64)
+        saved = sig_view[63::64].clone()
+        sig_view[63::64] = sig_view[62::64]
+        dt = timed(lambda: eng.batch_verify_keyed_randomized_device(*ptrs, seed, d_st.data_ptr(), stream=sh), args.steps, args.warmup)
+        assert int((d_st != 0).sum()) == n // 64 and int(d_st.view(-1)[63::64].min()) == 9
+        sig_view[63::64] = saved
+        res["rand128_one_bad_item_in_64"] = {"verifies_per_s": n / dt, "ms_per_step": 1e3 * dt}
+        out.update(metric="BN254 verifies/sec, keyed randomised batch verification (registered keys, groups of 64 per key) vs the exact keyed path",
+                   unit="verifies/s", value=res["rand128"]["verifies_per_s"], ms_per_step=res["rand128"]["ms_per_step"], modes=res,
+                   config={"workload": "configs[1]-shaped tuples over %d registered keys, opt-in randomised check of same-key groups" % pool, "batch": n},
+                   speedup_vs_exact_keyed=res["rand128"]["verifies_per_s"] / res["exact_keyed"]["verifies_per_s"])
+        print(json.dumps(out))
+        return
     elif args.workload == "hash":
         n = args.batch or (1 << 24)                                 # config 4: 16 Mi messages
         g = torch.Generator(device=dev)
@@ -895,7 +938,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pair-lanes", action="store_true", help="one lane per verify instead of lane pairs (A/B)")
     ap.add_argument("--split-miller", action="store_true", help="one pairing per lane instead of the fused 2-pair Miller loop (A/B)")
-    ap.add_argument("--workload", default="verify", choices=["verify", "pairing", "verify-host", "verify-keyed", "verify-compressed", "verify-randomized", "hash", "aggregate"],
+    ap.add_argument("--workload", default="verify", choices=["verify", "pairing", "verify-host", "verify-keyed", "verify-keyed-randomized", "verify-compressed", "verify-randomized", "hash", "aggregate"],
                     help="verify = the headline (configs[1]) and pairing = configs[3]: both run on N ranks; the others time configs 2, 4 or "
                          "other entry points on one GPU (informational — see DESIGN.md §4b)")
     args = ap.parse_args()

@@ -282,6 +282,19 @@ class ECDSA:
         return [None if s == 0 else Error(s) for s in st]
 
     @staticmethod
+    def batch_verify_keyed_randomized(messages, signatures, key_indices, seed=None, engine=None, rand64=False):
+        """batch_verify_keyed through the combined check of items that share a key (64 per pairing product; include/bn254_hip.h:
+        bn254_batch_verify_keyed_randomized).  Errors are exact; a None is wrong with probability <= 2^-128 per group."""
+        import os
+        n = len(messages)
+        if not (len(signatures) == n and len(key_indices) == n):
+            raise Error(ErrorKind.InvalidLength)
+        eng = engine or _eng()
+        st = eng.batch_verify_keyed_randomized([bytes(m) for m in messages], b"".join(s.raw for s in signatures), [int(k) for k in key_indices],
+                                               seed if seed is not None else os.urandom(32), flags=_engine.FLAG_RAND64 if rand64 else 0)
+        return [None if s == 0 else Error(s) for s in st]
+
+    @staticmethod
     def batch_verify_compressed(messages, signatures33, public_keys65, engine=None):
         """batch_verify straight from the compressed wire encodings (33-byte signatures, 65-byte public keys):
         result[i] is None, or the Error that Signature/PublicKey.from_compressed or verify would raise."""

@@ -80,7 +80,8 @@ KERNEL_PAIR void k_final_exp_pair(size_t n, size_t k, size_t item_stride, size_t
                                   uint8_t* status_out, int raw_only, size_t base, const uint32_t* map, const uint32_t* count) {
   size_t i = ((size_t)blockIdx.x * BN_PAIR_WG + threadIdx.x) >> 1;
   if (i >= n) return;
-  if (map) { if (i >= *count) return; i = map[i]; }
+  if (count && i >= *count) return;                 // a device-side item count (with or without an index map)
+  if (map) i = map[i];
   __shared__ Fp12PairSlot lds_acc[BN_PAIR_WG];
 #if defined(BN_PAIR_FE_CHAINS)
   Fp12 f;

@@ -121,6 +121,14 @@ KERNEL void k_register_keys(const uint8_t* pks, size_t n_keys, uint32_t flags, i
   key_inf[j] = q.inf;
 }
 
+// keyed verify against an EMPTY key set: every index is out of range — the signature's decode status first, else IndexOutOfBounds
+KERNEL_SMALL void k_keyed_no_keys(size_t n, Ws ws, uint8_t* status_out) {
+  const size_t i = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t st = ws_byte(ws, BY_ST_DECODE, i);
+  status_out[i] = st != ST_OK ? st : (uint8_t)ST_INDEX_OOB;
+}
+
 // hash_to_try_and_increment (hash.rs:29-63) in ROUNDS.  The reference tries counters 0,1,2,... per
 // message until one yields a point (p = 0.4726 per try, 2.12 tries on average, 20+ for the unluckiest
 // message of a 65 536 batch).  One-message-per-lane with a retry loop makes every wave wait for its
@@ -383,7 +391,7 @@ struct Seed { uint32_t w[8]; };
 struct G1JacSlot { G1Jac v; int32_t pad; };   // 31 words: odd stride, no LDS bank conflicts
 
 // mode: 0 = 128-bit scalar, 1 = 64-bit scalar, 2 = k1 + k2*lambda with 64-bit k1, k2 (BN254_FLAG_RAND_GLV)
-KERNEL void k_rand_scale(size_t n, Ws ws, Seed seed, int mode, size_t gbase) {
+KERNEL_SMALL void k_rand_scale(size_t n, Ws ws, Seed seed, int mode, size_t gbase) {
   const unsigned t = threadIdx.x;
   size_t i = (size_t)blockIdx.x * BN_WAVE + t;
   const bool live = i < n;                       // no early return: every lane reaches the barriers
@@ -501,6 +509,103 @@ KERNEL_SMALL void k_rand_collect(size_t n, Ws ws, const uint8_t* group_st, uint8
     ws.h_list[pos] = (uint32_t)i;
   }
   if (group_ok_out && threadIdx.x == 0) group_ok_out[i / BN_WAVE] = ok ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Keyed randomised batch verification (opt-in like section 4c; for REGISTERED keys): items that share a key share the G2
+// argument, so a whole group of them is ONE pairing product
+//     e(sum_i r_i H(m_i), pk) * e(sum_i r_i sig_i, -G2) == 1
+// — two table-driven Miller loops and one final exponentiation per 64 items, and per item only the two 128-bit scalar
+// multiplications.  Items are grouped by key on the device (counting sort: k_krand_prepare / scan / scatter), every key's
+// run padded to whole groups of 64; a group is a "virtual tuple" (H := sum r_i H(m_i), sig := sum r_i sig_i, key) at workspace
+// index gbase + g and goes through the kernels of the exact keyed verify; the items of a failing group are re-checked exactly.
+//   meta[0] = number of groups, meta[1] = number of slots of `perm` in use (both known on the device only)
+// ------------------------------------------------------------------------------------------
+#define KRAND_NONE 0xFFFFFFFFu
+KERNEL_SMALL void k_krand_prepare(size_t n, Ws ws, const uint32_t* key_idx, KeyTable kt, uint32_t* cnt, uint8_t* status_out) {
+  const size_t i = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
+  if (i == 0) ws.h_cnt[0] = 0;                          // queue of the exact re-check (the hash rounds are done with it)
+  if (i >= n) return;
+  uint8_t st = ws_byte(ws, BY_ST_DECODE, i);
+  const uint32_t key = key_idx[i];
+  if (st == ST_OK) st = key >= kt.n_keys ? (uint8_t)ST_INDEX_OOB : kt.st[key];
+  if (st == ST_OK) st = ws_byte(ws, BY_ST_HASH, i);
+  ws_byte(ws, BY_ST_DECODE, i) = st;                    // the item's final status unless the pairing check has the last word
+  if (st != ST_OK) status_out[i] = st;
+  else atomicAdd(&cnt[key], 1u);
+}
+// one wave: start[k] = first slot of key k (runs padded to multiples of 64), gkey[g] = key of group g, cnt reset (the scatter's cursors)
+KERNEL_SMALL void k_krand_scan(uint32_t n_keys, uint32_t* cnt, uint32_t* start, uint32_t* gkey, uint32_t* meta) {
+  const unsigned t = threadIdx.x;
+  uint32_t groups_before = 0;
+  for (uint32_t base = 0; base < n_keys; base += BN_WAVE) {
+    const uint32_t k = base + t;
+    const uint32_t ng = k < n_keys ? (cnt[k] + BN_WAVE - 1) / BN_WAVE : 0u;
+    uint32_t incl = ng;
+    for (int off = 1; off < BN_WAVE; off <<= 1) {
+      const uint32_t up = __shfl_up(incl, off, BN_WAVE);
+      if ((int)t >= off) incl += up;
+    }
+    const uint32_t first = groups_before + incl - ng;
+    if (k < n_keys) {
+      start[k] = first * BN_WAVE;
+      cnt[k] = 0;
+      for (uint32_t j = 0; j < ng; ++j) gkey[first + j] = k;
+    }
+    groups_before += __shfl(incl, BN_WAVE - 1, BN_WAVE);
+  }
+  if (t == 0) { meta[0] = groups_before; meta[1] = groups_before * BN_WAVE; }
+}
+KERNEL_SMALL void k_krand_scatter(size_t n, Ws ws, const uint32_t* key_idx, const uint32_t* start, uint32_t* cursor, uint32_t* perm) {
+  const size_t i = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
+  if (i >= n || ws_byte(ws, BY_ST_DECODE, i) != ST_OK) return;
+  const uint32_t key = key_idx[i];
+  perm[start[key] + atomicAdd(&cursor[key], 1u)] = (uint32_t)i;
+}
+// group g = one wave: r_i H(m_i) and r_i sig_i of its items, both summed over the wave (LDS trees), as the tuple gbase + g
+KERNEL_SMALL void k_krand_scale(const uint32_t* perm, const uint32_t* meta, Ws ws, Seed seed, int mode, size_t gbase) {
+  const unsigned t = threadIdx.x;
+  const size_t g = blockIdx.x;
+  if (g >= meta[0]) return;                              // the whole block together
+  const uint32_t item = perm[g * BN_WAVE + t];
+  const bool valid = item != KRAND_NONE;
+  const size_t ii = valid ? item : 0;
+  G1Affine sig, h;
+  ws_load_g1(ws, PL_P1X, BY_P1_INF, ii, sig);
+  ws_load_g1(ws, PL_P2X, BY_P2_INF, ii, h);
+  uint32_t k[4];
+  rand_scalar(k, seed.w, (uint64_t)ii, mode == 1);
+  G1Jac a, sj, id;
+  if (mode == 2) g1_mul_glv(a, h, k, k + 2); else if (mode == 1) jac_mul_u64(a, h, k); else jac_mul_u128(a, h, k);   // wave-uniform
+  if (mode == 2) g1_mul_glv(sj, sig, k, k + 2); else if (mode == 1) jac_mul_u64(sj, sig, k); else jac_mul_u128(sj, sig, k);
+  jac_set_identity(id);
+  jac_select(a, !valid, id, a);
+  jac_select(sj, !valid, id, sj);
+  __shared__ G1JacSlot lds_a[BN_WAVE], lds_s[BN_WAVE];
+  lds_a[t].v = a;
+  lds_s[t].v = sj;
+  __syncthreads();
+  for (unsigned stride = BN_WAVE / 2; stride >= 1; stride >>= 1) {
+    if (t < stride) { jac_add(lds_a[t].v, lds_a[t].v, lds_a[t + stride].v); jac_add(lds_s[t].v, lds_s[t].v, lds_s[t + stride].v); }
+    __syncthreads();
+  }
+  if (t == 0) {
+    G1Affine aa, sa;
+    jac_to_affine(aa, lds_a[0].v);
+    jac_to_affine(sa, lds_s[0].v);
+    ws_store_g1(ws, PL_P2X, BY_P2_INF, gbase + g, aa);
+    ws_store_g1(ws, PL_P1X, BY_P1_INF, gbase + g, sa);
+    ws_byte(ws, BY_ST_DECODE, gbase + g) = ST_OK;
+    ws_byte(ws, BY_ST_HASH, gbase + g) = ST_OK;
+  }
+}
+KERNEL_SMALL void k_krand_collect(size_t n_slots_max, const uint32_t* perm, const uint32_t* meta, const uint8_t* group_st, uint8_t* status_out, Ws ws) {
+  const size_t j = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
+  if (j >= n_slots_max || j >= meta[1]) return;
+  const uint32_t item = perm[j];
+  if (item == KRAND_NONE) return;
+  if (group_st[j / BN_WAVE] == ST_OK) status_out[item] = ST_OK;
+  else ws.h_list[atomicAdd(&ws.h_cnt[0], 1u)] = item;
 }
 
 // out[i] = a[i] + b[i]
@@ -1391,6 +1496,12 @@ int bn254_batch_verify_keyed_device(bn254_ctx* c, const uint8_t* d_msgs, const u
   KeyTable kt = {c->key_lines, c->key_st, c->key_inf, (uint32_t)c->n_keys};
   PROF_MARK(0);
   k_decode_g1<<<grid_for(n), BN_WAVE, 0, s>>>(d_sigs, n, flags, c->ws, PL_P1X, BY_P1_INF, 0);
+  if (c->n_keys == 0 || !c->key_lines) {             // nothing registered: no table to read — every item is out of range
+    c->msgs_len_declared = 0;
+    k_keyed_no_keys<<<grid_for(n), BN_WAVE, 0, s>>>(n, c->ws, d_status);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   PROF_MARK(1);
   if ((rc = launch_hash_rounds(c, s, d_msgs, d_off, n, PL_P2X, BY_P2_INF, nullptr))) return rc;
   PROF_MARK(2);
@@ -1418,6 +1529,77 @@ int bn254_batch_verify_keyed(bn254_ctx* c, const uint8_t* msgs, const uint64_t* 
   rc = bn254_batch_verify_keyed_device(c, c->stage[0], (const uint64_t*)c->stage[1], c->stage[2], (const uint32_t*)c->stage[3], n, flags, c->stage[4], nullptr);
   if (!rc) rc = stage_out(c, 4, status, n);
   hipError_t e = hipStreamSynchronize(c->stream);     // also on failure: the staged copies read the caller's buffers
+  return rc ? rc : -(int)e;
+}
+
+int bn254_batch_verify_keyed_randomized_device(bn254_ctx* c, const uint8_t* d_msgs, const uint64_t* d_off, const uint8_t* d_sigs,
+                                               const uint32_t* d_key_idx, size_t n, uint32_t flags, const uint8_t* seed32, uint8_t* d_status,
+                                               void* stream) {
+  if (!c || !seed32 || (n && (!d_msgs || !d_off || !d_sigs || !d_key_idx || !d_status))) return BN254_E_BAD_ARGUMENT;
+  if (n == 0) return 0;
+  if (n > 0xFFFFFFF0u) return BN254_E_BAD_ARGUMENT;
+  if (misaligned(d_sigs) || misaligned(d_key_idx) || ((uintptr_t)d_off & 7u)) return BN254_E_MISALIGNED;
+  const uint32_t dflags = flags & (BN254_FLAG_G2_SUBGROUP_CHECK | BN254_FLAG_REJECT_IDENTITY);
+  if (c->n_keys == 0 || !c->key_lines || n < (size_t)c->rand_min_batch)      // nothing to group by / too small to pay off: the exact keyed path
+    return bn254_batch_verify_keyed_device(c, d_msgs, d_off, d_sigs, d_key_idx, n, dflags, d_status, stream);
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t K = c->n_keys;
+  const size_t groups_max = n / BN_WAVE + (K < n ? K : n) + 1, slots_max = groups_max * BN_WAVE;
+  const size_t gbase = (n + 255) & ~(size_t)255;
+  int rc = ws_reserve(c, gbase + groups_max);
+  if (rc) return rc;
+  // scratch of this mode (device memory, grown on demand): [cnt K | start K | meta 2 | gkey groups_max | perm slots_max] words, group statuses
+  const size_t words = 2 * K + 2 + groups_max + slots_max;
+  if ((rc = stage_reserve(c, 5, words * sizeof(uint32_t)))) return rc;
+  if ((rc = stage_reserve(c, 7, groups_max))) return rc;
+  uint32_t* cnt = (uint32_t*)c->stage[5];
+  uint32_t *start = cnt + K, *meta = start + K, *gkey = meta + 2, *perm = gkey + groups_max;
+  uint8_t* d_group_st = c->stage[7];
+  hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  Seed seed;
+  for (int j = 0; j < 8; ++j)
+    seed.w[j] = ((uint32_t)seed32[4 * j] << 24) | ((uint32_t)seed32[4 * j + 1] << 16) | ((uint32_t)seed32[4 * j + 2] << 8) | seed32[4 * j + 3];
+  KeyTable kt = {c->key_lines, c->key_st, c->key_inf, (uint32_t)c->n_keys};
+  PROF_MARK(0);
+  k_decode_g1<<<grid_for(n), BN_WAVE, 0, s>>>(d_sigs, n, dflags, c->ws, PL_P1X, BY_P1_INF, 0);
+  PROF_MARK(1);
+  if ((rc = launch_hash_rounds(c, s, d_msgs, d_off, n, PL_P2X, BY_P2_INF, nullptr))) return rc;
+  PROF_MARK(2);
+  HIP_TRY(hipMemsetAsync(cnt, 0, K * sizeof(uint32_t), s));
+  HIP_TRY(hipMemsetAsync(perm, 0xFF, slots_max * sizeof(uint32_t), s));
+  k_krand_prepare<<<grid_for(n), BN_WAVE, 0, s>>>(n, c->ws, d_key_idx, kt, cnt, d_status);
+  k_krand_scan<<<1, BN_WAVE, 0, s>>>((uint32_t)K, cnt, start, gkey, meta);
+  k_krand_scatter<<<grid_for(n), BN_WAVE, 0, s>>>(n, c->ws, d_key_idx, start, cnt, perm);
+  k_krand_scale<<<(unsigned)groups_max, BN_WAVE, 0, s>>>(perm, meta, c->ws, seed, (flags & BN254_FLAG_RAND64) ? 1 : (flags & BN254_FLAG_RAND_GLV) ? 2 : 0, gbase);
+  PROF_MARK(3);                                        // ms[2] = grouping + scalar multiplications, ms[3] = group checks + exact re-checks
+  if ((rc = bn254_pair_miller_verify_keyed(groups_max, c->ws, gkey, kt, s, gbase, nullptr, meta))) return rc;
+  if ((rc = bn254_pair_final_exp(groups_max, c->ws, 0, d_group_st, nullptr, meta, s, gbase))) return rc;
+  k_krand_collect<<<grid_for(slots_max), BN_WAVE, 0, s>>>(slots_max, perm, meta, d_group_st, d_status, c->ws);
+  // exact re-check of the items of failed groups (none queued: both kernels leave at once)
+  if ((rc = bn254_pair_miller_verify_keyed(n, c->ws, d_key_idx, kt, s, 0, c->ws.h_list, c->ws.h_cnt))) return rc;
+  if ((rc = bn254_pair_final_exp(n, c->ws, 1, d_status, c->ws.h_list, c->ws.h_cnt, s))) return rc;
+  PROF_MARK(4);
+  if (c->profiling) { c->ev_valid = 1; c->ev_hash_first = 0; }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+int bn254_batch_verify_keyed_randomized(bn254_ctx* c, const uint8_t* msgs, const uint64_t* off, const uint8_t* sigs, const uint32_t* key_idx, size_t n,
+                                        uint32_t flags, const uint8_t* seed32, uint8_t* status) {
+  if (!c || !seed32 || (n && (!off || !sigs || !key_idx || !status))) return BN254_E_BAD_ARGUMENT;
+  if (n == 0) return 0;
+  HIP_TRY(hipSetDevice(c->device));
+  if (!offsets_ok(off, n)) return BN254_E_BAD_ARGUMENT;
+  if (off[n] && !msgs) return BN254_E_BAD_ARGUMENT;
+  int rc;
+  if ((rc = stage_in(c, 0, msgs, (size_t)off[n]))) return rc;
+  if ((rc = stage_in(c, 1, off, (n + 1) * sizeof(uint64_t)))) return rc;
+  if ((rc = stage_in(c, 2, sigs, n * 64))) return rc;
+  if ((rc = stage_in(c, 3, key_idx, n * sizeof(uint32_t)))) return rc;
+  if ((rc = stage_reserve(c, 4, n))) return rc;
+  rc = bn254_batch_verify_keyed_randomized_device(c, c->stage[0], (const uint64_t*)c->stage[1], c->stage[2], (const uint32_t*)c->stage[3], n, flags, seed32,
+                                                  c->stage[4], nullptr);
+  if (!rc) rc = stage_out(c, 4, status, n);
+  hipError_t e = hipStreamSynchronize(c->stream);
   return rc ? rc : -(int)e;
 }
 

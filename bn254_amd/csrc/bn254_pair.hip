@@ -175,10 +175,17 @@ KERNEL_PAIR void k_miller_verify_pair(size_t n, Ws ws, const uint32_t* map, cons
 // for a validator set), pair B from the constant table.  No twist-point arithmetic: 36 product slots per doubling step
 // against 48 (bn254_pairing.h: miller_loop_keyed).  Status: the signature's decode status stays first; then the key's
 // (index >= n_keys -> IndexOutOfBounds, else what registration found), written back for k_final_exp_pair.
-KERNEL_PAIR void k_miller_verify_keyed_pair(size_t n, Ws ws, const uint32_t* key_idx, KeyTable kt) {
-  const size_t i = ((size_t)blockIdx.x * BN_PAIR_WG + threadIdx.x) >> 1;
+// `base`: tuple i lives at workspace index base + i (the per-group tuples of the keyed randomised verify sit behind the items);
+// `count` / `map`: a device-side tuple count and index map (exact re-check of the items of failed groups); key_idx is indexed
+// by the tuple's own number in every case.
+KERNEL_PAIR void k_miller_verify_keyed_pair(size_t n, Ws ws, const uint32_t* key_idx, KeyTable kt, size_t base, const uint32_t* map,
+                                            const uint32_t* count) {
+  size_t i = ((size_t)blockIdx.x * BN_PAIR_WG + threadIdx.x) >> 1;
   if (i >= n) return;
+  if (count && i >= *count) return;
+  if (map) i = map[i];
   uint32_t key = key_idx[i];
+  i += base;
   uint8_t kst = ST_OK;
   if (key >= kt.n_keys) { kst = ST_INDEX_OOB; key = 0; }
   else kst = kt.st[key];
@@ -196,8 +203,9 @@ KERNEL_PAIR void k_miller_verify_keyed_pair(size_t n, Ws ws, const uint32_t* key
   miller_loop_keyed<true>(f, h, key_inf, (LinePtr)(kt.lines + (size_t)key * BN_N_FIXED_LINES * BN_KEY_LINE_WORDS), sig);
   ws_store_f12_own(ws, i, f);
 }
-int bn254_pair_miller_verify_keyed(size_t n, Ws ws, const uint32_t* key_idx, KeyTable kt, hipStream_t s) {
-  k_miller_verify_keyed_pair<<<(unsigned)((2 * n + BN_PAIR_WG - 1) / BN_PAIR_WG), BN_PAIR_WG, 0, s>>>(n, ws, key_idx, kt);
+int bn254_pair_miller_verify_keyed(size_t n, Ws ws, const uint32_t* key_idx, KeyTable kt, hipStream_t s, size_t base, const uint32_t* map,
+                                   const uint32_t* count) {
+  k_miller_verify_keyed_pair<<<(unsigned)((2 * n + BN_PAIR_WG - 1) / BN_PAIR_WG), BN_PAIR_WG, 0, s>>>(n, ws, key_idx, kt, base, map, count);
   HIP_TRY(hipGetLastError());
   return 0;
 }

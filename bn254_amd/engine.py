@@ -280,6 +280,21 @@ class Engine:
         _check("bn254_batch_verify_keyed", self._lib.bn254_batch_verify_keyed(self._h, msgs, off, bytes(sigs), idx, n, flags, status))
         return status.raw[:n]
 
+    def batch_verify_keyed_randomized(self, messages, sigs, key_idx, seed32, flags=0):
+        n = len(messages)
+        assert len(sigs) == n * G1_BYTES and len(key_idx) == n and len(seed32) == 32
+        msgs, off = pack_messages(messages)
+        idx = (ctypes.c_uint32 * max(n, 1))(*key_idx)
+        status = ctypes.create_string_buffer(max(n, 1))
+        _check("bn254_batch_verify_keyed_randomized",
+               self._lib.bn254_batch_verify_keyed_randomized(self._h, msgs, off, bytes(sigs), idx, n, flags, bytes(seed32), status))
+        return status.raw[:n]
+
+    def batch_verify_keyed_randomized_device(self, d_msgs, d_off, d_sigs, d_key_idx, n, seed32, d_status, flags=0, stream=None):
+        assert len(seed32) == 32
+        _check("bn254_batch_verify_keyed_randomized_device",
+               self._lib.bn254_batch_verify_keyed_randomized_device(self._h, d_msgs, d_off, d_sigs, d_key_idx, n, flags, bytes(seed32), d_status, stream))
+
     def batch_verify_keyed_device(self, d_msgs, d_off, d_sigs, d_key_idx, n, d_status, flags=0, stream=None):
         _check("bn254_batch_verify_keyed_device",
                self._lib.bn254_batch_verify_keyed_device(self._h, d_msgs, d_off, d_sigs, d_key_idx, n, flags, d_status, stream))

@@ -159,6 +159,30 @@ struct ECDSA {
     check_rc("bn254_batch_verify", bn254_batch_verify(e.raw(), msgs.data(), off.data(), sigs.data(), pks.data(), n, 0, status.data()));
     return status;
   }
+  // Keyed verify: a validator set registered once (PublicKey::from_uncompressed per key, types.rs:96-99, plus the key's Miller-loop
+  // lines tabulated in HBM), then tuples name their key by index.  register_keys: result[j] == 0 or the ErrorKind of key j.
+  static std::vector<uint8_t> register_keys(const std::vector<PublicKey>& keys, Engine& e = Engine::default_engine()) {
+    std::vector<uint8_t> pks(keys.size() * 128), status(keys.size(), 0);
+    for (size_t j = 0; j < keys.size(); ++j) std::memcpy(&pks[128 * j], keys[j].raw.data(), 128);
+    check_rc("bn254_ctx_register_keys", bn254_ctx_register_keys(e.raw(), pks.data(), keys.size(), 0, status.data()));
+    return status;
+  }
+  // result[i] == 0 iff verify(messages[i], signatures[i], registered[key_indices[i]]) succeeds; 2 (IndexOutOfBounds) outside the set
+  static std::vector<uint8_t> batch_verify_keyed(const std::vector<std::vector<uint8_t>>& messages, const std::vector<Signature>& signatures,
+                                                 const std::vector<uint32_t>& key_indices, Engine& e = Engine::default_engine()) {
+    size_t n = messages.size();
+    if (signatures.size() != n || key_indices.size() != n) throw Error(ErrorKind::InvalidLength);
+    std::vector<uint64_t> off(n + 1, 0);
+    std::vector<uint8_t> msgs, sigs(n * 64), status(n, 0);
+    for (size_t i = 0; i < n; ++i) {
+      off[i] = msgs.size();
+      msgs.insert(msgs.end(), messages[i].begin(), messages[i].end());
+      std::memcpy(&sigs[64 * i], signatures[i].raw.data(), 64);
+    }
+    off[n] = msgs.size();
+    check_rc("bn254_batch_verify_keyed", bn254_batch_verify_keyed(e.raw(), msgs.data(), off.data(), sigs.data(), key_indices.data(), n, 0, status.data()));
+    return status;
+  }
   // opt-in randomised mode (include/bn254_hip.h: bn254_batch_verify_randomized): same result shape; non-zero entries
   // are exact, a zero is wrong with probability <= 2^-128 per group of 64 for a fresh secret 32-byte seed
   static std::vector<uint8_t> batch_verify_randomized(const std::vector<std::vector<uint8_t>>& messages, const std::vector<Signature>& signatures,

@@ -21,6 +21,10 @@ int main() {
     printf("Successful aggregate signature verification\n");
     try { bn254::ECDSA::verify(msg, s1, pk2); printf("ERROR: wrong key accepted\n"); return 2; }
     catch (const bn254::Error& e) { if (e.kind != bn254::ErrorKind::VerificationFailed) return 3; }
+    // the same through the keyed verify: the two keys and their aggregate registered once, tuples name them by index
+    auto kst = bn254::ECDSA::register_keys({pk1, pk2, pk1 + pk2});
+    auto st = bn254::ECDSA::batch_verify_keyed({msg, msg, msg, msg, msg}, {s1, s2, s1 + s2, s1, s2}, {0, 1, 2, 1, 7});
+    if (kst != std::vector<uint8_t>{0, 0, 0} || st != std::vector<uint8_t>{0, 0, 0, 9, 2}) { printf("ERROR: keyed verify\n"); return 4; }
     return 0;
   } catch (const std::exception& e) { printf("failed: %s\n", e.what()); return 1; }
 }

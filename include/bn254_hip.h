@@ -134,6 +134,20 @@ int bn254_batch_verify_keyed(bn254_ctx *ctx, const uint8_t *msgs, const uint64_t
 int bn254_batch_verify_keyed_device(bn254_ctx *ctx, const uint8_t *d_msgs, const uint64_t *d_msg_off, const uint8_t *d_sigs,
                                     const uint32_t *d_key_idx, size_t n, uint32_t flags, uint8_t *d_status, void *stream);
 
+/* Keyed randomised batch verification — OPT-IN, probabilistic, for REGISTERED keys.  Items that share a public key share the G2
+ * argument of their pairings, so 64 of them are checked by ONE product  e(sum r_i H(m_i), pk) * e(sum r_i sig_i, -G2) == 1  (two
+ * table-driven Miller loops and one final exponentiation per 64 items; per item the two scalar multiplications by r_i).  Items are
+ * grouped by key on the device; r_i as in bn254_batch_verify_randomized (first 16 / 8 bytes of SHA-256(seed32 || le64(i)), same flags
+ * BN254_FLAG_RAND64 / BN254_FLAG_RAND_GLV); the items of a failing group are re-checked one by one with the exact keyed kernels.
+ * Same inputs and status bytes as bn254_batch_verify_keyed: a non-zero status is always the exact one, a zero is wrong with
+ * probability <= 2^-128 (2^-64) per group for a fresh secret seed.  Batches below BN254_OPT_RAND_MIN_BATCH, and contexts without
+ * registered keys, take the exact keyed path.  No counterpart in the reference (src/ecdsa.rs:49-64 verifies one tuple at a time). */
+int bn254_batch_verify_keyed_randomized(bn254_ctx *ctx, const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *sigs,
+                                        const uint32_t *key_idx, size_t n, uint32_t flags, const uint8_t *seed32, uint8_t *status);
+int bn254_batch_verify_keyed_randomized_device(bn254_ctx *ctx, const uint8_t *d_msgs, const uint64_t *d_msg_off, const uint8_t *d_sigs,
+                                               const uint32_t *d_key_idx, size_t n, uint32_t flags, const uint8_t *seed32,
+                                               uint8_t *d_status, void *stream);
+
 /* Randomised batch verification — OPT-IN, probabilistic.  No counterpart in the
  * reference, which verifies one tuple at a time (src/ecdsa.rs:49-64); same inputs and status bytes as
  * bn254_batch_verify.  Items are taken 64 at a time; with r_i = the first 16 bytes (BN254_FLAG_RAND64: 8) of

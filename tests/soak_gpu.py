@@ -107,6 +107,12 @@ def soak(args):
             w = (sig_only[i] if sig_only[i] in (3, 4, 6) else 2) if i in oob else want1[i]
             if got_keyed[i] != w:
                 raise SoakMismatch("MISMATCH keyed round %d n %d item %d got %d want %d" % (rounds, n, i, got_keyed[i], w))
+        for fl in (0, 0x100, 0x200):                          # ... and the keyed randomised mode (same-key groups of 64, exact re-check of failing groups)
+            got_kr = eng.batch_verify_keyed_randomized(msgs, sigs, kidx_call, seed, flags=fl)
+            for i in range(n):
+                w = (sig_only[i] if sig_only[i] in (3, 4, 6) else 2) if i in oob else want1[i]
+                if got_kr[i] != w:
+                    raise SoakMismatch("MISMATCH keyed randomised round %d n %d flags %x item %d got %d want %d" % (rounds, n, fl, i, got_kr[i], w))
         extra["keyed_tuples"] = extra.get("keyed_tuples", 0) + n
         for flags in (0, 1):
             want, _ = c.batch_verify(msgs, sigs, pks, flags=flags, nthreads=cores)
@@ -192,7 +198,7 @@ def soak(args):
             print("soak: %d s, %d rounds, %d tuples, no mismatch" % (last_note - t0, rounds, items), flush=True)
     res = {"rounds": rounds, "tuples": items, "comparisons": items * 2 * 8, "seconds": round(time.time() - t0, 1), "oracle_threads": cores,
            "status_histogram": {str(k): v for k, v in sorted(codes.items())}, "mismatches": 0, "seed": args.seed, "also_compared": extra,
-           "modes": ["keyed (registered keys, once per round with the subgroup check)", "exact, eight wave roles", "exact, four wave roles", "exact, lane groups of one wave (octet)", "exact on lane pairs", "exact, one lane per verify", "randomised 128-bit", "randomised GLV", "randomised 64-bit"],
+           "modes": ["keyed (registered keys, once per round with the subgroup check)", "keyed randomised 128-bit / 64-bit / GLV (once per round)", "exact, eight wave roles", "exact, four wave roles", "exact, lane groups of one wave (octet)", "exact on lane pairs", "exact, one lane per verify", "randomised 128-bit", "randomised GLV", "randomised 64-bit"],
            "flags": [0, 1]}
     return res
 

@@ -927,6 +927,27 @@ def test_keyed_verify_vs_oracle(eng, c, derived):
         eng.batch_verify_keyed_device(d_msgs.data_ptr(), d_off.data_ptr(), d_sigs.data_ptr(), d_idx.data_ptr(), n, d_st.data_ptr(), stream=stream.cuda_stream)
         stream.synchronize()
         assert d_st.cpu().numpy().tobytes() == bytes(want)
+        # the keyed randomised mode (forced on at this size): the same statuses — failing groups fall back to the exact kernels
+        from bn254_amd.engine import OPT_RAND_MIN_BATCH
+        eng.set_option(OPT_RAND_MIN_BATCH, 0)
+        for fl in (0, 0x100, 0x200):
+            got_r = eng.batch_verify_keyed_randomized(msgs, bytes(sigs), idx_call, RAND_SEED, flags=fl)
+            diff = [(i, got_r[i], want[i], kidx[i]) for i in range(n) if got_r[i] != want[i]]
+            assert not diff, (fl, diff[:10])
+        d_st.fill_(255)
+        eng.batch_verify_keyed_randomized_device(d_msgs.data_ptr(), d_off.data_ptr(), d_sigs.data_ptr(), d_idx.data_ptr(), n, RAND_SEED, d_st.data_ptr(),
+                                                 stream=stream.cuda_stream)
+        stream.synchronize()
+        assert d_st.cpu().numpy().tobytes() == bytes(want)
+        eng.set_option(OPT_RAND_MIN_BATCH, 131072)
+    # an all-valid batch: every group passes, nothing is re-checked
+    n = 5000
+    msgs = [D("keyed-ok", i) for i in range(n)]
+    kk = [i % 4 for i in range(n)]                                              # keys 0..3 are valid
+    sg, st = eng.batch_sign(msgs, b"".join(sks[k] for k in kk))
+    eng.set_option(OPT_RAND_MIN_BATCH, 0)
+    assert eng.batch_verify_keyed_randomized(msgs, sg, kk, RAND_SEED) == bytes(n)
+    eng.set_option(OPT_RAND_MIN_BATCH, 131072)
     # the Python mirror of the reference API
     import bn254_amd as bn
     good = [bn.PublicKey(bytes(keys[j])) for j in (0, 1, 2)]
@@ -936,6 +957,10 @@ def test_keyed_verify_vs_oracle(eng, c, derived):
     # an empty key set: every index is out of range
     assert eng.register_keys(b"") == b""
     assert eng.batch_verify_keyed(msgs[:3], bytes(sigs[:192]), [0, 1, 2]) == bytes([2, 2, 2])
+    # ... also on a context that never registered a key (no table in HBM at all); a malformed signature keeps its own status
+    fresh = bn.Engine(0)
+    bad_sig = bytearray(sigs[:64]); bad_sig[63] ^= 1
+    assert fresh.batch_verify_keyed(msgs[:2], bytes(bad_sig) + bytes(sigs[64:128]), [0, 5]) == bytes([4, 2])
 
 
 def test_cpp_host_mirror_example(eng):
