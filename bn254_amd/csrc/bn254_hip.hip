@@ -98,7 +98,7 @@ KERNEL void k_decode_g2(const uint8_t* pts, size_t n, uint32_t flags, Ws ws, int
 // below relies on it) and the 87 lines of its Miller loop are written in the c2 = 1 form (bn254_pairing.h: g2_line_table).
 // One key per lane; a refused key walks on with the generator so that the wave stays convergent.  One-time work per key
 // set (87 Fq2 inversions per key: ~15 ms for 256 keys), not part of any verify.
-KERNEL void k_register_keys(const uint8_t* pks, size_t n_keys, uint32_t flags, int32_t* lines, uint8_t* key_st, uint8_t* key_inf) {
+KERNEL void k_register_keys(const uint8_t* pks, size_t n_keys, uint32_t flags, int32_t* lines, uint8_t* key_st, uint8_t* key_inf, int32_t* key_xy) {
   const size_t j = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
   const bool live = j < n_keys;
   G2Affine q;
@@ -119,6 +119,30 @@ KERNEL void k_register_keys(const uint8_t* pks, size_t n_keys, uint32_t flags, i
   if (st == ST_OK && !q.inf && !ok) st = ST_INVALID_GROUP_POINT;   // a line with c2 = 0: not reachable from the order-r subgroup (~2^-250)
   key_st[j] = st;
   key_inf[j] = q.inf;
+  // the point itself (x.re, x.im, y.re, y.im; 4 x 9 words): small keyed batches run the small-batch kernels on expanded keys
+  const Fp xy[4] = {q.x.c0, q.x.c1, q.y.c0, q.y.c1};
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int k = 0; k < BN_LIMBS; ++k) key_xy[(j * 4 + e) * BN_LIMBS + k] = xy[e].v[k];
+}
+// keyed verify of a SMALL batch: the registered key of every tuple written into the Q planes (with the status rule of the keyed
+// kernel: signature first, then index out of range, then the key's own), after which the batch is an ordinary verify
+KERNEL_SMALL void k_keyed_expand(size_t n, Ws ws, const uint32_t* key_idx, KeyTable kt, const int32_t* key_xy) {
+  const size_t i = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
+  if (i >= n) return;
+  uint32_t key = key_idx[i];
+  uint8_t kst = ST_OK;
+  if (key >= kt.n_keys) { kst = ST_INDEX_OOB; key = 0; }
+  else kst = kt.st[key];
+  const uint8_t prev = ws_byte(ws, BY_ST_DECODE, i);
+  ws_byte(ws, BY_ST_DECODE, i) = prev != ST_OK ? prev : kst;
+  G2Affine q;
+  const int32_t* w = key_xy + (size_t)key * 4 * BN_LIMBS;
+  q.x.c0 = fp_load_const(w); q.x.c1 = fp_load_const(w + BN_LIMBS); q.y.c0 = fp_load_const(w + 2 * BN_LIMBS); q.y.c1 = fp_load_const(w + 3 * BN_LIMBS);
+  q.inf = kt.inf[key] != 0;
+  if (kst != ST_OK) g2_set_generator(q);               // a refused key: the tuple's status is set, the arithmetic walks on with the generator
+  ws_store_g2(ws, i, q);
 }
 
 // keyed verify against an EMPTY key set: every index is out of range — the signature's decode status first, else IndexOutOfBounds
@@ -1050,6 +1074,7 @@ struct bn254_ctx {
   uint64_t msgs_len_next;    // bn254_ctx_expect_msgs_len: size of the d_msgs buffer of the NEXT call that hashes messages
   int msgs_len_declared;
   int32_t* key_lines;        // keyed verify: registered keys (bn254_ctx_register_keys), see KeyTable in bn254_ws.h
+  int32_t* key_xy;           // ... and their affine coordinates (4 x 9 words per key) for the small-batch route
   uint8_t* key_st;
   uint8_t* key_inf;
   size_t n_keys, key_cap;
@@ -1229,6 +1254,7 @@ void bn254_ctx_destroy(bn254_ctx* c) {
   for (int i = 0; i < 5; ++i) { if (c->pool[i].planes) (void)hipFree(c->pool[i].planes); if (c->pool[i].st) (void)hipFree(c->pool[i].st); }
   for (int i = 0; i < 8; ++i) if (c->stage[i]) (void)hipFree(c->stage[i]);
   if (c->key_lines) (void)hipFree(c->key_lines);
+  if (c->key_xy) (void)hipFree(c->key_xy);
   if (c->key_st) (void)hipFree(c->key_st);
   if (c->key_inf) (void)hipFree(c->key_inf);
   for (int i = 0; i < 5; ++i) (void)hipEventDestroy(c->ev[i]);
@@ -1467,17 +1493,19 @@ int bn254_ctx_register_keys(bn254_ctx* c, const uint8_t* pks, size_t n_keys, uin
   if (n_keys == 0) return 0;
   if (n_keys > c->key_cap) {
     if (c->key_lines) { HIP_TRY(hipFree(c->key_lines)); c->key_lines = nullptr; }
+    if (c->key_xy) { HIP_TRY(hipFree(c->key_xy)); c->key_xy = nullptr; }
     if (c->key_st) { HIP_TRY(hipFree(c->key_st)); c->key_st = nullptr; }
     if (c->key_inf) { HIP_TRY(hipFree(c->key_inf)); c->key_inf = nullptr; }
     c->key_cap = 0;
     HIP_TRY(hipMalloc((void**)&c->key_lines, n_keys * (size_t)BN_N_FIXED_LINES * BN_KEY_LINE_WORDS * sizeof(int32_t)));
+    HIP_TRY(hipMalloc((void**)&c->key_xy, n_keys * 4 * BN_LIMBS * sizeof(int32_t)));
     HIP_TRY(hipMalloc((void**)&c->key_st, n_keys));
     HIP_TRY(hipMalloc((void**)&c->key_inf, n_keys));
     c->key_cap = n_keys;
   }
   int rc;
   if ((rc = stage_in(c, 3, pks, n_keys * 128))) return rc;
-  k_register_keys<<<grid_for(n_keys), BN_WAVE, 0, c->stream>>>(c->stage[3], n_keys, flags & FLAG_REJECT_IDENTITY, c->key_lines, c->key_st, c->key_inf);
+  k_register_keys<<<grid_for(n_keys), BN_WAVE, 0, c->stream>>>(c->stage[3], n_keys, flags & FLAG_REJECT_IDENTITY, c->key_lines, c->key_st, c->key_inf, c->key_xy);
   HIP_TRY(hipGetLastError());
   if (key_status) HIP_TRY(hipMemcpyAsync(key_status, c->key_st, n_keys, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1505,6 +1533,16 @@ int bn254_batch_verify_keyed_device(bn254_ctx* c, const uint8_t* d_msgs, const u
   PROF_MARK(1);
   if ((rc = launch_hash_rounds(c, s, d_msgs, d_off, n, PL_P2X, BY_P2_INF, nullptr))) return rc;
   PROF_MARK(2);
+  if (c->pair_lanes && c->trio_max_batch > 0 && n <= (size_t)c->trio_max_batch) {
+    // a batch that cannot fill the chip: latency counts — expand the keys and take the small-batch kernels (2.3 ms instead of the
+    // 6 ms of the lane-pair layout; the line tables pay off only where throughput binds)
+    k_keyed_expand<<<grid_for(n), BN_WAVE, 0, s>>>(n, c->ws, d_key_idx, kt, c->key_xy);
+    if ((rc = launch_pair_or_trio(c, s, n, 1, d_status, 0, true))) return rc;
+    PROF_MARK(4);
+    if (c->profiling) { c->ev_valid = 1; c->ev_hash_first = 0; }
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   if ((rc = bn254_pair_miller_verify_keyed(n, c->ws, d_key_idx, kt, s))) return rc;
   PROF_MARK(3);
   if ((rc = bn254_pair_final_exp(n, c->ws, 1, d_status, nullptr, nullptr, s))) return rc;

@@ -127,7 +127,8 @@ int bn254_batch_verify_compressed_device(bn254_ctx *ctx, const uint8_t *d_msgs, 
  * bn254_batch_verify_keyed[_device]: as bn254_batch_verify with key_idx[i] (uint32) in place of the i-th public key.
  * status[i] = the signature's decode error, else 2 (IndexOutOfBounds) if key_idx[i] >= n_keys, else the key's registration
  * status, else what verify gives.  Same result bytes as bn254_batch_verify(flags | BN254_FLAG_G2_SUBGROUP_CHECK) on the
- * expanded keys.  Always runs the lane-pair kernels (no small-batch layout). */
+ * expanded keys.  Batches of up to BN254_OPT_TRIO_MAX_BATCH tuples take the small-batch kernels on the expanded keys (latency); the line
+ * tables serve the larger ones (throughput). */
 int bn254_ctx_register_keys(bn254_ctx *ctx, const uint8_t *pks /* n_keys*128 */, size_t n_keys, uint32_t flags, uint8_t *key_status /* n_keys or NULL */);
 int bn254_batch_verify_keyed(bn254_ctx *ctx, const uint8_t *msgs, const uint64_t *msg_off /* n+1 */, const uint8_t *sigs /* n*64 */,
                              const uint32_t *key_idx /* n */, size_t n, uint32_t flags, uint8_t *status /* n */);
