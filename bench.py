@@ -943,7 +943,7 @@ def main():
                          "other entry points on one GPU (informational — see DESIGN.md §4b)")
     args = ap.parse_args()
     global PMC_WORKLOAD
-    PMC_WORKLOAD = args.workload
+    PMC_WORKLOAD = "verify" if args.workload in ("verify-host", "verify-compressed") else args.workload   # same kernels, same batch as the headline command
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

@@ -19,10 +19,10 @@ elif [ "$part" = b ]; then
   bash $R/tests/pmc_profile.sh r03_$tag "" verify 65536 > $O/pmc_verify.log 2>&1; cp $R/gpurun_out/pmc_r03_$tag.json $O/pmc.json; echo pmc verify done
   cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_verify -- python3 $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats_verify.err; echo stats done
 elif [ "$part" = c ]; then
-  cp $O/pmc.json $R/gpurun_out/pmc_r03_$tag.json 2>/dev/null
+  # (a separate gpurun call: the verify summary of part b is not on this box; tools/pmc_merge.py joins the two afterwards)
   for spec in "verify-keyed:65536" "pairing:524288" "hash:16777216" "aggregate:1048576"; do
     w=${spec%%:*}; b=${spec##*:}
-    OUTJ=$R/gpurun_out/pmc_r03_${tag}_$w.json; cp $O/pmc.json $OUTJ
+    OUTJ=$R/gpurun_out/pmc_r03_${tag}_$w.json; [ -f $O/pmc.json ] && cp $O/pmc.json $OUTJ
     bash $R/tests/pmc_profile.sh r03_${tag}_$w "--workload $w" $w $b "$SHORT" > $O/pmc_$w.log 2>&1; cp $OUTJ $O/pmc.json; echo pmc $w done
     cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$w -- python3 $R/bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_${w}_under_rocprof.json 2> $O/stats_$w.err; echo stats $w done
   done
