@@ -218,9 +218,23 @@ template <class F> BN_DEVN void jac_add_distinct(Jac<F>& r, const Jac<F>& p, con
 //   scalars up to 2^256-1): every addition is the complete jac_add.  Signing and key derivation
 //   (/root/reference/src/ecdsa.rs:31, src/types.rs:86, :156): 3.7 k products against 8.2 k for the
 //   bit-by-bit ladder this replaces.
+// entry |d| of the window table, negated for d < 0, the identity for d = 0.  The table lives in the lane's private segment and is
+// INDEXED per lane (27 words read) — the scalars here are public or throw-away random multipliers, there is no secret to hide
+// behind a scan over all eight entries (216 words per window: most of the scalar-multiplication kernels' private-segment traffic).
+template <class F> BN_DEV void jac_window_entry(Jac<F>& t, const Jac<F>* tab, int d) {
+  const int m = d < 0 ? -d : d;
+  t = tab[m == 0 ? 0 : m - 1];
+  Jac<F> id;
+  jac_set_identity(id);
+  jac_select(t, m == 0, id, t);
+  t.y = f_select(d < 0, f_neg(t.y), t.y);
+}
+// `r` is the running accumulator itself (doubled and added to in place through the reference): a caller that hands over an LDS
+// slot keeps the 4 doublings + 1 addition per window out of the private segment
 template <int WORDS, bool COMPLETE, class F> BN_DEVN void jac_mul_window(Jac<F>& r, const Affine<F>& p, const uint32_t* k) {
   constexpr int NW = 8 * WORDS;
-  Jac<F> tab[8], acc, t;
+  Jac<F> tab[8], t;
+  Jac<F>& acc = r;
   jac_from_affine(tab[0], p);
   jac_dbl(tab[1], tab[0]);
   for (int j = 2; j < 8; ++j) {
@@ -237,13 +251,9 @@ template <int WORDS, bool COMPLETE, class F> BN_DEVN void jac_mul_window(Jac<F>&
   jac_set_identity(acc);
   for (int j = NW; j >= 0; --j) {
     if (j != NW) { jac_dbl(acc, acc); jac_dbl(acc, acc); jac_dbl(acc, acc); jac_dbl(acc, acc); }
-    int d = digit[j], m = d < 0 ? -d : d;
-    jac_set_identity(t);
-    for (int e = 0; e < 8; ++e) jac_select(t, m == e + 1, tab[e], t);
-    t.y = f_select(d < 0, f_neg(t.y), t.y);
+    jac_window_entry(t, tab, (int)digit[j]);
     if constexpr (COMPLETE) jac_add(acc, acc, t); else jac_add_distinct(acc, acc, t);
   }
-  r = acc;
 }
 template <class F> BN_DEV void jac_mul_u128(Jac<F>& r, const Affine<F>& p, const uint32_t* k) { jac_mul_window<4, false>(r, p, k); }
 template <class F> BN_DEV void jac_mul_u64(Jac<F>& r, const Affine<F>& p, const uint32_t* k) { jac_mul_window<2, false>(r, p, k); }
@@ -258,7 +268,8 @@ template <class F> BN_DEV void jac_mul(Jac<F>& r, const Affine<F>& p, const uint
 // window is added the accumulator is (16a + 16b lambda) P with a, b < 2^60 prefixes, which equals +-d P or
 // +-d lambda P (d <= 8) only if it is the identity, again by the shortest-vector bound.
 BN_DEVN void g1_mul_glv(G1Jac& r, const G1Affine& p, const uint32_t* k1, const uint32_t* k2) {
-  G1Jac tab[8], acc, t;
+  G1Jac tab[8], t;
+  G1Jac& acc = r;                                               // accumulated in place, as in jac_mul_window
   jac_from_affine(tab[0], p);
   jac_dbl(tab[1], tab[0]);
   for (int j = 2; j < 8; ++j) jac_add_distinct(tab[j], tab[j - 1], tab[0]);
@@ -275,19 +286,12 @@ BN_DEVN void g1_mul_glv(G1Jac& r, const G1Affine& p, const uint32_t* k1, const u
   jac_set_identity(acc);
   for (int j = 16; j >= 0; --j) {
     if (j != 16) { jac_dbl(acc, acc); jac_dbl(acc, acc); jac_dbl(acc, acc); jac_dbl(acc, acc); }
-    int d = d1[j], m = d < 0 ? -d : d;
-    jac_set_identity(t);
-    for (int e = 0; e < 8; ++e) jac_select(t, m == e + 1, tab[e], t);
-    t.y = fp_select(d < 0, fp_neg(t.y), t.y);
+    jac_window_entry(t, tab, (int)d1[j]);
     jac_add_distinct(acc, acc, t);
-    d = d2[j]; m = d < 0 ? -d : d;
-    jac_set_identity(t);
-    for (int e = 0; e < 8; ++e) jac_select(t, m == e + 1, tab[e], t);
+    jac_window_entry(t, tab, (int)d2[j]);
     t.x = fp_mul(t.x, beta);                                   // phi: x -> beta x (the identity keeps z = 0)
-    t.y = fp_select(d < 0, fp_neg(t.y), t.y);
     jac_add_distinct(acc, acc, t);
   }
-  r = acc;
 }
 
 template <class F> BN_DEVN void jac_to_affine(Affine<F>& r, const Jac<F>& p) {

@@ -427,17 +427,17 @@ KERNEL_SMALL void k_rand_scale(size_t n, Ws ws, Seed seed, int mode, size_t gbas
   const bool valid = live && ws_byte(ws, BY_ST_DECODE, ii) == ST_OK && ws_byte(ws, BY_ST_HASH, ii) == ST_OK;
   uint32_t k[4];
   rand_scalar(k, seed.w, (uint64_t)ii, mode == 1);
-  G1Jac a, sj, id;
-  if (mode == 2) g1_mul_glv(a, h, k, k + 2); else if (mode == 1) jac_mul_u64(a, h, k); else jac_mul_u128(a, h, k);   // wave-uniform
+  __shared__ G1JacSlot lds_s[BN_WAVE];                 // the accumulator of both scalar multiplications (in place, see k_krand_scale)
+  G1Jac& sj = lds_s[t].v;
+  G1Jac id;
+  if (mode == 2) g1_mul_glv(sj, h, k, k + 2); else if (mode == 1) jac_mul_u64(sj, h, k); else jac_mul_u128(sj, h, k);   // wave-uniform
   G1Affine aa;
-  jac_to_affine(aa, a);
+  jac_to_affine(aa, sj);
   aa.inf = aa.inf || !valid;
   if (live) ws_store_g1(ws, PL_HASHX, BY_A_INF, i, aa);
   if (mode == 2) g1_mul_glv(sj, sig, k, k + 2); else if (mode == 1) jac_mul_u64(sj, sig, k); else jac_mul_u128(sj, sig, k);
   jac_set_identity(id);
   jac_select(sj, !valid, id, sj);
-  __shared__ G1JacSlot lds_s[BN_WAVE];
-  lds_s[t].v = sj;
   __syncthreads();
   for (unsigned stride = BN_WAVE / 2; stride >= 1; stride >>= 1) {
     if (t < stride) jac_add(lds_s[t].v, lds_s[t].v, lds_s[t + stride].v);
@@ -599,15 +599,16 @@ KERNEL_SMALL void k_krand_scale(const uint32_t* perm, const uint32_t* meta, Ws w
   ws_load_g1(ws, PL_P2X, BY_P2_INF, ii, h);
   uint32_t k[4];
   rand_scalar(k, seed.w, (uint64_t)ii, mode == 1);
-  G1Jac a, sj, id;
+  // both products are accumulated IN their LDS slots (jac_mul_window works in place through the reference): the 4 doublings + 1
+  // addition of every window stay out of the private segment
+  __shared__ G1JacSlot lds_a[BN_WAVE], lds_s[BN_WAVE];
+  G1Jac &a = lds_a[t].v, &sj = lds_s[t].v;
+  G1Jac id;
   if (mode == 2) g1_mul_glv(a, h, k, k + 2); else if (mode == 1) jac_mul_u64(a, h, k); else jac_mul_u128(a, h, k);   // wave-uniform
   if (mode == 2) g1_mul_glv(sj, sig, k, k + 2); else if (mode == 1) jac_mul_u64(sj, sig, k); else jac_mul_u128(sj, sig, k);
   jac_set_identity(id);
   jac_select(a, !valid, id, a);
   jac_select(sj, !valid, id, sj);
-  __shared__ G1JacSlot lds_a[BN_WAVE], lds_s[BN_WAVE];
-  lds_a[t].v = a;
-  lds_s[t].v = sj;
   __syncthreads();
   for (unsigned stride = BN_WAVE / 2; stride >= 1; stride >>= 1) {
     if (t < stride) { jac_add(lds_a[t].v, lds_a[t].v, lds_a[t + stride].v); jac_add(lds_s[t].v, lds_s[t].v, lds_s[t + stride].v); }
