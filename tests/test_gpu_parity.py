@@ -948,6 +948,24 @@ def test_keyed_verify_vs_oracle(eng, c, derived):
     eng.set_option(OPT_RAND_MIN_BATCH, 0)
     assert eng.batch_verify_keyed_randomized(msgs, sg, kk, RAND_SEED) == bytes(n)
     eng.set_option(OPT_RAND_MIN_BATCH, 131072)
+    # more keys than a wave has lanes (the grouping kernel scans the key counts 64 at a time), some of them unused
+    K2 = 150
+    sks2 = [sk_bytes(900 + j) for j in range(K2)]
+    pool2, st = eng.batch_g2_mul(None, b"".join(sks2), K2, reduce_scalar=True)
+    assert eng.register_keys(pool2) == bytes(K2)
+    n = 3000
+    msgs2 = [D("keyed-many", i) for i in range(n)]
+    kk2 = [(i * 7) % 140 for i in range(n)]                                    # keys 140 .. 149 never named
+    sg2, st = eng.batch_sign(msgs2, b"".join(sks2[k] for k in kk2))
+    sg2 = bytearray(sg2)
+    for i in range(5, n, 37):
+        sg2[64 * i:64 * i + 64] = sg2[64 * (i - 1):64 * i]
+    want2 = c.batch_verify(msgs2, bytes(sg2), b"".join(pool2[128 * k:128 * k + 128] for k in kk2), flags=1, nthreads=8)[0]
+    eng.set_option(OPT_RAND_MIN_BATCH, 0)
+    assert eng.batch_verify_keyed_randomized(msgs2, bytes(sg2), kk2, RAND_SEED) == want2 and want2.count(9) == len(range(5, n, 37))
+    eng.set_option(OPT_RAND_MIN_BATCH, 131072)
+    assert eng.batch_verify_keyed(msgs2, bytes(sg2), kk2) == want2
+    eng.register_keys(key_bytes)
     # the Python mirror of the reference API
     import bn254_amd as bn
     good = [bn.PublicKey(bytes(keys[j])) for j in (0, 1, 2)]
