@@ -9,7 +9,7 @@
 // exponentiation, G2 sums and subgroup tests) runs one item per LANE PAIR in bn254_pair.hip, with the
 // one-lane-per-item kernels of this file kept behind BN254_OPT_PAIR_LANES = 0.
 //
-//   batch_verify:  k_decode_g1, k_decode_g2 -> k_hash_init/round/finish -> k_miller_verify_pair -> k_final_exp_pair
+//   batch_verify:  k_decode_g1, k_decode_g2 -> k_hash_init/round/resolve/finish -> k_miller_verify_pair -> k_final_exp_pair
 //
 // HBM traffic per verify is 225 B of input/output + 2 x ~1 KB of workspace hand-off against ~19 k Montgomery
 // products: the path is bound by VALU integer-multiply issue, not by HBM.
@@ -182,41 +182,41 @@ __device__ __forceinline__ bool msg_span(const uint64_t* off, size_t i, uint64_t
 }
 KERNEL_SMALL void k_hash_init(size_t n, Ws ws) {
   size_t i = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
-  if (i < n) { ws.h_best[i] = HASH_NONE; ws.h_next[i] = 0; ws.h_done[i] = 0; }
+  if (i < n) { ws.h_best[i] = HASH_NONE; ws.h_next[i] = 0; }
   if (i <= HASH_MAX_ROUNDS) ws.h_cnt[i] = (i == 0) ? (uint32_t)n : 0u;
 }
 KERNEL_SMALL void k_hash_round(const uint8_t* msgs, const uint64_t* off, uint64_t msgs_len, Ws ws, int round, uint32_t width, uint32_t max_ctr) {
   const uint32_t n_act = ws.h_cnt[round];
   if (n_act == 0) return;
   const uint32_t* list = round == 0 ? nullptr : ws.h_list + (size_t)(round & 1) * ws.stride;
-  uint32_t* list_out = ws.h_list + (size_t)((round + 1) & 1) * ws.stride;
   const size_t total = (size_t)n_act * width;
   for (size_t w = (size_t)blockIdx.x * BN_WAVE + threadIdx.x; w < total; w += (size_t)gridDim.x * BN_WAVE) {
     uint32_t slot = (uint32_t)(w % n_act), j = (uint32_t)(w / n_act);
     uint32_t i = list ? list[slot] : slot;
     uint32_t ctr = (uint32_t)ws.h_next[i] + j;
-    if (ctr < max_ctr) {                                           // hash.rs:40: counters 0..=254
-      uint64_t lo, len;
-      msg_span(off, i, msgs_len, lo, len);
-      const uint8_t* msg = msgs + lo;
-      HashState hs;
-      hash_state_init(hs, msg, len);
-      if (hash_try_filter(hs, msg, len, ctr)) atomicMin(&ws.h_best[i], ctr);
-    }
-    // The round is RESOLVED here, by whichever of the message's `width` lanes reports last (they sit in different waves): a message
-    // without a passing counter is queued for the next round, or gives up at max_ctr (hash.rs:62: HashToPointError, k_hash_finish).
-    // The fence orders this lane's atomicMin before its report; the last reporter reads h_best back through an atomic.
-    __threadfence();
-    if (atomicAdd(&ws.h_done[i], 1u) == width - 1) {
-      ws.h_done[i] = 0;
-      if (atomicMin(&ws.h_best[i], HASH_NONE) == HASH_NONE) {
-        const uint32_t next = (uint32_t)ws.h_next[i] + width;
-        if (next < max_ctr) {
-          ws.h_next[i] = (uint8_t)next;
-          list_out[atomicAdd(&ws.h_cnt[round + 1], 1u)] = i;
-        }
-      }
-    }
+    if (ctr >= max_ctr) continue;                                  // hash.rs:40: counters 0..=254
+    uint64_t lo, len;
+    msg_span(off, i, msgs_len, lo, len);
+    const uint8_t* msg = msgs + lo;
+    HashState hs;
+    hash_state_init(hs, msg, len);
+    if (hash_try_filter(hs, msg, len, ctr)) atomicMin(&ws.h_best[i], ctr);
+  }
+}
+// after a round: messages without a passing counter are queued for the next round (or give up at max_ctr)
+KERNEL_SMALL void k_hash_resolve(Ws ws, int round, uint32_t width, uint32_t max_ctr) {
+  const uint32_t n_act = ws.h_cnt[round];
+  if (n_act == 0) return;
+  const uint32_t* list = round == 0 ? nullptr : ws.h_list + (size_t)(round & 1) * ws.stride;
+  uint32_t* list_out = ws.h_list + (size_t)((round + 1) & 1) * ws.stride;
+  for (size_t slot = (size_t)blockIdx.x * BN_WAVE + threadIdx.x; slot < n_act; slot += (size_t)gridDim.x * BN_WAVE) {
+    uint32_t i = list ? list[slot] : (uint32_t)slot;
+    if (ws.h_best[i] != HASH_NONE) continue;
+    uint32_t next = (uint32_t)ws.h_next[i] + width;
+    if (next >= max_ctr) continue;                                 // hash.rs:62: HashToPointError (k_hash_finish)
+    ws.h_next[i] = (uint8_t)next;
+    uint32_t pos = atomicAdd(&ws.h_cnt[round + 1], 1u);
+    list_out[pos] = i;
   }
 }
 // SMALL batches (n <= HASH_DIRECT_MAX_N): latency, not work, is what counts — the first `width` counters of a message
@@ -1095,14 +1095,12 @@ static int ws_reserve(bn254_ctx* c, size_t n) {
   if (c->ws.bytes) { HIP_TRY(hipFree(c->ws.bytes)); c->ws.bytes = nullptr; }
   if (c->ws.h_best) { HIP_TRY(hipFree(c->ws.h_best)); c->ws.h_best = nullptr; }
   if (c->ws.h_next) { HIP_TRY(hipFree(c->ws.h_next)); c->ws.h_next = nullptr; }
-  if (c->ws.h_done) { HIP_TRY(hipFree(c->ws.h_done)); c->ws.h_done = nullptr; }
   if (c->ws.h_list) { HIP_TRY(hipFree(c->ws.h_list)); c->ws.h_list = nullptr; }
   c->ws.stride = 0;
   HIP_TRY(hipMalloc((void**)&c->ws.planes, (size_t)N_PLANES * BN_LIMBS * sizeof(int32_t) * cap));
   HIP_TRY(hipMalloc((void**)&c->ws.bytes, (size_t)N_BYTE_PLANES * cap));
   HIP_TRY(hipMalloc((void**)&c->ws.h_best, sizeof(uint32_t) * cap));
   HIP_TRY(hipMalloc((void**)&c->ws.h_next, cap));
-  HIP_TRY(hipMalloc((void**)&c->ws.h_done, cap * sizeof(uint32_t)));
   HIP_TRY(hipMalloc((void**)&c->ws.h_list, 2 * sizeof(uint32_t) * cap));
   if (!c->ws.h_cnt) HIP_TRY(hipMalloc((void**)&c->ws.h_cnt, sizeof(uint32_t) * (HASH_MAX_ROUNDS + 1)));
   c->ws.stride = cap;
@@ -1191,6 +1189,7 @@ static int launch_hash_rounds(bn254_ctx* c, hipStream_t s, const uint8_t* d_msgs
     size_t lanes = (size_t)(bound * width);
     if (lanes > HASH_MAX_GRID_LANES) lanes = HASH_MAX_GRID_LANES;   // grid-stride loops cover the rest
     k_hash_round<<<grid_for(lanes), BN_WAVE, 0, s>>>(d_msgs, d_off, msgs_len, c->ws, round, width, max_ctr);
+    k_hash_resolve<<<grid_for((size_t)bound), BN_WAVE, 0, s>>>(c->ws, round, width, max_ctr);
     consumed += width;
     double pf = 1.0;
     for (uint32_t t = 0; t < width && pf > 1e-12; ++t) pf *= 0.5274;
@@ -1251,7 +1250,6 @@ void bn254_ctx_destroy(bn254_ctx* c) {
   if (c->ws.bytes) (void)hipFree(c->ws.bytes);
   if (c->ws.h_best) (void)hipFree(c->ws.h_best);
   if (c->ws.h_next) (void)hipFree(c->ws.h_next);
-  if (c->ws.h_done) (void)hipFree(c->ws.h_done);
   if (c->ws.h_list) (void)hipFree(c->ws.h_list);
   if (c->ws.h_cnt) (void)hipFree(c->ws.h_cnt);
   for (int i = 0; i < 5; ++i) { if (c->pool[i].planes) (void)hipFree(c->pool[i].planes); if (c->pool[i].st) (void)hipFree(c->pool[i].st); }

@@ -36,7 +36,6 @@ struct Ws {
   // hash-to-G1 round state (see k_hash_round)
   uint32_t* h_best;   // [stride]  smallest successful counter of the current round, or HASH_NONE
   uint8_t* h_next;    // [stride]  first counter not yet tried
-  uint32_t* h_done;   // [stride]  counters of the current round that have reported for the message (the last one resolves it)
   uint32_t* h_list;   // [2][stride] compacted indices of the messages still without a point
   uint32_t* h_cnt;    // [HASH_MAX_ROUNDS + 1] number of entries of the list feeding round r
 };
