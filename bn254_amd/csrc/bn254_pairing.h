@@ -1056,6 +1056,9 @@ BN_DEVN void final_exponentiation_check(Fp12& r, const Fp12& fin, Fp12& acc) {
 // array).  The interpreter loop has one switch; every Fq12 routine is inlined at its ONE case, no value lives across
 // iterations, and the only memory traffic left is what the chain itself needs: a slot read per multiplication (54 words per
 // lane), a slot written per stored intermediate.  Instruction = (opcode, slot or Frobenius power), wave-uniform.
+#ifndef BN_FE_PRIO_SHIFT
+#define BN_FE_PRIO_SHIFT 1     // the wave-priority cycle advances every 2^shift program steps (x the kernel's own BN_PRIO_SHIFT)
+#endif
 enum FeOpcode : int { FE_END = 0, FE_LOAD = 1, FE_STORE = 2, FE_CSQR = 3, FE_MUL = 4, FE_CONJ = 5, FE_FROB = 6, FE_INV = 7 };
 template <int NSLOTS>
 BN_DEV void fe_machine(Fp12& acc, Fp12 (&slot)[NSLOTS], const unsigned char (*prog)[2]) {
@@ -1065,7 +1068,7 @@ BN_DEV void fe_machine(Fp12& acc, Fp12 (&slot)[NSLOTS], const unsigned char (*pr
   for (int pc = 0;; ++pc) {
     const int op = prog[pc][0], arg = prog[pc][1];
     if (op == FE_END) break;
-    BN_SET_STEP_PRIORITY(pc >> 1);
+    BN_SET_STEP_PRIORITY(pc >> BN_FE_PRIO_SHIFT);
     switch (op) {
       case FE_LOAD: acc = slot[arg]; break;
       case FE_STORE: slot[arg] = acc; break;
