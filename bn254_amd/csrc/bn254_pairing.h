@@ -1057,7 +1057,7 @@ BN_DEVN void final_exponentiation_check(Fp12& r, const Fp12& fin, Fp12& acc) {
 // iterations, and the only memory traffic left is what the chain itself needs: a slot read per multiplication (54 words per
 // lane), a slot written per stored intermediate.  Instruction = (opcode, slot or Frobenius power), wave-uniform.
 #ifndef BN_FE_PRIO_SHIFT
-#define BN_FE_PRIO_SHIFT 1     // the wave-priority cycle advances every 2^shift program steps (x the kernel's own BN_PRIO_SHIFT)
+#define BN_FE_PRIO_SHIFT 2     // the wave-priority cycle advances every 2^shift program steps (x the kernel's own BN_PRIO_SHIFT); 0..5 measured: profiles/r03_x_ab_fe_priority_period.log
 #endif
 enum FeOpcode : int { FE_END = 0, FE_LOAD = 1, FE_STORE = 2, FE_CSQR = 3, FE_MUL = 4, FE_CONJ = 5, FE_FROB = 6, FE_INV = 7 };
 template <int NSLOTS>
