@@ -582,18 +582,39 @@ class Rank:
         # torch ops that prepare the inputs, and the RCCL collectives (torch orders a collective after the current
         # stream) — no reliance on the null stream or on the context's private non-blocking stream.
         self.stream = torch.cuda.Stream(device=self.dev)
+        self.own_elapsed = None          # this rank's own clock over the timed steps (the reported time is the MAX over ranks)
+        self.coll_events = []            # (start, end) events around every collective of the timed steps (RCCL)
+        self.coll_host_s = 0.0           # ... or its host time (gloo test mode: the collective is staged through the host)
+        self.timing = False
+
+    def _collective(self, fn):
+        """run one collective; inside the timed steps also take its own time: HIP events on the rank's stream around it
+        (torch orders an RCCL collective after the current stream and makes the stream wait for its result)"""
+        if not self.timing:
+            return fn()
+        if self.backend == "nccl":
+            e0, e1 = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
+            e0.record(self.stream)
+            out = fn()
+            e1.record(self.stream)
+            self.coll_events.append((e0, e1))
+            return out
+        t0 = time.perf_counter()
+        out = fn()
+        self.coll_host_s += time.perf_counter() - t0
+        return out
 
     def gather(self, local_status, out):
         """the one collective of a verify step: all-gather of the status bytes (RCCL over xGMI)"""
         from bn254_amd.sharding import gather_status
         if self.backend == "nccl":
-            gather_status(local_status, out=out)
+            self._collective(lambda: gather_status(local_status, out=out))
         else:                                                       # gloo test mode: staged through the host
-            out.copy_(gather_status(local_status.cpu()))
+            self._collective(lambda: out.copy_(gather_status(local_status.cpu())))
 
     def allreduce_checksum(self, local_sum):
         from bn254_amd.sharding import allreduce_checksum
-        return allreduce_checksum(local_sum if self.backend == "nccl" else local_sum.cpu())
+        return self._collective(lambda: allreduce_checksum(local_sum if self.backend == "nccl" else local_sum.cpu()))
 
     def time_steps(self, step, steps, warmup, after_warmup=None, per_step=None):
         """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks"""
@@ -607,20 +628,54 @@ class Rank:
             if self.dist_on:
                 dist.barrier()
             torch.cuda.synchronize()
+            self.timing = True
             t0 = time.perf_counter()
             for k in range(steps):
                 step(warmup + k)
                 if per_step:
                     per_step()
+            torch.cuda.synchronize()
+            self.own_elapsed = time.perf_counter() - t0            # this rank alone, before it waits for the others
             if self.dist_on:
                 dist.barrier()
             torch.cuda.synchronize()
             elapsed = time.perf_counter() - t0
+            self.timing = False
         if self.dist_on:
             t = torch.tensor([elapsed], dtype=torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         return elapsed
+
+    def scaling_detail(self, steps, kernel_ms_total=None):
+        """what makes an N-rank line diagnosable: every rank's own elapsed time over the timed steps (the headline uses the
+        max), the sum of its kernel times (HIP events inside the library) and the time of its collectives, all per step —
+        one all_gather of three doubles per rank AFTER the timed region.  None in a job without collectives."""
+        if not self.dist_on:
+            return None
+        torch, dist = self.torch, self.dist
+        coll_ms = 1e3 * self.coll_host_s
+        if self.coll_events:
+            torch.cuda.synchronize()
+            coll_ms = sum(a.elapsed_time(b) for a, b in self.coll_events)
+        mine = torch.tensor([self.own_elapsed or 0.0, (kernel_ms_total if kernel_ms_total is not None else float("nan")), coll_ms],
+                            dtype=torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
+        every = [torch.zeros_like(mine) for _ in range(self.world)]
+        dist.all_gather(every, mine)
+        rows = [[float(x) for x in t.cpu()] for t in every]
+
+        def stats(vals):
+            return {"min": min(vals), "max": max(vals), "mean": sum(vals) / len(vals), "per_rank": vals}
+        el = [1e3 * r[0] / steps for r in rows]
+        km = [r[1] / steps for r in rows]
+        cm = [r[2] / steps for r in rows]
+        return {"own_elapsed_ms_per_step": stats(el),
+                "kernel_ms_per_step": stats(km) if kernel_ms_total is not None else None,
+                "collective_ms_per_step": stats(cm),
+                "collective_timed_by": "HIP events on the rank's stream around the collective" if self.coll_events else "host clock (gloo test mode)",
+                "slowest_rank": max(range(len(el)), key=lambda i: el[i]),
+                "spread_pct": 100.0 * (max(el) - min(el)) / max(el) if max(el) > 0 else 0.0,
+                "note": "headline ms_per_step = max over ranks incl. the closing barrier; own_elapsed is each rank's clock before that barrier"}
 
     def finish(self):
         if self.dist_on:
@@ -722,6 +777,7 @@ def run_verify(args, R):
     ok_last = check(args.warmup + args.steps - 1)            # the LAST step's pattern (differs from the one before)
     assert ok_last, "GPU status bytes of the last timed step differ from the expected pattern"
 
+    detail = R.scaling_detail(args.steps, sum(kernel_ms.values()))      # a collective: every rank takes part
     verifies = n * world * args.steps
     verifies_per_s = verifies / elapsed
     result = {
@@ -744,6 +800,8 @@ def run_verify(args, R):
                    "collective": "all_gather_into_tensor(status bytes) per step over %s" % R.backend if R.dist_on else None},
     }
 
+    if detail is not None:
+        result["scaling_detail"] = detail
     if rank == 0:
         k_avg = {k: v / args.steps for k, v in kernel_ms.items()}
         dom = max(("miller_loop", "final_exp"), key=lambda k: k_avg[k])
@@ -755,6 +813,30 @@ def run_verify(args, R):
         achieved = mac_per_launch / (k_avg[dom] * 1e-3) / 1e12
         io_bytes = BYTES_PER_VERIFY_IO * n
         probe = issue_probe(eng) if world == 1 else None
+        # The clock the chip actually sustains under this load (it is power-limited below its nominal 2.4 GHz): a few more steps,
+        # OUTSIDE the timed region, with the kernels' clock probe on — shader-clock cycles over constant-rate ticks between entry and
+        # exit of every workgroup of the Miller kernel / the final exponentiation; the issue probe reports its own.
+        sclk = None
+        if pair:
+            try:
+                from bn254_amd.engine import OPT_CLOCK_PROBE
+                eng.set_option(OPT_CLOCK_PROBE, 1)
+                with torch.cuda.stream(R.stream):
+                    for k in range(4):                              # the library call alone: no collective (only this rank is here)
+                        eng.batch_verify_device(d_msgs.data_ptr(), d_off.data_ptr(), d_sigs[k & 1].data_ptr(), d_pks.data_ptr(), n,
+                                                d_status.data_ptr(), flags=0, stream=sh)
+                    torch.cuda.synchronize()
+                sclk = eng.last_clocks()
+                if world == 1:
+                    eng.probe_issue_rate(0, 2)
+                    sclk["issue_probe"] = eng.last_clocks()["issue_probe"]
+                eng.set_option(OPT_CLOCK_PROBE, 0)
+                sclk = {k: round(v, 1) for k, v in sclk.items()}
+                sclk["nominal"] = 2400.0
+                sclk["method"] = ("sum over workgroups of s_memtime cycles / s_memrealtime ticks x hipDeviceAttributeWallClockRate, 4 back-to-back "
+                                  "steps after the timed region (BN254_OPT_CLOCK_PROBE)")
+            except Exception as exc:                               # never lose the bench line over the extra
+                sclk = {"error": repr(exc)}
         lane_products = lane_product_counts().get(kname)
         traffic = measured_traffic(kname)
         result["roofline"] = {
@@ -763,6 +845,8 @@ def run_verify(args, R):
             "layout": "one verify per lane pair (Fq2 coefficients in adjacent lanes), two waves per SIMD" if pair else "one verify per lane",
             "achieved": achieved, "peak": PEAK_MAC32_THEORETICAL / 1e12, "unit": "TMAC32/s",
             "frac": achieved / (PEAK_MAC32_THEORETICAL / 1e12),
+            "effective_sclk_mhz": sclk,
+            "frac_at_effective_sclk": (achieved / (PEAK_MAC32_THEORETICAL / 1e12 * sclk[dom] / 2400.0)) if sclk and sclk.get(dom) else None,
             "peak_measured_in_this_run": probe["peak_mac32_measured"] / 1e12 if probe else None,
             "frac_of_measured_peak": achieved / (probe["peak_mac32_measured"] / 1e12) if probe else None,
             "issue_probe": probe,
@@ -891,6 +975,7 @@ def run_pairing(args, R):
     assert dup_ok, "items with identical inputs produced different Gt bytes"
     assert len(state["sums"]) == 1, "Gt checksum changed between steps"
     assert int(d_st.min()) == 9 and int(d_st.max()) == 9
+    detail = R.scaling_detail(args.steps)
     total = n * world * args.steps
     result = {
         "metric": "BN254 pairings/sec (independent pairings, canonical Gt out)",
@@ -902,6 +987,8 @@ def run_pairing(args, R):
                    "batch_per_gpu": n, "gt_checksum_u64": "%016x" % state["sum"], "duplicate_inputs_equal_gt": dup_ok,
                    "collective": ("all_gather_into_tensor(status bytes) + all_reduce(sum, 8-byte Gt checksum) per step over %s" % R.backend) if R.dist_on else None},
     }
+    if detail is not None:
+        result["scaling_detail"] = detail
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
         fp_mul = FP_MUL_MILLER_SINGLE + FP_MUL_FINAL_EXP_EXACT

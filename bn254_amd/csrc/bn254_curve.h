@@ -218,12 +218,22 @@ template <class F> BN_DEVN void jac_add_distinct(Jac<F>& r, const Jac<F>& p, con
 //   scalars up to 2^256-1): every addition is the complete jac_add.  Signing and key derivation
 //   (/root/reference/src/ecdsa.rs:31, src/types.rs:86, :156): 3.7 k products against 8.2 k for the
 //   bit-by-bit ladder this replaces.
-// entry |d| of the window table, negated for d < 0, the identity for d = 0.  The table lives in the lane's private segment and is
-// INDEXED per lane (27 words read) — the scalars here are public or throw-away random multipliers, there is no secret to hide
-// behind a scan over all eight entries (216 words per window: most of the scalar-multiplication kernels' private-segment traffic).
-template <class F> BN_DEV void jac_window_entry(Jac<F>& t, const Jac<F>* tab, int d) {
+// entry |d| of the window table, negated for d < 0, the identity for d = 0.  The table lives in the lane's private segment.
+// SECRET = false: the entry is INDEXED per lane (27 words read) — for the throw-away random multipliers of the randomised
+//   verifies (jac_mul_u128 / jac_mul_u64 / g1_mul_glv), which are no secret: the scan below was most of those kernels'
+//   private-segment traffic (216 words per window).
+// SECRET = true: every entry is read and the wanted one kept by selects, so neither the addresses nor the control flow
+//   depend on the digit — jac_mul is ECDSA::sign (scalar = the private key, /root/reference/src/ecdsa.rs:31) and
+//   PublicKey::from_private_key (src/types.rs:86, :156).
+template <bool SECRET, class F> BN_DEV void jac_window_entry(Jac<F>& t, const Jac<F>* tab, int d) {
   const int m = d < 0 ? -d : d;
-  t = tab[m == 0 ? 0 : m - 1];
+  if constexpr (SECRET) {
+    t = tab[0];
+#pragma unroll 1
+    for (int j = 1; j < 8; ++j) jac_select(t, m == j + 1, tab[j], t);
+  } else {
+    t = tab[m == 0 ? 0 : m - 1];
+  }
   Jac<F> id;
   jac_set_identity(id);
   jac_select(t, m == 0, id, t);
@@ -251,7 +261,7 @@ template <int WORDS, bool COMPLETE, class F> BN_DEVN void jac_mul_window(Jac<F>&
   jac_set_identity(acc);
   for (int j = NW; j >= 0; --j) {
     if (j != NW) { jac_dbl(acc, acc); jac_dbl(acc, acc); jac_dbl(acc, acc); jac_dbl(acc, acc); }
-    jac_window_entry(t, tab, (int)digit[j]);
+    jac_window_entry<COMPLETE>(t, tab, (int)digit[j]);      // COMPLETE = the 256-bit multiplication of sign / keygen: secret scalar
     if constexpr (COMPLETE) jac_add(acc, acc, t); else jac_add_distinct(acc, acc, t);
   }
 }
@@ -286,9 +296,9 @@ BN_DEVN void g1_mul_glv(G1Jac& r, const G1Affine& p, const uint32_t* k1, const u
   jac_set_identity(acc);
   for (int j = 16; j >= 0; --j) {
     if (j != 16) { jac_dbl(acc, acc); jac_dbl(acc, acc); jac_dbl(acc, acc); jac_dbl(acc, acc); }
-    jac_window_entry(t, tab, (int)d1[j]);
+    jac_window_entry<false>(t, tab, (int)d1[j]);
     jac_add_distinct(acc, acc, t);
-    jac_window_entry(t, tab, (int)d2[j]);
+    jac_window_entry<false>(t, tab, (int)d2[j]);
     t.x = fp_mul(t.x, beta);                                   // phi: x -> beta x (the identity keeps z = 0)
     jac_add_distinct(acc, acc, t);
   }

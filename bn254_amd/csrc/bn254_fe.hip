@@ -99,6 +99,7 @@ KERNEL_PAIR void k_final_exp_pair(size_t n, size_t k, size_t item_stride, size_t
     if (st == ST_OK) st = sj;
   }
   if (st == ST_OK && use_hash) st = ws_byte(ws, BY_ST_HASH, i);
+  BN_CLK_BEGIN(ws);
   if (!raw_only) {
 #if defined(BN_PAIR_FE_CHAINS)
     // A/B knob: the chains as straight-line code with real Fq12 calls (rounds 1-2)
@@ -111,6 +112,7 @@ KERNEL_PAIR void k_final_exp_pair(size_t n, size_t k, size_t item_stride, size_t
     fe_machine(f, slot, gt_out ? C_FE_EXACT : C_FE_CHECK);
 #endif
   }
+  BN_CLK_END(ws, 1);
   const unsigned role = threadIdx.x & 1u;
   if (gt_out) {
     const Fp2* c[6] = {&f.c0.c0, &f.c0.c1, &f.c0.c2, &f.c1.c0, &f.c1.c1, &f.c1.c2};
@@ -121,6 +123,7 @@ KERNEL_PAIR void k_final_exp_pair(size_t n, size_t k, size_t item_stride, size_t
 }
 
 int bn254_pair_final_exp(size_t n, Ws ws, int use_hash, uint8_t* status_out, const uint32_t* map, const uint32_t* count, hipStream_t s, size_t base) {
+  if (ws.clk) HIP_TRY(hipMemsetAsync(ws.clk + (size_t)BN_CLK_MAX_WG * 2, 0, sizeof(unsigned long long) * 2 * BN_CLK_MAX_WG, s));
   k_final_exp_pair<<<(unsigned)((2 * n + BN_PAIR_WG - 1) / BN_PAIR_WG), BN_PAIR_WG, 0, s>>>(n, 1, 1, 1, ws, use_hash, nullptr, status_out, 0, base, map, count);
   HIP_TRY(hipGetLastError());
   return 0;

@@ -14,6 +14,7 @@
 // HBM traffic per verify is 225 B of input/output + 2 x ~1 KB of workspace hand-off against ~19 k Montgomery
 // products: the path is bound by VALU integer-multiply issue, not by HBM.
 #include <hip/hip_runtime.h>
+#include <vector>
 
 #include <cstdio>
 #include <cstdlib>
@@ -1018,7 +1019,9 @@ KERNEL void k_debug_fp12_op(int op, const uint8_t* a, const uint8_t* b, size_t n
 #define PROBE_ITERS 4096
 #define PROBE_CHAINS 16
 template <int OP>
-__global__ void __launch_bounds__(256) k_issue_probe(uint32_t* out, uint32_t seed) {
+__global__ void __launch_bounds__(256) k_issue_probe(uint32_t* out, uint32_t seed, unsigned long long* clk) {
+  unsigned long long clk0 = 0, wall0 = 0;
+  if (clk && threadIdx.x == 0) { clk0 = clock64(); wall0 = wall_clock64(); }
   uint32_t a = seed + threadIdx.x * 2654435761u, b = seed ^ (threadIdx.x * 40503u + 977u);
   uint64_t acc[PROBE_CHAINS];
 #pragma unroll
@@ -1043,6 +1046,10 @@ __global__ void __launch_bounds__(256) k_issue_probe(uint32_t* out, uint32_t see
 #pragma unroll
   for (int j = 0; j < PROBE_CHAINS; ++j) sum += acc[j];
   out[(size_t)blockIdx.x * 256 + threadIdx.x] = (uint32_t)sum ^ (uint32_t)(sum >> 32);
+  if (clk && threadIdx.x == 0 && blockIdx.x < BN_CLK_MAX_WG) {     // slot 2 of the clock probe (bn254_ws.h): this kernel's own clock
+    unsigned long long* p = clk + ((size_t)2 * BN_CLK_MAX_WG + blockIdx.x) * 2;
+    p[0] = clock64() - clk0; p[1] = wall_clock64() - wall0;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1074,6 +1081,8 @@ struct bn254_ctx {
   hipEvent_t copy_done;
   uint64_t msgs_len_next;    // bn254_ctx_expect_msgs_len: size of the d_msgs buffer of the NEXT call that hashes messages
   int msgs_len_declared;
+  uint64_t msgs_len_call;    // ... as taken by the entry point now running (MsgsLenScope); UINT64_MAX = not declared
+  int entry_depth;           // the host-pointer entry points call their *_device forms: only the outermost one takes the declaration
   int32_t* key_lines;        // keyed verify: registered keys (bn254_ctx_register_keys), see KeyTable in bn254_ws.h
   int32_t* key_xy;           // ... and their affine coordinates (4 x 9 words per key) for the small-batch route
   uint8_t* key_st;
@@ -1090,7 +1099,7 @@ static int ws_reserve(bn254_ctx* c, size_t n) {
   if (n <= c->ws.stride) return 0;
   size_t cap = (n + 255) & ~(size_t)255;
   HIP_TRY(hipSetDevice(c->device));
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(hipDeviceSynchronize());     // a *_device call may still be running on a caller's stream, not only on c->stream
   if (c->ws.planes) { HIP_TRY(hipFree(c->ws.planes)); c->ws.planes = nullptr; }
   if (c->ws.bytes) { HIP_TRY(hipFree(c->ws.bytes)); c->ws.bytes = nullptr; }
   if (c->ws.h_best) { HIP_TRY(hipFree(c->ws.h_best)); c->ws.h_best = nullptr; }
@@ -1109,7 +1118,7 @@ static int ws_reserve(bn254_ctx* c, size_t n) {
 static int stage_reserve(bn254_ctx* c, int slot, size_t bytes) {
   if (bytes <= c->stage_cap[slot]) return 0;
   HIP_TRY(hipSetDevice(c->device));
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(hipDeviceSynchronize());
   if (c->stage[slot]) { HIP_TRY(hipFree(c->stage[slot])); c->stage[slot] = nullptr; c->stage_cap[slot] = 0; }
   size_t cap = (bytes + 4095) & ~(size_t)4095;
   HIP_TRY(hipMalloc((void**)&c->stage[slot], cap));
@@ -1138,7 +1147,7 @@ static int pool_reserve(bn254_ctx* c, int which, size_t n_fp, size_t entries) {
   Pool& p = c->pool[which];
   if (entries <= p.stride && c->pool_fp[which] == n_fp) return 0;
   HIP_TRY(hipSetDevice(c->device));
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(hipDeviceSynchronize());
   if (p.planes) { HIP_TRY(hipFree(p.planes)); p.planes = nullptr; }
   if (p.st) { HIP_TRY(hipFree(p.st)); p.st = nullptr; }
   p.stride = 0;
@@ -1158,6 +1167,22 @@ static int launch_decode_g2(bn254_ctx* c, hipStream_t s, const uint8_t* d_pts, s
   return 0;
 }
 
+// bn254_ctx_expect_msgs_len is consumed by the NEXT entry point that hashes messages — whatever that call goes on to do: every such
+// entry point opens with a MsgsLenScope, which takes the declaration and clears it before any argument check, staging step or
+// allocation can return early (a declaration left armed would bound-check an unrelated later call against the wrong length).
+struct MsgsLenScope {
+  bn254_ctx* c;
+  explicit MsgsLenScope(bn254_ctx* ctx) : c(ctx) {
+    if (c && c->entry_depth++ == 0) {
+      c->msgs_len_call = c->msgs_len_declared ? c->msgs_len_next : UINT64_MAX;
+      c->msgs_len_declared = 0;
+    }
+  }
+  ~MsgsLenScope() { if (c) --c->entry_depth; }
+  MsgsLenScope(const MsgsLenScope&) = delete;
+  MsgsLenScope& operator=(const MsgsLenScope&) = delete;
+};
+
 // Enqueue the hash-to-G1 rounds for n messages; points land in planes (px, px+1), statuses in BY_ST_HASH.
 // The schedule (widths, grid sizes) is fixed on the host from the EXPECTED survivor counts
 // (p_fail = 0.5274 per try); the kernels read the actual counts from device memory and use grid-stride
@@ -1165,8 +1190,7 @@ static int launch_decode_g2(bn254_ctx* c, hipStream_t s, const uint8_t* d_pts, s
 static int launch_hash_rounds(bn254_ctx* c, hipStream_t s, const uint8_t* d_msgs, const uint64_t* d_off, size_t n, int px, int inf_plane,
                               uint8_t* d_tries) {
   const uint32_t max_ctr = c->hash_max_tries ? (uint32_t)c->hash_max_tries : 255u;
-  const uint64_t msgs_len = c->msgs_len_declared ? c->msgs_len_next : UINT64_MAX;   // bn254_ctx_expect_msgs_len: one call only
-  c->msgs_len_declared = 0;
+  const uint64_t msgs_len = c->msgs_len_call;   // bn254_ctx_expect_msgs_len, taken by the entry point's MsgsLenScope
   k_hash_init<<<grid_for(n > HASH_MAX_ROUNDS + 1 ? n : HASH_MAX_ROUNDS + 1), BN_WAVE, 0, s>>>(n, c->ws);
   if (n <= HASH_DIRECT_MAX_N && c->hash_direct_width > 0) {
     const uint32_t width = (uint32_t)c->hash_direct_width;
@@ -1252,6 +1276,7 @@ void bn254_ctx_destroy(bn254_ctx* c) {
   if (c->ws.h_next) (void)hipFree(c->ws.h_next);
   if (c->ws.h_list) (void)hipFree(c->ws.h_list);
   if (c->ws.h_cnt) (void)hipFree(c->ws.h_cnt);
+  if (c->ws.clk) (void)hipFree(c->ws.clk);
   for (int i = 0; i < 5; ++i) { if (c->pool[i].planes) (void)hipFree(c->pool[i].planes); if (c->pool[i].st) (void)hipFree(c->pool[i].st); }
   for (int i = 0; i < 8; ++i) if (c->stage[i]) (void)hipFree(c->stage[i]);
   if (c->key_lines) (void)hipFree(c->key_lines);
@@ -1305,8 +1330,40 @@ int bn254_ctx_set_option(bn254_ctx* c, int option, int value) {
     c->hash_direct_width = value;
     return 0;
   }
+  if (option == BN254_OPT_CLOCK_PROBE) {
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipDeviceSynchronize());
+    if (value && !c->ws.clk) {
+      HIP_TRY(hipMalloc((void**)&c->ws.clk, sizeof(unsigned long long) * 3 * BN_CLK_MAX_WG * 2));
+      HIP_TRY(hipMemset(c->ws.clk, 0, sizeof(unsigned long long) * 3 * BN_CLK_MAX_WG * 2));
+    } else if (!value && c->ws.clk) {
+      HIP_TRY(hipFree(c->ws.clk));
+      c->ws.clk = nullptr;
+    }
+    return 0;
+  }
   if (option == BN254_OPT_HASH_MAX_TRIES) { if (value < 0 || value > 255) return BN254_E_BAD_ARGUMENT; c->hash_max_tries = value; return 0; }
   return BN254_E_BAD_ARGUMENT;
+}
+// clock probe (BN254_OPT_CLOCK_PROBE): the clock the chip ran the last Miller kernel [0], final exponentiation [1] and issue probe [2]
+// at, in MHz = shader-clock cycles / constant-rate ticks x the constant rate, summed over the workgroups that reported; 0 = none did
+int bn254_ctx_last_clocks(bn254_ctx* c, double sclk_mhz[3]) {
+  if (!c || !sclk_mhz || !c->ws.clk) return BN254_E_BAD_ARGUMENT;
+  HIP_TRY(hipSetDevice(c->device));
+  int wall_khz = 0;
+  HIP_TRY(hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, c->device));
+  std::vector<unsigned long long> h((size_t)3 * BN_CLK_MAX_WG * 2);
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(h.data(), c->ws.clk, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  for (int k = 0; k < 3; ++k) {
+    double cyc = 0, wall = 0;
+    for (size_t w = 0; w < BN_CLK_MAX_WG; ++w) {
+      const unsigned long long a = h[((size_t)k * BN_CLK_MAX_WG + w) * 2], b = h[((size_t)k * BN_CLK_MAX_WG + w) * 2 + 1];
+      if (b) { cyc += (double)a; wall += (double)b; }
+    }
+    sclk_mhz[k] = wall > 0 ? cyc / wall * (double)wall_khz * 1e-3 : 0.0;
+  }
+  return 0;
 }
 int bn254_ctx_last_kernel_ms(bn254_ctx* c, float ms[4]) {
   if (!c || !ms || !c->ev_valid) return BN254_E_BAD_ARGUMENT;
@@ -1362,6 +1419,7 @@ static int verify_after_decode(bn254_ctx* c, hipStream_t s, const uint8_t* d_msg
 
 int bn254_batch_verify_device(bn254_ctx* c, const uint8_t* d_msgs, const uint64_t* d_off, const uint8_t* d_sigs, const uint8_t* d_pks,
                               size_t n, uint32_t flags, uint8_t* d_status, void* stream) {
+  MsgsLenScope msgs_len_scope(c);
   if (!c || (n && (!d_msgs || !d_off || !d_sigs || !d_pks || !d_status))) return BN254_E_BAD_ARGUMENT;
   if (n == 0) return 0;
   if (misaligned(d_sigs) || misaligned(d_pks) || ((uintptr_t)d_off & 7u)) return BN254_E_MISALIGNED;
@@ -1383,6 +1441,7 @@ int bn254_batch_verify_device(bn254_ctx* c, const uint8_t* d_msgs, const uint64_
 // signatures 33 B (src/utils.rs:84-104), public keys 65 B (src/utils.rs:130-158, subgroup-checked on decode)
 int bn254_batch_verify_compressed_device(bn254_ctx* c, const uint8_t* d_msgs, const uint64_t* d_off, const uint8_t* d_sigs33,
                                          const uint8_t* d_pks65, size_t n, uint8_t* d_status, void* stream) {
+  MsgsLenScope msgs_len_scope(c);
   if (!c || (n && (!d_msgs || !d_off || !d_sigs33 || !d_pks65 || !d_status))) return BN254_E_BAD_ARGUMENT;
   if (n == 0) return 0;
   if ((uintptr_t)d_off & 7u) return BN254_E_MISALIGNED;
@@ -1398,6 +1457,7 @@ int bn254_batch_verify_compressed_device(bn254_ctx* c, const uint8_t* d_msgs, co
 }
 int bn254_batch_verify_compressed(bn254_ctx* c, const uint8_t* msgs, const uint64_t* off, const uint8_t* sigs33, const uint8_t* pks65, size_t n,
                                   uint8_t* status) {
+  MsgsLenScope msgs_len_scope(c);
   if (!c || (n && (!off || !sigs33 || !pks65 || !status))) return BN254_E_BAD_ARGUMENT;
   if (n == 0) return 0;
   HIP_TRY(hipSetDevice(c->device));
@@ -1456,6 +1516,7 @@ static int verify_host_overlapped(bn254_ctx* c, const uint8_t* msgs, const uint6
 // status bytes coming back.
 int bn254_batch_verify(bn254_ctx* c, const uint8_t* msgs, const uint64_t* off, const uint8_t* sigs, const uint8_t* pks, size_t n,
                        uint32_t flags, uint8_t* status) {
+  MsgsLenScope msgs_len_scope(c);
   if (!c || (n && (!off || !sigs || !pks || !status))) return BN254_E_BAD_ARGUMENT;
   if (n == 0) return 0;
   HIP_TRY(hipSetDevice(c->device));
@@ -1489,7 +1550,7 @@ int bn254_batch_verify(bn254_ctx* c, const uint8_t* msgs, const uint64_t* off, c
 int bn254_ctx_register_keys(bn254_ctx* c, const uint8_t* pks, size_t n_keys, uint32_t flags, uint8_t* key_status) {
   if (!c || (n_keys && !pks) || n_keys > 0xFFFFFFFFu) return BN254_E_BAD_ARGUMENT;
   HIP_TRY(hipSetDevice(c->device));
-  HIP_TRY(hipStreamSynchronize(c->stream));           // no verify may still be reading the previous table
+  HIP_TRY(hipDeviceSynchronize());                    // no keyed verify — on c->stream or on a caller's stream — may still be reading the previous tables
   c->n_keys = 0;
   if (n_keys == 0) return 0;
   if (n_keys > c->key_cap) {
@@ -1515,6 +1576,7 @@ int bn254_ctx_register_keys(bn254_ctx* c, const uint8_t* pks, size_t n_keys, uin
 }
 int bn254_batch_verify_keyed_device(bn254_ctx* c, const uint8_t* d_msgs, const uint64_t* d_off, const uint8_t* d_sigs, const uint32_t* d_key_idx,
                                     size_t n, uint32_t flags, uint8_t* d_status, void* stream) {
+  MsgsLenScope msgs_len_scope(c);
   if (!c || (n && (!d_msgs || !d_off || !d_sigs || !d_key_idx || !d_status))) return BN254_E_BAD_ARGUMENT;
   if (n == 0) return 0;
   if (misaligned(d_sigs) || misaligned(d_key_idx) || ((uintptr_t)d_off & 7u)) return BN254_E_MISALIGNED;
@@ -1526,7 +1588,6 @@ int bn254_batch_verify_keyed_device(bn254_ctx* c, const uint8_t* d_msgs, const u
   PROF_MARK(0);
   k_decode_g1<<<grid_for(n), BN_WAVE, 0, s>>>(d_sigs, n, flags, c->ws, PL_P1X, BY_P1_INF, 0);
   if (c->n_keys == 0 || !c->key_lines) {             // nothing registered: no table to read — every item is out of range
-    c->msgs_len_declared = 0;
     k_keyed_no_keys<<<grid_for(n), BN_WAVE, 0, s>>>(n, c->ws, d_status);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -1554,6 +1615,7 @@ int bn254_batch_verify_keyed_device(bn254_ctx* c, const uint8_t* d_msgs, const u
 }
 int bn254_batch_verify_keyed(bn254_ctx* c, const uint8_t* msgs, const uint64_t* off, const uint8_t* sigs, const uint32_t* key_idx, size_t n,
                              uint32_t flags, uint8_t* status) {
+  MsgsLenScope msgs_len_scope(c);
   if (!c || (n && (!off || !sigs || !key_idx || !status))) return BN254_E_BAD_ARGUMENT;
   if (n == 0) return 0;
   HIP_TRY(hipSetDevice(c->device));
@@ -1574,6 +1636,7 @@ int bn254_batch_verify_keyed(bn254_ctx* c, const uint8_t* msgs, const uint64_t* 
 int bn254_batch_verify_keyed_randomized_device(bn254_ctx* c, const uint8_t* d_msgs, const uint64_t* d_off, const uint8_t* d_sigs,
                                                const uint32_t* d_key_idx, size_t n, uint32_t flags, const uint8_t* seed32, uint8_t* d_status,
                                                void* stream) {
+  MsgsLenScope msgs_len_scope(c);
   if (!c || !seed32 || (n && (!d_msgs || !d_off || !d_sigs || !d_key_idx || !d_status))) return BN254_E_BAD_ARGUMENT;
   if (n == 0) return 0;
   if (n > 0xFFFFFFF0u) return BN254_E_BAD_ARGUMENT;
@@ -1624,6 +1687,7 @@ int bn254_batch_verify_keyed_randomized_device(bn254_ctx* c, const uint8_t* d_ms
 }
 int bn254_batch_verify_keyed_randomized(bn254_ctx* c, const uint8_t* msgs, const uint64_t* off, const uint8_t* sigs, const uint32_t* key_idx, size_t n,
                                         uint32_t flags, const uint8_t* seed32, uint8_t* status) {
+  MsgsLenScope msgs_len_scope(c);
   if (!c || !seed32 || (n && (!off || !sigs || !key_idx || !status))) return BN254_E_BAD_ARGUMENT;
   if (n == 0) return 0;
   HIP_TRY(hipSetDevice(c->device));
@@ -1645,6 +1709,7 @@ int bn254_batch_verify_keyed_randomized(bn254_ctx* c, const uint8_t* msgs, const
 int bn254_batch_verify_randomized_device(bn254_ctx* c, const uint8_t* d_msgs, const uint64_t* d_off, const uint8_t* d_sigs,
                                          const uint8_t* d_pks, size_t n, uint32_t flags, const uint8_t* seed32, uint8_t* d_status,
                                          uint8_t* d_group_ok, void* stream) {
+  MsgsLenScope msgs_len_scope(c);
   if (!c || !seed32 || (n && (!d_msgs || !d_off || !d_sigs || !d_pks || !d_status))) return BN254_E_BAD_ARGUMENT;
   if (n == 0) return 0;
   if (n > 0xFFFFFFFFu) return BN254_E_BAD_ARGUMENT;
@@ -1711,6 +1776,7 @@ int bn254_batch_verify_randomized_device(bn254_ctx* c, const uint8_t* d_msgs, co
 
 int bn254_batch_verify_randomized(bn254_ctx* c, const uint8_t* msgs, const uint64_t* off, const uint8_t* sigs, const uint8_t* pks, size_t n,
                                   uint32_t flags, const uint8_t* seed32, uint8_t* status, uint8_t* group_ok) {
+  MsgsLenScope msgs_len_scope(c);
   if (!c || !seed32 || (n && (!off || !sigs || !pks || !status))) return BN254_E_BAD_ARGUMENT;
   if (n == 0) return 0;
   HIP_TRY(hipSetDevice(c->device));
@@ -1733,6 +1799,7 @@ int bn254_batch_verify_randomized(bn254_ctx* c, const uint8_t* msgs, const uint6
 
 int bn254_batch_hash_to_g1_device(bn254_ctx* c, const uint8_t* d_msgs, const uint64_t* d_off, size_t n, uint8_t* d_points, uint8_t* d_status,
                                   uint8_t* d_tries, void* stream) {
+  MsgsLenScope msgs_len_scope(c);
   if (!c || (n && (!d_msgs || !d_off || !d_points || !d_status))) return BN254_E_BAD_ARGUMENT;
   if (n == 0) return 0;
   if (misaligned(d_points) || ((uintptr_t)d_off & 7u)) return BN254_E_MISALIGNED;
@@ -1753,6 +1820,7 @@ int bn254_batch_hash_to_g1_device(bn254_ctx* c, const uint8_t* d_msgs, const uin
   return 0;
 }
 int bn254_batch_hash_to_g1(bn254_ctx* c, const uint8_t* msgs, const uint64_t* off, size_t n, uint8_t* points, uint8_t* status, uint8_t* tries) {
+  MsgsLenScope msgs_len_scope(c);
   if (!c || (n && (!off || !points || !status))) return BN254_E_BAD_ARGUMENT;
   if (n == 0) return 0;
   HIP_TRY(hipSetDevice(c->device));
@@ -1924,6 +1992,7 @@ int bn254_batch_g2_mul(bn254_ctx* c, const uint8_t* p, const uint8_t* k, size_t 
 
 int bn254_batch_sign_device(bn254_ctx* c, const uint8_t* d_msgs, const uint64_t* d_off, const uint8_t* d_sks, size_t n, uint8_t* d_sigs,
                             uint8_t* d_status, void* stream) {
+  MsgsLenScope msgs_len_scope(c);
   if (!c || (n && (!d_msgs || !d_off || !d_sks || !d_sigs || !d_status))) return BN254_E_BAD_ARGUMENT;
   if (n == 0) return 0;
   if (misaligned(d_sks) || misaligned(d_sigs) || ((uintptr_t)d_off & 7u)) return BN254_E_MISALIGNED;
@@ -1937,6 +2006,7 @@ int bn254_batch_sign_device(bn254_ctx* c, const uint8_t* d_msgs, const uint64_t*
   return 0;
 }
 int bn254_batch_sign(bn254_ctx* c, const uint8_t* msgs, const uint64_t* off, const uint8_t* sks, size_t n, uint8_t* sigs, uint8_t* status) {
+  MsgsLenScope msgs_len_scope(c);
   if (!c || (n && (!off || !sks || !sigs || !status))) return BN254_E_BAD_ARGUMENT;
   if (n == 0) return 0;
   HIP_TRY(hipSetDevice(c->device));
@@ -1980,6 +2050,7 @@ int bn254_batch_g2_sum(bn254_ctx* c, const uint8_t* pts, const uint64_t* seg, si
 int bn254_batch_aggregate_verify_device(bn254_ctx* c, const uint8_t* d_msgs, const uint64_t* d_msg_off, size_t n_msgs, const uint8_t* d_pk_pool,
                                         size_t n_signers, const uint8_t* d_sig_pool, const uint32_t* d_tuple_msg, const uint64_t* d_tuple_off,
                                         const uint32_t* d_signer_idx, size_t n, uint32_t flags, uint8_t* d_status, void* stream) {
+  MsgsLenScope msgs_len_scope(c);
   if (!c || !n_msgs || !n_signers || (n && (!d_msgs || !d_msg_off || !d_pk_pool || !d_sig_pool || !d_tuple_msg || !d_tuple_off || !d_signer_idx || !d_status)))
     return BN254_E_BAD_ARGUMENT;
   if (n == 0) return 0;
@@ -2009,10 +2080,15 @@ int bn254_batch_aggregate_verify_device(bn254_ctx* c, const uint8_t* d_msgs, con
       // the signature tables are per message: worth it when a message's table (4 n_signers entries of ~2 additions + an inversion)
       // is shared by enough tuples, and only while it fits a budget of HBM
       const size_t entries = n_msgs * 2 * n_groups * 16;
-      if (n >= AGG_SUBSET_G1_TUPLES_PER_MSG * n_msgs && entries * (2 * BN_LIMBS * sizeof(int32_t) + 1) <= AGG_SUBSET_G1_MAX_BYTES) {
-        groups4 = 2 * n_groups;
-        if ((rc = pool_reserve(c, 4, 2, entries))) return rc;
-        k_pool_subsets_g1<<<grid_for(entries), BN_WAVE, 0, s>>>(c->pool[1], n_signers, groups4, n_msgs, c->pool[4]);
+      // priced at what pool_reserve allocates per entry (a record of BN_POOL_HALF_WORDS words + its status byte, entries rounded up to 256)
+      const size_t table_bytes = ((entries + 255) & ~(size_t)255) * (BN_POOL_HALF_WORDS * sizeof(int32_t) + 1);
+      if (n >= AGG_SUBSET_G1_TUPLES_PER_MSG * n_msgs && table_bytes <= AGG_SUBSET_G1_MAX_BYTES) {
+        if (pool_reserve(c, 4, 2, entries) == 0) {
+          groups4 = 2 * n_groups;
+          k_pool_subsets_g1<<<grid_for(entries), BN_WAVE, 0, s>>>(c->pool[1], n_signers, groups4, n_msgs, c->pool[4]);
+        } else {
+          (void)hipGetLastError();     // no HBM for the table: the signatures are added one by one (groups4 = 0), same statuses
+        }
       }
     }
     PROF_MARK(1);
@@ -2040,6 +2116,7 @@ int bn254_batch_aggregate_verify_device(bn254_ctx* c, const uint8_t* d_msgs, con
 int bn254_batch_aggregate_verify(bn254_ctx* c, const uint8_t* msgs, const uint64_t* msg_off, size_t n_msgs, const uint8_t* pk_pool, size_t n_signers,
                                  const uint8_t* sig_pool, const uint32_t* tuple_msg, const uint64_t* tuple_off, const uint32_t* signer_idx, size_t n,
                                  uint32_t flags, uint8_t* status) {
+  MsgsLenScope msgs_len_scope(c);
   if (!c || !n_msgs || !n_signers || (n && (!msg_off || !pk_pool || !sig_pool || !tuple_msg || !tuple_off || !signer_idx || !status))) return BN254_E_BAD_ARGUMENT;
   if (n == 0) return 0;
   if (!offsets_ok(tuple_off, n) || !offsets_ok(msg_off, n_msgs)) return BN254_E_BAD_ARGUMENT;
@@ -2097,9 +2174,10 @@ int bn254_probe_issue_rate(bn254_ctx* c, int op, int waves_per_simd, double* wav
   float best = 0;
   for (int rep = 0; rep < 3; ++rep) {       // first repetition warms up; keep the fastest
     HIP_TRY(hipEventRecord(e0, c->stream));
-    if (op == 0) k_issue_probe<0><<<blocks, 256, 0, c->stream>>>(out, 12345u);
-    else if (op == 1) k_issue_probe<1><<<blocks, 256, 0, c->stream>>>(out, 12345u);
-    else k_issue_probe<2><<<blocks, 256, 0, c->stream>>>(out, 12345u);
+    if (c->ws.clk) HIP_TRY(hipMemsetAsync(c->ws.clk + (size_t)2 * BN_CLK_MAX_WG * 2, 0, sizeof(unsigned long long) * 2 * BN_CLK_MAX_WG, c->stream));
+    if (op == 0) k_issue_probe<0><<<blocks, 256, 0, c->stream>>>(out, 12345u, c->ws.clk);
+    else if (op == 1) k_issue_probe<1><<<blocks, 256, 0, c->stream>>>(out, 12345u, c->ws.clk);
+    else k_issue_probe<2><<<blocks, 256, 0, c->stream>>>(out, 12345u, c->ws.clk);
     HIP_TRY(hipEventRecord(e1, c->stream));
     HIP_TRY(hipEventSynchronize(e1));
     float ms = 0;

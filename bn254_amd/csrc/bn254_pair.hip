@@ -167,7 +167,9 @@ KERNEL_PAIR void k_miller_verify_pair(size_t n, Ws ws, const uint32_t* map, cons
   pk.inf = ws_byte(ws, BY_Q_INF, i) != 0;
   __shared__ Fp12PairSlot lds_f[BN_PAIR_WG];
   Fp12& f = lds_f[threadIdx.x].v;
+  BN_CLK_BEGIN(ws);
   miller_loop<true, true, true>(f, h, pk, sig);
+  BN_CLK_END(ws, 0);
   ws_store_f12_own(ws, i, f);
 }
 // Keyed verify: f = miller(H(m), pk[key_idx[i]]) * miller(sig, -G2) with BOTH line sequences read from tables — pair A from
@@ -200,11 +202,14 @@ KERNEL_PAIR void k_miller_verify_keyed_pair(size_t n, Ws ws, const uint32_t* key
   __shared__ Fp12PairSlot lds_f[BN_PAIR_WG];
   Fp12& f = lds_f[threadIdx.x].v;
   typedef const int32_t (*LinePtr)[2][2][BN_LIMBS];
+  BN_CLK_BEGIN(ws);
   miller_loop_keyed<true>(f, h, key_inf, (LinePtr)(kt.lines + (size_t)key * BN_N_FIXED_LINES * BN_KEY_LINE_WORDS), sig);
+  BN_CLK_END(ws, 0);
   ws_store_f12_own(ws, i, f);
 }
 int bn254_pair_miller_verify_keyed(size_t n, Ws ws, const uint32_t* key_idx, KeyTable kt, hipStream_t s, size_t base, const uint32_t* map,
                                    const uint32_t* count) {
+  if (ws.clk) HIP_TRY(hipMemsetAsync(ws.clk, 0, sizeof(unsigned long long) * 2 * BN_CLK_MAX_WG, s));
   k_miller_verify_keyed_pair<<<(unsigned)((2 * n + BN_PAIR_WG - 1) / BN_PAIR_WG), BN_PAIR_WG, 0, s>>>(n, ws, key_idx, kt, base, map, count);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -457,6 +462,7 @@ int bn254_pair_aggregate(const uint32_t* tuple_msg, const uint64_t* tuple_off, c
   return 0;
 }
 int bn254_pair_miller_verify(size_t n, Ws ws, const uint32_t* map, const uint32_t* count, hipStream_t s, int mode) {
+  if (ws.clk) HIP_TRY(hipMemsetAsync(ws.clk, 0, sizeof(unsigned long long) * 2 * BN_CLK_MAX_WG, s));
   k_miller_verify_pair<<<(unsigned)((2 * n + BN_PAIR_WG - 1) / BN_PAIR_WG), BN_PAIR_WG, 0, s>>>(n, ws, map, count, mode);
   HIP_TRY(hipGetLastError());
   return 0;

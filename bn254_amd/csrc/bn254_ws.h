@@ -38,7 +38,22 @@ struct Ws {
   uint8_t* h_next;    // [stride]  first counter not yet tried
   uint32_t* h_list;   // [2][stride] compacted indices of the messages still without a point
   uint32_t* h_cnt;    // [HASH_MAX_ROUNDS + 1] number of entries of the list feeding round r
+  // clock probe (BN254_OPT_CLOCK_PROBE; nullptr = off): [2 kernels: Miller loop, final exponentiation][BN_CLK_MAX_WG][2] — per workgroup
+  // the shader-clock cycles (s_memtime) and the constant-rate ticks (s_memrealtime) its first lane saw between entry and exit:
+  // their ratio is the clock the chip actually ran that kernel at (bench.py: roofline.effective_sclk_mhz)
+  unsigned long long* clk;
 };
+#define BN_CLK_MAX_WG 4096
+#define BN_CLK_BEGIN(ws)                                                                         \
+  unsigned long long clk0_ = 0, wall0_ = 0;                                                      \
+  if ((ws).clk && threadIdx.x == 0) { clk0_ = clock64(); wall0_ = wall_clock64(); }
+#define BN_CLK_END(ws, slot)                                                                     \
+  do {                                                                                           \
+    if ((ws).clk && threadIdx.x == 0 && blockIdx.x < BN_CLK_MAX_WG) {                            \
+      unsigned long long* p_ = (ws).clk + ((size_t)(slot) * BN_CLK_MAX_WG + blockIdx.x) * 2;    \
+      p_[0] = clock64() - clk0_; p_[1] = wall_clock64() - wall0_;                                \
+    }                                                                                            \
+  } while (0)
 #define HASH_NONE 0xFFFFFFFFu
 #define HASH_DONE 0xFFFFFFFEu                    // k_hash_direct has already written the point of this message
 #define HASH_DIRECT_WIDTH_DEFAULT 32             // counters tried at once per message by k_hash_direct (lanes of one wave; 1, 2, .. 32)

@@ -21,6 +21,7 @@ OPT_TRIO_MAX_BATCH = 6
 OPT_HASH_DIRECT_WIDTH = 7
 OPT_TRIO_WAVE_ROLES = 8
 OPT_AGG_SUBSET_MIN_TUPLES = 9
+OPT_CLOCK_PROBE = 10
 
 
 class NativeError(RuntimeError):
@@ -99,6 +100,12 @@ class Engine:
         ms = (ctypes.c_float * 4)()
         _check("bn254_ctx_last_kernel_ms", self._lib.bn254_ctx_last_kernel_ms(self._h, ms))
         return {"decode": ms[0], "hash_to_g1": ms[1], "miller_loop": ms[2], "final_exp": ms[3]}
+
+    def last_clocks(self):
+        """OPT_CLOCK_PROBE on: achieved shader clock (MHz) of the last lane-pair Miller kernel, final exponentiation and issue probe"""
+        mhz = (ctypes.c_double * 3)()
+        _check("bn254_ctx_last_clocks", self._lib.bn254_ctx_last_clocks(self._h, mhz))
+        return {"miller_loop": mhz[0], "final_exp": mhz[1], "issue_probe": mhz[2]}
 
     # ---- host-pointer entry points ------------------------------------------------------
     def batch_verify(self, messages, sigs, pks, flags=0):

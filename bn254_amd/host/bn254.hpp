@@ -21,9 +21,11 @@
 
 namespace bn254 {
 
-enum class ErrorKind : uint8_t {
-  HashToPointError = 1, IndexOutOfBounds, InvalidEncoding, InvalidGroupPoint, InvalidLength, NotMemberError,
-  ToAffineConversion, PointInJacobian, VerificationFailed, SerializationError, HexDecodeFailed
+enum class ErrorKind : uint8_t {   // the status codes of include/bn254_hip.h = 1 + the variant's index in /root/reference/src/error.rs:6-29
+  HashToPointError = BN254_ERR_HASH_TO_POINT, IndexOutOfBounds = BN254_ERR_INDEX_OUT_OF_BOUNDS, InvalidEncoding = BN254_ERR_INVALID_ENCODING,
+  InvalidGroupPoint = BN254_ERR_INVALID_GROUP_POINT, InvalidLength = BN254_ERR_INVALID_LENGTH, NotMemberError = BN254_ERR_NOT_MEMBER,
+  ToAffineConversion = BN254_ERR_TO_AFFINE_CONVERSION, PointInJacobian = BN254_ERR_POINT_IN_JACOBIAN,
+  VerificationFailed = BN254_ERR_VERIFICATION_FAILED, SerializationError = BN254_ERR_SERIALIZATION, HexDecodeFailed = BN254_ERR_HEX_DECODE_FAILED
 };
 struct Error : std::runtime_error {
   ErrorKind kind;

@@ -70,12 +70,16 @@ typedef struct bn254_ctx bn254_ctx;
 /* status codes */
 #define BN254_OK 0
 #define BN254_ERR_HASH_TO_POINT 1
+#define BN254_ERR_INDEX_OUT_OF_BOUNDS 2 /* keyed verify: key_idx >= n_keys; aggregate verify: signer / message index out of range */
 #define BN254_ERR_INVALID_ENCODING 3
 #define BN254_ERR_INVALID_GROUP_POINT 4
 #define BN254_ERR_INVALID_LENGTH 5
 #define BN254_ERR_NOT_MEMBER 6
+#define BN254_ERR_TO_AFFINE_CONVERSION 7 /* never produced by the library (host mirrors: the reference's vocabulary, src/error.rs:6-29) */
 #define BN254_ERR_POINT_IN_JACOBIAN 8
 #define BN254_ERR_VERIFICATION_FAILED 9
+#define BN254_ERR_SERIALIZATION 10       /* host mirrors only */
+#define BN254_ERR_HEX_DECODE_FAILED 11   /* host mirrors only */
 
 const char *bn254_version(void);
 
@@ -122,7 +126,9 @@ int bn254_batch_verify_compressed_device(bn254_ctx *ctx, const uint8_t *d_msgs, 
  * memory).  key_status[j] (may be NULL) = what PublicKey::from_uncompressed reports for key j: 0, 6 (a coordinate >= q) or 4
  * (not on the curve / not in the order-r subgroup — the subgroup check ALWAYS runs here, as in AffineG2::new; flags: only
  * BN254_FLAG_REJECT_IDENTITY is looked at).  An all-zero key is the identity (its pair contributes 1).  The call
- * synchronises the context's stream; it must not overlap a keyed verify of the same context.
+ * waits for the whole device (hipDeviceSynchronize) before it touches the tables — a keyed verify enqueued earlier on any
+ * stream has finished reading them — and returns with the new set in place; the same holds whenever a call has to grow the
+ * context's workspace or staging buffers (presize with bn254_ctx_reserve to keep that out of the steady state).
  *
  * bn254_batch_verify_keyed[_device]: as bn254_batch_verify with key_idx[i] (uint32) in place of the i-th public key.
  * status[i] = the signature's decode error, else 2 (IndexOutOfBounds) if key_idx[i] >= n_keys, else the key's registration
@@ -288,6 +294,10 @@ int bn254_ctx_set_profiling(bn254_ctx *ctx, int enabled);
 #define BN254_OPT_AGG_SUBSET_MIN_TUPLES 9 /* aggregate verify: from this many tuples on (default 4096) the sums of all subsets of every 8 consecutive
                                             keys of the pool are tabulated once per call and a tuple adds one table entry per group instead of one
                                             key per signer (pools of up to 2048 signers, lists longer than n_signers / 8); 0 = never.  Same statuses. */
+#define BN254_OPT_CLOCK_PROBE 10 /* measurement: 1 = the lane-pair Miller / final-exponentiation kernels and the issue probe record, per workgroup,
+                                  shader-clock cycles (s_memtime) and constant-rate ticks (s_memrealtime) between entry and exit, read back by
+                                  bn254_ctx_last_clocks: the clock the chip actually sustains under this load (power-limited parts run below
+                                  their nominal 2.4 GHz).  Costs two scalar clock reads per workgroup; default 0 */
 #define BN254_OPT_HASH_MAX_TRIES 2 /* test knob: counters tried before HashToPointError; 0 = 255 as in src/hash.rs:40 */
 int bn254_ctx_set_option(bn254_ctx *ctx, int option, int value);
 /* per-kernel times of the last verify-shaped call with profiling on (HIP events on the call's stream):
@@ -296,6 +306,9 @@ int bn254_ctx_set_option(bn254_ctx *ctx, int option, int value);
  * hash_to_g1 ms[1] = the hash rounds, ms[2] = encoding the points, ms[0] = ms[3] = 0; aggregate_verify ms[0] = the pools
  * (decoding, hashing the messages, the subset-sum table), ms[1] = the aggregation kernel. */
 int bn254_ctx_last_kernel_ms(bn254_ctx *ctx, float ms[4]);
+/* with BN254_OPT_CLOCK_PROBE on: achieved shader clock in MHz of the most recent lane-pair Miller kernel [0], final exponentiation [1]
+ * and bn254_probe_issue_rate kernel [2] on this context (0 = that kernel has not run since the option was set).  Synchronises the device. */
+int bn254_ctx_last_clocks(bn254_ctx *ctx, double sclk_mhz[3]);
 
 #ifdef __cplusplus
 }

@@ -207,6 +207,23 @@ def test_bench_gpus2_pairing_command_line_checksum_vs_oracle():
     assert "%016x" % (total % (1 << 64)) == r["config"]["gt_checksum_u64"]
 
 
+def _check_scaling_detail(r, W, with_kernels):
+    """the N > 1 line carries what a sub-linear curve would be diagnosed with: per-rank elapsed (min / max / mean, one value per
+    rank), per-rank kernel time, the collectives' own time — consistent with the headline ms_per_step (= max over ranks)"""
+    d = r["scaling_detail"]
+    el = d["own_elapsed_ms_per_step"]
+    assert len(el["per_rank"]) == W and el["min"] <= el["mean"] <= el["max"] and el["min"] > 0
+    assert el["max"] <= r["ms_per_step"] * 1.0001                          # a rank's own clock stops before the closing barrier
+    assert 0 <= d["slowest_rank"] < W and 0.0 <= d["spread_pct"] < 100.0
+    co = d["collective_ms_per_step"]
+    assert len(co["per_rank"]) == W and 0.0 <= co["min"] <= co["max"] <= r["ms_per_step"]
+    if with_kernels:
+        km = d["kernel_ms_per_step"]
+        assert len(km["per_rank"]) == W and 0.0 < km["min"] and all(k <= e * 1.0001 for k, e in zip(km["per_rank"], el["per_rank"]))
+    else:
+        assert d["kernel_ms_per_step"] is None
+
+
 @pytest.mark.gpu
 @pytest.mark.timeout(900)
 def test_bench_gpus4_both_workloads_all_shards_checked():
@@ -224,12 +241,14 @@ def test_bench_gpus4_both_workloads_all_shards_checked():
     assert r["n_gpus"] == W and r["config"]["bit_exact_vs_expected"] is True and r["config"]["batch_per_gpu"] == 2048
     assert r["config"]["status_vectors_checked"] == 2 * (1 + W)              # 2 checks x (own shard + W gathered shards)
     assert abs(r["value"] - 2 * W * 2048 * 2 / (r["ms_per_step"] * 2e-3)) / r["value"] < 1e-6
+    _check_scaling_detail(r, W, with_kernels=True)
     n = 512
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(W), "--workload", "pairing", "--steps", "2", "--warmup", "1",
                         "--batch", str(n)], env=_two_rank_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=840)
     assert p.returncode == 0, p.stderr[-2000:]
     r = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert r["n_gpus"] == W and r["config"]["batch_per_gpu"] == n
+    _check_scaling_detail(r, W, with_kernels=False)
     spec = __import__("importlib.util").util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
     bench = __import__("importlib.util").util.module_from_spec(spec)
     spec.loader.exec_module(bench)
@@ -263,3 +282,6 @@ def test_bench_rccl_collectives_on_one_rank():
         assert p.returncode == 0, p.stderr[-2000:]
         r = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
         assert r["n_gpus"] == 1 and r["config"][key] is True and "nccl" in r["config"]["collective"]
+        # the RCCL collectives are timed by HIP events on the rank's stream
+        _check_scaling_detail(r, 1, with_kernels="--workload" not in extra)
+        assert "HIP events" in r["scaling_detail"]["collective_timed_by"] and r["scaling_detail"]["collective_ms_per_step"]["max"] > 0

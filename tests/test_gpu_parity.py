@@ -969,7 +969,9 @@ def test_keyed_verify_vs_oracle(eng, c, derived):
     # the Python mirror of the reference API
     import bn254_amd as bn
     good = [bn.PublicKey(bytes(keys[j])) for j in (0, 1, 2)]
-    assert bn.ECDSA.register_keys(good + [bn.PublicKey(bytes(keys[5]))]) == [None, None, None] + [bn.Error(4)] or True
+    got_reg = bn.ECDSA.register_keys(good + [bn.PublicKey(bytes(keys[j])) for j in (5, 6, 7, 8)])
+    assert got_reg == [None, None, None, bn.Error(4), bn.Error(6), bn.Error(4), None], got_reg      # the mirror's error mapping, key by key
+    assert got_reg[3].kind == bn.ErrorKind.InvalidGroupPoint and got_reg[4].kind == bn.ErrorKind.NotMemberError
     res = bn.ECDSA.batch_verify_keyed([b"api-keyed"] * 3, [bn.ECDSA.sign(b"api-keyed", bn.PrivateKey.try_from(sks[0].hex()))] * 3, [0, 1, 7])
     assert res[0] is None and res[1].kind == bn.ErrorKind.VerificationFailed and res[2].kind == bn.ErrorKind.IndexOutOfBounds
     # an empty key set: every index is out of range
