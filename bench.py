@@ -226,6 +226,10 @@ def other_workloads(args, torch, eng, dev, stream):
     if args.workload == "verify-host":
         n = args.batch or BATCH
         msgs, sigs, pks, expected = make_verify_batch(eng, n)
+        pin_threads = os.environ.get("BN254_PINNED_STAGING")             # A/B knob: threads of the pinned staging path (0 = off), default = the library's
+        if pin_threads is not None:
+            from bn254_amd.engine import OPT_PINNED_STAGING
+            eng.set_option(OPT_PINNED_STAGING, int(pin_threads))
         assert eng.batch_verify(msgs, sigs, pks) == expected
         packed = bn254_pack(msgs)
         st = __import__("ctypes").create_string_buffer(n)
@@ -234,7 +238,8 @@ def other_workloads(args, torch, eng, dev, stream):
         dt = timed(lambda: lib.bn254_batch_verify(h, packed[0], packed[1], sigs, pks, n, 0, st), args.steps, args.warmup, collect)
         assert st.raw == expected
         out.update(metric="BN254 pairings/sec (batch verify, host buffers: H2D + kernels + D2H + sync)", value=2 * n / dt, unit="pairings/s",
-                   ms_per_step=1e3 * dt, config={"workload": "configs[1] through the host-pointer entry point (PCIe-inclusive)", "batch": n},
+                   ms_per_step=1e3 * dt, config={"workload": "configs[1] through the host-pointer entry point (PCIe-inclusive)", "batch": n,
+                                                 "pinned_staging_threads": pin_threads},
                    roofline=kernel_roofline("k_miller_verify_pair", FP_MUL_MILLER * n, kms["miller_loop"]), kernel_ms=dict(kms))
         if cpu:
             from oracle import c_oracle
@@ -410,13 +415,19 @@ def other_workloads(args, torch, eng, dev, stream):
         assert int(d_st.max()) == 0
         fp_mul = (FP_MUL_HASH_FILTER * HASH_MEAN_TRIES + FP_MUL_HASH_FINISH) * n
         io = (32 + 8 + 64 + 1) * n
-        out.update(metric="hash_to_try_and_increment messages/sec", value=n / dt, unit="messages/s", ms_per_step=1e3 * dt, kernel_ms=dict(kms),
+        # the library's event slots for this entry point: [0] filter rounds, [1] k_hash_finish, [2] encode (include/bn254_hip.h)
+        k_hash = {"filter_rounds_init_round_resolve": kms["decode"], "finish_square_roots": kms["hash_to_g1"], "encode_points": kms["miller_loop"]}
+        whole_ms = kms["decode"] + kms["hash_to_g1"]
+        out.update(metric="hash_to_try_and_increment messages/sec", value=n / dt, unit="messages/s", ms_per_step=1e3 * dt, kernel_ms=k_hash,
                    config={"workload": "configs[4]: %d 32-byte messages -> G1 points (SHA-256 try-and-increment in rounds: Jacobi filter, then one "
                                        "square root per message)" % n, "batch": n},
                    roofline=kernel_roofline("k_hash_finish", FP_MUL_HASH_FINISH * n, kms["hash_to_g1"],
-                                            note="kernel_ms is the whole round sequence (k_hash_init / round / resolve / finish: HIP events around it); the "
-                                                 "products counted are those of k_hash_finish, the square roots — SHA-256 and the Jacobi symbols of the "
-                                                 "filter rounds are 32-bit integer work outside the MAC32 unit, so `frac` understates the utilisation"))
+                                            note="per kernel: the square roots of k_hash_finish over ITS OWN duration (HIP events around the kernel)"))
+        whole = kernel_roofline("k_hash_init / round / resolve / finish (whole sequence)", fp_mul, whole_ms,
+                                note="whole sequence: every Fq product of the filter rounds and the square roots over the duration of all four "
+                                     "kernels — SHA-256 and the Jacobi symbols of the filter rounds are 32-bit integer work outside the MAC32 unit, so "
+                                     "this figure understates the utilisation")
+        out["roofline"]["whole_sequence"] = {k: whole[k] for k in ("kernel", "achieved", "frac", "kernel_ms", "fp_products_per_launch", "note")}
         out["roofline"]["hbm"] = {"algorithmic_bytes_per_step": io, "achieved_GBps": io / dt / 1e9, "peak_GBps": HBM_PEAK_GBPS}
         out["roofline"]["fp_products_incl_filter_per_launch"] = fp_mul
         if cpu:
@@ -462,6 +473,13 @@ def other_workloads(args, torch, eng, dev, stream):
             eng.batch_aggregate_verify_device(d_msgs.data_ptr(), d_moff.data_ptr(), M, d_pk.data_ptr(), S, d_sig.data_ptr(), tuple_msg.data_ptr(),
                                               tuple_off.data_ptr(), signer_idx.data_ptr(), n, d_st.data_ptr(), stream=sh)
         eng.set_profiling(True)
+        # same batch in the caller's (random) tuple order, without the device-side bucketing by message (BN254_OPT_AGG_SORT_BY_MSG = 0)
+        eng.set_option(11, 0)
+        dt_unsorted = timed(call, max(1, args.steps // 2), 1, collect)
+        k_unsorted = {k: v * args.steps / max(1, args.steps // 2) for k, v in kms.items()}
+        for key in kms:
+            kms[key] = 0.0
+        eng.set_option(11, 1)
         dt = timed(call, args.steps, args.warmup, collect)
         assert int(d_st.max()) == 0
         k_table = dict(kms)
@@ -483,6 +501,8 @@ def other_workloads(args, torch, eng, dev, stream):
                            "mean_signers_per_tuple": total_signers / n, "key_route": "subset sums of the key pool: %d table additions per tuple" % groups,
                            "signature_route": ("per-message subset tables: %d table additions per tuple" % (2 * groups)) if sig_tables else "one addition per signer"},
                    without_subset_sum_table={"verifies_per_s": n / dt_direct, "ms_per_step": 1e3 * dt_direct},
+                   without_bucketing_by_message={"verifies_per_s": n / dt_unsorted, "ms_per_step": 1e3 * dt_unsorted, "aggregate_kernel_ms": k_unsorted["hash_to_g1"],
+                                                 "pools_hash_table_ms": k_unsorted["decode"]},
                    roofline=kernel_roofline("k_aggregate_pair", agg_products, k_table["hash_to_g1"],
                                             note="products per tuple: 13 per signature-table entry (group of 4 signers) or signature added + 26 per key-table entry "
                                                  "(group of 8 keys) + 52; the walk over the signer list (status checks, mask bits) is not MAC32 work"))

@@ -81,21 +81,30 @@ BN_DEV void hash_state_init(HashState& s, const uint8_t* msg, uint64_t len) {
 }
 
 // Is a (0 <= a < q, plain integer) a square mod q?  Jacobi symbol (a/q) by the binary algorithm — shifts,
-// subtractions and the quadratic-reciprocity sign rules, no multiplications: ~190 iterations of ~70 simple
-// instructions against the ~370 Montgomery products of the square-root exponentiation it guards.  Zero counts
-// as a square (its root is 0), exactly like fp_sqrt.
-BN_DEVN bool u256_is_square_mod_q(const U256& a_in) {
-  uint32_t a[8], n[8];
-  uint32_t any = 0;
+// subtractions and the quadratic-reciprocity sign rules, no multiplications: ~190-250 passes (every pass strips ALL trailing
+// zeros of a, applies (2/n) once for the strip, subtracts) against the ~370 Montgomery products of the square-root
+// exponentiation it guards.  Zero counts as a square (its root is 0), exactly like fp_sqrt.
+// The operands shrink by ~2 bits per pass, so the passes run in PHASES of 8, 6, 4 and 2 words: a phase ends when every lane of
+// the wave that is still working has both operands inside the next narrower width (one wave vote per pass) — on average the
+// multiword subtractions, shifts and selects touch little more than half of the eight words.
+#if defined(__HIPCC__)
+#define BN_WAVE_ALL(x) (__all((int)(x)) != 0)
+#else
+#define BN_WAVE_ALL(x) (x)
+#endif
+template <int W> BN_DEV void jacobi_passes(uint32_t* a, uint32_t* n, uint32_t& t, uint32_t& any, int& budget) {
+  while (budget > 0) {
+    const bool act = any != 0;
+    if (!BN_WAVE_ANY(act)) return;
+    if constexpr (W > 2) {
+      if (BN_WAVE_ALL(!act || (a[W - 1] | a[W - 2] | n[W - 1] | n[W - 2]) == 0)) return;      // everyone fits W - 2 words
+    }
+    --budget;                                          // each pass removes >= 1 bit of |a| + |n| (<= 508)
+    if (!act) continue;
+    if (a[0] == 0) {                                   // 32 trailing zeros: an even number of halvings, no sign change
 #pragma unroll
-  for (int i = 0; i < 8; ++i) { a[i] = a_in.w[i]; n[i] = C_Q[i]; any |= a[i]; }
-  if (any == 0) return true;
-  uint32_t t = 0;                                   // bit 0: parity of the sign flips
-  for (int iter = 0; iter < 600 && any != 0; ++iter) {   // each pass removes >= 1 bit of |a| + |n| (<= 508)
-    if (a[0] == 0) {                                // 32 trailing zeros: an even number of halvings, no sign change
-#pragma unroll
-      for (int i = 0; i < 7; ++i) a[i] = a[i + 1];
-      a[7] = 0;
+      for (int i = 0; i < W - 1; ++i) a[i] = a[i + 1];
+      a[W - 1] = 0;
       continue;
     }
     const uint32_t s = (uint32_t)__builtin_ctz(a[0]);
@@ -103,30 +112,43 @@ BN_DEVN bool u256_is_square_mod_q(const U256& a_in) {
     t ^= s & ((n[0] >> 1) ^ (n[0] >> 2));
     if (s) {
 #pragma unroll
-      for (int i = 0; i < 7; ++i) a[i] = (a[i] >> s) | (a[i + 1] << (32 - s));
-      a[7] >>= s;
+      for (int i = 0; i < W - 1; ++i) a[i] = (a[i] >> s) | (a[i + 1] << (32 - s));
+      a[W - 1] >>= s;
     }
     // a is odd: d1 = a - n, d2 = n - a
-    uint32_t d1[8], d2[8], b1 = 0, b2 = 0;
+    uint32_t d1[W], d2[W], b1 = 0, b2 = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < W; ++i) {
       uint64_t x = (uint64_t)a[i] - n[i] - b1, y = (uint64_t)n[i] - a[i] - b2;
       d1[i] = (uint32_t)x; b1 = (uint32_t)(x >> 63);
       d2[i] = (uint32_t)y; b2 = (uint32_t)(y >> 63);
     }
-    const bool lt = b1 != 0;                        // a < n: swap (reciprocity: flip iff both = 3 mod 4), then subtract
+    const bool lt = b1 != 0;                           // a < n: swap (reciprocity: flip iff both = 3 mod 4), then subtract
     t ^= lt ? ((a[0] & n[0]) >> 1) : 0u;
     any = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < W; ++i) {
       const uint32_t an = lt ? d2[i] : d1[i];
       n[i] = lt ? a[i] : n[i];
       a[i] = an;
       any |= an;
     }
   }
+}
+BN_DEVN bool u256_is_square_mod_q(const U256& a_in) {
+  uint32_t a[8], n[8];
+  uint32_t any = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { a[i] = a_in.w[i]; n[i] = C_Q[i]; any |= a[i]; }
+  const bool zero = any == 0;
+  uint32_t t = 0;                                      // bit 0: parity of the sign flips
+  int budget = 600;
+  jacobi_passes<8>(a, n, t, any, budget);
+  jacobi_passes<6>(a, n, t, any, budget);
+  jacobi_passes<4>(a, n, t, any, budget);
+  jacobi_passes<2>(a, n, t, any, budget);
   // gcd(a_in, q) = n = 1 for a prime q and 0 < a_in < q
-  return (t & 1u) == 0;
+  return zero || (t & 1u) == 0;
 }
 
 // The range rules applied to a digest value x (hash.rs:49-54): rejected if >= 5q, reduced by mod_u256's strict rule;

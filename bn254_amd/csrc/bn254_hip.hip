@@ -14,6 +14,7 @@
 // HBM traffic per verify is 225 B of input/output + 2 x ~1 KB of workspace hand-off against ~19 k Montgomery
 // products: the path is bound by VALU integer-multiply issue, not by HBM.
 #include <hip/hip_runtime.h>
+#include <thread>
 #include <vector>
 
 #include <cstdio>
@@ -204,20 +205,33 @@ KERNEL_SMALL void k_hash_round(const uint8_t* msgs, const uint64_t* off, uint64_
     if (hash_try_filter(hs, msg, len, ctr)) atomicMin(&ws.h_best[i], ctr);
   }
 }
-// after a round: messages without a passing counter are queued for the next round (or give up at max_ctr)
+// after a round: messages without a passing counter are queued for the next round (or give up at max_ctr).
+// The queue position comes from ONE atomic per wave (ballot of the survivors, the wave's first lane adds their count, every survivor
+// takes base + its rank among them): with an atomic per survivor — half of the 16 Mi lanes of configs[4]'s first round, all on one
+// counter — this kernel was 6.4 ms of a 63 ms step and 99 % wait (profiles/r03_z_pmc.json).
 KERNEL_SMALL void k_hash_resolve(Ws ws, int round, uint32_t width, uint32_t max_ctr) {
   const uint32_t n_act = ws.h_cnt[round];
   if (n_act == 0) return;
   const uint32_t* list = round == 0 ? nullptr : ws.h_list + (size_t)(round & 1) * ws.stride;
   uint32_t* list_out = ws.h_list + (size_t)((round + 1) & 1) * ws.stride;
-  for (size_t slot = (size_t)blockIdx.x * BN_WAVE + threadIdx.x; slot < n_act; slot += (size_t)gridDim.x * BN_WAVE) {
-    uint32_t i = list ? list[slot] : (uint32_t)slot;
-    if (ws.h_best[i] != HASH_NONE) continue;
-    uint32_t next = (uint32_t)ws.h_next[i] + width;
-    if (next >= max_ctr) continue;                                 // hash.rs:62: HashToPointError (k_hash_finish)
-    ws.h_next[i] = (uint8_t)next;
-    uint32_t pos = atomicAdd(&ws.h_cnt[round + 1], 1u);
-    list_out[pos] = i;
+  const size_t span = (size_t)gridDim.x * BN_WAVE;
+  for (size_t base = (size_t)blockIdx.x * BN_WAVE; base < n_act; base += span) {        // wave-uniform trip count: the vote needs every lane
+    const size_t slot = base + threadIdx.x;
+    bool survivor = false;
+    uint32_t i = 0;
+    if (slot < n_act) {
+      i = list ? list[slot] : (uint32_t)slot;
+      if (ws.h_best[i] == HASH_NONE) {
+        const uint32_t next = (uint32_t)ws.h_next[i] + width;
+        if (next < max_ctr) { ws.h_next[i] = (uint8_t)next; survivor = true; }           // else hash.rs:62: HashToPointError (k_hash_finish)
+      }
+    }
+    const uint64_t votes = __ballot(survivor);
+    if (votes == 0) continue;
+    uint32_t first = 0;
+    if (threadIdx.x == 0) first = atomicAdd(&ws.h_cnt[round + 1], (uint32_t)__popcll(votes));
+    first = __shfl(first, 0, BN_WAVE);
+    if (survivor) list_out[first + (uint32_t)__popcll(votes & ((1ull << threadIdx.x) - 1ull))] = i;
   }
 }
 // SMALL batches (n <= HASH_DIRECT_MAX_N): latency, not work, is what counts — the first `width` counters of a message
@@ -924,6 +938,37 @@ KERNEL void k_aggregate(const uint32_t* tuple_msg, const uint64_t* tuple_off, co
   ws_byte(ws, BY_ST_HASH, i) = h_pool.st[m];
 }
 // copy the hash planes of the M messages into a pool
+// Aggregate verify, large batches: the tuples are BUCKETED BY MESSAGE before the aggregation kernel (counting sort into an index
+// map; results still land at the tuple's own index).  The kernel gathers signature sums from per-message subset tables (~0.3 MB
+// each): with the caller's (random) order every lane pair of a workgroup reads another table and nothing stays in a cache; in
+// bucket order a workgroup reads ONE message's table, and lanes that share a group index fetch from the same 16-entry block.
+// Order inside a bucket depends on the atomics — irrelevant: every tuple is computed for itself.
+KERNEL_SMALL void k_agg_sort_count(const uint32_t* tuple_msg, size_t n, uint32_t n_msgs, uint32_t* cnt) {
+  const size_t i = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t m = tuple_msg[i];
+  atomicAdd(&cnt[m < n_msgs ? m : n_msgs], 1u);          // out-of-range message indices share the last bucket
+}
+// one wave: exclusive prefix sums of cnt[0 .. n_buckets) into cursor[] (the scatter's running positions)
+KERNEL_SMALL void k_agg_sort_scan(uint32_t n_buckets, const uint32_t* cnt, uint32_t* cursor) {
+  const unsigned t = threadIdx.x;
+  const uint32_t per = (n_buckets + BN_WAVE - 1) / BN_WAVE, lo = t * per, hi = lo + per < n_buckets ? lo + per : n_buckets;
+  uint32_t sum = 0;
+  for (uint32_t k = lo; k < hi; ++k) sum += cnt[k];
+  uint32_t incl = sum;
+  for (int off = 1; off < BN_WAVE; off <<= 1) {
+    const uint32_t up = __shfl_up(incl, off, BN_WAVE);
+    if ((int)t >= off) incl += up;
+  }
+  uint32_t run = incl - sum;
+  for (uint32_t k = lo; k < hi; ++k) { const uint32_t c = cnt[k]; cursor[k] = run; run += c; }
+}
+KERNEL_SMALL void k_agg_sort_scatter(const uint32_t* tuple_msg, size_t n, uint32_t n_msgs, uint32_t* cursor, uint32_t* perm) {
+  const size_t i = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t m = tuple_msg[i];
+  perm[atomicAdd(&cursor[m < n_msgs ? m : n_msgs], 1u)] = (uint32_t)i;
+}
 KERNEL_SMALL void k_hash_to_pool(size_t n_msgs, Ws ws, Pool h_pool) {
   size_t i = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
   if (i >= n_msgs) return;
@@ -1067,6 +1112,7 @@ struct bn254_ctx {
   Pool pool[5];       // aggregate verify: pk pool, sig pool, H(m) pool, subset sums of the pk pool and of the signature pool (grown on demand)
   size_t pool_fp[5];  // coordinates per entry: 4, 2, 2, 4, 2
   int agg_subset_min_tuples;  // aggregate verify: tabulate subset sums of the pk pool for batches of at least this many tuples (0 = never)
+  int agg_sort_by_msg;        // aggregate verify: bucket the tuples by message before the aggregation kernel (default 1; A/B and test knob)
   int pair_lanes;    // verify: Miller loop + final exponentiation on lane pairs (bn254_pair.hip); default on
   int rand_min_batch;      // randomised verify: batches below this size run the exact kernels (default RAND_MIN_BATCH_DEFAULT)
   int rand_items_per_lane; // randomised verify: 0 = by batch size, 1 or 2 forced (A/B and tests)
@@ -1078,6 +1124,9 @@ struct bn254_ctx {
   int ev_valid;
   int ev_hash_first;   // the recorded intervals are hash, decode, ... (host-pointer verify) instead of decode, hash, ...
   hipStream_t copy_stream;   // host-pointer verify: signatures and keys cross PCIe here while the hash rounds run on `stream`
+  uint8_t* pin;              // ... through this PINNED host buffer (hipHostMalloc, grown on demand): BN254_OPT_PINNED_STAGING
+  size_t pin_cap;
+  int pinned_staging;        // 0 = hipMemcpyAsync straight from the caller's (pageable) buffers
   hipEvent_t copy_done;
   uint64_t msgs_len_next;    // bn254_ctx_expect_msgs_len: size of the d_msgs buffer of the NEXT call that hashes messages
   int msgs_len_declared;
@@ -1188,7 +1237,7 @@ struct MsgsLenScope {
 // (p_fail = 0.5274 per try); the kernels read the actual counts from device memory and use grid-stride
 // loops, so a wrong estimate costs time, never correctness.  No host synchronisation.
 static int launch_hash_rounds(bn254_ctx* c, hipStream_t s, const uint8_t* d_msgs, const uint64_t* d_off, size_t n, int px, int inf_plane,
-                              uint8_t* d_tries) {
+                              uint8_t* d_tries, int mark_finish = -1) {      // mark_finish: profiling event recorded in front of k_hash_finish
   const uint32_t max_ctr = c->hash_max_tries ? (uint32_t)c->hash_max_tries : 255u;
   const uint64_t msgs_len = c->msgs_len_call;   // bn254_ctx_expect_msgs_len, taken by the entry point's MsgsLenScope
   k_hash_init<<<grid_for(n > HASH_MAX_ROUNDS + 1 ? n : HASH_MAX_ROUNDS + 1), BN_WAVE, 0, s>>>(n, c->ws);
@@ -1197,6 +1246,7 @@ static int launch_hash_rounds(bn254_ctx* c, hipStream_t s, const uint8_t* d_msgs
     k_hash_direct<<<grid_for(n * width), BN_WAVE, 0, s>>>(d_msgs, d_off, msgs_len, n, c->ws, width, max_ctr, px, inf_plane, d_tries);
     if (max_ctr > width)                 // the (rare) survivors: every remaining counter at once (grid-stride beyond 64 of them)
       k_hash_round<<<grid_for(64 * (max_ctr - width)), BN_WAVE, 0, s>>>(d_msgs, d_off, msgs_len, c->ws, 1, max_ctr - width, max_ctr);
+    if (mark_finish >= 0 && c->profiling) HIP_TRY(hipEventRecord(c->ev[mark_finish], s));
     k_hash_finish<<<grid_for(n), BN_WAVE, 0, s>>>(d_msgs, d_off, msgs_len, n, c->ws, max_ctr, px, inf_plane, d_tries);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -1219,6 +1269,7 @@ static int launch_hash_rounds(bn254_ctx* c, hipStream_t s, const uint8_t* d_msgs
     for (uint32_t t = 0; t < width && pf > 1e-12; ++t) pf *= 0.5274;
     expect *= pf;
   }
+  if (mark_finish >= 0 && c->profiling) HIP_TRY(hipEventRecord(c->ev[mark_finish], s));
   k_hash_finish<<<grid_for(n), BN_WAVE, 0, s>>>(d_msgs, d_off, msgs_len, n, c->ws, max_ctr, px, inf_plane, d_tries);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -1244,6 +1295,8 @@ int bn254_ctx_create(int hip_device, bn254_ctx** out) {
   c->hash_direct_width = HASH_DIRECT_WIDTH_DEFAULT;
   c->trio_wave_roles = TRIO_WAVE_ROLES_DEFAULT;
   c->agg_subset_min_tuples = AGG_SUBSET_MIN_TUPLES_DEFAULT;
+  c->agg_sort_by_msg = 1;
+  c->pinned_staging = PINNED_STAGING_DEFAULT;
   // the small-batch kernels ask for up to 156 KB of dynamic LDS per workgroup: on a part that cannot hold one, step down
   // (eight wave roles -> four -> lane groups -> lane pairs only) instead of failing at the first launch
   c->fits_w8 = bn254_quad_fits_device(1); c->fits_quad = bn254_quad_fits_device(0); c->fits_trio = bn254_trio_fits_device();
@@ -1277,6 +1330,7 @@ void bn254_ctx_destroy(bn254_ctx* c) {
   if (c->ws.h_list) (void)hipFree(c->ws.h_list);
   if (c->ws.h_cnt) (void)hipFree(c->ws.h_cnt);
   if (c->ws.clk) (void)hipFree(c->ws.clk);
+  if (c->pin) (void)hipHostFree(c->pin);
   for (int i = 0; i < 5; ++i) { if (c->pool[i].planes) (void)hipFree(c->pool[i].planes); if (c->pool[i].st) (void)hipFree(c->pool[i].st); }
   for (int i = 0; i < 8; ++i) if (c->stage[i]) (void)hipFree(c->stage[i]);
   if (c->key_lines) (void)hipFree(c->key_lines);
@@ -1330,6 +1384,8 @@ int bn254_ctx_set_option(bn254_ctx* c, int option, int value) {
     c->hash_direct_width = value;
     return 0;
   }
+  if (option == BN254_OPT_PINNED_STAGING) { if (value < 0 || value > 16) return BN254_E_BAD_ARGUMENT; c->pinned_staging = value; return 0; }
+  if (option == BN254_OPT_AGG_SORT_BY_MSG) { c->agg_sort_by_msg = value != 0; return 0; }
   if (option == BN254_OPT_CLOCK_PROBE) {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipDeviceSynchronize());
@@ -1474,6 +1530,41 @@ int bn254_batch_verify_compressed(bn254_ctx* c, const uint8_t* msgs, const uint6
   return 0;
 }
 
+// Pinned staging (BN254_OPT_PINNED_STAGING = T > 0): the caller's buffers are pageable, and a hipMemcpyAsync from pageable memory is
+// staged by the runtime on the calling thread.  With the option the bytes go through the context's own pinned buffer instead: T
+// threads (the caller's + T - 1 helpers, started per call) each copy a contiguous share of a buffer into it in 1 MB pieces and
+// enqueue the DMA of every piece as soon as it is in place, so page copies and DMA overlap and the DMA runs at the link's rate.
+static int pin_reserve(bn254_ctx* c, size_t bytes) {
+  if (bytes <= c->pin_cap) return 0;
+  HIP_TRY(hipDeviceSynchronize());
+  if (c->pin) { HIP_TRY(hipHostFree(c->pin)); c->pin = nullptr; c->pin_cap = 0; }
+  const size_t cap = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+  HIP_TRY(hipHostMalloc((void**)&c->pin, cap, hipHostMallocDefault));
+  c->pin_cap = cap;
+  return 0;
+}
+static int pinned_copy_in(bn254_ctx* c, uint8_t* d_dst, uint8_t* pin, const uint8_t* src, size_t bytes, hipStream_t stream, int threads) {
+  if (!bytes) return 0;
+  const size_t piece = (size_t)1 << 20;
+  if (threads > 1 && bytes < 4 * piece) threads = 1;
+  std::vector<int> rcs((size_t)threads, 0);
+  auto work = [&](int t) {
+    if (t && hipSetDevice(c->device) != hipSuccess) { rcs[t] = -1; return; }
+    const size_t share = ((bytes + threads - 1) / threads + 255) & ~(size_t)255, lo = (size_t)t * share, hi = lo + share < bytes ? lo + share : bytes;
+    for (size_t o = lo; o < hi; o += piece) {
+      const size_t len = o + piece < hi ? piece : hi - o;
+      memcpy(pin + o, src + o, len);
+      const hipError_t e = hipMemcpyAsync(d_dst + o, pin + o, len, hipMemcpyHostToDevice, stream);
+      if (e != hipSuccess) { rcs[t] = -(int)e; return; }
+    }
+  };
+  std::vector<std::thread> helpers;
+  for (int t = 1; t < threads; ++t) helpers.emplace_back(work, t);
+  work(0);
+  for (auto& h : helpers) h.join();
+  for (int r : rcs) if (r) return r;
+  return 0;
+}
 static int verify_host_overlapped(bn254_ctx* c, const uint8_t* msgs, const uint64_t* off, const uint8_t* sigs, const uint8_t* pks, size_t n,
                                   uint32_t flags, uint8_t* status, size_t msg_bytes) {
   int rc;
@@ -1483,12 +1574,26 @@ static int verify_host_overlapped(bn254_ctx* c, const uint8_t* msgs, const uint6
     if ((rc = stage_reserve(c, slot, need[slot]))) return rc;
   }
   hipStream_t s = c->stream;
+  const bool pinned = c->pinned_staging > 0 && n >= PINNED_STAGING_MIN_N;
+  auto up = [](size_t x) { return (x + 4095) & ~(size_t)4095; };
+  const size_t o_off = up(msg_bytes), o_sig = o_off + up((n + 1) * sizeof(uint64_t)), o_pk = o_sig + up(n * 64), pin_bytes = o_pk + up(n * 128);
+  if (pinned && (rc = pin_reserve(c, pin_bytes))) return rc;
   PROF_MARK(0);
-  if (msg_bytes) HIP_TRY(hipMemcpyAsync(c->stage[0], msgs, msg_bytes, hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync(c->stage[1], off, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+  if (pinned) {
+    if ((rc = pinned_copy_in(c, c->stage[0], c->pin, msgs, msg_bytes, s, c->pinned_staging))) return rc;
+    if ((rc = pinned_copy_in(c, c->stage[1], c->pin + o_off, (const uint8_t*)off, (n + 1) * sizeof(uint64_t), s, 1))) return rc;
+  } else {
+    if (msg_bytes) HIP_TRY(hipMemcpyAsync(c->stage[0], msgs, msg_bytes, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->stage[1], off, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+  }
   if ((rc = launch_hash_rounds(c, s, c->stage[0], (const uint64_t*)c->stage[1], n, PL_P2X, BY_P2_INF, nullptr))) return rc;
-  HIP_TRY(hipMemcpyAsync(c->stage[2], sigs, n * 64, hipMemcpyHostToDevice, c->copy_stream));
-  HIP_TRY(hipMemcpyAsync(c->stage[3], pks, n * 128, hipMemcpyHostToDevice, c->copy_stream));
+  if (pinned) {
+    if ((rc = pinned_copy_in(c, c->stage[2], c->pin + o_sig, sigs, n * 64, c->copy_stream, c->pinned_staging))) return rc;
+    if ((rc = pinned_copy_in(c, c->stage[3], c->pin + o_pk, pks, n * 128, c->copy_stream, c->pinned_staging))) return rc;
+  } else {
+    HIP_TRY(hipMemcpyAsync(c->stage[2], sigs, n * 64, hipMemcpyHostToDevice, c->copy_stream));
+    HIP_TRY(hipMemcpyAsync(c->stage[3], pks, n * 128, hipMemcpyHostToDevice, c->copy_stream));
+  }
   HIP_TRY(hipEventRecord(c->copy_done, c->copy_stream));
   HIP_TRY(hipStreamWaitEvent(s, c->copy_done, 0));
   PROF_MARK(1);
@@ -1808,9 +1913,8 @@ int bn254_batch_hash_to_g1_device(bn254_ctx* c, const uint8_t* d_msgs, const uin
   if (rc) return rc;
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
   unsigned g = grid_for(n);
-  PROF_MARK(0);
-  PROF_MARK(1);                                        // ms[0] = 0, ms[1] = the hash rounds, ms[2] = encoding the points, ms[3] = 0
-  if ((rc = launch_hash_rounds(c, s, d_msgs, d_off, n, PL_P1X, BY_P1_INF, d_tries))) return rc;
+  PROF_MARK(0);                                        // ms[0] = the filter rounds (init / round / resolve), ms[1] = k_hash_finish (the square roots),
+  if ((rc = launch_hash_rounds(c, s, d_msgs, d_off, n, PL_P1X, BY_P1_INF, d_tries, 1))) return rc;     // ms[2] = encoding the points, ms[3] = 0
   PROF_MARK(2);
   k_encode_g1<<<g, BN_WAVE, 0, s>>>(n, c->ws, PL_P1X, BY_P1_INF, d_points, d_status);
   PROF_MARK(3);
@@ -2091,9 +2195,22 @@ int bn254_batch_aggregate_verify_device(bn254_ctx* c, const uint8_t* d_msgs, con
         }
       }
     }
+    // with the per-message signature tables in use: bucket the tuples by message (see k_agg_sort_count).  The hash rounds of the
+    // messages are done with ws.h_list (2 x stride words): its first n words take the index map, the counters sit behind.
+    const uint32_t* perm = nullptr;
+    if (groups4 != 0 && c->agg_sort_by_msg && n >= 4 * n_msgs && n <= 0xFFFFFFFFull && n_msgs < 0xFFFFFFFFull && c->ws.stride >= 2 * (n_msgs + 1)) {
+      uint32_t* map = c->ws.h_list;
+      uint32_t* cnt = c->ws.h_list + c->ws.stride;
+      uint32_t* cursor = cnt + (n_msgs + 1);
+      HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(uint32_t) * (n_msgs + 1), s));
+      k_agg_sort_count<<<grid_for(n), BN_WAVE, 0, s>>>(d_tuple_msg, n, (uint32_t)n_msgs, cnt);
+      k_agg_sort_scan<<<1, BN_WAVE, 0, s>>>((uint32_t)n_msgs + 1, cnt, cursor);
+      k_agg_sort_scatter<<<grid_for(n), BN_WAVE, 0, s>>>(d_tuple_msg, n, (uint32_t)n_msgs, cursor, map);
+      perm = map;
+    }
     PROF_MARK(1);
     if ((rc = bn254_pair_aggregate(d_tuple_msg, d_tuple_off, d_signer_idx, n, n_signers, n_msgs, c->pool[0], c->pool[1], c->pool[2], c->pool[3], n_groups,
-                                   c->pool[4], groups4, c->ws, s))) return rc;
+                                   c->pool[4], groups4, c->ws, s, perm))) return rc;
   } else {
     PROF_MARK(1);
     k_aggregate<<<grid_for(n), BN_WAVE, 0, s>>>(d_tuple_msg, d_tuple_off, d_signer_idx, n, n_signers, n_msgs, c->pool[0], c->pool[1], c->pool[2], c->ws);

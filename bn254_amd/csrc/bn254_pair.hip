@@ -311,11 +311,20 @@ int bn254_pair_rand_tail(size_t n_groups, Ws ws, size_t gbase, hipStream_t s) {
 extern __shared__ uint32_t bn_agg_masks[];     // [BN_PAIR_WG / 2 tuples][mask_stride words], mask_stride odd
 KERNEL_PAIR void k_aggregate_pair(const uint32_t* tuple_msg, const uint64_t* tuple_off, const uint32_t* signer_idx, size_t n, size_t n_signers,
                                   size_t n_msgs, Pool pk_pool, Pool sig_pool, Pool h_pool, Pool sub_pool, unsigned n_groups, Pool sub1_pool, unsigned groups4,
-                                  unsigned mask_stride, Ws ws) {
+                                  unsigned mask_stride, Ws ws, const uint32_t* perm) {
   const unsigned role = threadIdx.x & 1u;
-  size_t i = ((size_t)blockIdx.x * BN_PAIR_WG + threadIdx.x) >> 1;
+  // `perm` (tuples bucketed by message, bn254_hip.hip: k_agg_sort_*): slot -> tuple.  Workgroups are dispatched to the 8 XCDs round
+  // robin and every XCD has its own L2: with the map, XCD x takes a CONTIGUOUS eighth of the slots, so that the ~8 workgroups that
+  // share a message's table share an L2 (64 resident workgroups per XCD = ~8 tables of 0.3 MB in 4 MB).
+  size_t blk = blockIdx.x;
+  if (perm) {
+    const size_t nb = gridDim.x, per = (nb + 7) / 8, x = blk & 7u, k = blk >> 3;
+    blk = x * per + k;                     // a bijection onto [0, 8 * per) >= nb: slots past the end are idle
+  }
+  size_t i = (blk * BN_PAIR_WG + threadIdx.x) >> 1;
   const bool live = i < n;                 // no early return: the wave-level votes and shuffles below need every lane
-  const size_t ii = live ? i : n - 1;
+  size_t ii = live ? i : n - 1;
+  if (perm) { ii = perm[ii]; i = ii; }     // every read and write below goes to the tuple's own index
   uint32_t m = tuple_msg[ii];
   uint64_t lo = tuple_off[ii], hi = live ? tuple_off[ii + 1] : lo;
   // the two running sums live in LDS (27 words each, odd stride): the additions are real functions that take them by reference
@@ -452,12 +461,14 @@ KERNEL_PAIR void k_aggregate_pair(const uint32_t* tuple_msg, const uint64_t* tup
   }
 }
 int bn254_pair_aggregate(const uint32_t* tuple_msg, const uint64_t* tuple_off, const uint32_t* signer_idx, size_t n, size_t n_signers, size_t n_msgs,
-                         Pool pk_pool, Pool sig_pool, Pool h_pool, Pool sub_pool, size_t n_groups, Pool sub1_pool, size_t groups4, Ws ws, hipStream_t s) {
+                         Pool pk_pool, Pool sig_pool, Pool h_pool, Pool sub_pool, size_t n_groups, Pool sub1_pool, size_t groups4, Ws ws, hipStream_t s,
+                         const uint32_t* perm) {
   const unsigned mask_stride = n_groups ? (unsigned)(((n_groups + 3) / 4) | 1u) : 1u;     // words per tuple, odd: the tuples of a wave hit different banks
   const size_t lds = n_groups ? (size_t)(BN_PAIR_WG / 2) * mask_stride * sizeof(uint32_t) : 0;
-  k_aggregate_pair<<<(unsigned)((2 * n + BN_PAIR_WG - 1) / BN_PAIR_WG), BN_PAIR_WG, lds, s>>>(tuple_msg, tuple_off, signer_idx, n, n_signers, n_msgs,
-                                                                                              pk_pool, sig_pool, h_pool, sub_pool, (unsigned)n_groups,
-                                                                                              sub1_pool, (unsigned)groups4, mask_stride, ws);
+  unsigned blocks = (unsigned)((2 * n + BN_PAIR_WG - 1) / BN_PAIR_WG);
+  if (perm) blocks = (blocks + 7u) & ~7u;            // the XCD-contiguous slot mapping needs a multiple of 8 (extra workgroups are idle)
+  k_aggregate_pair<<<blocks, BN_PAIR_WG, lds, s>>>(tuple_msg, tuple_off, signer_idx, n, n_signers, n_msgs, pk_pool, sig_pool, h_pool, sub_pool,
+                                                   (unsigned)n_groups, sub1_pool, (unsigned)groups4, mask_stride, ws, perm);
   HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -22,6 +22,8 @@ OPT_HASH_DIRECT_WIDTH = 7
 OPT_TRIO_WAVE_ROLES = 8
 OPT_AGG_SUBSET_MIN_TUPLES = 9
 OPT_CLOCK_PROBE = 10
+OPT_AGG_SORT_BY_MSG = 11
+OPT_PINNED_STAGING = 12
 
 
 class NativeError(RuntimeError):

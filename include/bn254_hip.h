@@ -294,6 +294,12 @@ int bn254_ctx_set_profiling(bn254_ctx *ctx, int enabled);
 #define BN254_OPT_AGG_SUBSET_MIN_TUPLES 9 /* aggregate verify: from this many tuples on (default 4096) the sums of all subsets of every 8 consecutive
                                             keys of the pool are tabulated once per call and a tuple adds one table entry per group instead of one
                                             key per signer (pools of up to 2048 signers, lists longer than n_signers / 8); 0 = never.  Same statuses. */
+#define BN254_OPT_PINNED_STAGING 12 /* bn254_batch_verify (host pointers), batches of >= 8192: T = 1..16 threads copy the caller's (pageable)
+                                     buffers through a pinned staging buffer of the context in 1 MB pieces, each piece's DMA enqueued as soon
+                                     as it is in place; 0 = hipMemcpyAsync straight from the caller's buffers (the runtime stages them) */
+#define BN254_OPT_AGG_SORT_BY_MSG 11 /* aggregate verify, batches that use the per-message signature tables: bucket the tuples by message on the
+                                      device (counting sort into an index map) so that a workgroup of the aggregation kernel gathers from ONE
+                                      message's table; statuses land at the tuples' own indices either way.  Default 1; 0 = the caller's order */
 #define BN254_OPT_CLOCK_PROBE 10 /* measurement: 1 = the lane-pair Miller / final-exponentiation kernels and the issue probe record, per workgroup,
                                   shader-clock cycles (s_memtime) and constant-rate ticks (s_memrealtime) between entry and exit, read back by
                                   bn254_ctx_last_clocks: the clock the chip actually sustains under this load (power-limited parts run below
@@ -303,7 +309,8 @@ int bn254_ctx_set_option(bn254_ctx *ctx, int option, int value);
 /* per-kernel times of the last verify-shaped call with profiling on (HIP events on the call's stream):
  * ms[0] decode, ms[1] hash-to-G1, ms[2] Miller loop, ms[3] final exponentiation.  The host-pointer bn254_batch_verify runs
  * the hash first and its ms[1] includes the transfer of the messages.  Other *_device calls reuse the slots: pairing ms[1] = 0;
- * hash_to_g1 ms[1] = the hash rounds, ms[2] = encoding the points, ms[0] = ms[3] = 0; aggregate_verify ms[0] = the pools
+ * hash_to_g1 ms[0] = the filter rounds (SHA-256 + Jacobi symbol per tested counter), ms[1] = the square roots (one per message), ms[2] = encoding the
+ * points, ms[3] = 0; aggregate_verify ms[0] = the pools
  * (decoding, hashing the messages, the subset-sum table), ms[1] = the aggregation kernel. */
 int bn254_ctx_last_kernel_ms(bn254_ctx *ctx, float ms[4]);
 /* with BN254_OPT_CLOCK_PROBE on: achieved shader clock in MHz of the most recent lane-pair Miller kernel [0], final exponentiation [1]

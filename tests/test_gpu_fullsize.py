@@ -240,3 +240,77 @@ def test_config3_aggregate_1m(env):
                                       tuple_off.data_ptr(), signer_idx.data_ptr(), k, d_st.data_ptr(), stream=stream)
     torch.cuda.synchronize()
     assert int(d_st[:k].min()) == 9 and int(d_st[:k].max()) == 9
+
+
+def test_two_contexts_two_threads_two_streams(env):
+    """include/bn254_hip.h: "distinct contexts are fully concurrent" / "for concurrent calls on several streams create one
+    context per stream".  Two contexts, each driven from its own Python thread (ctypes releases the GIL for the call) on its own
+    stream, each verifying a DIFFERENT 20 000-tuple batch several times while the other runs; every status vector equals the
+    oracle's for that batch.  (20 000 > the small-batch threshold: the lane-pair kernels, workspaces of both contexts live.)"""
+    import threading
+    import bn254_amd
+    torch, eng, c, dev = env
+    from tests.datagen import make_verify_batch
+    n, reps = 20000, 4
+    batches = []
+    for t, (tag, every) in enumerate((("bn254/conc-a", 7), ("bn254/conc-b", 11))):
+        msgs, sigs, pks, expected = make_verify_batch(eng, n, corrupt_every=every, tag=tag)
+        sigs = bytearray(sigs)
+        sigs[64 * (100 + t):64 * (100 + t) + 64] = bytes(64)                  # an identity signature, at a different place in each batch
+        sigs[64 * (200 + t) + 63] ^= 1                                        # an off-curve one
+        want, _ = c.batch_verify(msgs, bytes(sigs), pks, flags=0, nthreads=_cores())
+        assert want != bytes(n) and want.count(9) >= n // every - 2
+        batches.append((msgs, bytes(sigs), pks, want))
+    assert batches[0][3] != batches[1][3]
+    engines = [bn254_amd.Engine(0), bn254_amd.Engine(0)]
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    bufs = []
+    for (msgs, sigs, pks, _), e in zip(batches, engines):
+        e.reserve(n)
+        bufs.append((_dev(torch, dev, b"".join(msgs)), torch.arange(0, 32 * (n + 1), 32, dtype=torch.int64, device=dev), _dev(torch, dev, sigs),
+                     _dev(torch, dev, pks), [torch.full((n,), 255, dtype=torch.uint8, device=dev) for _ in range(reps)]))
+    torch.cuda.synchronize()
+    errors = []
+    start = threading.Barrier(2)
+
+    def worker(t):
+        try:
+            d_msgs, d_off, d_sigs, d_pks, outs = bufs[t]
+            start.wait()
+            for r in range(reps):
+                engines[t].batch_verify_device(d_msgs.data_ptr(), d_off.data_ptr(), d_sigs.data_ptr(), d_pks.data_ptr(), n, outs[r].data_ptr(),
+                                               flags=0, stream=streams[t].cuda_stream)
+            streams[t].synchronize()
+        except Exception as exc:                                              # surfaced below: an exception in a thread is otherwise lost
+            errors.append((t, repr(exc)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(300)
+        assert not th.is_alive()
+    assert not errors, errors
+    torch.cuda.synchronize()
+    for t in range(2):
+        for r in range(reps):
+            got = bytes(bufs[t][4][r].cpu().numpy())
+            assert got == batches[t][3], (t, r, [(i, got[i], batches[t][3][i]) for i in range(n) if got[i] != batches[t][3][i]][:5])
+    # host-pointer entry points of the two contexts from the two threads at once (each context stages through its own buffers)
+    res = [None, None]
+
+    def host_worker(t):
+        try:
+            start.wait()
+            msgs, sigs, pks, _ = batches[t]
+            res[t] = engines[t].batch_verify(msgs, sigs, pks, flags=0)
+        except Exception as exc:
+            errors.append((t, repr(exc)))
+
+    threads = [threading.Thread(target=host_worker, args=(t,)) for t in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(300)
+    assert not errors, errors
+    assert res[0] == batches[0][3] and res[1] == batches[1][3]

@@ -621,6 +621,58 @@ def test_aggregate_verify_subset_sum_table_vs_oracle(eng, c):
     eng.set_option(OPT_AGG_SUBSET_MIN_TUPLES, 4096)
 
 
+def test_aggregate_verify_bucketed_by_message_vs_oracle(eng, c):
+    """BN254_OPT_AGG_SORT_BY_MSG: with the per-message signature tables in use the tuples are bucketed by message on the device
+    (counting sort into an index map, XCD-contiguous slots) before the aggregation kernel.  Statuses must land at the tuples' OWN
+    indices: a batch whose tuple_msg is random, the same batch sorted by message, and one with every tuple on one message — each with
+    the sort on and off — against the oracle; message indices out of range (their own bucket), dense / short / duplicate / empty
+    signer lists, a tuple count that is not a multiple of the workgroup size."""
+    import random
+    from bn254_amd.engine import OPT_AGG_SUBSET_MIN_TUPLES, OPT_AGG_SORT_BY_MSG
+    from tests.datagen import sk_bytes
+    rnd = random.Random(2024)
+    M, S = 5, 40
+    msgs = [b"bucket-msg-%d" % m for m in range(M)]
+    sks = [sk_bytes(800 + s) for s in range(S)]
+    pk_pool, st = eng.batch_g2_mul(None, b"".join(sks), S, reduce_scalar=True)
+    sig_pool, st2 = eng.batch_sign([msgs[m] for m in range(M) for _ in range(S)], b"".join(sks * M))
+    assert st == bytes(S) and st2 == bytes(M * S)
+    sig_pool = bytearray(sig_pool)
+    sig_pool[64 * (2 * S + 7):64 * (2 * S + 8)] = sig_pool[64 * (2 * S + 8):64 * (2 * S + 9)]      # signer 7's signature on message 2 is wrong -> 9
+    sig_pool = bytes(sig_pool)
+    n = 64 * M + 128 * 3 + 37                                                # >= 64 tuples per message (tables), not a multiple of 128
+    tuples = []
+    for i in range(n):
+        k = rnd.choice([0, 1, 3, 9, 20, 33, S])
+        lst = rnd.sample(range(S), k)
+        if i % 17 == 4 and lst:
+            lst = lst + [lst[0]]                                             # a signer twice: direct route for that tuple
+        if i % 41 == 6:
+            lst = lst + [S + 1]                                              # signer out of range
+        m = rnd.randrange(M)
+        if i % 53 == 11:
+            m = M + rnd.randrange(3)                                         # message out of range -> 2, bucket M
+        tuples.append((m, lst))
+    orders = {"random": tuples, "sorted": sorted(tuples, key=lambda t: t[0]), "one message": [(3, t[1]) for t in tuples]}
+    eng.set_option(OPT_AGG_SUBSET_MIN_TUPLES, 1)
+    try:
+        for name, tl in orders.items():
+            off, flat = [0], []
+            for _, lst in tl:
+                flat += lst
+                off.append(len(flat))
+            want = c.batch_aggregate_verify(msgs, pk_pool, sig_pool, [t[0] for t in tl], off, flat)
+            assert {0, 2, 9} <= set(want) or name == "one message", (name, set(want))
+            for knob in (1, 0):
+                eng.set_option(OPT_AGG_SORT_BY_MSG, knob)
+                got = eng.batch_aggregate_verify(msgs, pk_pool, sig_pool, [t[0] for t in tl], [t[1] for t in tl])
+                diff = [(i, got[i], want[i], tl[i]) for i in range(n) if got[i] != want[i]]
+                assert not diff, (name, knob, diff[:5])
+    finally:
+        eng.set_option(OPT_AGG_SORT_BY_MSG, 1)
+        eng.set_option(OPT_AGG_SUBSET_MIN_TUPLES, 4096)
+
+
 def test_full_size_batch_properties(eng):
     """config-2 size (65 536): expected-status pattern (valid except every 64th), and
     permutation-equivariance of the result — size-independent properties, no oracle needed."""
