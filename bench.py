@@ -857,6 +857,19 @@ def run_verify(args, R):
                                   "steps after the timed region (BN254_OPT_CLOCK_PROBE)")
             except Exception as exc:                               # never lose the bench line over the extra
                 sclk = {"error": repr(exc)}
+        leaf_floor = None
+        if pair and world == 1:
+            try:                                                   # the product leaves of the Miller loop alone, same launch shape (include/bn254_hip.h)
+                floor_ms = eng.probe_leaf_floor(n)
+                leaf_instr = 3219 * 345 + 435 * 258 + 348 * 226    # VALU instructions per lane of that kernel's leaves (tools/isa_summary.py)
+                loop_instr = 3194 * 345 + 430 * 258 + 348 * 226    # ... and of the leaves of the real loop
+                leaf_floor = {"kernel": "k_leaf_floor_pair", "ms": floor_ms, "ms_scaled_to_the_loops_product_counts": floor_ms * loop_instr / leaf_instr,
+                              "miller_kernel_ms": k_avg["miller_loop"],
+                              "share_of_miller_kernel": floor_ms * loop_instr / leaf_instr / k_avg["miller_loop"] if k_avg["miller_loop"] else None,
+                              "note": "87 x (37 dual products + 5 squarings + 4 scalings) per lane, ~9 argument moves per call, nothing else: what the "
+                                      "Miller kernel would take if everything around its product calls were free"}
+            except Exception as exc:
+                leaf_floor = {"error": repr(exc)}
         lane_products = lane_product_counts().get(kname)
         traffic = measured_traffic(kname)
         result["roofline"] = {
@@ -866,6 +879,7 @@ def run_verify(args, R):
             "achieved": achieved, "peak": PEAK_MAC32_THEORETICAL / 1e12, "unit": "TMAC32/s",
             "frac": achieved / (PEAK_MAC32_THEORETICAL / 1e12),
             "effective_sclk_mhz": sclk,
+            "product_leaf_floor": leaf_floor,
             "frac_at_effective_sclk": (achieved / (PEAK_MAC32_THEORETICAL / 1e12 * sclk[dom] / 2400.0)) if sclk and sclk.get(dom) else None,
             "peak_measured_in_this_run": probe["peak_mac32_measured"] / 1e12 if probe else None,
             "frac_of_measured_peak": achieved / (probe["peak_mac32_measured"] / 1e12) if probe else None,

@@ -2308,6 +2308,31 @@ int bn254_probe_issue_rate(bn254_ctx* c, int op, int waves_per_simd, double* wav
   return 0;
 }
 
+// Measurement: the product leaves of one verify's Miller loop alone (k_leaf_floor_pair, bn254_pair.hip) on the planes the last verify
+// left in the workspace (n <= the size of that batch); ms = the kernel's duration (HIP events), best of 3 after a warm-up launch.
+int bn254_probe_leaf_floor(bn254_ctx* c, size_t n, float* ms) {
+  if (!c || !ms || n == 0 || n > c->ws.stride) return BN254_E_BAD_ARGUMENT;
+  HIP_TRY(hipSetDevice(c->device));
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  float best = 0;
+  int rc = 0;
+  for (int rep = 0; rep < 4 && rc == 0; ++rep) {
+    HIP_TRY(hipEventRecord(e0, c->stream));
+    rc = bn254_pair_leaf_floor(n, c->ws, c->stream);
+    HIP_TRY(hipEventRecord(e1, c->stream));
+    HIP_TRY(hipEventSynchronize(e1));
+    float t = 0;
+    HIP_TRY(hipEventElapsedTime(&t, e0, e1));
+    if (rep > 0 && (best == 0 || t < best)) best = t;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *ms = best;
+  return rc;
+}
+
 // ---- test hooks --------------------------------------------------------------------------
 int bn254_debug_fp_op(bn254_ctx* c, int op, const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out, uint8_t* status) {
   if (!c || (n && (!a || !out || !status))) return BN254_E_BAD_ARGUMENT;

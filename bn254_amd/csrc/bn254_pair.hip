@@ -401,15 +401,17 @@ KERNEL_PAIR void k_aggregate_pair(const uint32_t* tuple_msg, const uint64_t* tup
       p.x.c[0] = pool_load_fp(sub_pool, 0 + (int)role, j);
       p.y.c[0] = pool_load_fp(sub_pool, 2 + (int)role, j);
       p.inf = mask == 0 || (sub_pool.st[j] & 0x80);
-      jac_accumulate_mem(acc2, p);
+      // both table entries of the group are fetched BEFORE the first addition: a real function waits for every outstanding load at its
+      // entry, so a fetch issued between the two additions would be a second exposed round trip per group
+      G1Affine q;
       if (use_sub1) {                                                      // wave-uniform
         const uint32_t nib = (mask >> (4u * role)) & 15u;
         const size_t j1 = (((size_t)m * groups4) + 2u * g + role) * 16 + nib;
-        G1Affine q;
         q.x = pool_load_fp(sub1_pool, 0, j1); q.y = pool_load_fp(sub1_pool, 1, j1);
         q.inf = nib == 0 || (sub1_pool.st[j1] & 0x80);
-        jac_accumulate_mem(acc1, q);
       }
+      jac_accumulate_mem(acc2, p);
+      if (use_sub1) jac_accumulate_mem(acc1, q);
     }
     if (__builtin_amdgcn_ballot_w64(dup) != 0) {                          // rare: the tuples with a repeated signer add their keys one by one
       uint64_t longest2 = dup ? hi - lo : 0;

@@ -1,0 +1,65 @@
+// Measurement-only translation unit of libbn254hip.so (pair layout): kept apart from bn254_pair.hip so that the code object of the
+// Miller kernels does not change with it (their loop body is ~62 KB against a 64 KB instruction cache: DESIGN.md section 3).
+#include <hip/hip_runtime.h>
+
+#define BN_SPLIT_FP2 1
+#define BN_PAIR_SQR_DPP_ASM 1
+#define BN_PRIO_SHIFT 1
+#define BN_SET_STEP_PRIORITY(step)                                                        \
+  do {                                                                                    \
+    if (((step) & ((1 << BN_PRIO_SHIFT) - 1)) == 0) {                                     \
+      int q_ = ((step) >> BN_PRIO_SHIFT) & 3;                                             \
+      if (q_ == 0) __builtin_amdgcn_s_setprio(3);                                         \
+      else if (q_ == 1) __builtin_amdgcn_s_setprio(2);                                    \
+      else if (q_ == 2) __builtin_amdgcn_s_setprio(1);                                    \
+      else __builtin_amdgcn_s_setprio(0);                                                 \
+    }                                                                                     \
+  } while (0)
+#define bn254 bn254_probe   // own namespace, as in the other pair-layout translation units
+#include "bn254_curve.h"
+
+using namespace bn254;
+
+#include "bn254_ws.h"
+
+#define BN_PAIR_WG 256
+#define KERNEL_PAIR __global__ __launch_bounds__(BN_PAIR_WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
+struct Fp12PairSlot { Fp12 v; int32_t pad; };
+__device__ __forceinline__ Fp2 ws_load_fp2_own(const Ws& ws, int plane_re, size_t i) {
+  Fp2 r;
+  r.c[0] = ws_load_fp(ws, plane_re + (int)(threadIdx.x & 1u), i);
+  return r;
+}
+
+// Measurement only (bn254_probe_leaf_floor): the PRODUCT CALLS of one verify's Miller loop and nothing else — per lane 87 x (37 dual
+// products + 5 squarings + 4 scalings) = 3 219 / 435 / 348 against the loop's 3 194 / 430 / 348 — on the same launch shape, with f's LDS
+// slot allocated and the priority cycle running.  No twist point, no tower additions, no carries, no LDS traffic: what is left is the
+// leaves themselves plus ~9 argument moves per call, i.e. a floor for ANY way of writing the code around them.
+__device__ __noinline__ void leaf_floor_loop(Fp2& x, const Fp2& y, const Fp& k) {
+  for (int d = 0; d < 87; ++d) {
+    BN_SET_STEP_PRIORITY(d);
+#pragma unroll 1
+    for (int j = 0; j < 37; ++j) x = fp2_mul(x, y);
+#pragma unroll 1
+    for (int j = 0; j < 5; ++j) x = fp2_sqr(x);
+#pragma unroll 1
+    for (int j = 0; j < 4; ++j) x = fp2_mul_fp(x, k);
+  }
+}
+KERNEL_PAIR void k_leaf_floor_pair(size_t n, Ws ws) {
+  size_t i = ((size_t)blockIdx.x * BN_PAIR_WG + threadIdx.x) >> 1;
+  if (i >= n) return;
+  __shared__ Fp12PairSlot lds_f[BN_PAIR_WG];
+  Fp2 x = ws_load_fp2_own(ws, PL_QX0, i);
+  const Fp2 y = ws_load_fp2_own(ws, PL_QY0, i);
+  const Fp k = ws_load_fp(ws, PL_P1X, i);
+  lds_f[threadIdx.x].v.c0.c0 = x;
+  leaf_floor_loop(x, y, k);
+  x = fp2_add(x, lds_f[threadIdx.x].v.c0.c0);
+  ws_store_fp(ws, PL_F0 + (int)(threadIdx.x & 1u), i, x.c[0]);
+}
+int bn254_pair_leaf_floor(size_t n, Ws ws, hipStream_t s) {
+  k_leaf_floor_pair<<<(unsigned)((2 * n + BN_PAIR_WG - 1) / BN_PAIR_WG), BN_PAIR_WG, 0, s>>>(n, ws);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
