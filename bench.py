@@ -859,15 +859,22 @@ def run_verify(args, R):
                 sclk = {"error": repr(exc)}
         leaf_floor = None
         if pair and world == 1:
-            try:                                                   # the product leaves of the Miller loop alone, same launch shape (include/bn254_hip.h)
-                floor_ms = eng.probe_leaf_floor(n)
-                leaf_instr = 3219 * 345 + 435 * 258 + 348 * 226    # VALU instructions per lane of that kernel's leaves (tools/isa_summary.py)
-                loop_instr = 3194 * 345 + 430 * 258 + 348 * 226    # ... and of the leaves of the real loop
-                leaf_floor = {"kernel": "k_leaf_floor_pair", "ms": floor_ms, "ms_scaled_to_the_loops_product_counts": floor_ms * loop_instr / leaf_instr,
-                              "miller_kernel_ms": k_avg["miller_loop"],
-                              "share_of_miller_kernel": floor_ms * loop_instr / leaf_instr / k_avg["miller_loop"] if k_avg["miller_loop"] else None,
-                              "note": "87 x (37 dual products + 5 squarings + 4 scalings) per lane, ~9 argument moves per call, nothing else: what the "
-                                      "Miller kernel would take if everything around its product calls were free"}
+            try:                                                   # the product leaves of the two kernels alone, same launch shape (include/bn254_hip.h)
+                from bn254_amd.engine import OPT_CLOCK_PROBE
+                eng.set_option(OPT_CLOCK_PROBE, 1)
+                leaf_floor = {"note": "kernels that run ONLY the product calls of a verify's Miller loop / final exponentiation (~9 argument moves "
+                                      "per call, no tower additions, carries, twist point or LDS traffic): what the kernels would take if everything "
+                                      "around their product leaves were free.  VALU instructions per lane of the leaves: tools/isa_summary.py"}
+                for mode, key, kernel_key, probe_counts, real_counts in ((0, "miller_loop", "miller_loop", (3219, 435, 348), (3194, 430, 348)),
+                                                                         (1, "final_exp", "final_exp", (945, 1701, 0), (975, 1714, 0))):
+                    floor_ms = eng.probe_leaf_floor(n, mode)
+                    instr = lambda c: c[0] * 345 + c[1] * 258 + c[2] * 226          # noqa: E731
+                    scaled = floor_ms * instr(real_counts) / instr(probe_counts)
+                    leaf_floor[key] = {"probe_ms": floor_ms, "probe_products_dual_sqr_scale": probe_counts, "kernel_products_dual_sqr_scale": real_counts,
+                                       "ms_scaled_to_the_kernels_product_counts": scaled, "kernel_ms": k_avg[kernel_key],
+                                       "floor_share_of_kernel": scaled / k_avg[kernel_key] if k_avg[kernel_key] else None,
+                                       "probe_sclk_mhz": round(eng.last_clocks()["issue_probe"], 1)}
+                eng.set_option(OPT_CLOCK_PROBE, 0)
             except Exception as exc:
                 leaf_floor = {"error": repr(exc)}
         lane_products = lane_product_counts().get(kname)

@@ -111,7 +111,7 @@ def load():
     L.bn254_debug_miller_loop.argtypes = [vp, vp, vp, sz, vp]
     L.bn254_debug_hash_candidate.argtypes = [vp, vp, sz, vp, vp]
     L.bn254_probe_issue_rate.argtypes = [vp, i32, i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(i32)]
-    L.bn254_probe_leaf_floor.argtypes = [vp, sz, ctypes.POINTER(ctypes.c_float)]
+    L.bn254_probe_leaf_floor.argtypes = [vp, sz, i32, ctypes.POINTER(ctypes.c_float)]
     _lib = L
     return L
 

@@ -31,22 +31,23 @@ __device__ __forceinline__ Fp2 ws_load_fp2_own(const Ws& ws, int plane_re, size_
   return r;
 }
 
-// Measurement only (bn254_probe_leaf_floor): the PRODUCT CALLS of one verify's Miller loop and nothing else — per lane 87 x (37 dual
-// products + 5 squarings + 4 scalings) = 3 219 / 435 / 348 against the loop's 3 194 / 430 / 348 — on the same launch shape, with f's LDS
-// slot allocated and the priority cycle running.  No twist point, no tower additions, no carries, no LDS traffic: what is left is the
+// Measurement only (bn254_probe_leaf_floor): the PRODUCT CALLS of one verify's Miller loop (or final exponentiation) and nothing else,
+// on the same launch shape, with f's LDS slot allocated and the priority cycle running.  No twist point, no tower additions, no carries, no LDS traffic: what is left is the
 // leaves themselves plus ~9 argument moves per call, i.e. a floor for ANY way of writing the code around them.
-__device__ __noinline__ void leaf_floor_loop(Fp2& x, const Fp2& y, const Fp& k) {
-  for (int d = 0; d < 87; ++d) {
+// mode 0: the Miller loop's leaves — 87 x (37 dual products + 5 squarings + 4 scalings) = 3 219 / 435 / 348 per lane against the loop's
+//         3 194 / 430 / 348;  mode 1: the final exponentiation's — 189 x (5 dual + 9 squarings) = 945 / 1 701 against 975 / 1 714
+__device__ __noinline__ void leaf_floor_loop(Fp2& x, const Fp2& y, const Fp& k, int steps, int n_dual, int n_sqr, int n_scale) {
+  for (int d = 0; d < steps; ++d) {
     BN_SET_STEP_PRIORITY(d);
 #pragma unroll 1
-    for (int j = 0; j < 37; ++j) x = fp2_mul(x, y);
+    for (int j = 0; j < n_dual; ++j) x = fp2_mul(x, y);
 #pragma unroll 1
-    for (int j = 0; j < 5; ++j) x = fp2_sqr(x);
+    for (int j = 0; j < n_sqr; ++j) x = fp2_sqr(x);
 #pragma unroll 1
-    for (int j = 0; j < 4; ++j) x = fp2_mul_fp(x, k);
+    for (int j = 0; j < n_scale; ++j) x = fp2_mul_fp(x, k);
   }
 }
-KERNEL_PAIR void k_leaf_floor_pair(size_t n, Ws ws) {
+KERNEL_PAIR void k_leaf_floor_pair(size_t n, Ws ws, int mode) {
   size_t i = ((size_t)blockIdx.x * BN_PAIR_WG + threadIdx.x) >> 1;
   if (i >= n) return;
   __shared__ Fp12PairSlot lds_f[BN_PAIR_WG];
@@ -54,12 +55,16 @@ KERNEL_PAIR void k_leaf_floor_pair(size_t n, Ws ws) {
   const Fp2 y = ws_load_fp2_own(ws, PL_QY0, i);
   const Fp k = ws_load_fp(ws, PL_P1X, i);
   lds_f[threadIdx.x].v.c0.c0 = x;
-  leaf_floor_loop(x, y, k);
+  BN_CLK_BEGIN(ws);
+  if (mode == 0) leaf_floor_loop(x, y, k, 87, 37, 5, 4);
+  else leaf_floor_loop(x, y, k, 189, 5, 9, 0);
+  BN_CLK_END(ws, 2);                               // the probe's own clock slot
   x = fp2_add(x, lds_f[threadIdx.x].v.c0.c0);
   ws_store_fp(ws, PL_F0 + (int)(threadIdx.x & 1u), i, x.c[0]);
 }
-int bn254_pair_leaf_floor(size_t n, Ws ws, hipStream_t s) {
-  k_leaf_floor_pair<<<(unsigned)((2 * n + BN_PAIR_WG - 1) / BN_PAIR_WG), BN_PAIR_WG, 0, s>>>(n, ws);
+int bn254_pair_leaf_floor(size_t n, Ws ws, hipStream_t s, int mode) {
+  if (ws.clk) HIP_TRY(hipMemsetAsync(ws.clk + (size_t)2 * BN_CLK_MAX_WG * 2, 0, sizeof(unsigned long long) * 2 * BN_CLK_MAX_WG, s));
+  k_leaf_floor_pair<<<(unsigned)((2 * n + BN_PAIR_WG - 1) / BN_PAIR_WG), BN_PAIR_WG, 0, s>>>(n, ws, mode);
   HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -103,10 +103,11 @@ class Engine:
         _check("bn254_ctx_last_kernel_ms", self._lib.bn254_ctx_last_kernel_ms(self._h, ms))
         return {"decode": ms[0], "hash_to_g1": ms[1], "miller_loop": ms[2], "final_exp": ms[3]}
 
-    def probe_leaf_floor(self, n):
-        """ms of the kernel that runs only the product leaves of a verify's Miller loop, n lane pairs (include/bn254_hip.h)"""
+    def probe_leaf_floor(self, n, mode=0):
+        """ms of the kernel that runs only the product leaves of a verify's Miller loop (mode 0) / final exponentiation (mode 1), n lane
+        pairs (include/bn254_hip.h)"""
         ms = ctypes.c_float()
-        _check("bn254_probe_leaf_floor", self._lib.bn254_probe_leaf_floor(self._h, n, ctypes.byref(ms)))
+        _check("bn254_probe_leaf_floor", self._lib.bn254_probe_leaf_floor(self._h, n, mode, ctypes.byref(ms)))
         return ms.value
 
     def last_clocks(self):

@@ -267,10 +267,11 @@ int bn254_debug_miller_loop(bn254_ctx *ctx, const uint8_t *g1, const uint8_t *g2
  * instruction (op 0 v_mad_u64_u32, 1 v_add_u32, 2 v_mul_lo_u32; 16 independent chains) with waves_per_simd (1..8)
  * waves on every SIMD of the device; n_simd (optional) = SIMD count.  Synchronises the context's stream. */
 int bn254_probe_issue_rate(bn254_ctx *ctx, int op, int waves_per_simd, double *wave_inst_per_s, int *n_simd);
-/* measurement: duration in ms of a kernel that runs ONLY the field-product calls of one verify's Miller loop per lane pair (3 219 dual
- * products, 435 squarings, 348 scalings; no tower additions, carries, twist point or LDS traffic) for n lane pairs, on the launch shape
- * of the Miller kernel — a floor for any arrangement of the code around the product leaves.  n <= the size of the workspace. */
-int bn254_probe_leaf_floor(bn254_ctx *ctx, size_t n, float *ms);
+/* measurement: duration in ms of a kernel that runs ONLY the field-product calls of one verify's Miller loop (mode 0: 3 219 dual
+ * products, 435 squarings, 348 scalings per lane) or final exponentiation (mode 1: 945 dual products, 1 701 squarings) for n lane pairs —
+ * no tower additions, carries, twist point or LDS traffic — on the launch shape of those kernels: a floor for any arrangement of the
+ * code around the product leaves.  n <= the size of the workspace.  With BN254_OPT_CLOCK_PROBE its clock lands in slot [2]. */
+int bn254_probe_leaf_floor(bn254_ctx *ctx, size_t n, int mode, float *ms);
 /* timing of the most recent batch_verify*(…) on this context, from HIP events recorded on the
  * launch stream around each kernel: ms[0] decode, ms[1] hash-to-G1, ms[2] Miller loop,
  * ms[3] final exponentiation.  Synchronises the stream.  Requires bn254_ctx_set_profiling(ctx, 1). */

@@ -1,10 +1,10 @@
 #!/bin/bash
-# measurements behind profiles/r03_<tag>_*: usage profile_round.sh <tag> <part>   (parts keep every gpurun call under its limit)
+# measurements behind profiles/r04_<tag>_*: usage profile_round.sh <tag> <part>   (parts keep every gpurun call under its limit)
 #   part a: bench lines of every workload (roofline + cpu_baseline each), batch sweep
 #   part b: PMC passes of the headline command (all counter groups) + kernel-trace stats
 #   part c: PMC passes (traffic + SQ group) and kernel-trace stats of the other workloads
 tag=$1; part=$2
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03_$tag; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${ROUND:-r04}_$tag; mkdir -p $O
 SHORT="FETCH_SIZE;WRITE_SIZE;SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM SQ_WAIT_INST_ANY SQ_WAIT_ANY"
 if [ "$part" = a ]; then
   python $R/bench.py > $O/bench.json 2> $O/bench.err; echo bench done
@@ -16,14 +16,14 @@ if [ "$part" = a ]; then
   for b in 1 64 1024 4096 8192 16384 32768 65536 131072 262144 1048576; do python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --batch $b 2>/dev/null | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); print(json.dumps({'batch': $b, 'pairings_per_s': d['value'], 'ms_per_step': d['ms_per_step'], 'kernel_ms': d['roofline']['kernel_ms']}))" >> $O/batch_sweep.jsonl; done; echo sweep done
 elif [ "$part" = b ]; then
-  bash $R/tests/pmc_profile.sh r03_$tag "" verify 65536 > $O/pmc_verify.log 2>&1; cp $R/gpurun_out/pmc_r03_$tag.json $O/pmc.json; echo pmc verify done
+  bash $R/tests/pmc_profile.sh ${ROUND:-r04}_$tag "" verify 65536 > $O/pmc_verify.log 2>&1; cp $R/gpurun_out/pmc_${ROUND:-r04}_$tag.json $O/pmc.json; echo pmc verify done
   cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_verify -- python3 $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats_verify.err; echo stats done
 elif [ "$part" = c ]; then
   # (a separate gpurun call: the verify summary of part b is not on this box; tools/pmc_merge.py joins the two afterwards)
   for spec in "verify-keyed:65536" "pairing:524288" "hash:16777216" "aggregate:1048576"; do
     w=${spec%%:*}; b=${spec##*:}
-    OUTJ=$R/gpurun_out/pmc_r03_${tag}_$w.json; [ -f $O/pmc.json ] && cp $O/pmc.json $OUTJ
-    bash $R/tests/pmc_profile.sh r03_${tag}_$w "--workload $w" $w $b "$SHORT" > $O/pmc_$w.log 2>&1; cp $OUTJ $O/pmc.json; echo pmc $w done
+    OUTJ=$R/gpurun_out/pmc_${ROUND:-r04}_${tag}_$w.json; [ -f $O/pmc.json ] && cp $O/pmc.json $OUTJ
+    bash $R/tests/pmc_profile.sh ${ROUND:-r04}_${tag}_$w "--workload $w" $w $b "$SHORT" > $O/pmc_$w.log 2>&1; cp $OUTJ $O/pmc.json; echo pmc $w done
     cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$w -- python3 $R/bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_${w}_under_rocprof.json 2> $O/stats_$w.err; echo stats $w done
   done
 fi
