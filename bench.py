@@ -877,6 +877,38 @@ def run_verify(args, R):
                 eng.set_option(OPT_CLOCK_PROBE, 0)
             except Exception as exc:
                 leaf_floor = {"error": repr(exc)}
+        fe_split = None
+        if pair and world == 1:
+            try:
+                # the final exponentiation BY ROUTINE, measured: the kernel's own interpreter on programs of one operation kind each
+                # (include/bn254_hip.h: bn254_probe_fe_program), x the number of times the verify program (C_FE_CHECK) runs that operation
+                LOAD, STORE, CSQR, MUL, CONJ, FROB, INV = 1, 2, 3, 4, 5, 6, 7
+                counts = {"CSQR": 189, "MUL": 51, "CONJ": 50, "FROB": 4, "INV": 1, "STORE": 23, "LOAD": 7}      # gen_constants.py: C_FE_CHECK
+                base = eng.probe_fe_program(n, [(STORE, 0)])                                                      # launch + load / store of f + one STORE
+                reps = {"CSQR": 96, "MUL": 48, "CONJ": 96, "FROB": 12, "INV": 2, "STORE": 48, "LOAD": 48}
+                prog = {"CSQR": [(STORE, 0)] + [(CSQR, 0)] * reps["CSQR"], "MUL": [(STORE, 0)] + [(MUL, 0)] * reps["MUL"],
+                        "CONJ": [(STORE, 0)] + [(CONJ, 0)] * reps["CONJ"], "FROB": [(STORE, 0)] + [(FROB, 1 + (k % 3)) for k in range(reps["FROB"])],
+                        "INV": [(STORE, 0)] + [(INV, 0)] * reps["INV"], "STORE": [(STORE, k % 10) for k in range(reps["STORE"] + 1)],
+                        "LOAD": [(STORE, 0)] + [(LOAD, 0)] * reps["LOAD"]}
+                per_op, total = {}, 0.0
+                for name in counts:
+                    t_op = max(0.0, eng.probe_fe_program(n, prog[name]) - base) / reps[name]
+                    per_op[name] = {"ms_per_op": t_op, "ops_per_verify": counts[name], "ms": t_op * counts[name]}
+                    total += t_op * counts[name]
+                fe_split = {"per_routine": per_op, "sum_ms": total, "kernel_ms": k_avg["final_exp"], "launch_and_io_ms": base,
+                            "note": "batch of %d lane pairs, two waves per SIMD; values are not meaningful (the routines are timed, not checked)" % n}
+                # the same operations priced at their product leaves alone: dual product d and squaring s from the two leaf-floor kernels
+                # (3219 d + 741 s = Miller floor, 945 d + 1701 s = final-exponentiation floor; a scaling counts as 0.88 squarings)
+                try:
+                    fm, ff = leaf_floor["miller_loop"]["probe_ms"], leaf_floor["final_exp"]["probe_ms"]
+                    sq = (3219.0 * ff / 945.0 - fm) / (3219.0 * 1701.0 / 945.0 - 741.0)
+                    du = (ff - 1701.0 * sq) / 945.0
+                    fe_split["leaf_only_ms_per_op"] = {"dual_product": du, "squaring": sq, "CSQR_9_squarings": 9 * sq, "MUL_18_dual_products": 18 * du}
+                    fe_split["non_leaf_share"] = {"CSQR": 1.0 - 9 * sq / per_op["CSQR"]["ms_per_op"], "MUL": 1.0 - 18 * du / per_op["MUL"]["ms_per_op"]}
+                except Exception:
+                    pass
+            except Exception as exc:
+                fe_split = {"error": repr(exc)}
         lane_products = lane_product_counts().get(kname)
         traffic = measured_traffic(kname)
         result["roofline"] = {
@@ -887,6 +919,7 @@ def run_verify(args, R):
             "frac": achieved / (PEAK_MAC32_THEORETICAL / 1e12),
             "effective_sclk_mhz": sclk,
             "product_leaf_floor": leaf_floor,
+            "final_exp_split": fe_split,
             "frac_at_effective_sclk": (achieved / (PEAK_MAC32_THEORETICAL / 1e12 * sclk[dom] / 2400.0)) if sclk and sclk.get(dom) else None,
             "peak_measured_in_this_run": probe["peak_mac32_measured"] / 1e12 if probe else None,
             "frac_of_measured_peak": achieved / (probe["peak_mac32_measured"] / 1e12) if probe else None,

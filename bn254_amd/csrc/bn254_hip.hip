@@ -2333,6 +2333,43 @@ int bn254_probe_leaf_floor(bn254_ctx* c, size_t n, int mode, float* ms) {
   return rc;
 }
 
+// Measurement: the final exponentiation's accumulator machine on a caller-supplied program (pairs of bytes (opcode, argument), ended by
+// (0, 0); opcodes 1 LOAD s, 2 STORE s, 3 CSQR, 4 MUL s, 5 CONJ, 6 FROB k, 7 INV — bn254_pairing.h) for n lane pairs, on whatever the
+// F planes of the workspace hold (run a verify first).  ms = the kernel's duration, best of 3 after a warm-up launch.  The values are
+// meaningless (a cyclotomic squaring of a non-cyclotomic element): this times the routines in place, it does not check them.
+int bn254_probe_fe_program(bn254_ctx* c, size_t n, const uint8_t* prog, size_t n_steps, float* ms) {
+  if (!c || !ms || !prog || n == 0 || n > c->ws.stride || n_steps == 0 || n_steps > 4096) return BN254_E_BAD_ARGUMENT;
+  for (size_t k = 0; k < n_steps; ++k) {
+    const uint8_t op = prog[2 * k], arg = prog[2 * k + 1];
+    if (op == 0 || op > 7) return BN254_E_BAD_ARGUMENT;
+    if ((op == 1 || op == 2 || op == 4) && arg >= (BN_FE_EXACT_SLOTS > BN_FE_CHECK_SLOTS ? BN_FE_EXACT_SLOTS : BN_FE_CHECK_SLOTS)) return BN254_E_BAD_ARGUMENT;
+    if (op == 6 && (arg < 1 || arg > 3)) return BN254_E_BAD_ARGUMENT;
+  }
+  HIP_TRY(hipSetDevice(c->device));
+  int rc;
+  if ((rc = stage_reserve(c, 7, 2 * n_steps + 2))) return rc;
+  std::vector<uint8_t> buf(prog, prog + 2 * n_steps);
+  buf.push_back(0); buf.push_back(0);
+  HIP_TRY(hipMemcpy(c->stage[7], buf.data(), buf.size(), hipMemcpyHostToDevice));
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  float best = 0;
+  for (int rep = 0; rep < 4 && rc == 0; ++rep) {
+    HIP_TRY(hipEventRecord(e0, c->stream));
+    rc = bn254_pair_fe_program(n, c->ws, c->stage[7], c->stream);
+    HIP_TRY(hipEventRecord(e1, c->stream));
+    HIP_TRY(hipEventSynchronize(e1));
+    float t = 0;
+    HIP_TRY(hipEventElapsedTime(&t, e0, e1));
+    if (rep > 0 && (best == 0 || t < best)) best = t;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *ms = best;
+  return rc;
+}
+
 // ---- test hooks --------------------------------------------------------------------------
 int bn254_debug_fp_op(bn254_ctx* c, int op, const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out, uint8_t* status) {
   if (!c || (n && (!a || !out || !status))) return BN254_E_BAD_ARGUMENT;

@@ -15,8 +15,10 @@
       else __builtin_amdgcn_s_setprio(0);                                                 \
     }                                                                                     \
   } while (0)
+#define BN_INLINE_FP12_HOT 1        // the same inlining choices as bn254_fe.hip, so that fe_machine below is the code k_final_exp_pair runs
+#define BN_INLINE_FE_HOT 1
 #define bn254 bn254_probe   // own namespace, as in the other pair-layout translation units
-#include "bn254_curve.h"
+#include "bn254_pairing.h"
 
 using namespace bn254;
 
@@ -61,6 +63,29 @@ KERNEL_PAIR void k_leaf_floor_pair(size_t n, Ws ws, int mode) {
   BN_CLK_END(ws, 2);                               // the probe's own clock slot
   x = fp2_add(x, lds_f[threadIdx.x].v.c0.c0);
   ws_store_fp(ws, PL_F0 + (int)(threadIdx.x & 1u), i, x.c[0]);
+}
+// Measurement only (bn254_probe_fe_program): the accumulator machine of the final exponentiation (bn254_pairing.h: fe_machine, the very
+// interpreter of k_final_exp_pair) on a program handed over in global memory — programs of ONE operation kind time that operation in
+// place (LDS accumulator, slot file in the private segment, two waves per SIMD): the measured split of the kernel by routine.
+KERNEL_PAIR void k_fe_program_pair(size_t n, Ws ws, const unsigned char (*prog)[2]) {
+  size_t i = ((size_t)blockIdx.x * BN_PAIR_WG + threadIdx.x) >> 1;
+  if (i >= n) return;
+  __shared__ Fp12PairSlot lds_acc[BN_PAIR_WG];
+  Fp12& f = lds_acc[threadIdx.x].v;
+  Fp2* c[6] = {&f.c0.c0, &f.c0.c1, &f.c0.c2, &f.c1.c0, &f.c1.c1, &f.c1.c2};
+#pragma unroll
+  for (int k = 0; k < 6; ++k) *c[k] = ws_load_fp2_own(ws, PL_F0 + 2 * k, i);
+  Fp12 slot[BN_FE_EXACT_SLOTS > BN_FE_CHECK_SLOTS ? BN_FE_EXACT_SLOTS : BN_FE_CHECK_SLOTS];
+#pragma unroll
+  for (int k = 0; k < (int)(sizeof(slot) / sizeof(slot[0])); ++k) slot[k] = f;      // every slot readable
+  fe_machine(f, slot, prog);
+  Fp2 x = fp2_add(fp2_add(f.c0.c0, f.c0.c1), fp2_add(f.c1.c0, f.c1.c2));
+  ws_store_fp(ws, PL_HASHX + (int)(threadIdx.x & 1u), i, x.c[0]);                    // keep the result alive (a plane no later kernel reads before rewriting it)
+}
+int bn254_pair_fe_program(size_t n, Ws ws, const unsigned char* prog, hipStream_t s) {
+  k_fe_program_pair<<<(unsigned)((2 * n + BN_PAIR_WG - 1) / BN_PAIR_WG), BN_PAIR_WG, 0, s>>>(n, ws, (const unsigned char (*)[2])prog);
+  HIP_TRY(hipGetLastError());
+  return 0;
 }
 int bn254_pair_leaf_floor(size_t n, Ws ws, hipStream_t s, int mode) {
   if (ws.clk) HIP_TRY(hipMemsetAsync(ws.clk + (size_t)2 * BN_CLK_MAX_WG * 2, 0, sizeof(unsigned long long) * 2 * BN_CLK_MAX_WG, s));

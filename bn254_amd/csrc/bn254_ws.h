@@ -121,7 +121,8 @@ __device__ __forceinline__ void pool_store_fp(const Pool& p, int e, size_t j, co
 __attribute__((visibility("hidden"))) int bn254_pair_miller_verify(size_t n, Ws ws, const uint32_t* map, const uint32_t* count, hipStream_t s,
                                                                    int mode = 0);
 __attribute__((visibility("hidden"))) int bn254_pair_miller_var(size_t n, Ws ws, hipStream_t s);
-__attribute__((visibility("hidden"))) int bn254_pair_leaf_floor(size_t n, Ws ws, hipStream_t s, int mode);      // measurement only
+__attribute__((visibility("hidden"))) int bn254_pair_leaf_floor(size_t n, Ws ws, hipStream_t s, int mode);
+__attribute__((visibility("hidden"))) int bn254_pair_fe_program(size_t n, Ws ws, const unsigned char* prog, hipStream_t s);   // measurement only      // measurement only
 __attribute__((visibility("hidden"))) int bn254_pair_final_exp_product(size_t n, size_t k, Ws ws, uint8_t* gt_out, uint8_t* status_out, int raw_only,
                                                                        hipStream_t s);
 __attribute__((visibility("hidden"))) int bn254_pair_final_exp(size_t n, Ws ws, int use_hash, uint8_t* status_out, const uint32_t* map,

@@ -110,6 +110,13 @@ class Engine:
         _check("bn254_probe_leaf_floor", self._lib.bn254_probe_leaf_floor(self._h, n, mode, ctypes.byref(ms)))
         return ms.value
 
+    def probe_fe_program(self, n, steps):
+        """ms of the final exponentiation's accumulator machine on the program `steps` = [(opcode, arg), ...] (include/bn254_hip.h)"""
+        prog = bytes(b for st in steps for b in st)
+        ms = ctypes.c_float()
+        _check("bn254_probe_fe_program", self._lib.bn254_probe_fe_program(self._h, n, prog, len(steps), ctypes.byref(ms)))
+        return ms.value
+
     def last_clocks(self):
         """OPT_CLOCK_PROBE on: achieved shader clock (MHz) of the last lane-pair Miller kernel, final exponentiation and issue probe"""
         mhz = (ctypes.c_double * 3)()

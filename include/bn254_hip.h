@@ -272,6 +272,11 @@ int bn254_probe_issue_rate(bn254_ctx *ctx, int op, int waves_per_simd, double *w
  * no tower additions, carries, twist point or LDS traffic — on the launch shape of those kernels: a floor for any arrangement of the
  * code around the product leaves.  n <= the size of the workspace.  With BN254_OPT_CLOCK_PROBE its clock lands in slot [2]. */
 int bn254_probe_leaf_floor(bn254_ctx *ctx, size_t n, int mode, float *ms);
+/* measurement: duration in ms of the final exponentiation's accumulator machine (the interpreter of the lane-pair kernel) running a
+ * caller-supplied program of n_steps (opcode, argument) byte pairs — 1 LOAD slot, 2 STORE slot, 3 CSQR, 4 MUL slot, 5 CONJ, 6 FROB 1..3,
+ * 7 INV; slots 0..9 — for n lane pairs on the values the last verify left in the workspace.  Programs of one operation kind give the cost
+ * of that operation in place (bench.py: roofline.final_exp_split); results are not meaningful values. */
+int bn254_probe_fe_program(bn254_ctx *ctx, size_t n, const uint8_t *prog, size_t n_steps, float *ms);
 /* timing of the most recent batch_verify*(…) on this context, from HIP events recorded on the
  * launch stream around each kernel: ms[0] decode, ms[1] hash-to-G1, ms[2] Miller loop,
  * ms[3] final exponentiation.  Synchronises the stream.  Requires bn254_ctx_set_profiling(ctx, 1). */
