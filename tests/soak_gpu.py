@@ -44,7 +44,7 @@ def soak(args):
     """run the differential for args.seconds with args.seed; returns the summary, raises SoakMismatch on a difference
     (tests/test_gpu_fullsize.py runs a slice of it in the driver-run suite)"""
     import bn254_amd
-    from bn254_amd.engine import OPT_AGG_SUBSET_MIN_TUPLES, OPT_PAIR_LANES, OPT_RAND_MIN_BATCH, OPT_TRIO_MAX_BATCH, OPT_TRIO_WAVE_ROLES
+    from bn254_amd.engine import OPT_AGG_SORT_BY_MSG, OPT_AGG_SUBSET_MIN_TUPLES, OPT_PAIR_LANES, OPT_RAND_MIN_BATCH, OPT_TRIO_MAX_BATCH, OPT_TRIO_WAVE_ROLES
     from oracle import c_oracle as c
     from tests.datagen import sk_bytes
     eng = bn254_amd.Engine(0)
@@ -177,7 +177,12 @@ def soak(args):
             got_a = eng.batch_aggregate_verify(amsgs, apk_pool, asig_pool, [t[0] for t in tuples], [t[1] for t in tuples])
             eng.set_option(OPT_AGG_SUBSET_MIN_TUPLES, 1)     # ... forced on for this small batch: both routes must agree with the oracle
             got_b = eng.batch_aggregate_verify(amsgs, apk_pool, asig_pool, [t[0] for t in tuples], [t[1] for t in tuples])
+            eng.set_option(OPT_AGG_SORT_BY_MSG, 0)           # ... and the same without the device-side bucketing by message
+            got_c = eng.batch_aggregate_verify(amsgs, apk_pool, asig_pool, [t[0] for t in tuples], [t[1] for t in tuples])
+            eng.set_option(OPT_AGG_SORT_BY_MSG, 1)
             eng.set_option(OPT_AGG_SUBSET_MIN_TUPLES, 4096)
+            if got_c != got_b:
+                raise SoakMismatch("MISMATCH aggregate bucketed / caller order round %d %r %r" % (rounds, list(got_b), list(got_c)))
             if got_b != got_a:
                 raise SoakMismatch("MISMATCH aggregate routes round %d %r %r" % (rounds, list(got_a), list(got_b)))
             for j, (mi, lst) in enumerate(tuples):
@@ -196,7 +201,9 @@ def soak(args):
         if time.time() - last_note > 60:          # a progress line a minute (a silent GPU command is taken to be hung)
             last_note = time.time()
             print("soak: %d s, %d rounds, %d tuples, no mismatch" % (last_note - t0, rounds, items), flush=True)
-    res = {"rounds": rounds, "tuples": items, "comparisons": items * 2 * 8, "seconds": round(time.time() - t0, 1), "oracle_threads": cores,
+    from bn254_amd import _native
+    lib_sha = hashlib.sha256(open(_native.LIB_PATH, "rb").read()).hexdigest()[:16]
+    res = {"lib_sha256_16": lib_sha, "rounds": rounds, "tuples": items, "comparisons": items * 2 * 8, "seconds": round(time.time() - t0, 1), "oracle_threads": cores,
            "status_histogram": {str(k): v for k, v in sorted(codes.items())}, "mismatches": 0, "seed": args.seed, "also_compared": extra,
            "modes": ["keyed (registered keys, once per round with the subgroup check)", "keyed randomised 128-bit / 64-bit / GLV (once per round)", "exact, eight wave roles", "exact, four wave roles", "exact, lane groups of one wave (octet)", "exact on lane pairs", "exact, one lane per verify", "randomised 128-bit", "randomised GLV", "randomised 64-bit"],
            "flags": [0, 1]}
