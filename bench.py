@@ -1083,8 +1083,13 @@ def run_pairing(args, R):
             dt = time.perf_counter() - t1
             same_bytes = gt_cpu == gt[:sample].cpu().numpy().tobytes() and st_cpu == bytes([9]) * sample
             assert same_bytes, "oracle Gt bytes differ from the GPU's"
+            one = min(sample, 128)                            # the same oracle on ONE thread (the multi-thread figure depends on the box's cgroup quota)
+            t1 = time.perf_counter()
+            c_oracle.batch_pairing(Pn[pi[:one]].tobytes(), Qn[qi[:one]].tobytes(), one, 1, nthreads=1)
+            dt_one = time.perf_counter() - t1
             result["cpu_baseline"] = {"value": sample / dt, "unit": "pairings/s", "cores": cores, "kind": "port",
-                                      "sample": "first %d pairings of the shard, oracle/bn254_oracle.c; canonical Gt bytes equal the GPU's" % sample}
+                                      "sample": "first %d pairings of the shard, oracle/bn254_oracle.c; canonical Gt bytes equal the GPU's" % sample,
+                                      "single_thread_value": one / dt_one}
         result["pmc_as_of"] = pmc_as_of()
         print(json.dumps(result))
     R.finish()

@@ -206,9 +206,13 @@ KERNEL_SMALL void k_hash_round(const uint8_t* msgs, const uint64_t* off, uint64_
   }
 }
 // after a round: messages without a passing counter are queued for the next round (or give up at max_ctr).
-// The queue position comes from ONE atomic per wave (ballot of the survivors, the wave's first lane adds their count, every survivor
-// takes base + its rank among them): with an atomic per survivor — half of the 16 Mi lanes of configs[4]'s first round, all on one
-// counter — this kernel was 6.4 ms of a 63 ms step and 99 % wait (profiles/r03_z_pmc.json).
+// Queue positions: ONE atomic per 1024-slot tile.  An atomic per wave (what `atomicAdd` on a wave-uniform address compiles to anyway:
+// the backend already reduces it across the wave) is 262 144 same-address atomics in the first round of configs[4], which the L2 channel
+// that owns the counter serialises at ~10 ns each: 3 ms for that one launch, 6.3 ms per 16 Mi step, 99 % wait
+// (profiles/r04_m_kernel_stats_hash.csv).  A 1024-lane workgroup counts its survivors through LDS, its first lane reserves the tile's
+// range, every survivor takes base + the waves before it + its rank in its own wave.
+// Rounds of up to HASH_RESOLVE_TILES_MIN slots keep one wave per 64 slots (k_hash_resolve: a few thousand atomics at most, and no
+// workgroup barriers on the latency path of the headline's 65 536-message hash).
 KERNEL_SMALL void k_hash_resolve(Ws ws, int round, uint32_t width, uint32_t max_ctr) {
   const uint32_t n_act = ws.h_cnt[round];
   if (n_act == 0) return;
@@ -232,6 +236,41 @@ KERNEL_SMALL void k_hash_resolve(Ws ws, int round, uint32_t width, uint32_t max_
     if (threadIdx.x == 0) first = atomicAdd(&ws.h_cnt[round + 1], (uint32_t)__popcll(votes));
     first = __shfl(first, 0, BN_WAVE);
     if (survivor) list_out[first + (uint32_t)__popcll(votes & ((1ull << threadIdx.x) - 1ull))] = i;
+  }
+}
+#define HASH_RESOLVE_WG 1024
+#define HASH_RESOLVE_TILES_MIN ((size_t)1 << 20)
+__global__ void __launch_bounds__(HASH_RESOLVE_WG) k_hash_resolve_tiles(Ws ws, int round, uint32_t width, uint32_t max_ctr) {
+  const uint32_t n_act = ws.h_cnt[round];
+  if (n_act == 0) return;
+  const uint32_t* list = round == 0 ? nullptr : ws.h_list + (size_t)(round & 1) * ws.stride;
+  uint32_t* list_out = ws.h_list + (size_t)((round + 1) & 1) * ws.stride;
+  __shared__ uint32_t wave_cnt[HASH_RESOLVE_WG / BN_WAVE];
+  __shared__ uint32_t tile_base;
+  const unsigned wave = threadIdx.x / BN_WAVE, lane = threadIdx.x % BN_WAVE;
+  const size_t span = (size_t)gridDim.x * HASH_RESOLVE_WG;
+  for (size_t base = (size_t)blockIdx.x * HASH_RESOLVE_WG; base < n_act; base += span) {    // workgroup-uniform trip count: barriers inside
+    const size_t slot = base + threadIdx.x;
+    bool survivor = false;
+    uint32_t i = 0;
+    if (slot < n_act) {
+      i = list ? list[slot] : (uint32_t)slot;
+      if (ws.h_best[i] == HASH_NONE) {
+        const uint32_t next = (uint32_t)ws.h_next[i] + width;
+        if (next < max_ctr) { ws.h_next[i] = (uint8_t)next; survivor = true; }           // else hash.rs:62: HashToPointError (k_hash_finish)
+      }
+    }
+    const uint64_t votes = __ballot(survivor);
+    if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(votes);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t total = 0;
+      for (unsigned w = 0; w < HASH_RESOLVE_WG / BN_WAVE; ++w) { const uint32_t c = wave_cnt[w]; wave_cnt[w] = total; total += c; }   // -> exclusive prefix
+      tile_base = total ? atomicAdd(&ws.h_cnt[round + 1], total) : 0u;
+    }
+    __syncthreads();
+    if (survivor) list_out[tile_base + wave_cnt[wave] + (uint32_t)__popcll(votes & ((1ull << lane) - 1ull))] = i;
+    __syncthreads();                                                                      // wave_cnt / tile_base are rewritten by the next tile
   }
 }
 // SMALL batches (n <= HASH_DIRECT_MAX_N): latency, not work, is what counts — the first `width` counters of a message
@@ -1263,7 +1302,13 @@ static int launch_hash_rounds(bn254_ctx* c, hipStream_t s, const uint8_t* d_msgs
     size_t lanes = (size_t)(bound * width);
     if (lanes > HASH_MAX_GRID_LANES) lanes = HASH_MAX_GRID_LANES;   // grid-stride loops cover the rest
     k_hash_round<<<grid_for(lanes), BN_WAVE, 0, s>>>(d_msgs, d_off, msgs_len, c->ws, round, width, max_ctr);
-    k_hash_resolve<<<grid_for((size_t)bound), BN_WAVE, 0, s>>>(c->ws, round, width, max_ctr);
+    if ((size_t)bound > HASH_RESOLVE_TILES_MIN) {
+      size_t tiles = ((size_t)bound + HASH_RESOLVE_WG - 1) / HASH_RESOLVE_WG;
+      if (tiles > 16384) tiles = 16384;                     // grid-stride beyond
+      k_hash_resolve_tiles<<<(unsigned)tiles, HASH_RESOLVE_WG, 0, s>>>(c->ws, round, width, max_ctr);
+    } else {
+      k_hash_resolve<<<grid_for((size_t)bound), BN_WAVE, 0, s>>>(c->ws, round, width, max_ctr);
+    }
     consumed += width;
     double pf = 1.0;
     for (uint32_t t = 0; t < width && pf > 1e-12; ++t) pf *= 0.5274;

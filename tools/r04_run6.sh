@@ -1,0 +1,13 @@
+#!/bin/bash
+set -o pipefail
+out=gpurun_out/r04_f; mkdir -p $out
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > $out/pytest_gpu.log 2>&1; rc=$?; echo "pytest rc=$rc"; tail -3 $out/pytest_gpu.log
+[ $rc -eq 0 ] || exit 1
+timeout -k 10 600 python bench.py --workload hash --steps 4 --warmup 1 --no-cpu-baseline > $out/bench_hash.json 2> $out/bench_hash.err || exit 1
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r04_f/bench_hash.json').read().strip().splitlines()[-1])
+print('hash %.1f M/s' % (d['value']/1e6), d['ms_per_step'], d['kernel_ms'])
+PY
+for i in 1 2; do timeout -k 10 300 python bench.py --no-cpu-baseline --steps 10 --warmup 2 2>/dev/null | python -c "
+import json,sys;d=json.loads(sys.stdin.read().strip().splitlines()[-1]);print('headline %.3f M/s' % (d['value']/1e6), d['roofline']['kernel_ms'])"; done
