@@ -858,7 +858,8 @@ def run_verify(args, R):
             except Exception as exc:                               # never lose the bench line over the extra
                 sclk = {"error": repr(exc)}
         leaf_floor = None
-        if pair and world == 1:
+        lane_pair_kernels = pair and n > 16384                # batches of up to 16 384 take the small-batch kernels (BN254_OPT_TRIO_MAX_BATCH): other code
+        if lane_pair_kernels and world == 1:
             try:                                                   # the product leaves of the two kernels alone, same launch shape (include/bn254_hip.h)
                 from bn254_amd.engine import OPT_CLOCK_PROBE
                 eng.set_option(OPT_CLOCK_PROBE, 1)
@@ -878,7 +879,7 @@ def run_verify(args, R):
             except Exception as exc:
                 leaf_floor = {"error": repr(exc)}
         fe_split = None
-        if pair and world == 1:
+        if lane_pair_kernels and world == 1:
             try:
                 # the final exponentiation BY ROUTINE, measured: the kernel's own interpreter on programs of one operation kind each
                 # (include/bn254_hip.h: bn254_probe_fe_program), x the number of times the verify program (C_FE_CHECK) runs that operation
