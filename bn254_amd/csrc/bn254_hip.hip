@@ -1159,6 +1159,7 @@ struct bn254_ctx {
   int trio_wave_roles; // octet layout: the Miller loop's four lane pairs as the four waves of a workgroup (k_miller_verify_quad) instead of one wave
   int hash_direct_width; // small batches: counters tried at once with the square root itself (k_hash_direct); 0 = rounds only
   int trio_max_batch; // verify / check_public_keys batches up to this size run in the octet layout (bn254_trio.hip); 0 = never
+  int nonet_max_batch; // ... and up to this size their final exponentiation runs on nine lane pairs per verify (bn254_nonet.hip); 0 = never
   hipEvent_t ev[5];
   int ev_valid;
   int ev_hash_first;   // the recorded intervals are hash, decode, ... (host-pointer verify) instead of decode, hash, ...
@@ -1348,6 +1349,7 @@ int bn254_ctx_create(int hip_device, bn254_ctx** out) {
   if (c->trio_wave_roles == 2 && !c->fits_w8) c->trio_wave_roles = 1;
   if (c->trio_wave_roles == 1 && !c->fits_quad) c->trio_wave_roles = 0;
   if (!c->fits_trio) c->trio_max_batch = 0;
+  c->nonet_max_batch = bn254_nonet_fits_device() ? NONET_MAX_BATCH_DEFAULT : 0;
   c->device = hip_device;
   hipError_t err = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (err == hipSuccess) err = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
@@ -1429,6 +1431,11 @@ int bn254_ctx_set_option(bn254_ctx* c, int option, int value) {
     c->hash_direct_width = value;
     return 0;
   }
+  if (option == BN254_OPT_NONET_MAX_BATCH) {
+    if (value < 0 || (value > 0 && !bn254_nonet_fits_device())) return BN254_E_BAD_ARGUMENT;
+    c->nonet_max_batch = value;
+    return 0;
+  }
   if (option == BN254_OPT_PINNED_STAGING) { if (value < 0 || value > 16) return BN254_E_BAD_ARGUMENT; c->pinned_staging = value; return 0; }
   if (option == BN254_OPT_AGG_SORT_BY_MSG) { c->agg_sort_by_msg = value != 0; return 0; }
   if (option == BN254_OPT_CLOCK_PROBE) {
@@ -1487,6 +1494,9 @@ static int launch_pair_or_trio(bn254_ctx* c, hipStream_t s, size_t n, int use_ha
     if ((rc = c->trio_wave_roles == 2 ? bn254_w8_miller_verify(n, c->ws, s, mode)
               : c->trio_wave_roles ? bn254_quad_miller_verify(n, c->ws, s, mode) : bn254_trio_miller_verify(n, c->ws, s, mode))) return rc;
     if (mark) PROF_MARK(3);
+    // the smallest batches: nine lane pairs per verify (bn254_nonet.hip) — fewer instructions per lane again, while one pass of 3
+    // verifies per wave still covers the batch
+    if (c->nonet_max_batch > 0 && n <= (size_t)c->nonet_max_batch) return bn254_nonet_final_exp(n, c->ws, use_hash, d_status, s);
     return bn254_trio_final_exp(n, c->ws, use_hash, d_status, s);
   }
   if ((rc = bn254_pair_miller_verify(n, c->ws, nullptr, nullptr, s, mode))) return rc;

@@ -24,6 +24,7 @@ OPT_AGG_SUBSET_MIN_TUPLES = 9
 OPT_CLOCK_PROBE = 10
 OPT_AGG_SORT_BY_MSG = 11
 OPT_PINNED_STAGING = 12
+OPT_NONET_MAX_BATCH = 13
 
 
 class NativeError(RuntimeError):

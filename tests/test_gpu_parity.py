@@ -395,12 +395,15 @@ def test_pair_lanes_and_single_lane_agree(eng, derived):
             eng.set_option(OPT_PAIR_LANES, 1)
 
 
+NONET_DEFAULT = 0          # bn254_ws.h: NONET_MAX_BATCH_DEFAULT
+
+
 def test_octet_and_pair_layouts_agree_with_oracle(eng, c, derived, kats):
     """small batches run in the OCTET layout (eight lanes per verify, bn254_trio.hip; default up to 16384 items; the Miller loop
     with the four lane pairs of a verify as four waves with their own roles, or as lane groups of one wave), larger ones on
     lane pairs: all against the golden cases, the oracle on ragged sizes with faults of every class, and
     check_public_keys; the threshold itself (8192 octet, 8193 pairs) gives the same bytes on either side"""
-    from bn254_amd.engine import OPT_TRIO_MAX_BATCH, OPT_TRIO_WAVE_ROLES
+    from bn254_amd.engine import OPT_NONET_MAX_BATCH, OPT_TRIO_MAX_BATCH, OPT_TRIO_WAVE_ROLES
     from tests.datagen import make_verify_batch
     cs = derived["verify_cases"]
     args = ([H(v["message_hex"]) for v in cs], b"".join(H(v["sig"]) for v in cs), b"".join(H(v["pk"]) for v in cs))
@@ -435,9 +438,23 @@ def test_octet_and_pair_layouts_agree_with_oracle(eng, c, derived, kats):
             assert eng.batch_check_public_keys(g2s, g1s, len(cpk) * 3) == cpk_want, lim
             assert eng.batch_verify(edge[0], edge[1], edge[2]) == edge[3], lim
             assert eng.batch_verify(edge[0][:8192], edge[1][:8192 * 64], edge[2][:8192 * 128]) == edge[3][:8192], lim
+        # the final exponentiation on NINE lane pairs per verify (bn254_nonet.hip; 3 verifies per wave, 12 per workgroup): forced on for
+        # every small-batch size (1, 2, 7, 9, 65, 1027: not multiples of 3 or 12; 8192: several passes), and off
+        eng.set_option(OPT_TRIO_MAX_BATCH, 16384)
+        eng.set_option(OPT_TRIO_WAVE_ROLES, 2)
+        nonet_default = 3072
+        for lim in (1 << 20, 0, nonet_default):
+            eng.set_option(OPT_NONET_MAX_BATCH, lim)
+            assert list(eng.batch_verify(*args, flags=1)) == want, ("nonet", lim)
+            for msgs, sigs, pks, oracle in batches:
+                assert eng.batch_verify(msgs, sigs, pks, flags=1) == oracle, ("nonet", lim, len(msgs))
+            assert eng.batch_check_public_keys(g2s, g1s, len(cpk) * 3) == cpk_want, ("nonet", lim)
+            assert eng.batch_verify(edge[0][:8192], edge[1][:8192 * 64], edge[2][:8192 * 128]) == edge[3][:8192], ("nonet", lim)
+            assert eng.batch_verify(edge[0][:3073], edge[1][:3073 * 64], edge[2][:3073 * 128]) == edge[3][:3073], ("nonet", lim)
     finally:
         eng.set_option(OPT_TRIO_MAX_BATCH, 16384)                     # the defaults
         eng.set_option(OPT_TRIO_WAVE_ROLES, 2)
+        eng.set_option(OPT_NONET_MAX_BATCH, NONET_DEFAULT)
     # the default threshold itself: 16384 verifies in two passes of the small-batch kernels, 16385 on lane pairs
     big = make_verify_batch(eng, 16385, corrupt_every=13)
     assert eng.batch_verify(big[0], big[1], big[2]) == big[3]
