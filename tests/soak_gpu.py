@@ -44,7 +44,7 @@ def soak(args):
     """run the differential for args.seconds with args.seed; returns the summary, raises SoakMismatch on a difference
     (tests/test_gpu_fullsize.py runs a slice of it in the driver-run suite)"""
     import bn254_amd
-    from bn254_amd.engine import OPT_AGG_SORT_BY_MSG, OPT_AGG_SUBSET_MIN_TUPLES, OPT_PAIR_LANES, OPT_RAND_MIN_BATCH, OPT_TRIO_MAX_BATCH, OPT_TRIO_WAVE_ROLES
+    from bn254_amd.engine import OPT_AGG_SORT_BY_MSG, OPT_AGG_SUBSET_MIN_TUPLES, OPT_NONET_MAX_BATCH, OPT_PAIR_LANES, OPT_RAND_MIN_BATCH, OPT_TRIO_MAX_BATCH, OPT_TRIO_WAVE_ROLES
     from oracle import c_oracle as c
     from tests.datagen import sk_bytes
     eng = bn254_amd.Engine(0)
@@ -122,6 +122,11 @@ def soak(args):
                 eng.set_option(OPT_TRIO_WAVE_ROLES, roles)
                 got[name] = eng.batch_verify(msgs, sigs, pks, flags=flags)
             eng.set_option(OPT_TRIO_WAVE_ROLES, 2)
+            eng.set_option(OPT_NONET_MAX_BATCH, 0)           # the final exponentiation of the small-batch path in the octet layout (default: nine lane pairs up to 3072)
+            got["roles8_octet_fe"] = eng.batch_verify(msgs, sigs, pks, flags=flags)
+            eng.set_option(OPT_NONET_MAX_BATCH, 1 << 20)     # ... and on nine lane pairs whatever the size (several passes above 3072)
+            got["roles8_nonet_fe"] = eng.batch_verify(msgs, sigs, pks, flags=flags)
+            eng.set_option(OPT_NONET_MAX_BATCH, 3072)
             eng.set_option(OPT_TRIO_MAX_BATCH, 0)
             got["pair"] = eng.batch_verify(msgs, sigs, pks, flags=flags)
             eng.set_option(OPT_TRIO_MAX_BATCH, 16384)
@@ -203,9 +208,9 @@ def soak(args):
             print("soak: %d s, %d rounds, %d tuples, no mismatch" % (last_note - t0, rounds, items), flush=True)
     from bn254_amd import _native
     lib_sha = hashlib.sha256(open(_native.LIB_PATH, "rb").read()).hexdigest()[:16]
-    res = {"lib_sha256_16": lib_sha, "rounds": rounds, "tuples": items, "comparisons": items * 2 * 8, "seconds": round(time.time() - t0, 1), "oracle_threads": cores,
+    res = {"lib_sha256_16": lib_sha, "rounds": rounds, "tuples": items, "comparisons": items * 2 * 10, "seconds": round(time.time() - t0, 1), "oracle_threads": cores,
            "status_histogram": {str(k): v for k, v in sorted(codes.items())}, "mismatches": 0, "seed": args.seed, "also_compared": extra,
-           "modes": ["keyed (registered keys, once per round with the subgroup check)", "keyed randomised 128-bit / 64-bit / GLV (once per round)", "exact, eight wave roles", "exact, four wave roles", "exact, lane groups of one wave (octet)", "exact on lane pairs", "exact, one lane per verify", "randomised 128-bit", "randomised GLV", "randomised 64-bit"],
+           "modes": ["keyed (registered keys, once per round with the subgroup check)", "keyed randomised 128-bit / 64-bit / GLV (once per round)", "exact, eight wave roles + final exponentiation on nine lane pairs (default up to 3072)", "... + octet final exponentiation", "... + nine lane pairs at every size", "exact, four wave roles", "exact, lane groups of one wave (octet)", "exact on lane pairs", "exact, one lane per verify", "randomised 128-bit", "randomised GLV", "randomised 64-bit"],
            "flags": [0, 1]}
     return res
 

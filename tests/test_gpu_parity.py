@@ -395,7 +395,7 @@ def test_pair_lanes_and_single_lane_agree(eng, derived):
             eng.set_option(OPT_PAIR_LANES, 1)
 
 
-NONET_DEFAULT = 0          # bn254_ws.h: NONET_MAX_BATCH_DEFAULT
+NONET_DEFAULT = 3072       # bn254_ws.h: NONET_MAX_BATCH_DEFAULT
 
 
 def test_octet_and_pair_layouts_agree_with_oracle(eng, c, derived, kats):
