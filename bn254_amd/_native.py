@@ -20,7 +20,7 @@ def translation_units():
 
 
 def _dependencies():
-    return translation_units() + sorted(glob.glob(os.path.join(_CSRC, "*.h"))) + [
+    return translation_units() + sorted(glob.glob(os.path.join(_CSRC, "*.h"))) + sorted(glob.glob(os.path.join(_CSRC, "*.inc"))) + [
         os.path.join(_CSRC, "gen_constants.py"), os.path.join(os.path.dirname(_PKG), "include", "bn254_hip.h")]
 
 # -Wl,--no-undefined: a missing translation unit fails at link time.  max-ilp: the AMDGPU machine scheduler's ILP-first

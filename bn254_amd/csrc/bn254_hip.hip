@@ -2366,7 +2366,7 @@ int bn254_probe_issue_rate(bn254_ctx* c, int op, int waves_per_simd, double* wav
 // Measurement: the product leaves of one verify's Miller loop alone (k_leaf_floor_pair, bn254_pair.hip) on the planes the last verify
 // left in the workspace (n <= the size of that batch); ms = the kernel's duration (HIP events), best of 3 after a warm-up launch.
 int bn254_probe_leaf_floor(bn254_ctx* c, size_t n, int mode, float* ms) {
-  if (!c || !ms || n == 0 || n > c->ws.stride || mode < 0 || mode > 1) return BN254_E_BAD_ARGUMENT;
+  if (!c || !ms || n == 0 || n > c->ws.stride || mode < 0 || mode > 3) return BN254_E_BAD_ARGUMENT;
   HIP_TRY(hipSetDevice(c->device));
   hipEvent_t e0, e1;
   HIP_TRY(hipEventCreate(&e0));

@@ -49,6 +49,31 @@ __device__ __noinline__ void leaf_floor_loop(Fp2& x, const Fp2& y, const Fp& k, 
     for (int j = 0; j < n_scale; ++j) x = fp2_mul_fp(x, k);
   }
 }
+// mode 2: 87 x 37 dual products with the leaf INLINED into the loop (the body of fp_pair_mul_impl, bn254_fp2_pair.h) — no call, no return,
+// no wait at a function entry, no argument moves: what the calling convention itself costs per product
+__device__ __forceinline__ Fp2 fp2_mul_inlined(const Fp2& a, const Fp2& b) {
+  const int32_t one = 1 - (int32_t)(threadIdx.x & 1u), mask = -one;
+  int32_t ao[BN_LIMBS], ap[BN_LIMBS], x[BN_LIMBS], y[BN_LIMBS], r[BN_LIMBS];
+#pragma unroll
+  for (int i = 0; i < BN_LIMBS; ++i) {
+    ao[i] = a.c[0].v[i];
+    ap[i] = bn_partner_word(a.c[0].v[i]);
+    x[i] = bn_pair_re_word(b.c[0].v[i]);
+    y[i] = (bn_pair_im_word(b.c[0].v[i]) ^ mask) + one;
+  }
+  BN_MONT_DUAL_BODY(ao, x, ap, y, r);
+  Fp2 z;
+#pragma unroll
+  for (int i = 0; i < BN_LIMBS; ++i) z.c[0].v[i] = r[i];
+  return z;
+}
+__device__ __noinline__ void leaf_floor_loop_inlined(Fp2& x, const Fp2& y) {
+  for (int d = 0; d < 87; ++d) {
+    BN_SET_STEP_PRIORITY(d);
+#pragma unroll 1
+    for (int j = 0; j < 37; ++j) x = fp2_mul_inlined(x, y);
+  }
+}
 KERNEL_PAIR void k_leaf_floor_pair(size_t n, Ws ws, int mode) {
   size_t i = ((size_t)blockIdx.x * BN_PAIR_WG + threadIdx.x) >> 1;
   if (i >= n) return;
@@ -59,7 +84,9 @@ KERNEL_PAIR void k_leaf_floor_pair(size_t n, Ws ws, int mode) {
   lds_f[threadIdx.x].v.c0.c0 = x;
   BN_CLK_BEGIN(ws);
   if (mode == 0) leaf_floor_loop(x, y, k, 87, 37, 5, 4);
-  else leaf_floor_loop(x, y, k, 189, 5, 9, 0);
+  else if (mode == 1) leaf_floor_loop(x, y, k, 189, 5, 9, 0);
+  else if (mode == 2) leaf_floor_loop_inlined(x, y);
+  else leaf_floor_loop(x, y, k, 87, 37, 0, 0);          // mode 3: the same 3 219 dual products as mode 2, called
   BN_CLK_END(ws, 2);                               // the probe's own clock slot
   x = fp2_add(x, lds_f[threadIdx.x].v.c0.c0);
   ws_store_fp(ws, PL_F0 + (int)(threadIdx.x & 1u), i, x.c[0]);

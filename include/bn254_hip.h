@@ -270,7 +270,8 @@ int bn254_probe_issue_rate(bn254_ctx *ctx, int op, int waves_per_simd, double *w
 /* measurement: duration in ms of a kernel that runs ONLY the field-product calls of one verify's Miller loop (mode 0: 3 219 dual
  * products, 435 squarings, 348 scalings per lane) or final exponentiation (mode 1: 945 dual products, 1 701 squarings) for n lane pairs —
  * no tower additions, carries, twist point or LDS traffic — on the launch shape of those kernels: a floor for any arrangement of the
- * code around the product leaves.  n <= the size of the workspace.  With BN254_OPT_CLOCK_PROBE its clock lands in slot [2]. */
+ * code around the product leaves.  n <= the size of the workspace.  With BN254_OPT_CLOCK_PROBE its clock lands in slot [2].
+ * Modes 2 / 3: 3 219 dual products with the leaf inlined into the loop / called — what the calling convention costs per product. */
 int bn254_probe_leaf_floor(bn254_ctx *ctx, size_t n, int mode, float *ms);
 /* measurement: duration in ms of the final exponentiation's accumulator machine (the interpreter of the lane-pair kernel) running a
  * caller-supplied program of n_steps (opcode, argument) byte pairs — 1 LOAD slot, 2 STORE slot, 3 CSQR, 4 MUL slot, 5 CONJ, 6 FROB 1..3,
