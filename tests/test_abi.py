@@ -67,3 +67,20 @@ def test_every_source_makes_the_library_stale(monkeypatch):
         monkeypatch.setattr(os.path, "exists", lambda p: True)
         assert _native._stale() == (newer is not None), newer
     monkeypatch.setattr(os.path, "getmtime", real)
+
+
+def test_option_numbers_of_header_and_python_mirror_agree():
+    """every BN254_OPT_* of include/bn254_hip.h has the same number in bn254_amd.engine (OPT_*), and no number is used twice"""
+    import re
+    from bn254_amd import engine
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "include", "bn254_hip.h")).read()
+    header = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define BN254_OPT_(\w+) (\d+)", text)}
+    assert len(set(header.values())) == len(header), header
+    mirror = {k[4:]: v for k, v in vars(engine).items() if k.startswith("OPT_") and isinstance(v, int)}
+    assert mirror, "bn254_amd.engine exports no OPT_* constants"
+    for name, value in mirror.items():
+        assert header.get(name) == value, (name, value, header.get(name))
+    # the status codes the header names are the reference's Error variants, in order (src/error.rs:6-29)
+    codes = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define BN254_ERR_(\w+) (\d+)", text)}
+    assert sorted(codes.values()) == [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11] and codes["INDEX_OUT_OF_BOUNDS"] == 2 and codes["VERIFICATION_FAILED"] == 9

@@ -1125,3 +1125,39 @@ def test_randomized_small_batches_route_to_exact_kernels(c):
     st, gr = e.batch_verify_randomized(msgs, bytes(sigs), pks, RAND_SEED)
     want = c.batch_verify_randomized(msgs, bytes(sigs), pks, RAND_SEED, flags=0)
     assert (st, gr) == want and gr == bytes([1, 0, 0, 1]) and st[130] == 6
+
+
+def test_measurement_entry_points(eng):
+    """the round-4 measurement ABI: argument validation (bad programs, sizes, modes are BN254_E_BAD_ARGUMENT, never a launch), the clock
+    probe reports nothing until it is switched on and plausible clocks afterwards, and none of it disturbs verify results"""
+    import ctypes
+    from bn254_amd.engine import OPT_CLOCK_PROBE
+    from tests.datagen import make_verify_batch
+    BAD = -10001
+    lib, h = eng._lib, eng._h
+    n = 20000                                                           # above the small-batch threshold: the lane-pair kernels
+    msgs, sigs, pks, expected = make_verify_batch(eng, n, corrupt_every=9)
+    assert eng.batch_verify(msgs, sigs, pks) == expected
+    ms = ctypes.c_float()
+    mhz = (ctypes.c_double * 3)()
+    assert lib.bn254_ctx_last_clocks(h, mhz) == BAD                     # probe off: no buffer
+    assert lib.bn254_probe_leaf_floor(h, 0, 0, ctypes.byref(ms)) == BAD
+    assert lib.bn254_probe_leaf_floor(h, n, 4, ctypes.byref(ms)) == BAD
+    assert lib.bn254_probe_leaf_floor(h, 1 << 40, 0, ctypes.byref(ms)) == BAD          # beyond the workspace
+    for prog in (bytes([8, 0]), bytes([0, 0]), bytes([4, 10]), bytes([1, 200]), bytes([6, 0]), bytes([6, 4])):   # unknown opcode, END inside, slot out of range, bad Frobenius power
+        assert lib.bn254_probe_fe_program(h, n, prog, 1, ctypes.byref(ms)) == BAD, prog
+    assert lib.bn254_probe_fe_program(h, n, bytes([3, 0]), 0, ctypes.byref(ms)) == BAD
+    t_sq = eng.probe_fe_program(n, [(2, 0)] + [(3, 0)] * 20)
+    t_mul = eng.probe_fe_program(n, [(2, 0)] + [(4, 0)] * 20)
+    assert 0.0 < t_sq < t_mul < 50.0                                    # 20 Fq12 products cost more than 20 cyclotomic squarings
+    floor_miller, floor_fe = eng.probe_leaf_floor(n, 0), eng.probe_leaf_floor(n, 1)
+    assert 0.0 < floor_fe < floor_miller < 50.0
+    eng.set_option(OPT_CLOCK_PROBE, 1)
+    try:
+        assert eng.batch_verify(msgs, sigs, pks) == expected
+        clocks = eng.last_clocks()
+        assert 1000.0 < clocks["miller_loop"] < 3000.0 and 1000.0 < clocks["final_exp"] < 3000.0, clocks
+    finally:
+        eng.set_option(OPT_CLOCK_PROBE, 0)
+    assert lib.bn254_ctx_last_clocks(h, mhz) == BAD
+    assert eng.batch_verify(msgs, sigs, pks) == expected
