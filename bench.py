@@ -978,6 +978,154 @@ def run_verify(args, R):
     R.finish()
 
 
+def run_verify_mgpu(args):
+    """configs[1] on N GPUs from ONE process through the C ABI's multi-GPU layer (include/bn254_hip.h: bn254_mgpu_*): one context,
+    stream and parked worker thread per device, shard g resident on device g, the only exchange the in-place gather of the status
+    bytes (ncclAllGather on ncclCommInitAll communicators — RCCL's C API, no torch.distributed; peer copies when --mgpu-devices
+    lists a device twice, which is how a one-GPU box rehearses it).  Same metric, same per-GPU batch, same checks as `--workload
+    verify`; torch is used only to hold the device buffers."""
+    import torch
+    import bn254_amd
+    from bn254_amd.engine import MGPU_OPT_TIMING
+    from tests.datagen import KEY_POOL, sk_bytes
+    if int(os.environ.get("WORLD_SIZE", "1")) != 1:
+        raise SystemExit("--workload verify-mgpu is ONE process driving all devices: start it without torchrun")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (bn254_amd has no CPU fallback)")
+    devices = [int(x) for x in args.mgpu_devices.split(",")] if args.mgpu_devices else list(range(args.gpus))
+    G = len(devices)
+    n = args.batch or BATCH
+    N = n * G
+    mg = bn254_amd.MultiEngine(devices)
+    mg.reserve(2 * N, init_collectives=True)
+    mg.set_option(MGPU_OPT_TIMING, 1)
+
+    def corrupted(good, phase):
+        sigs = bytearray(good)
+        for i in range(phase, n, CORRUPT_EVERY):
+            j = i - 1 if i else i + 1
+            sigs[64 * i:64 * i + 64] = good[64 * j:64 * j + 64]
+        return bytes(sigs)
+
+    def expected_for(g, step, length=n):
+        e = bytearray(length)
+        for i in range(corrupt_phase(g, step), length, CORRUPT_EVERY):
+            e[i] = 9
+        return bytes(e)
+
+    keep, host = [], []
+    for g, d in enumerate(devices):
+        eng = mg.engine(g)
+        dev = torch.device("cuda", d)
+        base = g * n                                         # every entry owns a distinct shard, as a rank does in run_verify
+        msgs = [D("bn254/msg2", base + i) for i in range(n)]
+        pool = min(KEY_POOL, n)
+        sks = [sk_bytes(j) for j in range(pool)]
+        pk_pool, st = eng.batch_g2_mul(None, b"".join(sks), pool, reduce_scalar=True)
+        assert st == bytes(pool)
+        good, st = eng.batch_sign(msgs, b"".join(sks[(base + i) % pool] for i in range(n)))
+        assert st == bytes(n)
+        pks = b"".join(pk_pool[128 * ((base + i) % pool):128 * ((base + i) % pool) + 128] for i in range(n))
+        sig_sets = [corrupted(good, corrupt_phase(g, 0)), corrupted(good, corrupt_phase(g, 1))]
+
+        def to_dev(b, dev=dev):
+            return torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+        keep.append({"msgs": to_dev(b"".join(msgs)), "off": torch.arange(0, 32 * (n + 1), 32, dtype=torch.int64, device=dev),
+                     "sigs": [to_dev(sig_sets[0]), to_dev(sig_sets[1])], "pks": to_dev(pks),
+                     "all": torch.zeros(mg.gathered_len(N), dtype=torch.uint8, device=dev)})
+        if g == 0:
+            host = [msgs, sig_sets, pks]
+    ptr = lambda key: [k[key].data_ptr() for k in keep]      # noqa: E731
+    p_msgs, p_off, p_pks, p_all = ptr("msgs"), ptr("off"), ptr("pks"), ptr("all")
+    p_sigs = [[k["sigs"][b].data_ptr() for k in keep] for b in (0, 1)]
+
+    def sync_all():
+        mg.synchronize()
+        for d in set(devices):
+            torch.cuda.synchronize(d)
+
+    def step(k):
+        mg.batch_verify_device(p_msgs, p_off, p_sigs[k & 1], p_pks, N, p_all, flags=0)
+
+    checks = {"steps_checked": 0, "mismatches": 0}
+
+    def check(step_index):
+        sync_all()
+        bad = 0
+        for h in range(G):                                   # EVERY device's gathered buffer, every shard of it
+            allst = bytes(keep[h]["all"].cpu().numpy())
+            for g in range(G):
+                bad += int(allst[g * n:(g + 1) * n] != expected_for(g, step_index))
+        checks["steps_checked"] += 1
+        checks["mismatches"] += bad
+        return bad == 0
+
+    for k in range(args.warmup):
+        step(k)
+    assert args.warmup == 0 or check(args.warmup - 1), "GPU status bytes differ from the expected pattern"
+    comp_ms, coll_ms = [0.0] * G, [0.0] * G
+    sync_all()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(args.warmup + k)
+        a, b = mg.last_timing()                              # HIP events on every device's stream (synchronises them), as run_verify's per_step
+        comp_ms = [x + y for x, y in zip(comp_ms, a)]
+        coll_ms = [x + y for x, y in zip(coll_ms, b)]
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    assert check(args.warmup + args.steps - 1), "GPU status bytes of the last timed step differ from the expected pattern"
+
+    verifies_per_s = N * args.steps / elapsed
+    result = {
+        "metric": "BN254 pairings/sec (batch verify)", "value": 2.0 * verifies_per_s, "unit": "pairings/s", "n_gpus": G, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u32", "data": "synthetic",
+        "config": {"workload": "configs[1] through bn254_mgpu_batch_verify_device: ONE process, %d device entries %s, 65536-verify shard "
+                               "resident on each (32-byte messages, 1/64 corrupted, pattern alternates per step and differs per shard), "
+                               "2 pairings per verify" % (G, devices),
+                   "batch_per_gpu": n, "verifies_per_s": verifies_per_s, "bit_exact_vs_expected": checks["mismatches"] == 0,
+                   "status_vectors_checked": checks["steps_checked"] * G * G,
+                   "collective": ("ncclAllGather (RCCL C API, ncclCommInitAll, in place) of %d status bytes per device and step" % n)
+                   if len(set(devices)) == G else "peer copies (a device is listed twice: RCCL refuses two ranks on one device)"},
+        "scaling_detail": {"compute_ms_per_step": {"per_device": [x / args.steps for x in comp_ms]},
+                           "collective_ms_per_step": {"per_device": [x / args.steps for x in coll_ms]},
+                           "timed_by": "HIP events on each device's stream: before its shard's first kernel, after its last, after the gather",
+                           "note": "one process: ms_per_step is the host clock over K steps between synchronisations of every device"},
+    }
+    # what the layer costs: the same shard through the single-GPU entry point on device entry 0 alone, same process, same steps
+    eng0 = mg.engine(0)
+    torch.cuda.synchronize(devices[0])
+    t1 = time.perf_counter()
+    for k in range(args.steps):
+        eng0.batch_verify_device(p_msgs[0], p_off[0], p_sigs[k & 1][0], p_pks[0], n, p_all[0], flags=0)
+        eng0.synchronize()
+    direct = time.perf_counter() - t1
+    result["single_gpu_direct"] = {"ms_per_step": 1e3 * direct / args.steps, "pairings_per_s": 2.0 * n * args.steps / direct,
+                                   "mgpu_over_direct_ms": (1e3 * elapsed / args.steps) / (1e3 * direct / args.steps),
+                                   "note": "bn254_batch_verify_device on entry 0's context alone, synchronised per step like the timed loop above; "
+                                           "with one device entry the ratio is the overhead of the layer"}
+    # the host-pointer form (whole batch in pageable memory, statuses straight into the caller's slices): PCIe-inclusive, informational
+    try:
+        msgs0, sig_sets0, pks0 = host
+        reps = 3
+        hm, hs, hp = msgs0 * G, sig_sets0[0] * G, pks0 * G            # G copies of shard 0's bytes: every shard sees the same tuples
+        mg.batch_verify(hm, hs, hp)
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            got = mg.batch_verify(hm, hs, hp)
+        dt = time.perf_counter() - t1
+        assert got == expected_for(0, 0) * G, "host-pointer statuses differ from the expected pattern"
+        result["host_pointers"] = {"pairings_per_s": 2.0 * N * reps / dt, "ms_per_call": 1e3 * dt / reps,
+                                   "note": "bn254_mgpu_batch_verify incl. packing in Python; PCIe-inclusive, never `value`"}
+    except AssertionError:
+        raise
+    except Exception as exc:
+        result["host_pointers"] = {"error": repr(exc)}
+    result["pmc_as_of"] = pmc_as_of()
+    print(json.dumps(result))
+    mg.close()
+
+
 def lane_product_counts():
     """per-lane product counts of the pair kernels (dual-accumulated products / single products incl. squares) from
     the host instrumentation, committed by tests/test_workcount.py as profiles/lane_product_counts.json"""
@@ -1105,14 +1253,19 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pair-lanes", action="store_true", help="one lane per verify instead of lane pairs (A/B)")
     ap.add_argument("--split-miller", action="store_true", help="one pairing per lane instead of the fused 2-pair Miller loop (A/B)")
-    ap.add_argument("--workload", default="verify", choices=["verify", "pairing", "verify-host", "verify-keyed", "verify-keyed-randomized", "verify-compressed", "verify-randomized", "hash", "aggregate"],
+    ap.add_argument("--workload", default="verify", choices=["verify", "verify-mgpu", "pairing", "verify-host", "verify-keyed", "verify-keyed-randomized", "verify-compressed", "verify-randomized", "hash", "aggregate"],
                     help="verify = the headline (configs[1]) and pairing = configs[3]: both run on N ranks; the others time configs 2, 4 or "
                          "other entry points on one GPU (informational — see DESIGN.md §4b)")
+    ap.add_argument("--mgpu-devices", default="", help="--workload verify-mgpu: comma-separated HIP device list (default 0..gpus-1); a device "
+                                                       "may be listed more than once (one-GPU rehearsal, gather by peer copies)")
     args = ap.parse_args()
     global PMC_WORKLOAD
     PMC_WORKLOAD = "verify" if args.workload in ("verify-host", "verify-compressed") else args.workload   # same kernels, same batch as the headline command
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    if args.workload == "verify-mgpu":                       # ONE process for all devices: no ranks, no torch.distributed
+        PMC_WORKLOAD = "verify"
+        return run_verify_mgpu(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         if args.workload not in ("verify", "pairing"):
             raise SystemExit("--workload %s is a single-GPU measurement" % args.workload)

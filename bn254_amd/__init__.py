@@ -6,4 +6,4 @@ The hot path of sedaprotocol/bn254 (`ECDSA::verify` = try-and-increment hash-to-
 """
 from .api import (ECDSA, Error, ErrorKind, PrivateKey, PublicKey, PublicKeyG1, Signature, check_public_keys,  # noqa: F401
                   format_pairing_check_uncompressed_values, format_pairing_check_values)
-from .engine import Engine, NativeError, default_engine  # noqa: F401
+from .engine import Engine, MultiEngine, NativeError, default_engine  # noqa: F401

@@ -357,6 +357,134 @@ class Engine:
                self._lib.bn254_batch_g1_mul_device(self._h, d_points, d_scalars, n, int(reduce_scalar), d_out, d_status, stream))
 
 
+MGPU_OPT_GATHER = 1
+MGPU_OPT_TIMING = 2
+MGPU_GATHER_AUTO, MGPU_GATHER_RCCL, MGPU_GATHER_COPY = 0, 1, 2
+
+
+def shard_range(n_total, g, n_dev):
+    """contiguous slice [lo, hi) of ceil(n_total / n_dev) items owned by entry g — the arithmetic of bn254_mgpu_shard_range
+    (include/bn254_hip.h), restated here so that it can be checked without a GPU"""
+    per = (n_total + n_dev - 1) // n_dev
+    lo = min(n_total, g * per)
+    return lo, min(n_total, lo + per)
+
+
+class _EngineView(Engine):
+    """an Engine over a context OWNED by a MultiEngine (options, reserve, register_keys per device); never destroys it"""
+
+    def __init__(self, lib, handle, device):
+        self._lib, self._h, self.device = lib, handle, device
+
+    def close(self):
+        self._h = None
+
+
+class MultiEngine:
+    """The batch sharded over the GPUs of one node from ONE process (include/bn254_hip.h, section "Multi-GPU"): one context, one
+    stream and one parked worker thread per entry of `devices`; the only exchange between devices is the gather of the status bytes
+    (RCCL's C API; peer copies when a device is listed twice)."""
+
+    def __init__(self, devices):
+        self._lib = _native.load()
+        self.devices = list(devices)
+        arr = (ctypes.c_int * len(self.devices))(*self.devices)
+        h = ctypes.c_void_p()
+        _check("bn254_mgpu_create", self._lib.bn254_mgpu_create(arr, len(self.devices), ctypes.byref(h)))
+        self._h = h
+        self.n_dev = len(self.devices)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.bn254_mgpu_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, fn, rc):
+        if rc == -10004:
+            raise NativeError(fn + " [" + self._lib.bn254_mgpu_last_error(self._h).decode(errors="replace") + "]", rc)
+        _check(fn, rc)
+
+    def engine(self, g):
+        return _EngineView(self._lib, ctypes.c_void_p(self._lib.bn254_mgpu_ctx(self._h, g)), self.devices[g])
+
+    def shard_len(self, n):
+        return self._lib.bn254_mgpu_shard_len(self._h, n)
+
+    def gathered_len(self, n):
+        return self._lib.bn254_mgpu_gathered_len(self._h, n)
+
+    def shard_range(self, n, g):
+        lo, hi = ctypes.c_size_t(), ctypes.c_size_t()
+        _check("bn254_mgpu_shard_range", self._lib.bn254_mgpu_shard_range(self._h, n, g, ctypes.byref(lo), ctypes.byref(hi)))
+        return lo.value, hi.value
+
+    def reserve(self, n_total, init_collectives=False):
+        self._check("bn254_mgpu_reserve", self._lib.bn254_mgpu_reserve(self._h, n_total, int(init_collectives)))
+
+    def synchronize(self):
+        _check("bn254_mgpu_synchronize", self._lib.bn254_mgpu_synchronize(self._h))
+
+    def set_option(self, option, value):
+        _check("bn254_mgpu_set_option", self._lib.bn254_mgpu_set_option(self._h, option, value))
+
+    def last_timing(self):
+        """per device: (compute ms, collective ms) of the last call (MGPU_OPT_TIMING on)"""
+        a, b = (ctypes.c_float * self.n_dev)(), (ctypes.c_float * self.n_dev)()
+        _check("bn254_mgpu_last_timing", self._lib.bn254_mgpu_last_timing(self._h, a, b))
+        return list(a), list(b)
+
+    # ---- host-pointer entry points: the whole batch in, the whole result out ---------------------------------------------
+    def batch_verify(self, messages, sigs, pks, flags=0):
+        n = len(messages)
+        assert len(sigs) == n * G1_BYTES and len(pks) == n * G2_BYTES
+        msgs, off = pack_messages(messages)
+        status = ctypes.create_string_buffer(max(n, 1))
+        self._check("bn254_mgpu_batch_verify", self._lib.bn254_mgpu_batch_verify(self._h, msgs, off, bytes(sigs), bytes(pks), n, flags, status))
+        return status.raw[:n]
+
+    def batch_hash_to_g1(self, messages):
+        n = len(messages)
+        msgs, off = pack_messages(messages)
+        pts = ctypes.create_string_buffer(max(n, 1) * G1_BYTES)
+        status = ctypes.create_string_buffer(max(n, 1))
+        tries = ctypes.create_string_buffer(max(n, 1))
+        self._check("bn254_mgpu_batch_hash_to_g1", self._lib.bn254_mgpu_batch_hash_to_g1(self._h, msgs, off, n, pts, status, tries))
+        return pts.raw[:n * G1_BYTES], status.raw[:n], tries.raw[:n]
+
+    def batch_pairing(self, g1s, g2s, n, k=1, flags=0):
+        """-> (Gt bytes, status bytes, checksum = sum mod 2^64 of the little-endian 64-bit words of all Gt bytes)"""
+        assert len(g1s) == n * k * G1_BYTES and len(g2s) == n * k * G2_BYTES
+        gt = ctypes.create_string_buffer(max(n, 1) * GT_BYTES)
+        status = ctypes.create_string_buffer(max(n, 1))
+        cs = ctypes.c_uint64(0)
+        self._check("bn254_mgpu_batch_pairing",
+                    self._lib.bn254_mgpu_batch_pairing(self._h, bytes(g1s), bytes(g2s), n, k, flags, gt, status, ctypes.byref(cs)))
+        return gt.raw[:n * GT_BYTES], status.raw[:n], cs.value
+
+    # ---- device-pointer entry points: per-device lists of raw device pointers (ints), enqueue only ---------------------
+    def _ptrs(self, seq):
+        if seq is None:
+            return None
+        assert len(seq) == self.n_dev
+        return (ctypes.c_void_p * self.n_dev)(*[ctypes.c_void_p(p) if p else None for p in seq])
+
+    def batch_verify_device(self, d_msgs, d_off, d_sigs, d_pks, n, d_status_all, flags=0, streams=None):
+        self._check("bn254_mgpu_batch_verify_device",
+                    self._lib.bn254_mgpu_batch_verify_device(self._h, self._ptrs(d_msgs), self._ptrs(d_off), self._ptrs(d_sigs), self._ptrs(d_pks),
+                                                             n, flags, self._ptrs(d_status_all), self._ptrs(streams)))
+
+    def batch_pairing_device(self, d_g1, d_g2, n, k, d_gt, d_status_all, d_checksum=None, flags=0, streams=None):
+        self._check("bn254_mgpu_batch_pairing_device",
+                    self._lib.bn254_mgpu_batch_pairing_device(self._h, self._ptrs(d_g1), self._ptrs(d_g2), n, k, flags, self._ptrs(d_gt),
+                                                              self._ptrs(d_status_all), self._ptrs(d_checksum), self._ptrs(streams)))
+
+
 _default = {}
 
 

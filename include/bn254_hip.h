@@ -331,6 +331,80 @@ int bn254_ctx_last_kernel_ms(bn254_ctx *ctx, float ms[4]);
  * and bn254_probe_issue_rate kernel [2] on this context (0 = that kernel has not run since the option was set).  Synchronises the device. */
 int bn254_ctx_last_clocks(bn254_ctx *ctx, double sclk_mhz[3]);
 
+/* =====================================================================================================================
+ * Multi-GPU: the batch sharded over the GPUs of one node, ONE process (bn254_mgpu.hip).
+ *
+ * Every tuple of a batch is independent (/root/reference/src/ecdsa.rs:49-64 shares no state between calls), so a batch of n
+ * items splits into G contiguous shards of S = ceil(n / G) items (the last ones shorter or empty): shard g = items
+ * [g*S, min((g+1)*S, n)).  A bn254_mgpu owns, per entry of `devices`, one bn254_ctx, one stream and one host worker thread
+ * (started once at creation; no thread is created per call, nothing is ever exec'ed).  The ONLY exchange between devices is
+ * the gather of the per-item status bytes (and, for the pairing entry point, an 8-byte sum): RCCL's C API over xGMI
+ * (ncclAllGather / ncclAllReduce on ncclCommInitAll communicators; librccl.so.1 is loaded with dlopen at the first call that
+ * needs it, so single-GPU users of the library never load it).  A device may be listed more than once — several contexts on
+ * one GPU, which is how the single-GPU test rigs run this code; RCCL refuses two ranks on one device, so such a handle gathers
+ * with peer copies (hipMemcpyPeerAsync, pulled by every destination on its own stream) instead; BN254_MGPU_OPT_GATHER selects
+ * either explicitly.  This is the layer /root/reference/src/lib.rs:60-63 would grow an `ECDSA::batch_verify(&Gpus, ...)` on
+ * (INTEGRATION.md).
+ *
+ * Host-pointer entry points (bn254_mgpu_batch_verify, _batch_pairing, _batch_hash_to_g1): the caller passes the WHOLE batch;
+ * every worker stages its shard to its device, runs the single-GPU entry point of the same name and copies the results straight
+ * into the caller's slices — no collective.  They return when all shards are done; the return value is the first non-zero
+ * return code of any shard (all shards are always run to the end).
+ *
+ * *_device entry points: the caller passes, per device g, DEVICE pointers to shard g's inputs (resident on devices[g], offsets
+ * relative to that shard's own message buffer) and a status buffer d_status_all[g] of bn254_mgpu_gathered_len(mg, n) = G*S
+ * bytes; device g writes its shard's statuses at offset g*S of ITS buffer and the gather (in place) leaves every device with
+ * all n status bytes at d_status_all[g][0 .. n).  streams[g] (hipStream_t as void*; the array or an entry may be NULL = the
+ * handle's own stream of that device) carries the kernels and the collective of device g; the calls only enqueue.
+ * A handle carries one call in flight, like a context. */
+typedef struct bn254_mgpu bn254_mgpu;
+
+#define BN254_E_RCCL (-10004)      /* librccl.so.1 could not be loaded, or an RCCL call failed (bn254_mgpu_last_error has the text) */
+#define BN254_E_NO_MEMORY (-10005) /* host allocation or thread creation failed */
+
+int bn254_mgpu_create(const int *devices, int n_dev /* 1..64 */, bn254_mgpu **out);
+void bn254_mgpu_destroy(bn254_mgpu *mg);
+int bn254_mgpu_device_count(const bn254_mgpu *mg);
+/* the context of entry g (options, bn254_ctx_reserve, bn254_ctx_register_keys ... per device); owned by the handle */
+bn254_ctx *bn254_mgpu_ctx(bn254_mgpu *mg, int g);
+/* S = ceil(n / G); [lo, hi) of shard g; G * S */
+size_t bn254_mgpu_shard_len(const bn254_mgpu *mg, size_t n);
+int bn254_mgpu_shard_range(const bn254_mgpu *mg, size_t n, int g, size_t *lo, size_t *hi);
+size_t bn254_mgpu_gathered_len(const bn254_mgpu *mg, size_t n);
+/* presize every context for batches of n_total items over all devices (bn254_ctx_reserve(ceil(n_total / G)) each) and, when
+ * init_collectives != 0, create the RCCL communicators now instead of inside the first *_device call */
+int bn254_mgpu_reserve(bn254_mgpu *mg, size_t n_total, int init_collectives);
+int bn254_mgpu_synchronize(bn254_mgpu *mg); /* waits for the handle's own streams */
+#define BN254_MGPU_OPT_GATHER 1 /* 0 (default) = RCCL when the devices are distinct, peer copies otherwise; 1 = RCCL (an error for
+                                   duplicate devices); 2 = peer copies */
+#define BN254_MGPU_OPT_TIMING 2 /* 1 = record per device the time of its shard's compute and of the collective (bn254_mgpu_last_timing) */
+int bn254_mgpu_set_option(bn254_mgpu *mg, int option, int value);
+/* per device g of the last call, in ms: compute_ms[g] = its shard's kernels (device entry points: HIP events on its stream; host
+ * entry points: the worker's wall clock around staging + kernels + copy-back), collective_ms[g] = the gather / all-reduce as
+ * seen on its stream (0 for host entry points).  Synchronises the streams.  Needs BN254_MGPU_OPT_TIMING. */
+int bn254_mgpu_last_timing(bn254_mgpu *mg, float *compute_ms /* G */, float *collective_ms /* G */);
+/* text of the last RCCL / loader failure on this handle ("" if none); valid until the next call on the handle */
+const char *bn254_mgpu_last_error(const bn254_mgpu *mg);
+
+/* status[i] = ECDSA::verify(msg_i, sig_i, pk_i) (src/ecdsa.rs:49-64) for the whole batch, sharded over the devices */
+int bn254_mgpu_batch_verify(bn254_mgpu *mg, const uint8_t *msgs, const uint64_t *msg_off /* n+1 */, const uint8_t *sigs /* n*64 */,
+                            const uint8_t *pks /* n*128 */, size_t n, uint32_t flags, uint8_t *status /* n */);
+int bn254_mgpu_batch_verify_device(bn254_mgpu *mg, const uint8_t *const *d_msgs, const uint64_t *const *d_msg_off,
+                                   const uint8_t *const *d_sigs, const uint8_t *const *d_pks, size_t n /* whole batch */, uint32_t flags,
+                                   uint8_t *const *d_status_all /* G x gathered_len */, void *const *streams /* G or NULL */);
+/* gt[i], status[i] as bn254_batch_pairing (bn::pairing_batch, src/ecdsa.rs:57); *checksum (optional) = the sum mod 2^64 of all
+ * little-endian 64-bit words of the n*384 Gt bytes — BASELINE configs[3]'s cross-shard check.  Device form: d_gt[g] = shard g's
+ * n_g*384 bytes; d_checksum[g] (the array or NULL) = 8 bytes on every device receiving the all-reduced (ncclAllReduce, sum,
+ * uint64) checksum. */
+int bn254_mgpu_batch_pairing(bn254_mgpu *mg, const uint8_t *g1 /* n*k*64 */, const uint8_t *g2 /* n*k*128 */, size_t n, size_t k,
+                             uint32_t flags, uint8_t *gt /* n*384 */, uint8_t *status /* n or NULL */, uint64_t *checksum /* or NULL */);
+int bn254_mgpu_batch_pairing_device(bn254_mgpu *mg, const uint8_t *const *d_g1, const uint8_t *const *d_g2, size_t n, size_t k,
+                                    uint32_t flags, uint8_t *const *d_gt, uint8_t *const *d_status_all, uint64_t *const *d_checksum,
+                                    void *const *streams);
+/* points[i] = hash_to_try_and_increment(msg_i) (src/hash.rs:29-63) for the whole batch, sharded over the devices */
+int bn254_mgpu_batch_hash_to_g1(bn254_mgpu *mg, const uint8_t *msgs, const uint64_t *msg_off, size_t n, uint8_t *points /* n*64 */,
+                                uint8_t *status /* n */, uint8_t *tries /* n or NULL */);
+
 #ifdef __cplusplus
 }
 #endif
