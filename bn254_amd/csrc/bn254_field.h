@@ -211,6 +211,15 @@ BN_DEV Fp fp_select(bool c, const Fp& a, const Fp& b) {
   BN_TRK(r.bd = FpBounds({std::fmin(a.bd.lo, b.bd.lo), std::fmax(a.bd.hi, b.bd.hi), std::fmax(a.bd.top, b.bd.top), std::fmin(a.bd.vlo, b.bd.vlo), std::fmax(a.bd.vhi, b.bd.vhi)}));
   return r;
 }
+// r = c ? a : b where c is a constant of the lane's POSITION in a distributed layout (which coefficient / product / output its lane pair
+// handles: bn254_nonet.h), not data.  Same instructions as fp_select; the difference is the proof: fp_select is followed by the bound
+// tracker with the UNION of both operands' bounds (one pass covers every value of a data-dependent condition), this one with the bounds of
+// the operand the position takes — the host emulations run EVERY position, so every lane class is proven with its own bounds.
+BN_DEV Fp fp_select_pos(bool c, const Fp& a, const Fp& b) {
+  Fp r = fp_select(c, a, b);
+  BN_TRK(r.bd = c ? a.bd : b.bd);
+  return r;
+}
 // a >= b as 256-bit integers
 BN_DEV bool u256_geq(const uint32_t* a, const uint32_t* b) {
   uint32_t bw = 0;

@@ -106,6 +106,7 @@ BN_DEV Fp2 fp2_lin2_reduce(const Fp2& x, int32_t cx, const Fp2& y, int32_t cy) {
 BN_DEV bool fp2_is_zero(const Fp2& a) { bool z = true; BN_FOR_ROLES(k) z = fp_is_zero(a.c[k]) && z; return bn_pair_and(z); }
 BN_DEV bool fp2_eq(const Fp2& a, const Fp2& b) { return fp2_is_zero(fp2_sub(a, b)); }
 BN_DEV Fp2 fp2_select(bool c, const Fp2& a, const Fp2& b) { Fp2 r; BN_FOR_ROLES(k) r.c[k] = fp_select(c, a.c[k], b.c[k]); return r; }
+BN_DEV Fp2 fp2_select_pos(bool c, const Fp2& a, const Fp2& b) { Fp2 r; BN_FOR_ROLES(k) r.c[k] = fp_select_pos(c, a.c[k], b.c[k]); return r; }   // c = a constant of the lane's position (bn254_field.h)
 
 #if defined(__HIPCC__)
 // Device form of fp2_mul: the callee fetches the partner's operands itself (DPP) and picks its role's operand

@@ -1096,6 +1096,21 @@ KERNEL void k_debug_fp12_op(int op, const uint8_t* a, const uint8_t* b, size_t n
   encode_fp12(out + 384 * i, r);
 }
 
+// test hook: LIMB vectors straight into the F planes of the workspace (12 coefficients x 9 int32 limbs per item, Gt order) — the input of a
+// final exponentiation with non-canonical / extreme-digit representatives that no byte decoder would produce
+KERNEL_SMALL void k_debug_load_f(const int32_t* limbs, size_t n, Ws ws) {
+  size_t i = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
+  if (i >= n) return;
+  for (int e = 0; e < 12; ++e) {
+    Fp x;
+#pragma unroll
+    for (int k = 0; k < BN_LIMBS; ++k) x.v[k] = limbs[(i * 12 + e) * BN_LIMBS + k];
+    ws_store_fp(ws, PL_F0 + e, i, x);
+  }
+  ws_byte(ws, BY_ST_DECODE, i) = ST_OK;
+  ws_byte(ws, BY_ST_HASH, i) = ST_OK;
+}
+
 // ---- in-process issue-rate probe (bench.py's roofline calibration) --------------------------------------------
 // 16 independent chains of one instruction, 4096 trips, on every SIMD of the device with `waves_per_simd` waves each
 // (256-thread workgroups = one wave per SIMD of a CU, like the pair kernels).  op 0: v_mad_u64_u32, 1: v_add_u32,
@@ -2455,6 +2470,36 @@ int bn254_debug_hash_candidate(bn254_ctx* c, const uint8_t* h, size_t n, uint8_t
   if ((rc = stage_out(c, 2, out, n * 64))) return rc;
   if ((rc = stage_out(c, 3, status, n))) return rc;
   HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+// layout: 0 one lane per item, exact chain (Gt out) | 1 lane pairs, program C_FE_EXACT (Gt out) | 2 lane pairs, program C_FE_CHECK |
+// 3 octet (straight-line chains below 128 items, accumulator machine from 128 on) | 4 nonet | 5 one lane per item, check chain
+int bn254_debug_final_exp_limbs(bn254_ctx* c, int layout, const int32_t* limbs, size_t n, uint8_t* gt, uint8_t* status) {
+  if (!c || layout < 0 || layout > 5 || (n && (!limbs || !status)) || (gt && layout > 1)) return BN254_E_BAD_ARGUMENT;
+  if (n == 0) return 0;
+  if ((layout == 3 && !c->fits_trio) || (layout == 4 && !bn254_nonet_fits_device())) return BN254_E_BAD_ARGUMENT;
+  HIP_TRY(hipSetDevice(c->device));
+  int rc;
+  if ((rc = ws_reserve(c, n))) return rc;
+  if ((rc = stage_in(c, 0, limbs, n * 12 * BN_LIMBS * sizeof(int32_t)))) return rc;
+  if ((rc = stage_reserve(c, 1, n * 384))) return rc;
+  if ((rc = stage_reserve(c, 2, n))) return rc;
+  hipStream_t s = c->stream;
+  uint8_t* d_gt = gt ? c->stage[1] : nullptr;
+  k_debug_load_f<<<grid_for(n), BN_WAVE, 0, s>>>((const int32_t*)c->stage[0], n, c->ws);
+  switch (layout) {
+    case 0: k_final_exp<<<grid_for(n), BN_WAVE, 0, s>>>(n, 1, 1, 1, c->ws, 0, d_gt ? d_gt : c->stage[1], c->stage[2], 0, 0, nullptr, nullptr); break;
+    case 1: rc = bn254_pair_final_exp_product(n, 1, c->ws, d_gt ? d_gt : c->stage[1], c->stage[2], 0, s); break;
+    case 2: rc = bn254_pair_final_exp(n, c->ws, 0, c->stage[2], nullptr, nullptr, s); break;
+    case 3: rc = bn254_trio_final_exp(n, c->ws, 0, c->stage[2], s); break;
+    case 4: rc = bn254_nonet_final_exp(n, c->ws, 0, c->stage[2], s); break;
+    default: k_final_exp<<<grid_for(n), BN_WAVE, 0, s>>>(n, 1, 1, 1, c->ws, 0, nullptr, c->stage[2], 0, 0, nullptr, nullptr); break;
+  }
+  if (rc) return rc;
+  HIP_TRY(hipGetLastError());
+  if (gt && (rc = stage_out(c, 1, gt, n * 384))) return rc;
+  if ((rc = stage_out(c, 2, status, n))) return rc;
+  HIP_TRY(hipStreamSynchronize(s));
   return 0;
 }
 int bn254_debug_fp12_op(bn254_ctx* c, int op, const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out) {

@@ -274,6 +274,15 @@ class Engine:
         _check("bn254_debug_fp12_op", self._lib.bn254_debug_fp12_op(self._h, op, bytes(a), None if b is None else bytes(b), n, out))
         return out.raw[:n * GT_BYTES]
 
+    def debug_final_exp_limbs(self, layout, limbs, n, want_gt=False):
+        """final exponentiation of layout 0..5 on n x 108 int32 limbs (include/bn254_hip.h) -> (Gt bytes or None, status bytes)"""
+        assert len(limbs) == n * 108
+        arr = (ctypes.c_int32 * max(len(limbs), 1))(*limbs)
+        gt = ctypes.create_string_buffer(max(n, 1) * GT_BYTES) if want_gt else None
+        status = ctypes.create_string_buffer(max(n, 1))
+        _check("bn254_debug_final_exp_limbs", self._lib.bn254_debug_final_exp_limbs(self._h, layout, arr, n, gt, status))
+        return (gt.raw[:n * GT_BYTES] if want_gt else None), status.raw[:n]
+
     def debug_miller_loop(self, g1s, g2s, n):
         out = ctypes.create_string_buffer(max(n, 1) * GT_BYTES)
         _check("bn254_debug_miller_loop", self._lib.bn254_debug_miller_loop(self._h, bytes(g1s), bytes(g2s), n, out))

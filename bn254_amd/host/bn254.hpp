@@ -50,6 +50,20 @@ class Engine {   // one per GPU; not thread-safe (one thread at a time per conte
   bn254_ctx* ctx_ = nullptr;
 };
 
+// All the GPUs of a node behind one handle (include/bn254_hip.h, section "Multi-GPU"): the batch is cut into contiguous shards, one per
+// device entry, each verified by that device's own context from its own parked worker thread; ECDSA::batch_verify(gpus, ...) below.
+class Gpus {
+ public:
+  explicit Gpus(const std::vector<int>& devices) { check_rc("bn254_mgpu_create", bn254_mgpu_create(devices.data(), (int)devices.size(), &mg_)); }
+  ~Gpus() { bn254_mgpu_destroy(mg_); }
+  Gpus(const Gpus&) = delete;
+  Gpus& operator=(const Gpus&) = delete;
+  bn254_mgpu* raw() const { return mg_; }
+  int count() const { return bn254_mgpu_device_count(mg_); }
+ private:
+  bn254_mgpu* mg_ = nullptr;
+};
+
 struct PrivateKey {   // PrivateKey(Fr): 32-byte big-endian scalar, reduced mod r on use
   std::array<uint8_t, 32> bytes{};
   static PrivateKey try_from(const uint8_t* data, size_t len) {
@@ -159,6 +173,23 @@ struct ECDSA {
     }
     off[n] = msgs.size();
     check_rc("bn254_batch_verify", bn254_batch_verify(e.raw(), msgs.data(), off.data(), sigs.data(), pks.data(), n, 0, status.data()));
+    return status;
+  }
+  // the same over all the GPUs of a node: shard g of the batch on device entry g, statuses straight into result's slices
+  static std::vector<uint8_t> batch_verify(Gpus& gpus, const std::vector<std::vector<uint8_t>>& messages, const std::vector<Signature>& signatures,
+                                           const std::vector<PublicKey>& public_keys) {
+    size_t n = messages.size();
+    if (signatures.size() != n || public_keys.size() != n) throw Error(ErrorKind::InvalidLength);
+    std::vector<uint64_t> off(n + 1, 0);
+    std::vector<uint8_t> msgs, sigs(n * 64), pks(n * 128), status(n, 0);
+    for (size_t i = 0; i < n; ++i) {
+      off[i] = msgs.size();
+      msgs.insert(msgs.end(), messages[i].begin(), messages[i].end());
+      std::memcpy(&sigs[64 * i], signatures[i].raw.data(), 64);
+      std::memcpy(&pks[128 * i], public_keys[i].raw.data(), 128);
+    }
+    off[n] = msgs.size();
+    check_rc("bn254_mgpu_batch_verify", bn254_mgpu_batch_verify(gpus.raw(), msgs.data(), off.data(), sigs.data(), pks.data(), n, 0, status.data()));
     return status;
   }
   // Keyed verify: a validator set registered once (PublicKey::from_uncompressed per key, types.rs:96-99, plus the key's Miller-loop

@@ -25,6 +25,10 @@ int main() {
     auto kst = bn254::ECDSA::register_keys({pk1, pk2, pk1 + pk2});
     auto st = bn254::ECDSA::batch_verify_keyed({msg, msg, msg, msg, msg}, {s1, s2, s1 + s2, s1, s2}, {0, 1, 2, 1, 7});
     if (kst != std::vector<uint8_t>{0, 0, 0} || st != std::vector<uint8_t>{0, 0, 0, 9, 2}) { printf("ERROR: keyed verify\n"); return 4; }
+    // and over "all the GPUs of the node" — here two contexts on device 0, the batch cut in two shards (three tuples and two)
+    bn254::Gpus gpus({0, 0});
+    auto mst = bn254::ECDSA::batch_verify(gpus, {msg, msg, msg, msg, msg}, {s1, s2, s1 + s2, s1, s2}, {pk1, pk2, pk1 + pk2, pk2, pk1});
+    if (gpus.count() != 2 || mst != std::vector<uint8_t>{0, 0, 0, 9, 9}) { printf("ERROR: multi-GPU verify\n"); return 5; }
     return 0;
   } catch (const std::exception& e) { printf("failed: %s\n", e.what()); return 1; }
 }

@@ -255,6 +255,14 @@ int bn254_batch_g2_decompress(bn254_ctx *ctx, const uint8_t *in /* n*65 */, size
  *            8 final exponentiation                                                    [384 B] */
 int bn254_debug_fp_op(bn254_ctx *ctx, int op, const uint8_t *a, const uint8_t *b, size_t n, uint8_t *out, uint8_t *status);
 int bn254_debug_fp12_op(bn254_ctx *ctx, int op, const uint8_t *a, const uint8_t *b, size_t n, uint8_t *out);
+/* the final exponentiation of ECDSA::verify / bn::pairing_batch (src/ecdsa.rs:57-59) on caller-supplied LIMB vectors — n x 12 coefficients
+ * (Gt order) x 9 int32 limbs, value = sum limb_k 2^(29 k) in Montgomery form (R = 2^261) — in the layout named: 0 one lane per item, exact
+ * exponent, gt = canonical Gt bytes | 1 lane pairs, exact, gt | 2 lane pairs, the == one chain | 3 lane octets (straight-line chains below
+ * 128 items, accumulator machine from 128 on) | 4 nine lane pairs per item | 5 one lane, the == one chain.  status[i] = 0 (the value is one) or 9.
+ * Exists so that the parity tests can hand every layout NON-CANONICAL representatives with extreme balanced digits — what the interval
+ * tracker's contract for a Miller value allows (limbs 0..7 in [-2^28, 2^28], |value| <= 0.5215 q) but no byte decoder produces. */
+int bn254_debug_final_exp_limbs(bn254_ctx *ctx, int layout, const int32_t *limbs /* n*108 */, size_t n, uint8_t *gt /* n*384, layouts 0 / 1, or NULL */,
+                                uint8_t *status /* n */);
 /* what ONE pass of the try loop of hash_to_try_and_increment does with a chosen 256-bit digest value h (32 B
  * big-endian each) instead of SHA-256(msg || ctr): the h >= 5q rule (src/hash.rs:49-51), mod_u256's strict '>'
  * (src/utils.rs:27-37) and G1::from_compressed(0x02 || x) (src/utils.rs:56-63).  status 0: out = the point; 1: the

@@ -18,6 +18,7 @@ static struct BnSiteInit { BnSiteInit() { for (int i = 0; i < 1024; ++i) bn_site
 
 #include "../../bn254_amd/csrc/bn254_pairing.h"
 #include "../../bn254_amd/csrc/bn254_codec_g2.h"
+#include "../../bn254_amd/csrc/bn254_nonet.h"
 
 using namespace bn254;
 
@@ -88,6 +89,80 @@ int hp_verify_decoded(const uint8_t* h64, const uint8_t* sig64, const uint8_t* p
   const bool one_check = fp12_is_one(g), one_exact = fp12_is_one(f);
   if (one_check != one_exact) return 255;
   return one_check ? 0 : 9;
+}
+// The NONET schedule of the final exponentiation (bn254_nonet.hip: one verify on nine lane pairs; bn254_nonet.h: nn_machine_model — the very
+// phase functions of the kernel on a host box, the nine pairs of every exchange step one after the other): program C_FE_CHECK on the
+// Miller value of the tuple.  0 / 9 = its verdict, which must be fe_machine_check's; 248 = some coefficient differs in VALUE from the
+// pair layout's accumulator machine.  *words_equal (may be null): 1 if all 6 x 2 x 9 limbs are the same words as well (they are wherever
+// the "strictest site mode of the three" rule changes no site of the flow).  Under -DBN_TRACK_BOUNDS one call is the bound proof of the flow.
+int hp_nonet_check(const uint8_t* h64, const uint8_t* sig64, const uint8_t* pk128, int* words_equal) {
+  G1Affine h, sig;
+  G2Affine pk;
+  load_g1(h, h64); load_g1(sig, sig64); load_g2(pk, pk128);
+  Fp12 f;
+  miller_loop<true, true>(f, h, pk, sig);
+  Fp12 a = f, b = f;
+  fe_machine_check(a);
+  nn_machine_model(b, C_FE_CHECK);
+  const Fp2* x[6] = {&a.c0.c0, &a.c0.c1, &a.c0.c2, &a.c1.c0, &a.c1.c1, &a.c1.c2};
+  const Fp2* y[6] = {&b.c0.c0, &b.c0.c1, &b.c0.c2, &b.c1.c0, &b.c1.c1, &b.c1.c2};
+  int same = 1;
+  for (int k = 0; k < 6; ++k) {
+    if (!fp2_eq(*x[k], *y[k])) return 248;
+    for (int r = 0; r < 2; ++r) for (int i = 0; i < BN_LIMBS; ++i) if (x[k]->c[r].v[i] != y[k]->c[r].v[i]) same = 0;
+  }
+  if (words_equal) *words_equal = same;
+  const bool one_a = fp12_is_one(a), one_b = fp12_is_one(b);
+  if (one_a != one_b) return 247;
+  return one_b ? 0 : 9;
+}
+#if defined(BN_TRACK_BOUNDS)
+// What the interval tracker knows about the Miller value a verify hands to its final exponentiation: per coefficient (12, Gt order)
+// {limb lo, limb hi, |top limb| max, value/q lo, value/q hi} — the contract an adversarial-limb test may fill to the brim
+// (tests/test_bounds.py::test_fe_input_contract_matches_tracker, tests/golden/adversarial_fe_vectors.json).
+void hp_miller_output_bounds(const uint8_t* h64, const uint8_t* sig64, const uint8_t* pk128, double* out60) {
+  G1Affine h, sig;
+  G2Affine pk;
+  load_g1(h, h64); load_g1(sig, sig64); load_g2(pk, pk128);
+  Fp12 f;
+  miller_loop<true, true>(f, h, pk, sig);
+  const Fp2* c[6] = {&f.c0.c0, &f.c0.c1, &f.c0.c2, &f.c1.c0, &f.c1.c1, &f.c1.c2};
+  for (int k = 0; k < 6; ++k)
+    for (int r = 0; r < 2; ++r) {
+      const FpBounds& b = c[k]->c[r].bd;
+      double* o = out60 + (2 * k + r) * 5;
+      o[0] = b.lo; o[1] = b.hi; o[2] = b.top; o[3] = b.vlo; o[4] = b.vhi;
+    }
+}
+#endif
+// The final exponentiation on caller-supplied LIMB vectors (12 coefficients x 9 limbs, Montgomery form, Gt order) through the pair layout's
+// accumulator machine (exact != 0: program C_FE_EXACT, canonical Gt bytes out; else C_FE_CHECK) and, for the check program, through the
+// nonet schedule as well: returns 0 / 9 (is one / is not), 248 if the two schedules differ.  The host twin of bn254_debug_final_exp_limbs.
+int hp_final_exp_limbs(const int32_t* limbs108, int exact, uint8_t* gt384) {
+  Fp12 f;
+  Fp2* c[6] = {&f.c0.c0, &f.c0.c1, &f.c0.c2, &f.c1.c0, &f.c1.c1, &f.c1.c2};
+  for (int k = 0; k < 6; ++k)
+    for (int r = 0; r < 2; ++r) {
+      Fp x = fp_zero();
+      for (int i = 0; i < BN_LIMBS; ++i) x.v[i] = limbs108[(2 * k + r) * BN_LIMBS + i];
+#if defined(BN_TRACK_BOUNDS)
+      // the contract of a Miller output (hp_miller_output_bounds): tight limbs, |value| <= 0.5215 q
+      bn_set_tight(x, -0.5215, 0.5215);
+#endif
+      c[k]->c[r] = x;
+    }
+  if (exact) {
+    fe_machine_exact(f);
+    if (gt384) for (int k = 0; k < 6; ++k) { fp_to_be32(gt384 + 64 * k, c[k]->c[0]); fp_to_be32(gt384 + 64 * k + 32, c[k]->c[1]); }
+    return fp12_is_one(f) ? 0 : 9;
+  }
+  Fp12 g = f;
+  fe_machine_check(f);
+  nn_machine_model(g, C_FE_CHECK);
+  const Fp2* d[6] = {&g.c0.c0, &g.c0.c1, &g.c0.c2, &g.c1.c0, &g.c1.c1, &g.c1.c2};
+  for (int k = 0; k < 6; ++k) if (!fp2_eq(*c[k], *d[k])) return 248;
+  if (gt384) for (int k = 0; k < 6; ++k) { fp_to_be32(gt384 + 64 * k, c[k]->c[0]); fp_to_be32(gt384 + 64 * k + 32, c[k]->c[1]); }
+  return fp12_is_one(f) ? 0 : 9;
 }
 // The keyed verify (k_register_keys + k_miller_verify_keyed_pair): the key's 87 lines tabulated once (c2 = 1 form, canonical
 // limbs as the kernel stores them), then the table-driven loop; returns 0 / 9 as hp_verify_decoded, 250 if its Gt value

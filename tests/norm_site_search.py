@@ -86,6 +86,7 @@ def main():
             return False
         assert pair.L.hp_verify_decoded(h, sig, pk) == 0 or pair.failed.value
         pair.L.hp_pairing(ps[0], qs[0], o)
+        pair.L.hp_nonet_check(h, sig, pk, None)           # the nonet schedule of the final exponentiation (bn254_nonet.h) shares sites 20..43, 170..179
         if pair.failed.value:
             return False
         pair.L.hp_pairing_product4(b"".join(ps), b"".join(qs), o)

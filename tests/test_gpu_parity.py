@@ -103,6 +103,48 @@ def test_fp12_ops(eng, c):
     assert eng.debug_fp12_op(4, f1, None, 66) == f2 and eng.debug_fp12_op(4, f2, None, 66) == f3
 
 
+def test_adversarial_limbs_in_every_final_exponentiation_layout(eng):
+    """Every layout of the final exponentiation of ECDSA::verify (/root/reference/src/ecdsa.rs:57-59) — one lane (exact and == one chains),
+    lane pairs (both programs of the accumulator machine), lane octets (straight-line chains below 128 items, machine from 128 on), nine
+    lane pairs (the default for every single verify) — on LIMB vectors at the edge of the interval tracker's contract for a Miller value:
+    non-canonical representatives, extreme balanced digits and top limbs (tests/golden/adversarial_fe_vectors.json; expected results
+    from the independent big-integer model).  Family "full" (all 12 coefficients adversarial): canonical Gt bytes where a layout writes
+    them, status 9 everywhere; family "one" (f = g^r s, s in Fq6 forcing six adversarial coefficients): status 0 from every layout — a
+    column overflow anywhere in a status-only kernel would turn it into 9."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "adversarial_fe_vectors.json")) as f:
+        adv = json.load(f)
+    vec = adv["vectors"]
+    want_st = bytes(v["status"] for v in vec)
+    want_gt = b"".join(bytes.fromhex(v["gt"]) for v in vec)
+    assert set(want_st) == {0, 9}
+    limbs = [x for v in vec for x in v["limbs"]]
+    n = len(vec)
+    for layout in (0, 1):
+        gt, st = eng.debug_final_exp_limbs(layout, limbs, n, want_gt=True)
+        assert st == want_st, (layout, st, want_st)
+        assert gt == want_gt, layout
+    for layout in (2, 3, 4, 5):
+        _, st = eng.debug_final_exp_limbs(layout, limbs, n)
+        assert st == want_st, (layout, st, want_st)
+    # sizes that change the kernels' own arrangement: the octet layout's accumulator machine (>= 128 items), several workgroups of the
+    # nonet kernel (12 verifies each) incl. a ragged last one, lane pairs over several waves
+    reps = 5
+    big = limbs * reps + limbs[:108 * 7]
+    for layout in (1, 2, 3, 4):
+        gt, st = eng.debug_final_exp_limbs(layout, big, reps * n + 7, want_gt=(layout == 1))
+        assert st == want_st * reps + want_st[:7], layout
+        if gt is not None:
+            assert gt == want_gt * reps + want_gt[:384 * 7]
+    # the hook refuses what it cannot do
+    import ctypes
+    arr = (ctypes.c_int32 * 108)()
+    out = ctypes.create_string_buffer(384)
+    assert eng._lib.bn254_debug_final_exp_limbs(eng._h, 6, arr, 1, None, out) == -10001
+    assert eng._lib.bn254_debug_final_exp_limbs(eng._h, 4, arr, 1, out, out) == -10001      # Gt bytes only from layouts 0 and 1
+
+
 # ---- golden vectors --------------------------------------------------------------------------
 def test_hash_to_g1_golden(eng, kats, derived):
     vs = [(H(v["message_hex"]), v["uncompressed"], v["tries"]) for v in derived["hash_to_g1"]]

@@ -136,6 +136,35 @@ def test_pair_layout_g2_decompress(pair_lib, kats, derived):
         assert (st, out.raw if st == 0 else None) == (wst, want if wst == 0 else None), enc.hex()[:20]
 
 
+def test_nonet_schedule_matches_fe_machine(pair_lib, derived):
+    """the final exponentiation on NINE lane pairs per verify (bn254_nonet.hip, default for every batch <= 3 072, i.e. for every single
+    ECDSA::verify, /root/reference/src/ecdsa.rs:57-59): the kernel's own phase functions (bn254_nonet.h) on a host box, the nine pairs of
+    every exchange step run one after the other, give the accumulator machine's result coefficient for coefficient on every verify case
+    and on random signed tuples (valid, foreign key, identity operands)"""
+    import hashlib
+    pair_lib.hp_nonet_check.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]
+    n, words = 0, []
+    for v in derived["verify_cases"]:
+        if v["status"] not in (0, 9):
+            continue
+        st, h, _ = c.hash_to_g1(H(v["message_hex"]))
+        w = ctypes.c_int(-1)
+        assert pair_lib.hp_nonet_check(h, H(v["sig"]), H(v["pk"]), ctypes.byref(w)) == v["status"], v["name"]
+        words.append(w.value)
+        n += 1
+    assert n >= 10
+    g1, g2 = c.g1_generator(), c.g2_generator()
+    for i in range(4):
+        sk = hashlib.sha256(b"nonet-sk%d" % i).digest()
+        _, h, _ = c.hash_to_g1(b"nonet-msg-%d" % i)
+        sig, pk = c.g1_mul(h, sk), c.g2_mul(g2, sk)
+        assert pair_lib.hp_nonet_check(h, sig, pk, None) == 0
+        assert pair_lib.hp_nonet_check(h, sig, c.g2_mul(g2, hashlib.sha256(sk).digest()), None) == 9
+        assert pair_lib.hp_nonet_check(h, bytes(64), pk, None) == 9
+        assert pair_lib.hp_nonet_check(h, c.g1_mul(g1, sk), bytes(128), None) == 9
+    assert set(words) <= {0, 1}
+
+
 DRIVER = r'''
 import ctypes, json, sys
 root = sys.argv[1]
@@ -148,6 +177,7 @@ for v in d["verify_cases"]:
     if v["status"] in (0, 9):
         L.hp_verify_decoded(g1, H(v["sig"]), H(v["pk"]))      # any G1 point exercises the same operation sequence
         assert L.hp_verify_keyed_decoded(g1, H(v["sig"]), H(v["pk"]), None) <= 9      # keyed verify: line table + table-driven loop
+        assert L.hp_nonet_check(g1, H(v["sig"]), H(v["pk"]), None) <= 9               # the nonet schedule of the final exponentiation (bn254_nonet.h)
 g2 = H(d["g2_generator"]); o = ctypes.create_string_buffer(384)
 L.hp_pairing_product4(g1 * 4, g2 * 4, o)
 o = ctypes.create_string_buffer(128)
@@ -160,6 +190,91 @@ print("ok")
 
 def test_pair_layout_bounds_hold(pair_lib):
     p = subprocess.run([sys.executable, "-c", DRIVER, ROOT], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and p.stdout.strip() == "ok", (p.stdout[-500:], p.stderr[-2000:])
+
+
+def test_nonet_schedule_bounds_hold(pair_lib):
+    """the nonet schedule under the interval tracker, on its own (the DRIVER above runs it too): no 64-bit column, int32 limb or value
+    bound can be exceeded in the nine-pair arrangement — identity operands included (data-independent control flow: one pass per
+    flow is a proof).  The tracker build ABORTS on a violation."""
+    drv = r'''
+import ctypes, json, sys
+root = sys.argv[1]
+L = ctypes.CDLL(root + "/tests/hostsim/libhostsim_pair_bounds.so")
+d = json.load(open(root + "/tests/golden/derived_vectors.json"))
+H = bytes.fromhex
+g1 = (1).to_bytes(32, "big") + (2).to_bytes(32, "big")
+n = 0
+for v in d["verify_cases"]:
+    if v["status"] in (0, 9):
+        assert L.hp_nonet_check(g1, H(v["sig"]), H(v["pk"]), None) <= 9
+        n += 1
+assert L.hp_nonet_check(g1, bytes(64), H(d["g2_generator"]), None) <= 9
+assert L.hp_nonet_check(g1, g1, bytes(128), None) <= 9
+assert n >= 10
+print("ok")
+'''
+    p = subprocess.run([sys.executable, "-c", drv, ROOT], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and p.stdout.strip() == "ok", (p.stdout[-500:], p.stderr[-2000:])
+
+
+def _adversarial():
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "adversarial_fe_vectors.json")) as f:
+        return json.load(f)
+
+
+def test_adversarial_limb_vectors_through_host_emulations(pair_lib):
+    """final exponentiation inputs at the edge of the tracker's contract for a Miller value — non-canonical representatives, extreme
+    balanced digits, extreme top limbs (tests/golden/gen_adversarial_fe.py; expected results from the big-integer model): the pair
+    layout's accumulator machine gives the model's canonical Gt bytes (exact program) and verdict (check program), and the nonet
+    schedule agrees with it coefficient for coefficient (hp_final_exp_limbs returns 248 otherwise)"""
+    adv = _adversarial()
+    pair_lib.hp_final_exp_limbs.argtypes = [ctypes.POINTER(ctypes.c_int32), ctypes.c_int, ctypes.c_char_p]
+    fams = set()
+    for v in adv["vectors"]:
+        limbs = (ctypes.c_int32 * 108)(*v["limbs"])
+        gt = ctypes.create_string_buffer(384)
+        assert pair_lib.hp_final_exp_limbs(limbs, 1, gt) == v["status"]
+        assert gt.raw.hex() == v["gt"]
+        assert pair_lib.hp_final_exp_limbs(limbs, 0, None) == v["status"]
+        fams.add((v["family"], v["status"]))
+    assert fams == {("full", 9), ("one", 0)}
+
+
+def test_adversarial_contract_is_inside_what_the_tracker_proves(pair_lib):
+    """the fixture's contract (limb, top-limb and value maxima) lies inside the bounds the tracker derives for EVERY coefficient of a
+    Miller value — the domain on which the final-exponentiation flows are proven — and the vectors fill it to within 0.1 %; the
+    tracker build runs all of them (it aborts on a violation)."""
+    drv = r'''
+import ctypes, json, sys
+root = sys.argv[1]
+L = ctypes.CDLL(root + "/tests/hostsim/libhostsim_pair_bounds.so")
+d = json.load(open(root + "/tests/golden/derived_vectors.json"))
+adv = json.load(open(root + "/tests/golden/adversarial_fe_vectors.json"))
+H = bytes.fromhex
+g1 = (1).to_bytes(32, "big") + (2).to_bytes(32, "big")
+c = adv["contract"]
+out = (ctypes.c_double * 60)()
+for v in d["verify_cases"]:
+    if v["status"] in (0, 9):
+        L.hp_miller_output_bounds(g1, H(v["sig"]), H(v["pk"]), out)
+        for e in range(12):
+            lo, hi, top, vlo, vhi = out[5 * e:5 * e + 5]
+            assert -lo >= c["limb_abs_max"] and hi >= c["limb_abs_max"] and top >= c["top_abs_max"], (e, lo, hi, top)
+            assert -vlo >= c["value_over_q_abs_max"] and vhi >= c["value_over_q_abs_max"], (e, vlo, vhi)
+            assert top < 1.03 * c["top_abs_max"] and vhi < 1.03 * c["value_over_q_abs_max"]      # the contract is not lax either
+L.hp_final_exp_limbs.argtypes = [ctypes.POINTER(ctypes.c_int32), ctypes.c_int, ctypes.c_char_p]
+tops = 0
+for v in adv["vectors"]:
+    limbs = (ctypes.c_int32 * 108)(*v["limbs"])
+    assert L.hp_final_exp_limbs(limbs, 1, None) == v["status"] and L.hp_final_exp_limbs(limbs, 0, None) == v["status"]
+    tops = max(tops, max(abs(v["limbs"][9 * e + 8]) for e in range(12)))
+    assert max(abs(x) for e in range(12) for x in v["limbs"][9 * e:9 * e + 8]) == c["limb_abs_max"] or v["family"] == "one"
+assert tops == c["top_abs_max"]
+print("ok")
+'''
+    p = subprocess.run([sys.executable, "-c", drv, ROOT], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and p.stdout.strip() == "ok", (p.stdout[-500:], p.stderr[-2000:])
 
 
