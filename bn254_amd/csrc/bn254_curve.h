@@ -190,6 +190,29 @@ template <class F> BN_DEV void jac_accumulate_mem(Jac<F>& acc, Affine<F> q) {
   }
 }
 
+// The same with the affine operand PRODUCED INSIDE the function by `src(q)` (a small functor passed by value, i.e. in registers: a
+// table-record pointer and an identity flag in the aggregation kernel).  An Affine passed by reference to a real function lives in the
+// caller's private segment: 19 dwords written by the caller and read back by the callee per addition — in k_aggregate_pair 47 GB of
+// writes per 1 Mi tuples and a store -> load round trip on the critical path of every call (profiles/r04_z_pmc.json).
+template <class F, class Src> BN_DEVN bool jac_madd_inplace_from(Jac<F>& acc, Src src) {
+  Affine<F> q;
+  src(q);
+  Jac<F> o;
+  bool ex;
+  jac_madd_common_body(o, ex, acc, q);
+  if (!ex) acc = o;
+  return ex;
+}
+template <class F, class Src> BN_DEV void jac_accumulate_from(Jac<F>& acc, Src src) {
+  const bool ex = jac_madd_inplace_from(acc, src);
+  if (BN_WAVE_ANY(ex)) {                            // rare: the complete formula for the lanes that need it, nothing for the others
+    Affine<F> q;
+    src(q);
+    q.inf = q.inf || !ex;
+    jac_madd(acc, acc, q);
+  }
+}
+
 // P + Q for operands known to satisfy P != +-Q unless one of them is the identity (add-2007-bl without
 // the doubling / cancellation overrides of jac_add, which cost a jac_dbl per call).
 template <class F> BN_DEVN void jac_add_distinct(Jac<F>& r, const Jac<F>& p, const Jac<F>& q) {
@@ -302,6 +325,17 @@ BN_DEVN void g1_mul_glv(G1Jac& r, const G1Affine& p, const uint32_t* k1, const u
     t.x = fp_mul(t.x, beta);                                   // phi: x -> beta x (the identity keeps z = 0)
     jac_add_distinct(acc, acc, t);
   }
+}
+
+// A + B for two AFFINE points with x_A != x_B (neither the identity), given dinv = 1 / (x_B - x_A): the chord formula, 2 products + 1
+// square — what an addition costs once the inversion is shared (Montgomery's trick over a batch of denominators: the table builders
+// k_pool_widen_*, bn254_hip.hip).  Outputs carried and weakly reduced: they are stored as table entries and meet jac_madd next.
+template <class F> BN_DEV void aff_add_given_inv(Affine<F>& r, const Affine<F>& a, const Affine<F>& b, const F& dinv) {
+  const F lam = f_mul(f_norm(f_sub(b.y, a.y)), dinv);
+  const F x3 = f_reduce(f_sub(f_sub(f_sqr(lam), a.x), b.x));
+  r.y = f_reduce(f_sub(f_mul(lam, f_norm(f_sub(a.x, x3))), a.y));
+  r.x = x3;
+  r.inf = false;
 }
 
 template <class F> BN_DEVN void jac_to_affine(Affine<F>& r, const Jac<F>& p) {

@@ -921,6 +921,96 @@ KERNEL_SMALL void k_pool_subsets_g1(Pool sig_pool, size_t n_signers, size_t grou
   pool_store_fp(sub, 0, j, a.x); pool_store_fp(sub, 1, j, a.y);
   sub.st[j] = a.inf ? 0x80 : 0;
 }
+// ---- WIDER subset tables for the largest aggregate batches (BN254_OPT_AGG_WIDE_MIN_TUPLES) ---------------------------------------------
+// k_aggregate_pair adds one table entry per window of signers; twice the window is half the additions.  From a table of windows of w
+// signers one of 2w signers is its "outer sum": T2w[hi * 2^w + lo] = Tw[group 2k][lo] + Tw[group 2k + 1][hi] — ONE affine addition per
+// entry, 2^(2w) entries per doubled group: keys 8 -> 16 signers per entry (n_signers / 16 x 65 536 entries, 671 MB for 1 024 signers:
+// HBM is what this machine has), signatures per message 4 -> 8.  An affine addition needs 1 / (x_B - x_A); a lane owns one `hi` and
+// walks its `lo` values in batches of 8 whose denominators share ONE inversion (Montgomery's trick: prefix products up, the inverse
+// peeled off on the way down; the B points are re-read from the source table, an L2 hit, instead of being kept in registers): 2
+// products + 1 square for the chord, 3 products for the trick, an eighth of an inversion — ~16 products per entry where accumulate +
+// jac_to_affine costs ~100.  Entries with an identity operand are copies; the rare lo with x_B = x_A (B = +-A: a pool that holds a
+// point twice, or a point and its negative) takes the complete Jacobian formula and an inversion of its own.
+__device__ __forceinline__ void pool_load_aff(const Pool& p, size_t j, G1Affine& q) { q.x = pool_load_fp(p, 0, j); q.y = pool_load_fp(p, 1, j); q.inf = (p.st[j] & 0x80) != 0; }
+__device__ __forceinline__ void pool_load_aff(const Pool& p, size_t j, G2Affine& q) {
+  q.x.c0 = pool_load_fp(p, 0, j); q.x.c1 = pool_load_fp(p, 1, j); q.y.c0 = pool_load_fp(p, 2, j); q.y.c1 = pool_load_fp(p, 3, j);
+  q.inf = (p.st[j] & 0x80) != 0;
+}
+__device__ __forceinline__ void pool_store_aff(const Pool& p, size_t j, const G1Affine& q) { pool_store_fp(p, 0, j, q.x); pool_store_fp(p, 1, j, q.y); p.st[j] = q.inf ? 0x80 : 0; }
+__device__ __forceinline__ void pool_store_aff(const Pool& p, size_t j, const G2Affine& q) {
+  pool_store_fp(p, 0, j, q.x.c0); pool_store_fp(p, 1, j, q.x.c1); pool_store_fp(p, 2, j, q.y.c0); pool_store_fp(p, 3, j, q.y.c1);
+  p.st[j] = q.inf ? 0x80 : 0;
+}
+// one lane: dst[dst0 + lo] = src[b0 + lo] + A for NLO consecutive lo (an entry of src may be the identity: the empty subset, or a sum that
+// cancelled)
+template <class F> __device__ __forceinline__ void aff_select(Affine<F>& r, bool c, const Affine<F>& a, const Affine<F>& b) {
+  r.x = f_select(c, a.x, b.x); r.y = f_select(c, a.y, b.y); r.inf = c ? a.inf : b.inf;
+}
+template <class F, int NLO> __device__ __forceinline__ void pool_widen_lane(bool live, const Pool& src, size_t b0, Affine<F> A, const Pool& dst, size_t dst0) {
+  constexpr int BATCH = 8;
+  static_assert(NLO % BATCH == 0, "whole batches");
+  for (int base = 0; base < NLO; base += BATCH) {
+    F d[BATCH], pre[BATCH];
+    bool exc[BATCH];
+#pragma unroll
+    for (int i = 0; i < BATCH; ++i) {
+      Affine<F> B;
+      pool_load_aff(src, b0 + base + i, B);
+      d[i] = f_norm(f_sub(B.x, A.x));
+      const bool zero = f_is_zero(d[i]);
+      exc[i] = zero && !A.inf && !B.inf;              // B = +-A
+      if (zero || A.inf || B.inf) f_set_one(d[i]);    // keeps the batch's product invertible; the chord of such an entry is not used
+      pre[i] = i ? f_mul(pre[i - 1], d[i]) : d[i];
+    }
+    F inv = f_inv(pre[BATCH - 1]);
+#pragma unroll
+    for (int i = BATCH - 1; i >= 0; --i) {
+      const F dinv = i ? f_mul(inv, pre[i - 1]) : inv;
+      if (i) inv = f_mul(inv, d[i]);
+      Affine<F> B, R;
+      pool_load_aff(src, b0 + base + i, B);
+      aff_add_given_inv(R, A, B, dinv);
+      aff_select(R, B.inf, A, R);                     // identity operands: copies
+      aff_select(R, A.inf, B, R);
+      if (BN_WAVE_ANY(exc[i])) {                      // rare: the complete formula (and an inversion of its own) for the lanes that met B = +-A
+        Jac<F> J;
+        Affine<F> Bc = B, C;
+        jac_from_affine(J, A);
+        Bc.inf = !exc[i];                             // the other lanes add nothing here
+        jac_madd(J, J, Bc);
+        jac_to_affine(C, J);
+        if (exc[i]) R = C;
+      }
+      if (live) pool_store_aff(dst, dst0 + base + i, R);
+    }
+  }
+}
+// keys: T16[k][hi * 256 + lo] = T8[2k][lo] + T8[2k + 1][hi]; lane = (k, hi, block of 32 lo values) — 2 048 waves for 1 024 signers.  A
+// chunk whose second group does not exist (an odd number of groups) only ever sees hi = 0.
+#define BN_WIDEN_G2_NLO 32
+KERNEL void k_pool_widen_g2(Pool t8, size_t n_groups, size_t n_chunks, Pool t16) {
+  const size_t lane = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
+  constexpr size_t BLK = 256 / BN_WIDEN_G2_NLO;
+  const bool live = lane < n_chunks * 256 * BLK;
+  const size_t ll = live ? lane : 0, blk = ll % BLK, hi = (ll / BLK) & 255u, k = ll / (BLK * 256);
+  const bool has_hi = 2 * k + 1 < n_groups;
+  G2Affine A;
+  pool_load_aff(t8, (has_hi ? 2 * k + 1 : 2 * k) * 256 + hi, A);
+  A.inf = A.inf || !has_hi || hi == 0;
+  if (A.inf) g2_set_generator_keep_inf(A);
+  pool_widen_lane<Fp2, BN_WIDEN_G2_NLO>(live, t8, 2 * k * 256 + blk * BN_WIDEN_G2_NLO, A, t16, k * 65536 + hi * 256 + blk * BN_WIDEN_G2_NLO);
+}
+// signatures, per message: T8[m][g][hi * 16 + lo] = T4[m][2g][lo] + T4[m][2g + 1][hi]; lane = (m, g, hi)
+KERNEL_SMALL void k_pool_widen_g1(Pool t4, size_t groups4, size_t n_groups, size_t n_msgs, Pool t8) {
+  const size_t lane = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
+  const bool live = lane < n_msgs * n_groups * 16;
+  const size_t ll = live ? lane : 0, hi = ll & 15u, g = (ll >> 4) % n_groups, m = (ll >> 4) / n_groups;
+  G1Affine A;
+  pool_load_aff(t4, (m * groups4 + 2 * g + 1) * 16 + hi, A);
+  A.inf = A.inf || hi == 0;
+  if (A.inf) { A.x = fp_load_const(C_G1_GEN[0]); A.y = fp_load_const(C_G1_GEN[1]); }
+  pool_widen_lane<Fp, 16>(live, t4, (m * groups4 + 2 * g) * 16, A, t8, (m * n_groups + g) * 256 + hi * 16);
+}
 // tuple i: agg_sig = sum_s sig_pool[msg_i * S + s], agg_pk = sum_s pk_pool[s] over its signer list
 // (Add for Signature / PublicKey, types.rs:264-270, :126-132); results + H(msg_i) go to the verify planes.
 // A wave walks its lanes' lists in lockstep until the longest is exhausted.
@@ -1163,8 +1253,10 @@ struct bn254_ctx {
   size_t stage_cap[8];
   int profiling;
   int split_miller;  // A/B knob: one pairing per lane (k_miller_verify_split) instead of the fused 2-pair loop
-  Pool pool[5];       // aggregate verify: pk pool, sig pool, H(m) pool, subset sums of the pk pool and of the signature pool (grown on demand)
-  size_t pool_fp[5];  // coordinates per entry: 4, 2, 2, 4, 2
+  Pool pool[7];       // aggregate verify: pk pool, sig pool, H(m) pool, subset sums of the pk pool and of the signature pool, and their widened
+                      // forms (16 keys / 8 signatures per entry) for the largest batches (grown on demand)
+  size_t pool_fp[7];  // coordinates per entry: 4, 2, 2, 4, 2, 4, 2
+  int agg_wide_min_tuples;    // aggregate verify: the widened tables from this many tuples on (0 = never)
   int agg_subset_min_tuples;  // aggregate verify: tabulate subset sums of the pk pool for batches of at least this many tuples (0 = never)
   int agg_sort_by_msg;        // aggregate verify: bucket the tuples by message before the aggregation kernel (default 1; A/B and test knob)
   int pair_lanes;    // verify: Miller loop + final exponentiation on lane pairs (bn254_pair.hip); default on
@@ -1357,6 +1449,7 @@ int bn254_ctx_create(int hip_device, bn254_ctx** out) {
   c->trio_wave_roles = TRIO_WAVE_ROLES_DEFAULT;
   c->agg_subset_min_tuples = AGG_SUBSET_MIN_TUPLES_DEFAULT;
   c->agg_sort_by_msg = 1;
+  c->agg_wide_min_tuples = AGG_WIDE_MIN_TUPLES_DEFAULT;
   c->pinned_staging = PINNED_STAGING_DEFAULT;
   // the small-batch kernels ask for up to 156 KB of dynamic LDS per workgroup: on a part that cannot hold one, step down
   // (eight wave roles -> four -> lane groups -> lane pairs only) instead of failing at the first launch
@@ -1393,7 +1486,7 @@ void bn254_ctx_destroy(bn254_ctx* c) {
   if (c->ws.h_cnt) (void)hipFree(c->ws.h_cnt);
   if (c->ws.clk) (void)hipFree(c->ws.clk);
   if (c->pin) (void)hipHostFree(c->pin);
-  for (int i = 0; i < 5; ++i) { if (c->pool[i].planes) (void)hipFree(c->pool[i].planes); if (c->pool[i].st) (void)hipFree(c->pool[i].st); }
+  for (int i = 0; i < 7; ++i) { if (c->pool[i].planes) (void)hipFree(c->pool[i].planes); if (c->pool[i].st) (void)hipFree(c->pool[i].st); }
   for (int i = 0; i < 8; ++i) if (c->stage[i]) (void)hipFree(c->stage[i]);
   if (c->key_lines) (void)hipFree(c->key_lines);
   if (c->key_xy) (void)hipFree(c->key_xy);
@@ -1453,6 +1546,7 @@ int bn254_ctx_set_option(bn254_ctx* c, int option, int value) {
   }
   if (option == BN254_OPT_PINNED_STAGING) { if (value < 0 || value > 16) return BN254_E_BAD_ARGUMENT; c->pinned_staging = value; return 0; }
   if (option == BN254_OPT_AGG_SORT_BY_MSG) { c->agg_sort_by_msg = value != 0; return 0; }
+  if (option == BN254_OPT_AGG_WIDE_MIN_TUPLES) { if (value < 0) return BN254_E_BAD_ARGUMENT; c->agg_wide_min_tuples = value; return 0; }
   if (option == BN254_OPT_CLOCK_PROBE) {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipDeviceSynchronize());
@@ -2278,9 +2372,34 @@ int bn254_batch_aggregate_verify_device(bn254_ctx* c, const uint8_t* d_msgs, con
       k_agg_sort_scatter<<<grid_for(n), BN_WAVE, 0, s>>>(d_tuple_msg, n, (uint32_t)n_msgs, cursor, map);
       perm = map;
     }
+    // the largest batches: tables of twice the window, built from the ones above by one batched affine addition per entry
+    // (k_pool_widen_*): half the additions per tuple.  A table that does not fit its budget (or HBM) is simply not used.
+    const Pool* wide2 = nullptr;
+    const Pool* wide1 = nullptr;
+    if (n_groups != 0 && c->agg_wide_min_tuples > 0 && n >= (size_t)c->agg_wide_min_tuples) {
+      const size_t n_chunks = (n_groups + 1) / 2;
+      const size_t e2 = n_chunks * 65536, bytes2 = e2 * (2 * BN_POOL_HALF_WORDS * sizeof(int32_t) + 1);
+      if (bytes2 <= AGG_WIDE_G2_MAX_BYTES) {
+        if (pool_reserve(c, 5, 4, e2) == 0) {
+          k_pool_widen_g2<<<grid_for(n_chunks * 256 * (256 / BN_WIDEN_G2_NLO)), BN_WAVE, 0, s>>>(c->pool[3], n_groups, n_chunks, c->pool[5]);
+          wide2 = &c->pool[5];
+        } else {
+          (void)hipGetLastError();
+        }
+      }
+      const size_t e1 = n_msgs * n_groups * 256, bytes1 = ((e1 + 255) & ~(size_t)255) * (BN_POOL_HALF_WORDS * sizeof(int32_t) + 1);
+      if (groups4 != 0 && n >= AGG_WIDE_G1_TUPLES_PER_MSG * n_msgs && bytes1 <= AGG_SUBSET_G1_MAX_BYTES) {
+        if (pool_reserve(c, 6, 2, e1) == 0) {
+          k_pool_widen_g1<<<grid_for(n_msgs * n_groups * 16), BN_WAVE, 0, s>>>(c->pool[4], groups4, n_groups, n_msgs, c->pool[6]);
+          wide1 = &c->pool[6];
+        } else {
+          (void)hipGetLastError();
+        }
+      }
+    }
     PROF_MARK(1);
     if ((rc = bn254_pair_aggregate(d_tuple_msg, d_tuple_off, d_signer_idx, n, n_signers, n_msgs, c->pool[0], c->pool[1], c->pool[2], c->pool[3], n_groups,
-                                   c->pool[4], groups4, c->ws, s, perm))) return rc;
+                                   c->pool[4], groups4, c->ws, s, perm, wide2, wide1))) return rc;
   } else {
     PROF_MARK(1);
     k_aggregate<<<grid_for(n), BN_WAVE, 0, s>>>(d_tuple_msg, d_tuple_off, d_signer_idx, n, n_signers, n_msgs, c->pool[0], c->pool[1], c->pool[2], c->ws);

@@ -308,10 +308,26 @@ int bn254_pair_rand_tail(size_t n_groups, Ws ws, size_t gbase, hipStream_t s) {
 //     With the per-message signature tables (k_pool_subsets_g1, groups4 != 0) the walk adds no signature either: the same
 //     mask bytes, read as two nibbles, select one table entry per group of 4 signers — the real-part lane takes the low
 //     nibbles, the imaginary-part lane the high ones, one G1 and one G2 addition per lane and group of 8.
+// a table record as the source of an in-place addition (bn254_curve.h: jac_madd_inplace_from): the lane's half of a G2 record or a G1
+// record (bn254_ws.h: Pool — x at word 0, y at word 9), loaded inside the addition; pointer and flag travel in registers
+struct PoolRec {
+  const int32_t* p;
+  bool inf;
+  __device__ __forceinline__ void operator()(G1Affine& q) const {
+#pragma unroll
+    for (int k = 0; k < BN_LIMBS; ++k) { q.x.v[k] = p[k]; q.y.v[k] = p[BN_LIMBS + k]; }
+    q.inf = inf;
+  }
+  __device__ __forceinline__ void operator()(G2Affine& q) const {
+#pragma unroll
+    for (int k = 0; k < BN_LIMBS; ++k) { q.x.c[0].v[k] = p[k]; q.y.c[0].v[k] = p[BN_LIMBS + k]; }
+    q.inf = inf;
+  }
+};
 extern __shared__ uint32_t bn_agg_masks[];     // [BN_PAIR_WG / 2 tuples][mask_stride words], mask_stride odd
 KERNEL_PAIR void k_aggregate_pair(const uint32_t* tuple_msg, const uint64_t* tuple_off, const uint32_t* signer_idx, size_t n, size_t n_signers,
                                   size_t n_msgs, Pool pk_pool, Pool sig_pool, Pool h_pool, Pool sub_pool, unsigned n_groups, Pool sub1_pool, unsigned groups4,
-                                  unsigned mask_stride, Ws ws, const uint32_t* perm) {
+                                  unsigned mask_stride, Ws ws, const uint32_t* perm, Pool wide2_pool, int wide2, Pool wide1_pool, int wide1) {
   const unsigned role = threadIdx.x & 1u;
   // `perm` (tuples bucketed by message, bn254_hip.hip: k_agg_sort_*): slot -> tuple.  Workgroups are dispatched to the 8 XCDs round
   // robin and every XCD has its own L2: with the map, XCD x takes a CONTIGUOUS eighth of the slots, so that the ~8 workgroups that
@@ -394,24 +410,54 @@ KERNEL_PAIR void k_aggregate_pair(const uint32_t* tuple_msg, const uint64_t* tup
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     const int32_t partner_dup = bn_partner_word((int32_t)dup);           // unconditionally: a DPP fetch must not sit behind a short-circuit
     dup = dup || partner_dup != 0;                                       // either lane of the pair saw a repeated signer
-    for (unsigned g = 0; g < n_groups; ++g) {                            // wave-uniform
-      const uint32_t mask = dup ? 0u : (my_masks[g >> 2] >> (8u * (g & 3u))) & 255u;
-      const size_t j = (size_t)g * 256 + mask;
-      G2Affine p;
-      p.x.c[0] = pool_load_fp(sub_pool, 0 + (int)role, j);
-      p.y.c[0] = pool_load_fp(sub_pool, 2 + (int)role, j);
-      p.inf = mask == 0 || (sub_pool.st[j] & 0x80);
-      // both table entries of the group are fetched BEFORE the first addition: a real function waits for every outstanding load at its
-      // entry, so a fetch issued between the two additions would be a second exposed round trip per group
-      G1Affine q;
-      if (use_sub1) {                                                      // wave-uniform
-        const uint32_t nib = (mask >> (4u * role)) & 15u;
-        const size_t j1 = (((size_t)m * groups4) + 2u * g + role) * 16 + nib;
-        q.x = pool_load_fp(sub1_pool, 0, j1); q.y = pool_load_fp(sub1_pool, 1, j1);
-        q.inf = nib == 0 || (sub1_pool.st[j1] & 0x80);
+    // Two mask bytes (16 signers) per iteration.  Keys: ONE entry of the 16-signer table (wide2: k_pool_widen_g2) or the two 8-signer
+    // entries; signatures (use_sub1): with the per-message 8-signer tables (wide1: k_pool_widen_g1) each lane of the pair takes ONE entry —
+    // the real-part lane the low byte's, the imaginary-part lane the high byte's — else its nibble of both bytes from the 4-signer tables.
+    // The records are named, not loaded: the additions fetch them themselves (PoolRec) — an Affine handed to a real function by reference
+    // went through the private segment.  One word at either end of each record is touched first, all together, so that the fetches of an
+    // iteration overlap (a real function waits for every outstanding load at its entry: the records then sit in the L1 when it reads them).
+    const unsigned n_chunks = (n_groups + 1) / 2;
+    for (unsigned k = 0; k < n_chunks; ++k) {                              // wave-uniform
+      const uint32_t m16 = dup ? 0u : (my_masks[k >> 1] >> (16u * (k & 1u))) & 0xFFFFu;
+      const uint32_t byte0 = m16 & 255u, byte1 = m16 >> 8;
+      const bool second = 2 * k + 1 < n_groups;                            // wave-uniform (false only in the last chunk of an odd group count: byte1 = 0)
+      PoolRec k2[2], s1[2];
+      unsigned nk2, ns1 = 0;
+      if (wide2) {
+        const size_t j = (size_t)k * 65536 + m16;
+        k2[0] = {wide2_pool.planes + pool_word(wide2_pool, (int)role, j), m16 == 0 || (wide2_pool.st[j] & 0x80)};
+        nk2 = 1;
+      } else {
+        const size_t j0 = (size_t)(2 * k) * 256 + byte0, j1 = (size_t)(second ? 2 * k + 1 : 2 * k) * 256 + byte1;
+        k2[0] = {sub_pool.planes + pool_word(sub_pool, (int)role, j0), byte0 == 0 || (sub_pool.st[j0] & 0x80)};
+        k2[1] = {sub_pool.planes + pool_word(sub_pool, (int)role, j1), byte1 == 0 || (sub_pool.st[j1] & 0x80)};
+        nk2 = second ? 2 : 1;
       }
-      jac_accumulate_mem(acc2, p);
-      if (use_sub1) jac_accumulate_mem(acc1, q);
+      if (use_sub1 && wide1) {
+        const unsigned g = second ? 2 * k + role : 2 * k;                  // this lane's byte
+        const uint32_t byte = (role && second) ? byte1 : (role ? 0u : byte0);
+        const size_t j = ((size_t)m * n_groups + g) * 256 + byte;
+        s1[0] = {wide1_pool.planes + pool_word(wide1_pool, 0, j), byte == 0 || (wide1_pool.st[j] & 0x80)};
+        ns1 = 1;
+      } else if (use_sub1) {
+        const uint32_t nib0 = (byte0 >> (4u * role)) & 15u, nib1 = (byte1 >> (4u * role)) & 15u;
+        const size_t j0 = (((size_t)m * groups4) + 2u * (2 * k) + role) * 16 + nib0;
+        const size_t j1 = (((size_t)m * groups4) + 2u * (second ? 2 * k + 1 : 2 * k) + role) * 16 + nib1;
+        s1[0] = {sub1_pool.planes + pool_word(sub1_pool, 0, j0), nib0 == 0 || (sub1_pool.st[j0] & 0x80)};
+        s1[1] = {sub1_pool.planes + pool_word(sub1_pool, 0, j1), nib1 == 0 || (sub1_pool.st[j1] & 0x80)};
+        ns1 = second ? 2 : 1;
+      }
+      {
+        int32_t t = k2[0].p[0] ^ k2[0].p[2 * BN_LIMBS - 1];
+        if (nk2 > 1) t ^= k2[1].p[0] ^ k2[1].p[2 * BN_LIMBS - 1];
+        if (ns1 > 0) t ^= s1[0].p[0] ^ s1[0].p[2 * BN_LIMBS - 1];
+        if (ns1 > 1) t ^= s1[1].p[0] ^ s1[1].p[2 * BN_LIMBS - 1];
+        asm volatile("" ::"v"(t));
+      }
+      jac_accumulate_from(acc2, k2[0]);
+      if (nk2 > 1) jac_accumulate_from(acc2, k2[1]);
+      if (ns1 > 0) jac_accumulate_from(acc1, s1[0]);
+      if (ns1 > 1) jac_accumulate_from(acc1, s1[1]);
     }
     if (__builtin_amdgcn_ballot_w64(dup) != 0) {                          // rare: the tuples with a repeated signer add their keys one by one
       uint64_t longest2 = dup ? hi - lo : 0;
@@ -464,13 +510,14 @@ KERNEL_PAIR void k_aggregate_pair(const uint32_t* tuple_msg, const uint64_t* tup
 }
 int bn254_pair_aggregate(const uint32_t* tuple_msg, const uint64_t* tuple_off, const uint32_t* signer_idx, size_t n, size_t n_signers, size_t n_msgs,
                          Pool pk_pool, Pool sig_pool, Pool h_pool, Pool sub_pool, size_t n_groups, Pool sub1_pool, size_t groups4, Ws ws, hipStream_t s,
-                         const uint32_t* perm) {
+                         const uint32_t* perm, const Pool* wide2_pool, const Pool* wide1_pool) {
   const unsigned mask_stride = n_groups ? (unsigned)(((n_groups + 3) / 4) | 1u) : 1u;     // words per tuple, odd: the tuples of a wave hit different banks
   const size_t lds = n_groups ? (size_t)(BN_PAIR_WG / 2) * mask_stride * sizeof(uint32_t) : 0;
   unsigned blocks = (unsigned)((2 * n + BN_PAIR_WG - 1) / BN_PAIR_WG);
   if (perm) blocks = (blocks + 7u) & ~7u;            // the XCD-contiguous slot mapping needs a multiple of 8 (extra workgroups are idle)
   k_aggregate_pair<<<blocks, BN_PAIR_WG, lds, s>>>(tuple_msg, tuple_off, signer_idx, n, n_signers, n_msgs, pk_pool, sig_pool, h_pool, sub_pool,
-                                                   (unsigned)n_groups, sub1_pool, (unsigned)groups4, mask_stride, ws, perm);
+                                                   (unsigned)n_groups, sub1_pool, (unsigned)groups4, mask_stride, ws, perm, wide2_pool ? *wide2_pool : sub_pool,
+                                                   wide2_pool != nullptr, wide1_pool ? *wide1_pool : sub1_pool, wide1_pool != nullptr);
   HIP_TRY(hipGetLastError());
   return 0;
 }

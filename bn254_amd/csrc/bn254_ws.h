@@ -11,6 +11,10 @@
 #define AGG_SUBSET_MAX_SIGNERS ((size_t)2048)     // ... one mask byte per group of 8 keys and tuple in LDS: 256 groups at most
 #define AGG_SUBSET_G1_TUPLES_PER_MSG ((size_t)64)  // ... signature tables (per message) once a message is shared by this many tuples on average
 #define AGG_SUBSET_G1_MAX_BYTES ((size_t)8 << 30)  // ... and while they stay below 8 GB of HBM
+#define AGG_WIDE_MIN_TUPLES_DEFAULT 262144         // ... tables of twice the window (keys: 16 signers per entry, signatures: 8) from this many tuples on: half the additions
+                                                   //     per tuple for ~6 ms of table building per call (k_pool_widen_g2 / _g1); 0 = never
+#define AGG_WIDE_G1_TUPLES_PER_MSG ((size_t)512)   // ... the signature half only when a message's (16 x larger) table is shared by this many tuples
+#define AGG_WIDE_G2_MAX_BYTES ((size_t)2 << 30)    // ... and the tables stay below these budgets of HBM
 #define PINNED_STAGING_DEFAULT 0                    // host-pointer verify: threads copying through the pinned staging buffer; 0 = off (A/B in profiles/r04_*)
 #define PINNED_STAGING_MIN_N ((size_t)8192)        // ... only batches whose transfer is worth overlapping
 #define RAND_MIN_BATCH_DEFAULT 131072              // randomised verify pays off from about here
@@ -133,7 +137,8 @@ __attribute__((visibility("hidden"))) int bn254_pair_rand_tail(size_t n_groups, 
 __attribute__((visibility("hidden"))) int bn254_pair_aggregate(const uint32_t* tuple_msg, const uint64_t* tuple_off, const uint32_t* signer_idx, size_t n,
                                                                size_t n_signers, size_t n_msgs, Pool pk_pool, Pool sig_pool, Pool h_pool, Pool sub_pool,
                                                                size_t n_groups, Pool sub1_pool, size_t groups4, Ws ws, hipStream_t s,
-                                                               const uint32_t* perm = nullptr);
+                                                               const uint32_t* perm = nullptr, const Pool* wide2_pool = nullptr,
+                                                               const Pool* wide1_pool = nullptr);
 __attribute__((visibility("hidden"))) int bn254_pair_decode_g2(const uint8_t* pts, size_t n, uint32_t flags, Ws ws, int accumulate, hipStream_t s);
 __attribute__((visibility("hidden"))) int bn254_pair_decompress_g2(const uint8_t* in, size_t n, Ws ws, hipStream_t s);
 

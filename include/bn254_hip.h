@@ -322,6 +322,10 @@ int bn254_ctx_set_profiling(bn254_ctx *ctx, int enabled);
 #define BN254_OPT_AGG_SORT_BY_MSG 11 /* aggregate verify, batches that use the per-message signature tables: bucket the tuples by message on the
                                       device (counting sort into an index map) so that a workgroup of the aggregation kernel gathers from ONE
                                       message's table; statuses land at the tuples' own indices either way.  Default 1; 0 = the caller's order */
+#define BN254_OPT_AGG_WIDE_MIN_TUPLES 14 /* aggregate verify: from this many tuples on (default 262144) the subset-sum tables are WIDENED once more —
+                                          keys: the sums of all subsets of every 16 consecutive signers (n_signers / 16 x 65536 entries, 671 MB
+                                          for 1024 signers), signatures per message: of every 8 — by one batched affine addition per entry, so
+                                          that a tuple adds half as many entries; 0 = never.  Same statuses. */
 #define BN254_OPT_CLOCK_PROBE 10 /* measurement: 1 = the lane-pair Miller / final-exponentiation kernels and the issue probe record, per workgroup,
                                   shader-clock cycles (s_memtime) and constant-rate ticks (s_memrealtime) between entry and exit, read back by
                                   bn254_ctx_last_clocks: the clock the chip actually sustains under this load (power-limited parts run below

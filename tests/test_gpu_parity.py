@@ -680,6 +680,84 @@ def test_aggregate_verify_subset_sum_table_vs_oracle(eng, c):
     eng.set_option(OPT_AGG_SUBSET_MIN_TUPLES, 4096)
 
 
+def test_aggregate_verify_widened_tables_vs_oracle(eng, c):
+    """BN254_OPT_AGG_WIDE_MIN_TUPLES: the subset-sum tables widened once more (keys: 16 signers per entry, k_pool_widen_g2; signatures per
+    message: 8, k_pool_widen_g1 — one batched AFFINE addition per entry, eight denominators per inversion) and the aggregation loop over
+    16-signer chunks give the oracle's statuses (aggregation = `Add`, /root/reference/src/types.rs:126-132, :264-270).  The pools are
+    built to hit the builders' exceptional paths: a key that appears twice and a key next to its NEGATIVE inside one 8-signer group and
+    across the two groups of a chunk (x_B = x_A: the doubling / the identity by the complete formula), identity and undecodable entries,
+    a pool size that leaves the last chunk with one group only and that group partly empty; all four combinations of wide / narrow
+    key and signature tables, each against the same oracle result."""
+    import random
+    from bn254_amd.engine import OPT_AGG_SUBSET_MIN_TUPLES, OPT_AGG_WIDE_MIN_TUPLES, OPT_AGG_SORT_BY_MSG
+    from tests.datagen import sk_bytes
+    Qm = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47
+    rnd = random.Random(4242)
+    M, S = 2, 43                                                           # 6 groups of 8 -> 3 chunks of 16; the last group holds 3 keys
+    msgs = [b"wide-msg-%d" % m for m in range(M)]
+    sks = [sk_bytes(900 + s) for s in range(S)]
+    sks[5] = sks[2]                                                        # signer 5 IS signer 2 (same group of 8)
+    sks[17] = sks[9]                                                       # signer 17 IS signer 9 (the two groups of chunk 0 ... no: 9 is group 1, 17 group 2)
+    sks[12] = sks[3]                                                       # signer 12 (group 1) IS signer 3 (group 0): the two halves of chunk 0
+    pk_pool, st = eng.batch_g2_mul(None, b"".join(sks), S, reduce_scalar=True)
+    sig_pool, st2 = eng.batch_sign([msgs[m] for m in range(M) for _ in range(S)], b"".join(sks * M))
+    assert st == bytes(S) and st2 == bytes(M * S)
+    pk_pool, sig_pool = bytearray(pk_pool), bytearray(sig_pool)
+
+    def neg_g1(p):
+        return p[:32] + ((Qm - int.from_bytes(p[32:], "big")) % Qm).to_bytes(32, "big")
+
+    def neg_g2(p):
+        return p[:64] + b"".join(((Qm - int.from_bytes(p[64 + 32 * k:96 + 32 * k], "big")) % Qm).to_bytes(32, "big") for k in range(2))
+    # signer 30 = MINUS signer 27 (same group 3), signer 38 = MINUS signer 24 (groups 4 and 3: different chunks), signer 41 = MINUS signer 33
+    # (groups 5 and 4: the two halves of chunk 2): subsets holding both cancel to the identity inside the tables
+    for a, b in ((30, 27), (38, 24), (41, 33)):
+        pk_pool[128 * a:128 * a + 128] = neg_g2(bytes(pk_pool[128 * b:128 * b + 128]))
+        for m in range(M):
+            sig_pool[64 * (m * S + a):64 * (m * S + a) + 64] = neg_g1(bytes(sig_pool[64 * (m * S + b):64 * (m * S + b) + 64]))
+    pk_pool[128 * 11:128 * 12] = bytes(128)                                 # identity key 11 with identity signatures
+    for m in range(M):
+        sig_pool[64 * (m * S + 11):64 * (m * S + 12)] = bytes(64)
+    pk_pool[128 * 20 + 127] ^= 1                                            # key 20 does not decode -> status 4 for its tuples
+    pk_pool, sig_pool = bytes(pk_pool), bytes(sig_pool)
+    n = 512 * M + 77                                                        # >= 512 tuples per message: the per-message 8-signer tables qualify
+    tuples = []
+    for i in range(n):
+        kk = rnd.choice([0, 1, 7, 12, 25, 40, S, S])
+        lst = rnd.sample(range(S), kk)
+        if i % 7 == 0:
+            lst = sorted(lst, reverse=True)
+        if i % 11 == 1:
+            lst = sorted(set(lst) | {2, 5, 3, 12, 27, 30})                   # the equal and the opposite pairs together
+        if i % 13 == 5 and lst:
+            lst = lst + [lst[0]]                                             # a signer twice: direct route for that tuple
+        if i % 31 == 3:
+            lst = lst + [S + 2]                                              # out of range
+        if i % 37 == 8:
+            lst = [24, 38] + [s for s in lst if s not in (24, 38)]           # cancels across chunks: in the running sum, not in a table
+        tuples.append((rnd.randrange(M), lst))
+    off, flat = [0], []
+    for _, lst in tuples:
+        flat += lst
+        off.append(len(flat))
+    want = c.batch_aggregate_verify(msgs, pk_pool, sig_pool, [t[0] for t in tuples], off, flat, nthreads=8)
+    assert {0, 2, 4} <= set(want)
+    e2 = __import__("bn254_amd").Engine(0)                                   # a context of its own: the option changes stay local
+    e2.set_option(OPT_AGG_SUBSET_MIN_TUPLES, 1)
+    for wide, sort in ((1, 1), (1, 0), (0, 1)):
+        e2.set_option(OPT_AGG_WIDE_MIN_TUPLES, wide)
+        e2.set_option(OPT_AGG_SORT_BY_MSG, sort)
+        got = e2.batch_aggregate_verify(msgs, pk_pool, sig_pool, [t[0] for t in tuples], [t[1] for t in tuples])
+        diff = [(i, got[i], want[i], tuples[i]) for i in range(n) if got[i] != want[i]]
+        assert not diff, (wide, sort, diff[:5])
+    # wide keys with NARROW signature tables (fewer than 512 tuples per message), and 64 tuples (no signature tables at all)
+    e2.set_option(OPT_AGG_WIDE_MIN_TUPLES, 1)
+    for cut in (300, 64):
+        got = e2.batch_aggregate_verify(msgs, pk_pool, sig_pool, [t[0] for t in tuples[:cut]], [t[1] for t in tuples[:cut]])
+        assert got == want[:cut], cut
+    e2.close()
+
+
 def test_aggregate_verify_bucketed_by_message_vs_oracle(eng, c):
     """BN254_OPT_AGG_SORT_BY_MSG: with the per-message signature tables in use the tuples are bucketed by message on the device
     (counting sort into an index map, XCD-contiguous slots) before the aggregation kernel.  Statuses must land at the tuples' OWN
