@@ -326,7 +326,8 @@ def other_workloads(args, torch, eng, dev, stream):
         # generated in chunks so that the message list stays small on the host
         n = args.batch or (1 << 20)
         seed = hashlib.sha256(b"bench-seed").digest()
-        eng.set_option(5, 0)                                  # BN254_OPT_RAND_MIN_BATCH: time the randomised kernels at every size
+        from bn254_amd.engine import OPT_RAND_MIN_BATCH
+        eng.set_option(OPT_RAND_MIN_BATCH, 0)                 # time the randomised kernels at every size
         chunk = 1 << 16
         parts = [make_verify_batch(eng, min(chunk, n - lo), corrupt_every=0, tag="bn254/msgR%d" % lo) for lo in range(0, n, chunk)]
         msgs = b"".join(b"".join(p[0]) for p in parts)
@@ -337,11 +338,17 @@ def other_workloads(args, torch, eng, dev, stream):
         eng.reserve(n + n // 64 + 512)
         ptrs = (d_msgs.data_ptr(), d_off.data_ptr(), d_sigs.data_ptr(), d_pks.data_ptr(), n)
         res = {}
+        eng.set_profiling(True)
         for name, flags in (("rand128", 0), ("rand128_glv", 0x200), ("rand64", 0x100)):
+            for key in kms:
+                kms[key] = 0.0
             dt = timed(lambda: eng.batch_verify_randomized_device(*ptrs, seed, d_st.data_ptr(), d_gr.data_ptr(), flags=flags, stream=sh),
-                       args.steps, args.warmup)
+                       args.steps, args.warmup, collect)
             assert int(d_st.max()) == 0 and int(d_gr.min()) == 1
-            res[name] = {"verifies_per_s": n / dt, "ms_per_step": 1e3 * dt}
+            res[name] = {"verifies_per_s": n / dt, "ms_per_step": 1e3 * dt,
+                         "kernel_ms": {"decode": kms["decode"], "hash_to_g1": kms["hash_to_g1"], "scalar_muls_and_miller_loops": kms["miller_loop"],
+                                       "group_tails_final_exp_collect": kms["final_exp"]}}
+        eng.set_profiling(False)
         dt = timed(lambda: eng.batch_verify_device(*ptrs, d_st.data_ptr(), flags=0, stream=sh), args.steps, args.warmup)
         assert int(d_st.max()) == 0
         res["exact"] = {"verifies_per_s": n / dt, "ms_per_step": 1e3 * dt}
@@ -356,13 +363,37 @@ def other_workloads(args, torch, eng, dev, stream):
         out.update(metric="BN254 verifies/sec, randomised batch verification (groups of 64) vs exact, all-valid batch", unit="verifies/s",
                    value=res["rand128"]["verifies_per_s"], ms_per_step=res["rand128"]["ms_per_step"], modes=res,
                    config={"workload": "configs[1]-shaped tuples, opt-in randomised batch verification", "batch": n},
-                   speedup_vs_exact=res["rand128"]["verifies_per_s"] / res["exact"]["verifies_per_s"])
+                   speedup_vs_exact=res["rand128"]["verifies_per_s"] / res["exact"]["verifies_per_s"],
+                   kernel_ms=res["rand128"]["kernel_ms"])
+        # dominant interval of the 128-bit mode: k_rand_scale (r_i H(m_i), r_i sig_i: two 128-bit ladders of 4-bit windows in G1) + the per-item
+        # Miller loops (two items per lane pair sharing f^2 from 131 072 items on).  Products per item: DESIGN.md section 4c.
+        two = n >= 131072
+        fp_rand = 2 * (128 * 7 + 33 * 16) + (6800 if two else 8400)
+        out["roofline"] = kernel_roofline("k_rand_scale + k_miller_rand2_pair" if two else "k_rand_scale + k_miller_rand_pair", fp_rand * n,
+                                          res["rand128"]["kernel_ms"]["scalar_muls_and_miller_loops"],
+                                          note="HIP-event interval of the two kernels together (the library's slot [2]); per item 2 x (128 doublings x 7 + 33 "
+                                               "additions x 16) products for the two scalar multiplications + %d for its Miller loop; one final exponentiation per "
+                                               "64 items is in the next slot" % (6800 if two else 8400))
+        if cpu:
+            from oracle import c_oracle
+            sample = min(n, 2048)
+            msg_list = [msgs[32 * i:32 * i + 32] for i in range(sample)]
+            sg, pk = bytes(d_sigs[:64 * sample].cpu().numpy()), bytes(d_pks[:128 * sample].cpu().numpy())
+            t1 = time.perf_counter()
+            st_cpu, gr_cpu = c_oracle.batch_verify_randomized(msg_list, sg, pk, seed, flags=0)
+            dtc = time.perf_counter() - t1
+            st_gpu, gr_gpu = eng.batch_verify_randomized(msg_list, sg, pk, seed, flags=0)
+            assert st_cpu == st_gpu and gr_cpu == gr_gpu, "oracle's randomised verdicts differ from the GPU's"
+            out["cpu_baseline"] = {"value": sample / dtc, "unit": "verifies/s", "cores": 1, "kind": "port",
+                                   "sample": "first %d tuples (%d groups of 64), oracle/bn254_oracle.c: the same randomised derivation restated (one thread); "
+                                             "statuses and group verdicts equal the GPU's" % (sample, sample // 64)}
     elif args.workload == "verify-keyed-randomized":
         # opt-in: registered keys + the combined check of items that share a key (64 per pairing product), against the exact keyed path
         from tests.datagen import KEY_POOL
         n = args.batch or (1 << 20)
         seed = hashlib.sha256(b"bench-seed").digest()
-        eng.set_option(5, 0)                                  # BN254_OPT_RAND_MIN_BATCH: the randomised kernels at every size
+        from bn254_amd.engine import OPT_RAND_MIN_BATCH
+        eng.set_option(OPT_RAND_MIN_BATCH, 0)                 # the randomised kernels at every size
         chunk = 1 << 16
         parts = [make_verify_batch(eng, min(chunk, n - lo), corrupt_every=0, tag="bn254/msgK%d" % lo) for lo in range(0, n, chunk)]
         pool = min(KEY_POOL, n)
@@ -472,40 +503,59 @@ def other_workloads(args, torch, eng, dev, stream):
         def call():
             eng.batch_aggregate_verify_device(d_msgs.data_ptr(), d_moff.data_ptr(), M, d_pk.data_ptr(), S, d_sig.data_ptr(), tuple_msg.data_ptr(),
                                               tuple_off.data_ptr(), signer_idx.data_ptr(), n, d_st.data_ptr(), stream=sh)
+        from bn254_amd.engine import OPT_AGG_SORT_BY_MSG, OPT_AGG_SUBSET_MIN_TUPLES, OPT_AGG_WIDE_MIN_TUPLES
         eng.set_profiling(True)
-        # same batch in the caller's (random) tuple order, without the device-side bucketing by message (BN254_OPT_AGG_SORT_BY_MSG = 0)
-        eng.set_option(11, 0)
-        dt_unsorted = timed(call, max(1, args.steps // 2), 1, collect)
-        k_unsorted = {k: v * args.steps / max(1, args.steps // 2) for k, v in kms.items()}
-        for key in kms:
-            kms[key] = 0.0
-        eng.set_option(11, 1)
+        half = max(1, args.steps // 2)
+
+        def side_run(option, value, restore):
+            """the same batch with one option changed: (seconds per step, kernel ms per step)"""
+            for key in kms:
+                kms[key] = 0.0
+            eng.set_option(option, value)
+            t = timed(call, half, 1, collect)
+            k = {kk: v * args.steps / half for kk, v in kms.items()}
+            eng.set_option(option, restore)
+            assert int(d_st.max()) == 0
+            for key in kms:
+                kms[key] = 0.0
+            return t, k
+        # in the caller's (random) tuple order, without the device-side bucketing by message
+        dt_unsorted, k_unsorted = side_run(OPT_AGG_SORT_BY_MSG, 0, 1)
+        # without the widened tables (keys: 8 signers per table entry, signatures: 4 — rounds 3-4)
+        dt_narrow, k_narrow = side_run(OPT_AGG_WIDE_MIN_TUPLES, 0, 262144)
         dt = timed(call, args.steps, args.warmup, collect)
         assert int(d_st.max()) == 0
         k_table = dict(kms)
-        eng.set_option(9, 0)                                       # BN254_OPT_AGG_SUBSET_MIN_TUPLES = 0: every key added one by one (rounds 1-2)
-        dt_direct = timed(call, max(1, args.steps // 2), 1)
+        eng.set_option(OPT_AGG_SUBSET_MIN_TUPLES, 0)               # every key added one by one (rounds 1-2)
+        dt_direct = timed(call, half, 1)
         assert int(d_st.max()) == 0
-        eng.set_option(9, 4096)
+        eng.set_option(OPT_AGG_SUBSET_MIN_TUPLES, 4096)
         total_signers = int(signer_idx.numel())
         groups = (S + 7) // 8
-        # route of this batch (bn254_hip.hip: bn254_batch_aggregate_verify_device): key sums from the 8-bit subset table, and — a message
-        # being shared by >= 64 tuples on average — signature sums from the per-message 4-bit tables
+        # route of this batch (bn254_hip.hip: bn254_batch_aggregate_verify_device): key sums from the subset tables — 16 signers per entry
+        # from 262 144 tuples on, else 8 — and, a message being shared by >= 64 tuples on average, signature sums from the per-message
+        # tables — 8 signers per entry when a message is shared by >= 512 tuples, else 4
         sig_tables = n >= 64 * M
-        agg_products = (FP_MUL_G1_MADD * 2 * groups * n if sig_tables else FP_MUL_G1_MADD * total_signers) + (FP_MUL_G2_MADD * groups + FP_MUL_AGG_TAIL) * n
+        wide_keys = n >= 262144
+        wide_sigs = wide_keys and n >= 512 * M
+        key_adds = (groups + 1) // 2 if wide_keys else groups
+        sig_adds = groups if wide_sigs else 2 * groups
+        agg_products = (FP_MUL_G1_MADD * sig_adds * n if sig_tables else FP_MUL_G1_MADD * total_signers) + (FP_MUL_G2_MADD * key_adds + FP_MUL_AGG_TAIL) * n
         out.update(metric="aggregate verifies/sec (1024 signers, ~512 per tuple)", value=n / dt, unit="verifies/s",
                    ms_per_step=1e3 * dt, kernel_ms={"pools_hash_table": k_table["decode"], "aggregate": k_table["hash_to_g1"],
                                                     "miller_loop": k_table["miller_loop"], "final_exp": k_table["final_exp"]},
                    config={"workload": "configs[2]: %d aggregate verifies over pools of %d signers x %d messages (random subsets, %.1f signers per "
                                        "tuple): G1 / G2 sums, then one verify each" % (n, S, M, total_signers / n), "batch": n,
-                           "mean_signers_per_tuple": total_signers / n, "key_route": "subset sums of the key pool: %d table additions per tuple" % groups,
-                           "signature_route": ("per-message subset tables: %d table additions per tuple" % (2 * groups)) if sig_tables else "one addition per signer"},
+                           "mean_signers_per_tuple": total_signers / n, "key_route": "subset sums of the key pool: %d table additions per tuple" % key_adds,
+                           "signature_route": ("per-message subset tables: %d table additions per tuple" % sig_adds) if sig_tables else "one addition per signer"},
                    without_subset_sum_table={"verifies_per_s": n / dt_direct, "ms_per_step": 1e3 * dt_direct},
+                   without_widened_tables={"verifies_per_s": n / dt_narrow, "ms_per_step": 1e3 * dt_narrow, "aggregate_kernel_ms": k_narrow["hash_to_g1"],
+                                           "pools_hash_table_ms": k_narrow["decode"]},
                    without_bucketing_by_message={"verifies_per_s": n / dt_unsorted, "ms_per_step": 1e3 * dt_unsorted, "aggregate_kernel_ms": k_unsorted["hash_to_g1"],
                                                  "pools_hash_table_ms": k_unsorted["decode"]},
                    roofline=kernel_roofline("k_aggregate_pair", agg_products, k_table["hash_to_g1"],
-                                            note="products per tuple: 13 per signature-table entry (group of 4 signers) or signature added + 26 per key-table entry "
-                                                 "(group of 8 keys) + 52; the walk over the signer list (status checks, mask bits) is not MAC32 work"))
+                                            note="products per tuple: 13 per signature-table entry added + 26 per key-table entry added + 52; the walk over "
+                                                 "the signer list (status checks, mask bits) is not MAC32 work; building the tables is in pools_hash_table"))
         out["roofline"]["whole_step"] = {"fp_products_per_tuple": agg_products / n + FP_MUL_MILLER + FP_MUL_FINAL_EXP,
                                          "frac": (agg_products / n + FP_MUL_MILLER + FP_MUL_FINAL_EXP) * MAC32_PER_FP_MUL * n / dt / PEAK_MAC32_THEORETICAL}
         if cpu:
@@ -717,9 +767,9 @@ def run_verify(args, R):
     n = args.batch or BATCH
     eng.reserve(2 * n)
     if args.split_miller:
-        eng.set_option(1, 1)
+        eng.set_option(bn254_amd.engine.OPT_SPLIT_MILLER, 1)
     if args.no_pair_lanes:
-        eng.set_option(4, 0)
+        eng.set_option(bn254_amd.engine.OPT_PAIR_LANES, 0)
     rank, world, dev = R.rank, R.world, R.dev
 
     # ---- synthetic inputs, generated on the GPU by the product's own sign / keygen kernels -------
@@ -783,10 +833,23 @@ def run_verify(args, R):
 
     eng.set_profiling(True)
     kernel_ms = {"decode": 0.0, "hash_to_g1": 0.0, "miller_loop": 0.0, "final_exp": 0.0}
+    pair = not (args.no_pair_lanes or args.split_miller)
+    # the clock the chip sustains DURING the timed steps: the lane-pair kernels accumulate, per workgroup, shader-clock cycles and
+    # constant-rate ticks between entry and exit (two scalar clock reads per workgroup); read and cleared after the warm-up, read again
+    # after the last timed step (include/bn254_hip.h: BN254_OPT_CLOCK_PROBE, bn254_ctx_last_clocks)
+    clock_probe = False
+    if pair and n > 16384:
+        try:
+            eng.set_option(bn254_amd.engine.OPT_CLOCK_PROBE, 1)
+            clock_probe = True
+        except Exception:
+            clock_probe = False
 
     def after_warmup():
         # parity gate before any timing is accepted
         assert args.warmup == 0 or check(args.warmup - 1), "GPU status bytes differ from the expected pattern"
+        if clock_probe:
+            eng.last_clocks()                                # clears the counters: what is read next belongs to the timed steps alone
 
     def per_step():
         ms = eng.last_kernel_ms()                            # HIP events on the launch stream (synchronises it)
@@ -794,6 +857,7 @@ def run_verify(args, R):
             kernel_ms[key] += ms[key]
 
     elapsed = R.time_steps(step, args.steps, args.warmup, after_warmup, per_step)
+    timed_clocks = eng.last_clocks() if clock_probe else None   # accumulated over the K timed steps, nothing else
     ok_last = check(args.warmup + args.steps - 1)            # the LAST step's pattern (differs from the one before)
     assert ok_last, "GPU status bytes of the last timed step differ from the expected pattern"
 
@@ -825,7 +889,6 @@ def run_verify(args, R):
     if rank == 0:
         k_avg = {k: v / args.steps for k, v in kernel_ms.items()}
         dom = max(("miller_loop", "final_exp"), key=lambda k: k_avg[k])
-        pair = not (args.no_pair_lanes or args.split_miller)
         kname = {("miller_loop", True): "k_miller_verify_pair", ("miller_loop", False): "k_miller_verify",
                  ("final_exp", True): "k_final_exp_pair", ("final_exp", False): "k_final_exp"}[(dom, pair)]
         fp_mul = FP_MUL_MILLER if dom == "miller_loop" else FP_MUL_FINAL_EXP
@@ -837,24 +900,15 @@ def run_verify(args, R):
         # OUTSIDE the timed region, with the kernels' clock probe on — shader-clock cycles over constant-rate ticks between entry and
         # exit of every workgroup of the Miller kernel / the final exponentiation; the issue probe reports its own.
         sclk = None
-        if pair:
+        if timed_clocks is not None:
             try:
-                from bn254_amd.engine import OPT_CLOCK_PROBE
-                eng.set_option(OPT_CLOCK_PROBE, 1)
-                with torch.cuda.stream(R.stream):
-                    for k in range(4):                              # the library call alone: no collective (only this rank is here)
-                        eng.batch_verify_device(d_msgs.data_ptr(), d_off.data_ptr(), d_sigs[k & 1].data_ptr(), d_pks.data_ptr(), n,
-                                                d_status.data_ptr(), flags=0, stream=sh)
-                    torch.cuda.synchronize()
-                sclk = eng.last_clocks()
+                sclk = {"miller_loop": round(timed_clocks["miller_loop"], 1), "final_exp": round(timed_clocks["final_exp"], 1)}
                 if world == 1:
                     eng.probe_issue_rate(0, 2)
-                    sclk["issue_probe"] = eng.last_clocks()["issue_probe"]
-                eng.set_option(OPT_CLOCK_PROBE, 0)
-                sclk = {k: round(v, 1) for k, v in sclk.items()}
+                    sclk["issue_probe"] = round(eng.last_clocks()["issue_probe"], 1)
                 sclk["nominal"] = 2400.0
-                sclk["method"] = ("sum over workgroups of s_memtime cycles / s_memrealtime ticks x hipDeviceAttributeWallClockRate, 4 back-to-back "
-                                  "steps after the timed region (BN254_OPT_CLOCK_PROBE)")
+                sclk["method"] = ("sum over workgroups and launches of s_memtime cycles / s_memrealtime ticks x hipDeviceAttributeWallClockRate, accumulated "
+                                  "over the %d TIMED steps themselves (BN254_OPT_CLOCK_PROBE on from before the warm-up; counters cleared after it)" % args.steps)
             except Exception as exc:                               # never lose the bench line over the extra
                 sclk = {"error": repr(exc)}
         leaf_floor = None
@@ -863,18 +917,31 @@ def run_verify(args, R):
             try:                                                   # the product leaves of the two kernels alone, same launch shape (include/bn254_hip.h)
                 from bn254_amd.engine import OPT_CLOCK_PROBE
                 eng.set_option(OPT_CLOCK_PROBE, 1)
-                leaf_floor = {"note": "kernels that run ONLY the product calls of a verify's Miller loop / final exponentiation (~9 argument moves "
-                                      "per call, no tower additions, carries, twist point or LDS traffic): what the kernels would take if everything "
-                                      "around their product leaves were free.  VALU instructions per lane of the leaves: tools/isa_summary.py"}
+                leaf_floor = {"note": "kernels that run ONLY the product calls of a verify's Miller loop / final exponentiation (no tower additions, "
+                                      "carries, twist point or LDS traffic): what the kernels would take if everything around their product leaves "
+                                      "were free.  Round 5: the r04 probe's own loop (accumulator by reference in a real function) cost 20-25 % on top "
+                                      "of the leaves it was meant to isolate — the floors below come from the inlined loops and are that much lower"}
                 for mode, key, kernel_key, probe_counts, real_counts in ((0, "miller_loop", "miller_loop", (3219, 435, 348), (3194, 430, 348)),
                                                                          (1, "final_exp", "final_exp", (945, 1701, 0), (975, 1714, 0))):
-                    floor_ms = eng.probe_leaf_floor(n, mode)
+                    variants = {}
+                    # the same product calls in three loops: r04's probe (a real function taking the accumulator by reference, run-time trip
+                    # counts, every product waiting for its predecessor), and one inlined loop with compile-time counts carrying one chain or
+                    # four independent ones.  A floor must not lose to what it bounds: the figure quoted is the smallest.
+                    for name, md in (("loop_in_a_real_function_ms", mode), ("one_chain_inlined_ms", 6 if mode == 0 else None), ("four_chains_inlined_ms", mode + 4)):
+                        if md is None:
+                            continue
+                        eng.last_clocks()
+                        variants[name] = {"ms": eng.probe_leaf_floor(n, md), "sclk_mhz": round(eng.last_clocks()["issue_probe"], 1)}
+                    best = min(variants, key=lambda kk: variants[kk]["ms"])
+                    floor_ms = variants[best]["ms"]
                     instr = lambda c: c[0] * 345 + c[1] * 258 + c[2] * 226          # noqa: E731
                     scaled = floor_ms * instr(real_counts) / instr(probe_counts)
-                    leaf_floor[key] = {"probe_ms": floor_ms, "probe_products_dual_sqr_scale": probe_counts, "kernel_products_dual_sqr_scale": real_counts,
+                    leaf_floor[key] = {"probe_ms": floor_ms, "probe_variant": best, "variants": variants,
+                                       "independent_chains_ms": variants["four_chains_inlined_ms"]["ms"],
+                                       "probe_products_dual_sqr_scale": probe_counts, "kernel_products_dual_sqr_scale": real_counts,
                                        "ms_scaled_to_the_kernels_product_counts": scaled, "kernel_ms": k_avg[kernel_key],
                                        "floor_share_of_kernel": scaled / k_avg[kernel_key] if k_avg[kernel_key] else None,
-                                       "probe_sclk_mhz": round(eng.last_clocks()["issue_probe"], 1)}
+                                       "probe_sclk_mhz": variants[best]["sclk_mhz"]}
                 eng.set_option(OPT_CLOCK_PROBE, 0)
             except Exception as exc:
                 leaf_floor = {"error": repr(exc)}

@@ -194,7 +194,15 @@ template <class F> BN_DEV void jac_accumulate_mem(Jac<F>& acc, Affine<F> q) {
 // table-record pointer and an identity flag in the aggregation kernel).  An Affine passed by reference to a real function lives in the
 // caller's private segment: 19 dwords written by the caller and read back by the callee per addition — in k_aggregate_pair 47 GB of
 // writes per 1 Mi tuples and a store -> load round trip on the critical path of every call (profiles/r04_z_pmc.json).
-template <class F, class Src> BN_DEVN bool jac_madd_inplace_from(Jac<F>& acc, Src src) {
+// inlined into its (one) loop: with the sums in LDS and the operand fetched inside, what stays alive across the addition in
+// k_aggregate_pair is a handful of pointers — 43.25 -> 41.35 ms per 1 Mi tuples same box (profiles/r05_b_ab_aggregate.log); -DBN_AGG_CALL_MADD
+// restores the call
+#if defined(BN_AGG_CALL_MADD)
+#define BN_DEV_MADD_FROM BN_DEVN
+#else
+#define BN_DEV_MADD_FROM BN_DEV
+#endif
+template <class F, class Src> BN_DEV_MADD_FROM bool jac_madd_inplace_from(Jac<F>& acc, Src src) {
   Affine<F> q;
   src(q);
   Jac<F> o;

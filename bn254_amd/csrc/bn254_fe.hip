@@ -123,7 +123,6 @@ KERNEL_PAIR void k_final_exp_pair(size_t n, size_t k, size_t item_stride, size_t
 }
 
 int bn254_pair_final_exp(size_t n, Ws ws, int use_hash, uint8_t* status_out, const uint32_t* map, const uint32_t* count, hipStream_t s, size_t base) {
-  if (ws.clk) HIP_TRY(hipMemsetAsync(ws.clk + (size_t)BN_CLK_MAX_WG * 2, 0, sizeof(unsigned long long) * 2 * BN_CLK_MAX_WG, s));
   k_final_exp_pair<<<(unsigned)((2 * n + BN_PAIR_WG - 1) / BN_PAIR_WG), BN_PAIR_WG, 0, s>>>(n, 1, 1, 1, ws, use_hash, nullptr, status_out, 0, base, map, count);
   HIP_TRY(hipGetLastError());
   return 0;

@@ -1237,7 +1237,7 @@ __global__ void __launch_bounds__(256) k_issue_probe(uint32_t* out, uint32_t see
   out[(size_t)blockIdx.x * 256 + threadIdx.x] = (uint32_t)sum ^ (uint32_t)(sum >> 32);
   if (clk && threadIdx.x == 0 && blockIdx.x < BN_CLK_MAX_WG) {     // slot 2 of the clock probe (bn254_ws.h): this kernel's own clock
     unsigned long long* p = clk + ((size_t)2 * BN_CLK_MAX_WG + blockIdx.x) * 2;
-    p[0] = clock64() - clk0; p[1] = wall_clock64() - wall0;
+    p[0] += clock64() - clk0; p[1] += wall_clock64() - wall0;
   }
 }
 
@@ -1289,6 +1289,17 @@ struct bn254_ctx {
 
 
 
+struct ScopedEvents {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipError_t create() {
+    hipError_t e = hipEventCreate(&e0);
+    return e == hipSuccess ? hipEventCreate(&e1) : e;
+  }
+  ~ScopedEvents() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
+  ScopedEvents() = default;
+  ScopedEvents(const ScopedEvents&) = delete;
+  ScopedEvents& operator=(const ScopedEvents&) = delete;
+};
 static inline unsigned grid_for(size_t n) { return (unsigned)((n + BN_WAVE - 1) / BN_WAVE); }
 
 static int ws_reserve(bn254_ctx* c, size_t n) {
@@ -1569,9 +1580,13 @@ int bn254_ctx_last_clocks(bn254_ctx* c, double sclk_mhz[3]) {
   HIP_TRY(hipSetDevice(c->device));
   int wall_khz = 0;
   HIP_TRY(hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, c->device));
-  std::vector<unsigned long long> h((size_t)3 * BN_CLK_MAX_WG * 2);
-  HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(h.data(), c->ws.clk, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  const size_t words = (size_t)3 * BN_CLK_MAX_WG * 2;
+  unsigned long long* h = (unsigned long long*)malloc(words * sizeof(unsigned long long));
+  if (!h) return BN254_E_NO_MEMORY;
+  hipError_t e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(h, c->ws.clk, words * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemset(c->ws.clk, 0, words * sizeof(unsigned long long));     // read AND cleared: the next reading covers the launches from here on
+  if (e != hipSuccess) { free(h); return -(int)e; }
   for (int k = 0; k < 3; ++k) {
     double cyc = 0, wall = 0;
     for (size_t w = 0; w < BN_CLK_MAX_WG; ++w) {
@@ -1580,6 +1595,7 @@ int bn254_ctx_last_clocks(bn254_ctx* c, double sclk_mhz[3]) {
     }
     sclk_mhz[k] = wall > 0 ? cyc / wall * (double)wall_khz * 1e-3 : 0.0;
   }
+  free(h);
   return 0;
 }
 int bn254_ctx_last_kernel_ms(bn254_ctx* c, float ms[4]) {
@@ -2474,13 +2490,12 @@ int bn254_probe_issue_rate(bn254_ctx* c, int op, int waves_per_simd, double* wav
   int rc;
   if ((rc = stage_reserve(c, 0, sizeof(uint32_t) * 256 * (size_t)blocks))) return rc;
   uint32_t* out = (uint32_t*)c->stage[0];
-  hipEvent_t e0, e1;
-  HIP_TRY(hipEventCreate(&e0));
-  HIP_TRY(hipEventCreate(&e1));
+  ScopedEvents ev;                                   // destroyed on every path out, the early error returns included
+  HIP_TRY(ev.create());
+  hipEvent_t e0 = ev.e0, e1 = ev.e1;
   float best = 0;
   for (int rep = 0; rep < 3; ++rep) {       // first repetition warms up; keep the fastest
     HIP_TRY(hipEventRecord(e0, c->stream));
-    if (c->ws.clk) HIP_TRY(hipMemsetAsync(c->ws.clk + (size_t)2 * BN_CLK_MAX_WG * 2, 0, sizeof(unsigned long long) * 2 * BN_CLK_MAX_WG, c->stream));
     if (op == 0) k_issue_probe<0><<<blocks, 256, 0, c->stream>>>(out, 12345u, c->ws.clk);
     else if (op == 1) k_issue_probe<1><<<blocks, 256, 0, c->stream>>>(out, 12345u, c->ws.clk);
     else k_issue_probe<2><<<blocks, 256, 0, c->stream>>>(out, 12345u, c->ws.clk);
@@ -2490,8 +2505,6 @@ int bn254_probe_issue_rate(bn254_ctx* c, int op, int waves_per_simd, double* wav
     HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
     if (rep > 0 && (best == 0 || ms < best)) best = ms;
   }
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
   *wave_inst_per_s = (double)PROBE_ITERS * PROBE_CHAINS * 4.0 * blocks / (best * 1e-3);
   if (n_simd) *n_simd = n_cu * 4;
   return 0;
@@ -2500,11 +2513,11 @@ int bn254_probe_issue_rate(bn254_ctx* c, int op, int waves_per_simd, double* wav
 // Measurement: the product leaves of one verify's Miller loop alone (k_leaf_floor_pair, bn254_pair.hip) on the planes the last verify
 // left in the workspace (n <= the size of that batch); ms = the kernel's duration (HIP events), best of 3 after a warm-up launch.
 int bn254_probe_leaf_floor(bn254_ctx* c, size_t n, int mode, float* ms) {
-  if (!c || !ms || n == 0 || n > c->ws.stride || mode < 0 || mode > 3) return BN254_E_BAD_ARGUMENT;
+  if (!c || !ms || n == 0 || n > c->ws.stride || mode < 0 || mode > 7) return BN254_E_BAD_ARGUMENT;
   HIP_TRY(hipSetDevice(c->device));
-  hipEvent_t e0, e1;
-  HIP_TRY(hipEventCreate(&e0));
-  HIP_TRY(hipEventCreate(&e1));
+  ScopedEvents ev;                                   // destroyed on every path out, the early error returns included
+  HIP_TRY(ev.create());
+  hipEvent_t e0 = ev.e0, e1 = ev.e1;
   float best = 0;
   int rc = 0;
   for (int rep = 0; rep < 4 && rc == 0; ++rep) {
@@ -2516,8 +2529,6 @@ int bn254_probe_leaf_floor(bn254_ctx* c, size_t n, int mode, float* ms) {
     HIP_TRY(hipEventElapsedTime(&t, e0, e1));
     if (rep > 0 && (best == 0 || t < best)) best = t;
   }
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
   *ms = best;
   return rc;
 }
@@ -2540,9 +2551,9 @@ int bn254_probe_fe_program(bn254_ctx* c, size_t n, const uint8_t* prog, size_t n
   std::vector<uint8_t> buf(prog, prog + 2 * n_steps);
   buf.push_back(0); buf.push_back(0);
   HIP_TRY(hipMemcpy(c->stage[7], buf.data(), buf.size(), hipMemcpyHostToDevice));
-  hipEvent_t e0, e1;
-  HIP_TRY(hipEventCreate(&e0));
-  HIP_TRY(hipEventCreate(&e1));
+  ScopedEvents ev;                                   // destroyed on every path out, the early error returns included
+  HIP_TRY(ev.create());
+  hipEvent_t e0 = ev.e0, e1 = ev.e1;
   float best = 0;
   for (int rep = 0; rep < 4 && rc == 0; ++rep) {
     HIP_TRY(hipEventRecord(e0, c->stream));
@@ -2553,8 +2564,6 @@ int bn254_probe_fe_program(bn254_ctx* c, size_t n, const uint8_t* prog, size_t n
     HIP_TRY(hipEventElapsedTime(&t, e0, e1));
     if (rep > 0 && (best == 0 || t < best)) best = t;
   }
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
   *ms = best;
   return rc;
 }

@@ -209,7 +209,6 @@ KERNEL_PAIR void k_miller_verify_keyed_pair(size_t n, Ws ws, const uint32_t* key
 }
 int bn254_pair_miller_verify_keyed(size_t n, Ws ws, const uint32_t* key_idx, KeyTable kt, hipStream_t s, size_t base, const uint32_t* map,
                                    const uint32_t* count) {
-  if (ws.clk) HIP_TRY(hipMemsetAsync(ws.clk, 0, sizeof(unsigned long long) * 2 * BN_CLK_MAX_WG, s));
   k_miller_verify_keyed_pair<<<(unsigned)((2 * n + BN_PAIR_WG - 1) / BN_PAIR_WG), BN_PAIR_WG, 0, s>>>(n, ws, key_idx, kt, base, map, count);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -522,7 +521,6 @@ int bn254_pair_aggregate(const uint32_t* tuple_msg, const uint64_t* tuple_off, c
   return 0;
 }
 int bn254_pair_miller_verify(size_t n, Ws ws, const uint32_t* map, const uint32_t* count, hipStream_t s, int mode) {
-  if (ws.clk) HIP_TRY(hipMemsetAsync(ws.clk, 0, sizeof(unsigned long long) * 2 * BN_CLK_MAX_WG, s));
   k_miller_verify_pair<<<(unsigned)((2 * n + BN_PAIR_WG - 1) / BN_PAIR_WG), BN_PAIR_WG, 0, s>>>(n, ws, map, count, mode);
   HIP_TRY(hipGetLastError());
   return 0;

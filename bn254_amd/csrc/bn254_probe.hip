@@ -49,6 +49,36 @@ __device__ __noinline__ void leaf_floor_loop(Fp2& x, const Fp2& y, const Fp& k, 
     for (int j = 0; j < n_scale; ++j) x = fp2_mul_fp(x, k);
   }
 }
+// modes 4 / 5: the product counts of modes 0 / 1 spread over FOUR independent chains.  In leaf_floor_loop every product waits for its
+// predecessor's last digits at its own first instructions; with one wave per SIMD (batches of 16 385 .. 32 768 verifies) nothing hides that
+// and the Miller kernel, whose consecutive products are mostly independent, ran 10 % FASTER than that "floor" (DESIGN.md section 9.6).
+// A floor must not lose to what it bounds: the figure to quote is min(dependent, independent).
+template <int CH, int N_DUAL, int N_SQR, int N_SCALE> __device__ __forceinline__ void leaf_floor_chains(Fp2 (&x)[CH], const Fp2& y, const Fp& k, int steps) {   // inlined: the chains stay in registers
+  for (int d = 0; d < steps; ++d) {
+    BN_SET_STEP_PRIORITY(d);
+#pragma unroll 1
+    for (int j = 0; j < N_DUAL / CH; ++j) {
+#pragma unroll
+      for (int c = 0; c < CH; ++c) x[c] = fp2_mul(x[c], y);
+    }
+#pragma unroll
+    for (int j = 0; j < N_DUAL % CH; ++j) x[j] = fp2_mul(x[j], y);
+#pragma unroll 1
+    for (int j = 0; j < N_SQR / CH; ++j) {
+#pragma unroll
+      for (int c = 0; c < CH; ++c) x[c] = fp2_sqr(x[c]);
+    }
+#pragma unroll
+    for (int j = 0; j < N_SQR % CH; ++j) x[j] = fp2_sqr(x[j]);
+#pragma unroll 1
+    for (int j = 0; j < N_SCALE / CH; ++j) {
+#pragma unroll
+      for (int c = 0; c < CH; ++c) x[c] = fp2_mul_fp(x[c], k);
+    }
+#pragma unroll
+    for (int j = 0; j < N_SCALE % CH; ++j) x[j] = fp2_mul_fp(x[j], k);
+  }
+}
 // mode 2: 87 x 37 dual products with the leaf INLINED into the loop (the body of fp_pair_mul_impl, bn254_fp2_pair.h) — no call, no return,
 // no wait at a function entry, no argument moves: what the calling convention itself costs per product
 __device__ __forceinline__ Fp2 fp2_mul_inlined(const Fp2& a, const Fp2& b) {
@@ -86,6 +116,20 @@ KERNEL_PAIR void k_leaf_floor_pair(size_t n, Ws ws, int mode) {
   if (mode == 0) leaf_floor_loop(x, y, k, 87, 37, 5, 4);
   else if (mode == 1) leaf_floor_loop(x, y, k, 189, 5, 9, 0);
   else if (mode == 2) leaf_floor_loop_inlined(x, y);
+  else if (mode == 4 || mode == 5) {
+    Fp2 c4[4] = {x, fp2_add(x, y), fp2_sub(x, y), fp2_add(x, x)};
+    if (mode == 4) leaf_floor_chains<4, 37, 5, 4>(c4, y, k, 87);
+    else leaf_floor_chains<4, 5, 9, 0>(c4, y, k, 189);
+    x = fp2_add(fp2_add(c4[0], c4[1]), fp2_add(c4[2], c4[3]));
+  } else if (mode == 6) {                           // controls for mode 4: the same inlined loop with ONE chain ...
+    Fp2 c1[1] = {x};
+    leaf_floor_chains<1, 37, 5, 4>(c1, y, k, 87);
+    x = c1[0];
+  } else if (mode == 7) {                           // ... and with two
+    Fp2 c2[2] = {x, fp2_add(x, y)};
+    leaf_floor_chains<2, 37, 5, 4>(c2, y, k, 87);
+    x = fp2_add(c2[0], c2[1]);
+  }
   else leaf_floor_loop(x, y, k, 87, 37, 0, 0);          // mode 3: the same 3 219 dual products as mode 2, called
   BN_CLK_END(ws, 2);                               // the probe's own clock slot
   x = fp2_add(x, lds_f[threadIdx.x].v.c0.c0);
@@ -115,7 +159,6 @@ int bn254_pair_fe_program(size_t n, Ws ws, const unsigned char* prog, hipStream_
   return 0;
 }
 int bn254_pair_leaf_floor(size_t n, Ws ws, hipStream_t s, int mode) {
-  if (ws.clk) HIP_TRY(hipMemsetAsync(ws.clk + (size_t)2 * BN_CLK_MAX_WG * 2, 0, sizeof(unsigned long long) * 2 * BN_CLK_MAX_WG, s));
   k_leaf_floor_pair<<<(unsigned)((2 * n + BN_PAIR_WG - 1) / BN_PAIR_WG), BN_PAIR_WG, 0, s>>>(n, ws, mode);
   HIP_TRY(hipGetLastError());
   return 0;

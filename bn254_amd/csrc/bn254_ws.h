@@ -45,9 +45,10 @@ struct Ws {
   uint8_t* h_next;    // [stride]  first counter not yet tried
   uint32_t* h_list;   // [2][stride] compacted indices of the messages still without a point
   uint32_t* h_cnt;    // [HASH_MAX_ROUNDS + 1] number of entries of the list feeding round r
-  // clock probe (BN254_OPT_CLOCK_PROBE; nullptr = off): [2 kernels: Miller loop, final exponentiation][BN_CLK_MAX_WG][2] — per workgroup
-  // the shader-clock cycles (s_memtime) and the constant-rate ticks (s_memrealtime) its first lane saw between entry and exit:
-  // their ratio is the clock the chip actually ran that kernel at (bench.py: roofline.effective_sclk_mhz)
+  // clock probe (BN254_OPT_CLOCK_PROBE; nullptr = off): [3 slots: Miller loop, final exponentiation, probes][BN_CLK_MAX_WG][2] — per workgroup
+  // index the shader-clock cycles (s_memtime) and the constant-rate ticks (s_memrealtime) its first lane saw between entry and exit,
+  // ACCUMULATED over every launch since bn254_ctx_last_clocks last read (and cleared) them: their ratio is the clock the chip actually
+  // ran those kernels at — over exactly the launches in between, e.g. the timed steps of bench.py (roofline.effective_sclk_mhz)
   unsigned long long* clk;
 };
 #define BN_CLK_MAX_WG 4096
@@ -58,7 +59,7 @@ struct Ws {
   do {                                                                                           \
     if ((ws).clk && threadIdx.x == 0 && blockIdx.x < BN_CLK_MAX_WG) {                            \
       unsigned long long* p_ = (ws).clk + ((size_t)(slot) * BN_CLK_MAX_WG + blockIdx.x) * 2;    \
-      p_[0] = clock64() - clk0_; p_[1] = wall_clock64() - wall0_;                                \
+      p_[0] += clock64() - clk0_; p_[1] += wall_clock64() - wall0_;                              \
     }                                                                                            \
   } while (0)
 #define HASH_NONE 0xFFFFFFFFu

@@ -279,7 +279,10 @@ int bn254_probe_issue_rate(bn254_ctx *ctx, int op, int waves_per_simd, double *w
  * products, 435 squarings, 348 scalings per lane) or final exponentiation (mode 1: 945 dual products, 1 701 squarings) for n lane pairs —
  * no tower additions, carries, twist point or LDS traffic — on the launch shape of those kernels: a floor for any arrangement of the
  * code around the product leaves.  n <= the size of the workspace.  With BN254_OPT_CLOCK_PROBE its clock lands in slot [2].
- * Modes 2 / 3: 3 219 dual products with the leaf inlined into the loop / called — what the calling convention costs per product. */
+ * Modes 2 / 3: 3 219 dual products with the leaf inlined into the loop / called — what the calling convention costs per product.
+ * Modes 4 / 5: the product counts of modes 0 / 1 as FOUR independent chains per lane (in modes 0 / 1 every product waits for its
+ * predecessor, which a lone wave per SIMD cannot hide): the floor to quote is the smaller of the two.  Modes 6 / 7: controls for mode 4 —
+ * the same loop with one chain / two chains. */
 int bn254_probe_leaf_floor(bn254_ctx *ctx, size_t n, int mode, float *ms);
 /* measurement: duration in ms of the final exponentiation's accumulator machine (the interpreter of the lane-pair kernel) running a
  * caller-supplied program of n_steps (opcode, argument) byte pairs — 1 LOAD slot, 2 STORE slot, 3 CSQR, 4 MUL slot, 5 CONJ, 6 FROB 1..3,
@@ -339,8 +342,10 @@ int bn254_ctx_set_option(bn254_ctx *ctx, int option, int value);
  * points, ms[3] = 0; aggregate_verify ms[0] = the pools
  * (decoding, hashing the messages, the subset-sum table), ms[1] = the aggregation kernel. */
 int bn254_ctx_last_kernel_ms(bn254_ctx *ctx, float ms[4]);
-/* with BN254_OPT_CLOCK_PROBE on: achieved shader clock in MHz of the most recent lane-pair Miller kernel [0], final exponentiation [1]
- * and bn254_probe_issue_rate kernel [2] on this context (0 = that kernel has not run since the option was set).  Synchronises the device. */
+/* with BN254_OPT_CLOCK_PROBE on: achieved shader clock in MHz of the lane-pair Miller kernels [0], final exponentiations [1] and probe
+ * kernels (bn254_probe_issue_rate, bn254_probe_leaf_floor) [2] launched on this context SINCE THE PREVIOUS CALL of this function (or
+ * since the option was set) — the counters accumulate over launches and every call reads and clears them, so a caller brackets exactly
+ * the launches it wants the clock of (bench.py: the timed steps).  0 = no such kernel ran in between.  Synchronises the device. */
 int bn254_ctx_last_clocks(bn254_ctx *ctx, double sclk_mhz[3]);
 
 /* =====================================================================================================================

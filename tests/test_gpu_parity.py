@@ -1262,21 +1262,26 @@ def test_measurement_entry_points(eng):
     mhz = (ctypes.c_double * 3)()
     assert lib.bn254_ctx_last_clocks(h, mhz) == BAD                     # probe off: no buffer
     assert lib.bn254_probe_leaf_floor(h, 0, 0, ctypes.byref(ms)) == BAD
-    assert lib.bn254_probe_leaf_floor(h, n, 4, ctypes.byref(ms)) == BAD
+    assert lib.bn254_probe_leaf_floor(h, n, 8, ctypes.byref(ms)) == BAD
     assert lib.bn254_probe_leaf_floor(h, 1 << 40, 0, ctypes.byref(ms)) == BAD          # beyond the workspace
     for prog in (bytes([8, 0]), bytes([0, 0]), bytes([4, 10]), bytes([1, 200]), bytes([6, 0]), bytes([6, 4])):   # unknown opcode, END inside, slot out of range, bad Frobenius power
         assert lib.bn254_probe_fe_program(h, n, prog, 1, ctypes.byref(ms)) == BAD, prog
     assert lib.bn254_probe_fe_program(h, n, bytes([3, 0]), 0, ctypes.byref(ms)) == BAD
     t_sq = eng.probe_fe_program(n, [(2, 0)] + [(3, 0)] * 20)
     t_mul = eng.probe_fe_program(n, [(2, 0)] + [(4, 0)] * 20)
-    assert 0.0 < t_sq < t_mul < 50.0                                    # 20 Fq12 products cost more than 20 cyclotomic squarings
-    floor_miller, floor_fe = eng.probe_leaf_floor(n, 0), eng.probe_leaf_floor(n, 1)
-    assert 0.0 < floor_fe < floor_miller < 50.0
+    assert 0.0 < t_sq < 200.0 and 0.0 < t_mul < 200.0                   # plausible durations only: orderings and tight windows flake on a shared box
+    for mode in range(8):                                               # dependent chains, inlined / called leaf, four / one / two independent chains
+        assert 0.0 < eng.probe_leaf_floor(n, mode) < 200.0, mode
     eng.set_option(OPT_CLOCK_PROBE, 1)
     try:
         assert eng.batch_verify(msgs, sigs, pks) == expected
         clocks = eng.last_clocks()
-        assert 1000.0 < clocks["miller_loop"] < 3000.0 and 1000.0 < clocks["final_exp"] < 3000.0, clocks
+        assert 500.0 < clocks["miller_loop"] < 4000.0 and 500.0 < clocks["final_exp"] < 4000.0, clocks
+        again = eng.last_clocks()                                       # read AND cleared: nothing ran in between
+        assert again["miller_loop"] == 0.0 and again["final_exp"] == 0.0, again
+        assert eng.batch_verify(msgs, sigs, pks) == expected and eng.batch_verify(msgs, sigs, pks) == expected
+        two = eng.last_clocks()                                         # accumulated over two launches: still a clock, not a sum of clocks
+        assert 500.0 < two["miller_loop"] < 4000.0, two
     finally:
         eng.set_option(OPT_CLOCK_PROBE, 0)
     assert lib.bn254_ctx_last_clocks(h, mhz) == BAD
