@@ -491,20 +491,6 @@ BN_DEV Fp fp_mul(const Fp& a, const Fp& b) {
   BN_TRK(bn_trk_mul(r, a, b));
   return r;
 }
-// the squaring INLINED at its call site (A/B knob BN_INLINE_POW_LEAVES for the runs of squarings of the fixed-exponent ladders below): in
-// a loop of nothing but dependent products a call costs 11-13 % of a product (profiles/r04_h_leaf_call_cost.jsonl), in the kernels the
-// inlined form was never faster (profiles/r04_h_ab_inline_pow_leaves.log, r04_h_ab_inline_csqr_leaves.log)
-BN_DEV Fp fp_sqr_inl(const Fp& a) {
-  BN_LIMB_VEC x;
-#pragma unroll
-  for (int i = 0; i < BN_LIMBS; ++i) x[i] = a.v[i];
-  BN_LIMB_VEC z = fp_sqr_body(x);
-  Fp r;
-#pragma unroll
-  for (int i = 0; i < BN_LIMBS; ++i) r.v[i] = z[i];
-  BN_TRK(bn_trk_mul(r, a, a));
-  return r;
-}
 BN_DEV Fp fp_sqr(const Fp& a) {
   BN_LIMB_VEC x;
 #pragma unroll
@@ -653,11 +639,7 @@ BN_DEVN Fp fp_pow_sched(Fp a, const unsigned char (*sched)[2], int n_steps) {
   Fp acc = odd[sched[0][1] >> 1];
   for (int s = 1; s < n_steps; ++s) {
     BN_SET_STEP_PRIORITY(s);
-#if defined(BN_INLINE_POW_LEAVES)      // A/B knob (profiles/r04_h_ab_inline_pow_leaves.log): k_hash_finish 33.5 instead of 32.2 ms per 16 Mi — not taken
-    for (int k = 0; k < sched[s][0]; ++k) acc = fp_sqr_inl(acc);
-#else
-    for (int k = 0; k < sched[s][0]; ++k) acc = fp_sqr(acc);
-#endif
+    for (int k = 0; k < sched[s][0]; ++k) acc = fp_sqr(acc);      // (the leaf inlined here: 33.5 against 32.2 ms per 16 Mi, profiles/r04_h_ab_inline_pow_leaves.log)
     if (sched[s][1]) acc = fp_mul(acc, odd[sched[s][1] >> 1]);
   }
   return acc;
@@ -857,11 +839,7 @@ BN_DEVN Fp2 fp2_pow_sched(Fp2 a, const unsigned char (*sched)[2], int n_steps) {
   Fp2 acc = odd[sched[0][1] >> 1];
   for (int s = 1; s < n_steps; ++s) {
     BN_SET_STEP_PRIORITY(s);
-#if defined(BN_INLINE_POW_LEAVES) && defined(BN_SPLIT_FP2)
-    for (int k = 0; k < sched[s][0]; ++k) acc = fp2_sqr_pow(acc);     // pair layout: the squaring leaf inlined into this loop (A/B knob, neutral)
-#else
     for (int k = 0; k < sched[s][0]; ++k) acc = fp2_sqr(acc);
-#endif
     if (sched[s][1]) acc = fp2_mul(acc, odd[sched[s][1] >> 1]);
   }
   return acc;
@@ -1277,12 +1255,9 @@ BN_DEV void fp12_frob_body(Fp12& r, const Fp12& a, int power) {
 }
 BN_DEVN void fp12_frob(Fp12& r, const Fp12& a, int power) { fp12_frob_body(r, a, power); }
 // (a + b s)^2 in Fq4 = Fq2[s]/(s^2 - xi): r0 = a^2 + xi b^2, r1 = 2ab; a, b tight.  Sites S .. S+2.
-#if !defined(BN_SPLIT_FP2)
-BN_DEV Fp2 fp2_sqr_inl(const Fp2& a) { return fp2_sqr(a); }
-#endif
 template <int S> BN_DEV void fp4_sqr(Fp2& r0, Fp2& r1, const Fp2& a, const Fp2& b) {
-  Fp2 a2 = fp2_sqr_inl(a), b2 = fp2_sqr_inl(b);       // fp2_sqr unless the translation unit asks for the leaves of this routine inline (BN_INLINE_CSQR_LEAVES)
-  r1 = NS(S + 1, fp2_sub(fp2_sub(fp2_sqr_inl(NS(S, fp2_add(a, b))), a2), b2));
+  Fp2 a2 = fp2_sqr(a), b2 = fp2_sqr(b);               // (the three leaves inlined here: no gain, profiles/r04_h_ab_inline_csqr_leaves.log)
+  r1 = NS(S + 1, fp2_sub(fp2_sub(fp2_sqr(NS(S, fp2_add(a, b))), a2), b2));
   r0 = NS(S + 2, fp2_add(a2, fp2_mul_xi(b2)));
 }
 // Granger-Scott squaring for the cyclotomic subgroup (after the easy part of the final exp.).

@@ -112,26 +112,6 @@ BN_DEV Fp2 fp2_select_pos(bool c, const Fp2& a, const Fp2& b) { Fp2 r; BN_FOR_RO
 // Device form of fp2_mul: the callee fetches the partner's operands itself (DPP) and picks its role's operand
 // pairing, so a call passes 20 words in registers (a 40-word call spills 8 argument words to the stack) and the
 // exchange / select code exists once instead of at every call site.
-#if defined(BN_ASM_MUL_LEAF) && defined(__HIP_DEVICE_COMPILE__)
-// The same routine as ONE inline-asm statement with a fixed register map (gen_leaf_asm.py -> bn254_leaf_asm.h): instruction for instruction
-// what the compiler makes of the C++ below, except that the unused carry-out of the 243 v_mad_i64_i32 rotates over four SGPR pairs — the
-// register allocator gives them all the same pair, and the write-after-write on it costs two co-resident waves 10-14 % of this routine
-// (profiles/r04_h_leaf_variants_microbench.jsonl).  Operands in / out through the C calling convention; every temporary is a caller-saved
-// register in the clobber list.
-}  // namespace bn254
-#include "bn254_leaf_asm.h"
-namespace bn254 {
-BN_DEVN BN_VEC10 fp_pair_mul_impl(BN_VEC10 a, BN_VEC10 b) {
-  int32_t r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7], r8 = a[8];
-  asm(BN_LEAF_PAIR_MUL_TEXT
-      : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7), "+v"(r8)
-      : "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]), "v"(b[8])
-      : BN_LEAF_PAIR_MUL_CLOBBERS);
-  BN_VEC10 z;
-  z[0] = r0; z[1] = r1; z[2] = r2; z[3] = r3; z[4] = r4; z[5] = r5; z[6] = r6; z[7] = r7; z[8] = r8;
-  return z;
-}
-#else
 BN_DEVN BN_VEC10 fp_pair_mul_impl(BN_VEC10 a, BN_VEC10 b) {
   // own * b0 + partner * (+-b1):   re lane  a0*b0 + a1*(-b1)     im lane  a1*b0 + a0*b1
   // b0 and b1 are broadcasts within the pair
@@ -152,7 +132,6 @@ BN_DEVN BN_VEC10 fp_pair_mul_impl(BN_VEC10 a, BN_VEC10 b) {
   for (int i = 0; i < BN_LIMBS; ++i) z[i] = r[i];
   return z;
 }
-#endif
 #endif
 BN_DEV Fp2 fp2_mul(const Fp2& a, const Fp2& b) {   // outputs are tight
   Fp2 r;
@@ -179,11 +158,6 @@ BN_DEV Fp2 fp2_mul(const Fp2& a, const Fp2& b) {   // outputs are tight
 BN_DEVN BN_VEC10 fp_pair_sqr_impl(BN_VEC10 a) {
 #include "bn254_pair_sqr_body.inc"
 }
-// the same body inlined at its call site (A/B knob BN_INLINE_CSQR_LEAVES: the nine squarings of a cyclotomic squaring without call,
-// return, entry wait and argument moves — 13 % of a product's time in isolation, profiles/r04_h_leaf_call_cost.jsonl — at 18 KB of code)
-BN_DEV BN_VEC10 fp_pair_sqr_inl(BN_VEC10 a) {
-#include "bn254_pair_sqr_body.inc"
-}
 #endif
 BN_DEV Fp2 fp2_sqr(const Fp2& a) {
   Fp2 r;
@@ -203,35 +177,6 @@ BN_DEV Fp2 fp2_sqr(const Fp2& a) {
     r.c[k] = fp_mul(fp_select(im, fp_dbl(a.c[k]), fp_add(a.c[k], ap)), fp_select(im, ap, fp_sub(a.c[k], ap)));
   }
   return r;
-}
-// for the squaring runs of fp2_pow_sched (square roots of G2 decompression): the leaf inlined into that small loop
-BN_DEV Fp2 fp2_sqr_pow(const Fp2& a) {
-#if defined(__HIPCC__)
-  Fp2 r;
-  BN_VEC10 x;
-#pragma unroll
-  for (int i = 0; i < BN_LIMBS; ++i) x[i] = a.c[0].v[i];
-  BN_VEC10 z = fp_pair_sqr_inl(x);
-#pragma unroll
-  for (int i = 0; i < BN_LIMBS; ++i) r.c[0].v[i] = z[i];
-  return r;
-#else
-  return fp2_sqr(a);
-#endif
-}
-BN_DEV Fp2 fp2_sqr_inl(const Fp2& a) {
-#if defined(__HIPCC__) && defined(BN_INLINE_CSQR_LEAVES)
-  Fp2 r;
-  BN_VEC10 x;
-#pragma unroll
-  for (int i = 0; i < BN_LIMBS; ++i) x[i] = a.c[0].v[i];
-  BN_VEC10 z = fp_pair_sqr_inl(x);
-#pragma unroll
-  for (int i = 0; i < BN_LIMBS; ++i) r.c[0].v[i] = z[i];
-  return r;
-#else
-  return fp2_sqr(a);
-#endif
 }
 BN_DEV Fp2 fp2_mul_fp(const Fp2& a, const Fp& s) { Fp2 r; BN_FOR_ROLES(k) r.c[k] = fp_mul(a.c[k], s); return r; }
 BN_DEV Fp2 fp2_mul_xi(const Fp2& a) {              // (9 + i) * a; 8 * own by fp_mul8_spread: limbs <= 2^28 + |own_i| + |partner_i|

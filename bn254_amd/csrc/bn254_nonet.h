@@ -2,7 +2,7 @@
 // Granger-Scott squaring at once, the 18 products of a Karatsuba Fq12 product in two rounds of nine, everything linear distributed as
 // well — written ONCE against a "box" (where the exchanged values live) so that the SAME source is
 //   * the kernel k_final_exp_nonet (box = the workgroup's LDS, references = word offsets of the lane's verify and role), and
-//   * a host emulation (box = plain arrays, the nine pairs run one after the other per exchange step; tests/hostsim/hostsim_pair.cpp:
+//   * a host emulation (box = plain arrays, the nine pairs run one after the other per exchange step; tests/hostsim:
 //     hp_nonet_check) that the CPU suite runs against fe_machine on every verify case and, built with -DBN_TRACK_BOUNDS, under the
 //     interval tracker — the proof that no 64-bit column, int32 limb or value bound can be exceeded in THIS arrangement of the pair
 //     layout's formulas (tests/test_pair_layout.py::test_nonet_schedule_*).

@@ -10,8 +10,10 @@ compiler cannot be told:
 Calling convention = the AMDGPU C convention of the functions they replace: a in v0..v8, b in v9..v17, result in v0..v8, return address in
 s[30:31]; only caller-saved registers are touched (v0-v39, v48-v55, v64-v71; s4-s29, vcc untouched).
 
-    gen_leaf_asm.py header  > bn254_leaf_asm.h      (file-scope asm for the library; included by bn254_fp2_pair.h under BN_ASM_LEAVES)
-    gen_leaf_asm.py bench   > microbench/leaf_variants.hip   (the same bodies in a timing loop, carry-out rotation on / off)
+    gen_leaf_asm.py header  > bn254_leaf_asm.h      (the leaf as one inline-asm statement: the round-4 A/B build -DBN_ASM_MUL_LEAF included it from
+                                                     bn254_fp2_pair.h — bit-exact, no faster (profiles/r04_h_ab_asm_mul_leaf.log); the hook was removed
+                                                     from the library sources in round 5, this generator and its output are kept as the record)
+    gen_leaf_asm.py bench   > leaf_variants.hip     (the same bodies in a timing loop, carry-out rotation on / off)
 """
 import sys
 
