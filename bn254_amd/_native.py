@@ -23,10 +23,13 @@ def _dependencies():
     return translation_units() + sorted(glob.glob(os.path.join(_CSRC, "*.h"))) + sorted(glob.glob(os.path.join(_CSRC, "*.inc"))) + [
         os.path.join(_CSRC, "gen_constants.py"), os.path.join(os.path.dirname(_PKG), "include", "bn254_hip.h")]
 
-# -Wl,--no-undefined: a missing translation unit fails at link time.  max-ilp: the AMDGPU machine scheduler's ILP-first
-# strategy — these kernels are VALU-issue bound at a fixed occupancy (amdgpu_waves_per_eu), so the default strategy's
-# occupancy-driven choices buy nothing; same-box A/B +1.3 % on the verify step (profiles/r02_c_ab_sched_strategy.log)
-HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-Wl,--no-undefined", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+# max-ilp: the AMDGPU machine scheduler's ILP-first strategy — these kernels are VALU-issue bound at a fixed occupancy
+# (amdgpu_waves_per_eu), so the default strategy's occupancy-driven choices buy nothing; same-box A/B +1.3 % on the verify step
+# (profiles/r02_c_ab_sched_strategy.log).  -Wl,--no-undefined: a missing translation unit fails at link time.
+HIPCC_COMPILE_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+HIPCC_LINK_FLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--no-undefined"]
+HIPCC_FLAGS = HIPCC_COMPILE_FLAGS + ["-shared", "-Wl,--no-undefined"]      # the one-command form (tools/build_variant.sh)
+_OBJ = os.path.join(_PKG, "build")
 
 
 def _stale():
@@ -36,18 +39,35 @@ def _stale():
     return any(os.path.getmtime(p) > t for p in _dependencies())
 
 
-def build(force=False, verbose=False):
-    """Compile the HIP extension for gfx950 (hipcc cross-compiles without a GPU)."""
+def build(force=False, verbose=False, jobs=None):
+    """Compile the HIP extension for gfx950 (hipcc cross-compiles without a GPU): every translation unit to an object of its own, side by
+    side (the eleven units are independent; one after the other they take over a minute), then one link."""
     const_h = os.path.join(_CSRC, "bn254_constants.h")
     gen = os.path.join(_CSRC, "gen_constants.py")
     if not os.path.exists(const_h) or os.path.getmtime(const_h) < os.path.getmtime(gen):
         subprocess.check_call(["python3", gen], stdout=None if verbose else subprocess.DEVNULL)
     if force or _stale():
+        import time
+        from concurrent.futures import ThreadPoolExecutor
         hipcc = os.environ.get("HIPCC", "hipcc")
-        cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB_PATH] + translation_units()
+        os.makedirs(_OBJ, exist_ok=True)
+        units = translation_units()
+        objs = [os.path.join(_OBJ, os.path.basename(u)[:-4] + ".o") for u in units]
+        t0 = time.time()
+
+        def compile_one(pair):
+            cmd = [hipcc] + HIPCC_COMPILE_FLAGS + ["-c", "-o", pair[1], pair[0]]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        with ThreadPoolExecutor(jobs or min(8, os.cpu_count() or 1)) as ex:
+            list(ex.map(compile_one, zip(units, objs)))
+        cmd = [hipcc] + HIPCC_LINK_FLAGS + ["-o", LIB_PATH] + objs
         if verbose:
-            print(" ".join(cmd))
+            print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+        if verbose:
+            print("libbn254hip.so: %d translation units compiled and linked in %.1f s" % (len(units), time.time() - t0), flush=True)
     return LIB_PATH
 
 
@@ -69,6 +89,7 @@ def load():
     L.bn254_ctx_destroy.argtypes = [vp]
     L.bn254_ctx_destroy.restype = None
     L.bn254_ctx_reserve.argtypes = [vp, sz]
+    L.bn254_ctx_reserve_host.argtypes = [vp, sz, sz]
     L.bn254_ctx_synchronize.argtypes = [vp]
     L.bn254_ctx_set_profiling.argtypes = [vp, i32]
     L.bn254_ctx_expect_msgs_len.argtypes = [vp, ctypes.c_uint64]
@@ -144,7 +165,7 @@ def load():
 
 # every symbol include/bn254_hip.h declares (checked by tests/test_abi.py without a GPU)
 EXPORTED_SYMBOLS = [
-    "bn254_version", "bn254_ctx_create", "bn254_ctx_destroy", "bn254_ctx_reserve", "bn254_ctx_synchronize",
+    "bn254_version", "bn254_ctx_create", "bn254_ctx_destroy", "bn254_ctx_reserve", "bn254_ctx_reserve_host", "bn254_ctx_synchronize",
     "bn254_batch_verify", "bn254_batch_verify_device", "bn254_batch_verify_randomized", "bn254_batch_verify_randomized_device", "bn254_batch_verify_compressed", "bn254_batch_verify_compressed_device", "bn254_batch_hash_to_g1", "bn254_batch_hash_to_g1_device",
     "bn254_batch_pairing_check", "bn254_batch_pairing", "bn254_batch_pairing_device", "bn254_batch_check_public_keys",
     "bn254_batch_g1_add", "bn254_batch_g2_add", "bn254_batch_g1_mul", "bn254_batch_g2_mul", "bn254_batch_g1_mul_device",

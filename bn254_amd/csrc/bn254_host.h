@@ -1,0 +1,118 @@
+// Host side shared by the translation units that implement the C ABI (include/bn254_hip.h): the context, its buffers, and the launchers of
+// the kernels more than one unit needs.  bn254_hip.hip owns the definitions; everything here is internal to libbn254hip.so (hidden).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "../../include/bn254_hip.h"
+
+#define BN_HIDDEN __attribute__((visibility("hidden")))
+
+struct bn254_ctx {
+  int device;
+  hipStream_t stream;
+  Ws ws;
+  // staging buffers for the host-pointer entry points (device memory, grown on demand)
+  uint8_t* stage[8];
+  size_t stage_cap[8];
+  int profiling;
+  int split_miller;  // A/B knob: one pairing per lane (k_miller_verify_split) instead of the fused 2-pair loop
+  Pool pool[7];       // aggregate verify: pk pool, sig pool, H(m) pool, subset sums of the pk pool and of the signature pool, and their widened
+                      // forms (16 keys / 8 signatures per entry) for the largest batches (grown on demand)
+  size_t pool_fp[7];  // coordinates per entry: 4, 2, 2, 4, 2, 4, 2
+  int agg_wide_min_tuples;    // aggregate verify: the widened tables from this many tuples on (0 = never)
+  int agg_subset_min_tuples;  // aggregate verify: tabulate subset sums of the pk pool for batches of at least this many tuples (0 = never)
+  int agg_sort_by_msg;        // aggregate verify: bucket the tuples by message before the aggregation kernel (default 1; A/B and test knob)
+  int pair_lanes;    // verify: Miller loop + final exponentiation on lane pairs (bn254_pair.hip); default on
+  int rand_min_batch;      // randomised verify: batches below this size run the exact kernels (default RAND_MIN_BATCH_DEFAULT)
+  int rand_items_per_lane; // randomised verify: 0 = by batch size, 1 or 2 forced (A/B and tests)
+  int hash_max_tries; // test knob: counters tried before HashToPointError (0 = the reference's 255)
+  int trio_wave_roles; // octet layout: the Miller loop's four lane pairs as the four waves of a workgroup (k_miller_verify_quad) instead of one wave
+  int hash_direct_width; // small batches: counters tried at once with the square root itself (k_hash_direct); 0 = rounds only
+  int trio_max_batch; // verify / check_public_keys batches up to this size run in the octet layout (bn254_trio.hip); 0 = never
+  int nonet_max_batch; // ... and up to this size their final exponentiation runs on nine lane pairs per verify (bn254_nonet.hip); 0 = never
+  hipEvent_t ev[5];
+  int ev_valid;
+  int ev_hash_first;   // the recorded intervals are hash, decode, ... (host-pointer verify) instead of decode, hash, ...
+  hipStream_t copy_stream;   // host-pointer verify: signatures and keys cross PCIe here while the hash rounds run on `stream`
+  uint8_t* pin;              // ... through this PINNED host buffer (hipHostMalloc, grown on demand): BN254_OPT_PINNED_STAGING
+  size_t pin_cap;
+  int pinned_staging;        // 0 = hipMemcpyAsync straight from the caller's (pageable) buffers
+  hipEvent_t copy_done;
+  uint64_t msgs_len_next;    // bn254_ctx_expect_msgs_len: size of the d_msgs buffer of the NEXT call that hashes messages
+  int msgs_len_declared;
+  uint64_t msgs_len_call;    // ... as taken by the entry point now running (MsgsLenScope); UINT64_MAX = not declared
+  int entry_depth;           // the host-pointer entry points call their *_device forms: only the outermost one takes the declaration
+  int32_t* key_lines;        // keyed verify: registered keys (bn254_ctx_register_keys), see KeyTable in bn254_ws.h
+  int32_t* key_xy;           // ... and their affine coordinates (4 x 9 words per key) for the small-batch route
+  uint8_t* key_st;
+  uint8_t* key_inf;
+  size_t n_keys, key_cap;
+  hipStream_t last_stream;   // the stream of the most recent *_device call (a context carries ONE call in flight: what must drain before a buffer goes)
+  bool fits_w8, fits_quad, fits_trio;   // the device can hold a workgroup of the small-batch kernels (LDS), asked at creation
+};
+
+struct ScopedEvents {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipError_t create() {
+    hipError_t e = hipEventCreate(&e0);
+    return e == hipSuccess ? hipEventCreate(&e1) : e;
+  }
+  ~ScopedEvents() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
+  ScopedEvents() = default;
+  ScopedEvents(const ScopedEvents&) = delete;
+  ScopedEvents& operator=(const ScopedEvents&) = delete;
+};
+static inline unsigned grid_for(size_t n) { return (unsigned)((n + BN_WAVE - 1) / BN_WAVE); }
+
+// before a buffer of the context is freed or rewritten: wait for the context's own streams and for the stream of its last *_device call —
+// not for the whole device (other contexts, other streams and a stream capture running elsewhere in the process are left alone)
+BN_HIDDEN int ctx_quiesce(bn254_ctx* c);
+BN_HIDDEN int ws_reserve(bn254_ctx* c, size_t n);
+BN_HIDDEN int stage_reserve(bn254_ctx* c, int slot, size_t bytes);
+BN_HIDDEN int stage_in(bn254_ctx* c, int slot, const void* host, size_t bytes);
+BN_HIDDEN int stage_out(bn254_ctx* c, int slot, void* host, size_t bytes);
+BN_HIDDEN int pool_reserve(bn254_ctx* c, int which, size_t n_fp, size_t entries);
+static inline bool misaligned(const void* p) { return ((uintptr_t)p & 3u) != 0; }
+// host-pointer entry points: an offsets array (n + 1 entries) must be non-decreasing — a kernel computes lengths as
+// off[i+1] - off[i], and a wrapped length walks far outside the staged buffer.  O(n) on memory the host already has.
+// (The *_device variants cannot look: there the kernels check every span themselves, include/bn254_hip.h.)
+static inline bool offsets_ok(const uint64_t* off, size_t n) {
+  for (size_t i = 0; i < n; ++i) if (off[i] > off[i + 1]) return false;
+  return true;
+}
+// bn254_ctx_expect_msgs_len is consumed by the NEXT entry point that hashes messages — whatever that call goes on to do: every such
+// entry point opens with a MsgsLenScope, which takes the declaration and clears it before any argument check, staging step or
+// allocation can return early (a declaration left armed would bound-check an unrelated later call against the wrong length).
+struct MsgsLenScope {
+  bn254_ctx* c;
+  explicit MsgsLenScope(bn254_ctx* ctx) : c(ctx) {
+    if (c && c->entry_depth++ == 0) {
+      c->msgs_len_call = c->msgs_len_declared ? c->msgs_len_next : UINT64_MAX;
+      c->msgs_len_declared = 0;
+    }
+  }
+  ~MsgsLenScope() { if (c) --c->entry_depth; }
+  MsgsLenScope(const MsgsLenScope&) = delete;
+  MsgsLenScope& operator=(const MsgsLenScope&) = delete;
+};
+
+// Enqueue the hash-to-G1 rounds for n messages; points land in planes (px, px+1), statuses in BY_ST_HASH.
+
+#define PROF_MARK(idx) do { if (c->profiling) HIP_TRY(hipEventRecord(c->ev[idx], s)); } while (0)
+
+// launchers of kernels that live in bn254_hip.hip and are used by other units too (a kernel is launched from the unit that defines it)
+BN_HIDDEN int launch_decode_g1(bn254_ctx* c, hipStream_t s, const uint8_t* d_pts, size_t n, uint32_t flags, int px, int inf_plane, int accumulate);
+BN_HIDDEN int launch_decode_g2(bn254_ctx* c, hipStream_t s, const uint8_t* d_pts, size_t n, uint32_t flags, int accumulate);
+BN_HIDDEN int launch_hash_rounds(bn254_ctx* c, hipStream_t s, const uint8_t* d_msgs, const uint64_t* d_off, size_t n, int px, int inf_plane,
+                                 uint8_t* d_tries, int mark_finish = -1);
+BN_HIDDEN int launch_pair_or_trio(bn254_ctx* c, hipStream_t s, size_t n, int use_hash, uint8_t* d_status, int mode, bool mark);
+// one lane per item: k_miller_verify (map / count: a device-side queue of items, or null) and k_final_exp (the arguments of the kernel)
+BN_HIDDEN int launch_miller_verify_lane(bn254_ctx* c, hipStream_t s, size_t n, const uint32_t* map, const uint32_t* count);
+BN_HIDDEN int launch_final_exp_lane(bn254_ctx* c, hipStream_t s, size_t n, size_t k, size_t item_stride, size_t pair_stride, int use_hash, uint8_t* gt_out,
+                                    uint8_t* status_out, int raw_only, size_t base, const uint32_t* map, const uint32_t* count);
+BN_HIDDEN int launch_encode_g1(bn254_ctx* c, hipStream_t s, size_t n, int px, int inf_plane, uint8_t* out, uint8_t* status_out);

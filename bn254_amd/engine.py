@@ -80,6 +80,10 @@ class Engine:
     def reserve(self, n):
         _check("bn254_ctx_reserve", self._lib.bn254_ctx_reserve(self._h, n))
 
+    def reserve_host(self, n, msg_bytes):
+        """presize workspace + staging for host-pointer batch_verify calls of up to n tuples / msg_bytes message bytes"""
+        _check("bn254_ctx_reserve_host", self._lib.bn254_ctx_reserve_host(self._h, n, msg_bytes))
+
     def synchronize(self):
         _check("bn254_ctx_synchronize", self._lib.bn254_ctx_synchronize(self._h))
 

@@ -66,6 +66,8 @@ typedef struct bn254_ctx bn254_ctx;
 #define BN254_E_BAD_ARGUMENT (-10001)
 #define BN254_E_MISALIGNED (-10002)
 #define BN254_E_NO_DEVICE (-10003)
+#define BN254_E_RCCL (-10004)      /* multi-GPU layer: librccl.so.1 could not be loaded, or an RCCL call failed (bn254_mgpu_last_error has the text) */
+#define BN254_E_NO_MEMORY (-10005) /* host allocation or thread creation failed */
 
 /* status codes */
 #define BN254_OK 0
@@ -89,6 +91,10 @@ void bn254_ctx_destroy(bn254_ctx *ctx);
 /* pre-size the HBM workspace for batches of up to n items / n*k pairs (optional; avoids a
  * hipMalloc inside a later *_device call) */
 int bn254_ctx_reserve(bn254_ctx *ctx, size_t n_items);
+/* the same for the HOST-pointer bn254_batch_verify: workspace plus the staging buffers in HBM for n_items tuples whose messages total
+ * msg_bytes, so that the steady state allocates nothing.  (Whenever a call does have to grow a buffer it first waits for the context's
+ * own streams and for the stream of the context's last *_device call — not for the whole device.) */
+int bn254_ctx_reserve_host(bn254_ctx *ctx, size_t n_items, size_t msg_bytes);
 int bn254_ctx_synchronize(bn254_ctx *ctx);
 /* Declares the size in bytes of the d_msgs buffer of the NEXT call on this context that hashes messages (verify, verify_compressed,
  * verify_randomized, hash_to_g1, sign, aggregate_verify and their *_device forms); the declaration is consumed by that call.
@@ -126,9 +132,10 @@ int bn254_batch_verify_compressed_device(bn254_ctx *ctx, const uint8_t *d_msgs, 
  * memory).  key_status[j] (may be NULL) = what PublicKey::from_uncompressed reports for key j: 0, 6 (a coordinate >= q) or 4
  * (not on the curve / not in the order-r subgroup — the subgroup check ALWAYS runs here, as in AffineG2::new; flags: only
  * BN254_FLAG_REJECT_IDENTITY is looked at).  An all-zero key is the identity (its pair contributes 1).  The call
- * waits for the whole device (hipDeviceSynchronize) before it touches the tables — a keyed verify enqueued earlier on any
- * stream has finished reading them — and returns with the new set in place; the same holds whenever a call has to grow the
- * context's workspace or staging buffers (presize with bn254_ctx_reserve to keep that out of the steady state).
+ * waits for the context's own streams and for the stream of its last *_device call before it touches the tables — a keyed
+ * verify enqueued earlier has finished reading them (a context carries one call in flight) — and returns with the new set in
+ * place; the same holds whenever a call has to grow the context's workspace or staging buffers (presize with bn254_ctx_reserve /
+ * bn254_ctx_reserve_host to keep that out of the steady state).  Other contexts and streams are not waited for.
  *
  * bn254_batch_verify_keyed[_device]: as bn254_batch_verify with key_idx[i] (uint32) in place of the i-th public key.
  * status[i] = the signature's decode error, else 2 (IndexOutOfBounds) if key_idx[i] >= n_keys, else the key's registration
@@ -248,47 +255,6 @@ int bn254_batch_aggregate_verify_device(bn254_ctx *ctx, const uint8_t *d_msgs, c
 int bn254_batch_g1_decompress(bn254_ctx *ctx, const uint8_t *in /* n*33 */, size_t n, uint8_t *out /* n*64 */, uint8_t *status);
 int bn254_batch_g2_decompress(bn254_ctx *ctx, const uint8_t *in /* n*65 */, size_t n, uint8_t *out /* n*128 */, uint8_t *status);
 
-/* test hooks: element-wise field/tower operations on byte-encoded operands, used by the parity
- * tests to compare each layer of the HIP arithmetic with the oracle.
- *   op: 0 mul, 1 add, 2 sub, 3 inverse(a), 4 square(a), 5 sqrt(a) (status 6 if none)   [Fq, 32 B]
- *   fp12 op: 0 mul, 1 square, 2 inverse, 3 conj, 4 frobenius^1, 5 ^2, 6 ^3, 7 cyclotomic square,
- *            8 final exponentiation                                                    [384 B] */
-int bn254_debug_fp_op(bn254_ctx *ctx, int op, const uint8_t *a, const uint8_t *b, size_t n, uint8_t *out, uint8_t *status);
-int bn254_debug_fp12_op(bn254_ctx *ctx, int op, const uint8_t *a, const uint8_t *b, size_t n, uint8_t *out);
-/* the final exponentiation of ECDSA::verify / bn::pairing_batch (src/ecdsa.rs:57-59) on caller-supplied LIMB vectors — n x 12 coefficients
- * (Gt order) x 9 int32 limbs, value = sum limb_k 2^(29 k) in Montgomery form (R = 2^261) — in the layout named: 0 one lane per item, exact
- * exponent, gt = canonical Gt bytes | 1 lane pairs, exact, gt | 2 lane pairs, the == one chain | 3 lane octets (straight-line chains below
- * 128 items, accumulator machine from 128 on) | 4 nine lane pairs per item | 5 one lane, the == one chain.  status[i] = 0 (the value is one) or 9.
- * Exists so that the parity tests can hand every layout NON-CANONICAL representatives with extreme balanced digits — what the interval
- * tracker's contract for a Miller value allows (limbs 0..7 in [-2^28, 2^28], |value| <= 0.5215 q) but no byte decoder produces. */
-int bn254_debug_final_exp_limbs(bn254_ctx *ctx, int layout, const int32_t *limbs /* n*108 */, size_t n, uint8_t *gt /* n*384, layouts 0 / 1, or NULL */,
-                                uint8_t *status /* n */);
-/* what ONE pass of the try loop of hash_to_try_and_increment does with a chosen 256-bit digest value h (32 B
- * big-endian each) instead of SHA-256(msg || ctr): the h >= 5q rule (src/hash.rs:49-51), mod_u256's strict '>'
- * (src/utils.rs:27-37) and G1::from_compressed(0x02 || x) (src/utils.rs:56-63).  status 0: out = the point; 1: the
- * loop would move to the next counter (out = zeros).  Exists because h = k*q has no known preimage. */
-int bn254_debug_hash_candidate(bn254_ctx *ctx, const uint8_t *h /* n*32 */, size_t n, uint8_t *out /* n*64 */, uint8_t *status);
-/* un-exponentiated Miller-loop value of each single pair (debugging aid) */
-int bn254_debug_miller_loop(bn254_ctx *ctx, const uint8_t *g1, const uint8_t *g2, size_t n, uint8_t *f /* n*384 */);
-
-/* calibration probe for the roofline figures of bench.py: sustained wave-instructions per second of one VALU
- * instruction (op 0 v_mad_u64_u32, 1 v_add_u32, 2 v_mul_lo_u32; 16 independent chains) with waves_per_simd (1..8)
- * waves on every SIMD of the device; n_simd (optional) = SIMD count.  Synchronises the context's stream. */
-int bn254_probe_issue_rate(bn254_ctx *ctx, int op, int waves_per_simd, double *wave_inst_per_s, int *n_simd);
-/* measurement: duration in ms of a kernel that runs ONLY the field-product calls of one verify's Miller loop (mode 0: 3 219 dual
- * products, 435 squarings, 348 scalings per lane) or final exponentiation (mode 1: 945 dual products, 1 701 squarings) for n lane pairs —
- * no tower additions, carries, twist point or LDS traffic — on the launch shape of those kernels: a floor for any arrangement of the
- * code around the product leaves.  n <= the size of the workspace.  With BN254_OPT_CLOCK_PROBE its clock lands in slot [2].
- * Modes 2 / 3: 3 219 dual products with the leaf inlined into the loop / called — what the calling convention costs per product.
- * Modes 4 / 5: the product counts of modes 0 / 1 as FOUR independent chains per lane (in modes 0 / 1 every product waits for its
- * predecessor, which a lone wave per SIMD cannot hide): the floor to quote is the smaller of the two.  Modes 6 / 7: controls for mode 4 —
- * the same loop with one chain / two chains. */
-int bn254_probe_leaf_floor(bn254_ctx *ctx, size_t n, int mode, float *ms);
-/* measurement: duration in ms of the final exponentiation's accumulator machine (the interpreter of the lane-pair kernel) running a
- * caller-supplied program of n_steps (opcode, argument) byte pairs — 1 LOAD slot, 2 STORE slot, 3 CSQR, 4 MUL slot, 5 CONJ, 6 FROB 1..3,
- * 7 INV; slots 0..9 — for n lane pairs on the values the last verify left in the workspace.  Programs of one operation kind give the cost
- * of that operation in place (bench.py: roofline.final_exp_split); results are not meaningful values. */
-int bn254_probe_fe_program(bn254_ctx *ctx, size_t n, const uint8_t *prog, size_t n_steps, float *ms);
 /* timing of the most recent batch_verify*(…) on this context, from HIP events recorded on the
  * launch stream around each kernel: ms[0] decode, ms[1] hash-to-G1, ms[2] Miller loop,
  * ms[3] final exponentiation.  Synchronises the stream.  Requires bn254_ctx_set_profiling(ctx, 1). */
@@ -376,9 +342,6 @@ int bn254_ctx_last_clocks(bn254_ctx *ctx, double sclk_mhz[3]);
  * A handle carries one call in flight, like a context. */
 typedef struct bn254_mgpu bn254_mgpu;
 
-#define BN254_E_RCCL (-10004)      /* librccl.so.1 could not be loaded, or an RCCL call failed (bn254_mgpu_last_error has the text) */
-#define BN254_E_NO_MEMORY (-10005) /* host allocation or thread creation failed */
-
 int bn254_mgpu_create(const int *devices, int n_dev /* 1..64 */, bn254_mgpu **out);
 void bn254_mgpu_destroy(bn254_mgpu *mg);
 int bn254_mgpu_device_count(const bn254_mgpu *mg);
@@ -421,6 +384,56 @@ int bn254_mgpu_batch_pairing_device(bn254_mgpu *mg, const uint8_t *const *d_g1, 
 /* points[i] = hash_to_try_and_increment(msg_i) (src/hash.rs:29-63) for the whole batch, sharded over the devices */
 int bn254_mgpu_batch_hash_to_g1(bn254_mgpu *mg, const uint8_t *msgs, const uint64_t *msg_off, size_t n, uint8_t *points /* n*64 */,
                                 uint8_t *status /* n */, uint8_t *tries /* n or NULL */);
+
+/* =====================================================================================================================
+ * BN254_DEV_HOOKS — developer hooks, NOT part of the drop-in ABI (bn254_devhooks.hip).  No reference function corresponds to any of
+ * them; a binding of the reference's API never needs them.  bn254_debug_* let the parity tests compare every layer of
+ * the HIP arithmetic with the oracle; bn254_probe_* are the measurement kernels behind bench.py's roofline figures.  Define
+ * BN254_NO_DEV_HOOKS before including this header to hide the declarations.
+ * ===================================================================================================================== */
+#ifndef BN254_NO_DEV_HOOKS
+/* test hooks: element-wise field/tower operations on byte-encoded operands, used by the parity
+ * tests to compare each layer of the HIP arithmetic with the oracle.
+ *   op: 0 mul, 1 add, 2 sub, 3 inverse(a), 4 square(a), 5 sqrt(a) (status 6 if none)   [Fq, 32 B]
+ *   fp12 op: 0 mul, 1 square, 2 inverse, 3 conj, 4 frobenius^1, 5 ^2, 6 ^3, 7 cyclotomic square,
+ *            8 final exponentiation                                                    [384 B] */
+int bn254_debug_fp_op(bn254_ctx *ctx, int op, const uint8_t *a, const uint8_t *b, size_t n, uint8_t *out, uint8_t *status);
+int bn254_debug_fp12_op(bn254_ctx *ctx, int op, const uint8_t *a, const uint8_t *b, size_t n, uint8_t *out);
+/* the final exponentiation of ECDSA::verify / bn::pairing_batch (src/ecdsa.rs:57-59) on caller-supplied LIMB vectors — n x 12 coefficients
+ * (Gt order) x 9 int32 limbs, value = sum limb_k 2^(29 k) in Montgomery form (R = 2^261) — in the layout named: 0 one lane per item, exact
+ * exponent, gt = canonical Gt bytes | 1 lane pairs, exact, gt | 2 lane pairs, the == one chain | 3 lane octets (straight-line chains below
+ * 128 items, accumulator machine from 128 on) | 4 nine lane pairs per item | 5 one lane, the == one chain.  status[i] = 0 (the value is one) or 9.
+ * Exists so that the parity tests can hand every layout NON-CANONICAL representatives with extreme balanced digits — what the interval
+ * tracker's contract for a Miller value allows (limbs 0..7 in [-2^28, 2^28], |value| <= 0.5215 q) but no byte decoder produces. */
+int bn254_debug_final_exp_limbs(bn254_ctx *ctx, int layout, const int32_t *limbs /* n*108 */, size_t n, uint8_t *gt /* n*384, layouts 0 / 1, or NULL */,
+                                uint8_t *status /* n */);
+/* what ONE pass of the try loop of hash_to_try_and_increment does with a chosen 256-bit digest value h (32 B
+ * big-endian each) instead of SHA-256(msg || ctr): the h >= 5q rule (src/hash.rs:49-51), mod_u256's strict '>'
+ * (src/utils.rs:27-37) and G1::from_compressed(0x02 || x) (src/utils.rs:56-63).  status 0: out = the point; 1: the
+ * loop would move to the next counter (out = zeros).  Exists because h = k*q has no known preimage. */
+int bn254_debug_hash_candidate(bn254_ctx *ctx, const uint8_t *h /* n*32 */, size_t n, uint8_t *out /* n*64 */, uint8_t *status);
+/* un-exponentiated Miller-loop value of each single pair (debugging aid) */
+int bn254_debug_miller_loop(bn254_ctx *ctx, const uint8_t *g1, const uint8_t *g2, size_t n, uint8_t *f /* n*384 */);
+
+/* calibration probe for the roofline figures of bench.py: sustained wave-instructions per second of one VALU
+ * instruction (op 0 v_mad_u64_u32, 1 v_add_u32, 2 v_mul_lo_u32; 16 independent chains) with waves_per_simd (1..8)
+ * waves on every SIMD of the device; n_simd (optional) = SIMD count.  Synchronises the context's stream. */
+int bn254_probe_issue_rate(bn254_ctx *ctx, int op, int waves_per_simd, double *wave_inst_per_s, int *n_simd);
+/* measurement: duration in ms of a kernel that runs ONLY the field-product calls of one verify's Miller loop (mode 0: 3 219 dual
+ * products, 435 squarings, 348 scalings per lane) or final exponentiation (mode 1: 945 dual products, 1 701 squarings) for n lane pairs —
+ * no tower additions, carries, twist point or LDS traffic — on the launch shape of those kernels: a floor for any arrangement of the
+ * code around the product leaves.  n <= the size of the workspace.  With BN254_OPT_CLOCK_PROBE its clock lands in slot [2].
+ * Modes 2 / 3: 3 219 dual products with the leaf inlined into the loop / called — what the calling convention costs per product.
+ * Modes 4 / 5: the product counts of modes 0 / 1 as FOUR independent chains per lane (in modes 0 / 1 every product waits for its
+ * predecessor, which a lone wave per SIMD cannot hide): the floor to quote is the smaller of the two.  Modes 6 / 7: controls for mode 4 —
+ * the same loop with one chain / two chains. */
+int bn254_probe_leaf_floor(bn254_ctx *ctx, size_t n, int mode, float *ms);
+/* measurement: duration in ms of the final exponentiation's accumulator machine (the interpreter of the lane-pair kernel) running a
+ * caller-supplied program of n_steps (opcode, argument) byte pairs — 1 LOAD slot, 2 STORE slot, 3 CSQR, 4 MUL slot, 5 CONJ, 6 FROB 1..3,
+ * 7 INV; slots 0..9 — for n lane pairs on the values the last verify left in the workspace.  Programs of one operation kind give the cost
+ * of that operation in place (bench.py: roofline.final_exp_split); results are not meaningful values. */
+int bn254_probe_fe_program(bn254_ctx *ctx, size_t n, const uint8_t *prog, size_t n_steps, float *ms);
+#endif /* BN254_NO_DEV_HOOKS */
 
 #ifdef __cplusplus
 }

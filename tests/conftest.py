@@ -32,3 +32,13 @@ def kats():
 def derived():
     with open(os.path.join(GOLDEN, "derived_vectors.json")) as f:
         return json.load(f)
+
+
+def ws_default(name):
+    """the value of `#define <name> <integer>` in bn254_amd/csrc/bn254_ws.h — tests restore library defaults from the header, not from
+    literals that would silently drift"""
+    import re
+    text = open(os.path.join(ROOT, "bn254_amd", "csrc", "bn254_ws.h")).read()
+    m = re.search(r"#define\s+%s\s+(\d+)" % re.escape(name), text)
+    assert m, name
+    return int(m.group(1))

@@ -44,7 +44,8 @@ def soak(args):
     """run the differential for args.seconds with args.seed; returns the summary, raises SoakMismatch on a difference
     (tests/test_gpu_fullsize.py runs a slice of it in the driver-run suite)"""
     import bn254_amd
-    from bn254_amd.engine import OPT_AGG_SORT_BY_MSG, OPT_AGG_SUBSET_MIN_TUPLES, OPT_NONET_MAX_BATCH, OPT_PAIR_LANES, OPT_RAND_MIN_BATCH, OPT_TRIO_MAX_BATCH, OPT_TRIO_WAVE_ROLES
+    from tests.conftest import ws_default
+    from bn254_amd.engine import OPT_AGG_WIDE_MIN_TUPLES, OPT_AGG_SORT_BY_MSG, OPT_AGG_SUBSET_MIN_TUPLES, OPT_NONET_MAX_BATCH, OPT_PAIR_LANES, OPT_RAND_MIN_BATCH, OPT_TRIO_MAX_BATCH, OPT_TRIO_WAVE_ROLES
     from oracle import c_oracle as c
     from tests.datagen import sk_bytes
     eng = bn254_amd.Engine(0)
@@ -126,10 +127,10 @@ def soak(args):
             got["roles8_octet_fe"] = eng.batch_verify(msgs, sigs, pks, flags=flags)
             eng.set_option(OPT_NONET_MAX_BATCH, 1 << 20)     # ... and on nine lane pairs whatever the size (several passes above 3072)
             got["roles8_nonet_fe"] = eng.batch_verify(msgs, sigs, pks, flags=flags)
-            eng.set_option(OPT_NONET_MAX_BATCH, 3072)
+            eng.set_option(OPT_NONET_MAX_BATCH, ws_default("NONET_MAX_BATCH_DEFAULT"))
             eng.set_option(OPT_TRIO_MAX_BATCH, 0)
             got["pair"] = eng.batch_verify(msgs, sigs, pks, flags=flags)
-            eng.set_option(OPT_TRIO_MAX_BATCH, 16384)
+            eng.set_option(OPT_TRIO_MAX_BATCH, ws_default("TRIO_MAX_BATCH_DEFAULT"))
             eng.set_option(OPT_PAIR_LANES, 0)
             got["single"] = eng.batch_verify(msgs, sigs, pks, flags=flags)
             eng.set_option(OPT_PAIR_LANES, 1)
@@ -185,7 +186,24 @@ def soak(args):
             eng.set_option(OPT_AGG_SORT_BY_MSG, 0)           # ... and the same without the device-side bucketing by message
             got_c = eng.batch_aggregate_verify(amsgs, apk_pool, asig_pool, [t[0] for t in tuples], [t[1] for t in tuples])
             eng.set_option(OPT_AGG_SORT_BY_MSG, 1)
-            eng.set_option(OPT_AGG_SUBSET_MIN_TUPLES, 4096)
+            eng.set_option(OPT_AGG_WIDE_MIN_TUPLES, 1)       # ... and with the WIDENED key table (16 signers per entry; the signatures stay on their 4-signer tables here)
+            got_w = eng.batch_aggregate_verify(amsgs, apk_pool, asig_pool, [t[0] for t in tuples], [t[1] for t in tuples])
+            # both tables widened: >= 512 tuples on ONE message; against the narrow route on the same tuples, which the oracle checks below for the first 210
+            one_msg = [(0, t[1]) for t in tuples] + [(0, rnd.sample(range(S), rnd.randrange(0, S + 1))) for _ in range(330)]
+            got_ww = eng.batch_aggregate_verify(amsgs, apk_pool, asig_pool, [t[0] for t in one_msg], [t[1] for t in one_msg])
+            eng.set_option(OPT_AGG_WIDE_MIN_TUPLES, 0)
+            got_wn = eng.batch_aggregate_verify(amsgs, apk_pool, asig_pool, [t[0] for t in one_msg], [t[1] for t in one_msg])
+            eng.set_option(OPT_AGG_WIDE_MIN_TUPLES, ws_default("AGG_WIDE_MIN_TUPLES_DEFAULT"))
+            eng.set_option(OPT_AGG_SUBSET_MIN_TUPLES, ws_default("AGG_SUBSET_MIN_TUPLES_DEFAULT"))
+            if got_w != got_b or got_ww != got_wn:
+                raise SoakMismatch("MISMATCH aggregate widened tables round %d %r %r" % (rounds, list(got_b), list(got_w)))
+            for j in rnd.sample(range(len(one_msg)), 24):    # the one-message batch against the oracle on a sample
+                asig, apk = bytes(64), bytes(128)
+                for sg in one_msg[j][1]:
+                    asig = c.g1_add(asig, asig_pool[64 * sg:64 * sg + 64])
+                    apk = c.g2_add(apk, apk_pool[128 * sg:128 * sg + 128])
+                if got_ww[j] != c.verify(amsgs[0], asig, apk, 0):
+                    raise SoakMismatch("MISMATCH aggregate widened tables vs oracle round %d tuple %d" % (rounds, j))
             if got_c != got_b:
                 raise SoakMismatch("MISMATCH aggregate bucketed / caller order round %d %r %r" % (rounds, list(got_b), list(got_c)))
             if got_b != got_a:

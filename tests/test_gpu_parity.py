@@ -437,7 +437,9 @@ def test_pair_lanes_and_single_lane_agree(eng, derived):
             eng.set_option(OPT_PAIR_LANES, 1)
 
 
-NONET_DEFAULT = 3072       # bn254_ws.h: NONET_MAX_BATCH_DEFAULT
+from tests.conftest import ws_default  # noqa: E402
+NONET_DEFAULT = ws_default("NONET_MAX_BATCH_DEFAULT")
+TRIO_DEFAULT = ws_default("TRIO_MAX_BATCH_DEFAULT")
 
 
 def test_octet_and_pair_layouts_agree_with_oracle(eng, c, derived, kats):
@@ -482,9 +484,9 @@ def test_octet_and_pair_layouts_agree_with_oracle(eng, c, derived, kats):
             assert eng.batch_verify(edge[0][:8192], edge[1][:8192 * 64], edge[2][:8192 * 128]) == edge[3][:8192], lim
         # the final exponentiation on NINE lane pairs per verify (bn254_nonet.hip; 3 verifies per wave, 12 per workgroup): forced on for
         # every small-batch size (1, 2, 7, 9, 65, 1027: not multiples of 3 or 12; 8192: several passes), and off
-        eng.set_option(OPT_TRIO_MAX_BATCH, 16384)
+        eng.set_option(OPT_TRIO_MAX_BATCH, TRIO_DEFAULT)
         eng.set_option(OPT_TRIO_WAVE_ROLES, 2)
-        nonet_default = 3072
+        nonet_default = NONET_DEFAULT
         for lim in (1 << 20, 0, nonet_default):
             eng.set_option(OPT_NONET_MAX_BATCH, lim)
             assert list(eng.batch_verify(*args, flags=1)) == want, ("nonet", lim)
@@ -494,7 +496,7 @@ def test_octet_and_pair_layouts_agree_with_oracle(eng, c, derived, kats):
             assert eng.batch_verify(edge[0][:8192], edge[1][:8192 * 64], edge[2][:8192 * 128]) == edge[3][:8192], ("nonet", lim)
             assert eng.batch_verify(edge[0][:3073], edge[1][:3073 * 64], edge[2][:3073 * 128]) == edge[3][:3073], ("nonet", lim)
     finally:
-        eng.set_option(OPT_TRIO_MAX_BATCH, 16384)                     # the defaults
+        eng.set_option(OPT_TRIO_MAX_BATCH, TRIO_DEFAULT)               # the defaults
         eng.set_option(OPT_TRIO_WAVE_ROLES, 2)
         eng.set_option(OPT_NONET_MAX_BATCH, NONET_DEFAULT)
     # the default threshold itself: 16384 verifies in two passes of the small-batch kernels, 16385 on lane pairs
@@ -677,7 +679,7 @@ def test_aggregate_verify_subset_sum_table_vs_oracle(eng, c):
         got = eng.batch_aggregate_verify(msgs, pk_pool, sig_pool, [t[0] for t in tuples], [t[1] for t in tuples])
         diff = [(i, got[i], want[i], tuples[i]) for i in range(len(tuples)) if got[i] != want[i]]
         assert not diff, (knob, diff[:5])
-    eng.set_option(OPT_AGG_SUBSET_MIN_TUPLES, 4096)
+    eng.set_option(OPT_AGG_SUBSET_MIN_TUPLES, ws_default("AGG_SUBSET_MIN_TUPLES_DEFAULT"))
 
 
 def test_aggregate_verify_widened_tables_vs_oracle(eng, c):
@@ -807,7 +809,7 @@ def test_aggregate_verify_bucketed_by_message_vs_oracle(eng, c):
                 assert not diff, (name, knob, diff[:5])
     finally:
         eng.set_option(OPT_AGG_SORT_BY_MSG, 1)
-        eng.set_option(OPT_AGG_SUBSET_MIN_TUPLES, 4096)
+        eng.set_option(OPT_AGG_SUBSET_MIN_TUPLES, ws_default("AGG_SUBSET_MIN_TUPLES_DEFAULT"))
 
 
 def test_full_size_batch_properties(eng):
