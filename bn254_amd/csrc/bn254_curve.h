@@ -70,7 +70,7 @@ template <class F> BN_DEV void jac_select(Jac<F>& r, bool c, const Jac<F>& a, co
 // Coordinates in and out are tight (carried limbs).  Products and squares give tight results; f_norm stands where a
 // lazy sum meets a product whose 64-bit columns it would overflow (an Fq2 square takes a tight operand, an Fq2
 // product limb magnitudes with A * B <= 6 units of 2^28 — bn254_field.h; tests/test_bounds.py proves every flow).
-template <class F> BN_DEVN void jac_dbl(Jac<F>& r, const Jac<F>& p) {
+template <class F> BN_DEV void jac_dbl_body(Jac<F>& r, const Jac<F>& p) {
   F a = f_sqr(p.x), b = f_sqr(p.y), c = f_sqr(b);
   F d = f_norm(f_dbl(f_sub(f_sub(f_sqr(f_norm(f_add(p.x, b))), a), c)));
   F e = f_norm(f_add(f_dbl(a), a)), f = f_sqr(e);
@@ -78,6 +78,15 @@ template <class F> BN_DEVN void jac_dbl(Jac<F>& r, const Jac<F>& p) {
   F z3 = f_norm(f_dbl(f_mul(p.y, p.z)));                              // coordinates of a long chain of group operations would
   F y3 = f_reduce(f_sub(f_mul(e, f_norm(f_sub(d, x3))), f_mul8(c)));  // otherwise grow; 8 C through the limb-crossing shift
   r.x = x3; r.y = y3; r.z = z3;
+}
+template <class F> BN_DEVN void jac_dbl(Jac<F>& r, const Jac<F>& p) { jac_dbl_body(r, p); }
+// the same IN PLACE on an accumulator the caller keeps in LDS (the subgroup ladder of the lane-pair decoders): as a real function taking
+// its operand by reference the doubling moved 27 words in and out of the private segment per call
+template <class F> BN_DEVN void jac_dbl_lds(Jac<F>& acc) {
+  BN_ASSUME_LDS(&acc);
+  Jac<F> o;
+  jac_dbl_body(o, acc);
+  acc = o;
 }
 
 // add-2007-bl with every exceptional case resolved by selects (lanes never diverge):
@@ -381,18 +390,9 @@ BN_DEV bool g2_jac_equal(const G2Jac& a, const G2Jac& b) {
 // membership tests for G1, G2 and GT on BLS pairing-friendly curves", BN case): one 63-bit ladder
 // (NAF of u, mixed additions).  tests/test_oracle_model.py checks the identity against [r]P == O on
 // random twist points in and out of the subgroup; the CPU suite also runs this implementation on them.
-BN_DEVN bool g2_in_subgroup(const G2Affine& p) {
-  G2Affine pn = p;
-  pn.y = fp2_neg(p.y);
-  G2Jac up, t, lhs, rhs;
-  jac_from_affine(up, p);
-  for (int i = 0; i < BN_U_NAF_LEN; ++i) {        // wave-uniform: u is a public constant
-    BN_SET_STEP_PRIORITY(i);
-    jac_dbl(up, up);
-    int d = C_U_NAF[i];
-    if (d > 0) jac_accumulate(up, p);              // common-case addition; complete formula if any lane needs it
-    else if (d < 0) jac_accumulate(up, pn);        // (a crafted low-order twist point can reach P = +-Q)
-  }
+// the tail shared by both forms below: given up = [u]P
+BN_DEV bool g2_in_subgroup_tail(const G2Affine& p, const G2Jac& up) {
+  G2Jac t, lhs, rhs;
   lhs = up;
   jac_accumulate(lhs, p);                          // [u+1]P
   g2_psi(t, up);
@@ -402,6 +402,41 @@ BN_DEVN bool g2_in_subgroup(const G2Affine& p) {
   jac_dbl(rhs, up);
   g2_psi(rhs, rhs); g2_psi(rhs, rhs); g2_psi(rhs, rhs);
   return p.inf || g2_jac_equal(lhs, rhs);
+}
+BN_DEVN bool g2_in_subgroup(const G2Affine& p) {
+  G2Affine pn = p;
+  pn.y = fp2_neg(p.y);
+  G2Jac up;
+  jac_from_affine(up, p);
+  for (int i = 0; i < BN_U_NAF_LEN; ++i) {        // wave-uniform: u is a public constant
+    BN_SET_STEP_PRIORITY(i);
+    jac_dbl(up, up);
+    int d = C_U_NAF[i];
+    if (d > 0) jac_accumulate(up, p);              // common-case addition; complete formula if any lane needs it
+    else if (d < 0) jac_accumulate(up, pn);        // (a crafted low-order twist point can reach P = +-Q)
+  }
+  return g2_in_subgroup_tail(p, up);
+}
+// The same with the ladder's accumulator in an LDS slot of the caller (the lane-pair decoders: k_decode_g2_pair, k_decompress_g2_pair):
+// 63 doublings and 22 additions update it in place — no Jacobian point crosses the private segment inside the ladder; the point itself
+// rides into the additions in registers (AffSrc).
+struct G2AffSrc {
+  Fp2 x, y;
+  bool inf;
+  BN_DEV void operator()(G2Affine& q) const { q.x = x; q.y = y; q.inf = inf; }
+};
+BN_DEVN bool g2_in_subgroup_lds(const G2Affine& p, G2Jac& up) {
+  BN_ASSUME_LDS(&up);
+  const G2AffSrc sp = {p.x, p.y, p.inf}, sn = {p.x, fp2_neg(p.y), p.inf};
+  jac_from_affine(up, p);
+  for (int i = 0; i < BN_U_NAF_LEN; ++i) {
+    BN_SET_STEP_PRIORITY(i);
+    jac_dbl_lds(up);
+    int d = C_U_NAF[i];
+    if (d > 0) jac_accumulate_from(up, sp);
+    else if (d < 0) jac_accumulate_from(up, sn);
+  }
+  return g2_in_subgroup_tail(p, up);
 }
 
 }  // namespace bn254

@@ -103,7 +103,12 @@ KERNEL_PAIR void k_decode_g2_pair(const uint8_t* pts, size_t n, uint32_t flags, 
   gen.x = fp2_load_const(C_G2_GEN[0]); gen.y = fp2_load_const(C_G2_GEN[1]); gen.inf = false;
   if (st != ST_OK) q = gen;                          // failed lanes walk on with the generator (pairs decide together)
   if (flags & FLAG_G2_SUBGROUP_CHECK) {              // wave-uniform
+    __shared__ G2Jac lds_up[BN_PAIR_WG];             // the ladder's accumulator, 27 words per lane
+#if defined(BN_SUBGROUP_PRIVATE)
     bool in = g2_in_subgroup(q);
+#else
+    bool in = g2_in_subgroup_lds(q, lds_up[threadIdx.x]);
+#endif
     if (st == ST_OK && !in) { st = ST_INVALID_GROUP_POINT; q = gen; }
   }
   if (!live) return;
@@ -127,7 +132,12 @@ KERNEL_PAIR void k_decompress_g2_pair(const uint8_t* in, size_t n, Ws ws) {
   G2Affine gen;
   gen.x = fp2_load_const(C_G2_GEN[0]); gen.y = fp2_load_const(C_G2_GEN[1]); gen.inf = false;
   if (st != ST_OK) q = gen;
+  __shared__ G2Jac lds_up[BN_PAIR_WG];               // the subgroup ladder's accumulator, 27 words per lane
+#if defined(BN_SUBGROUP_PRIVATE)
   bool in_sub = g2_in_subgroup(q);
+#else
+  bool in_sub = g2_in_subgroup_lds(q, lds_up[threadIdx.x]);
+#endif
   if (st == ST_OK && !in_sub) { st = ST_NOT_MEMBER; q = gen; }
   if (!live) return;
   ws_store_fp(ws, PL_QX0 + (int)role, i, q.x.c[0]);
