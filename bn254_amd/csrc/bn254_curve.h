@@ -212,6 +212,7 @@ template <class F> BN_DEV void jac_accumulate_mem(Jac<F>& acc, Affine<F> q) {
 #define BN_DEV_MADD_FROM BN_DEV
 #endif
 template <class F, class Src> BN_DEV_MADD_FROM bool jac_madd_inplace_from(Jac<F>& acc, Src src) {
+#if defined(BN_MADD_FROM_SELECTS)
   Affine<F> q;
   src(q);
   Jac<F> o;
@@ -219,6 +220,34 @@ template <class F, class Src> BN_DEV_MADD_FROM bool jac_madd_inplace_from(Jac<F>
   jac_madd_common_body(o, ex, acc, q);
   if (!ex) acc = o;
   return ex;
+#else
+  // The formula of jac_madd_common_body STREAMED: every coordinate of the accumulator is read where it is needed and written back as soon as
+  // it is final (z first, then x and y), so that at most four or five field elements are alive at once — the form with one result
+  // triple and selects at the end kept q, the old and the new point alive together and spilled 35 registers per addition once inlined
+  // (k_aggregate_pair: 26 GB of private-segment writes per 1 Mi tuples).  The lanes that must not take the common formula write nothing:
+  // q = O keeps the accumulator; P = O and P = +-Q are reported to the caller, which redoes them with the complete formula.
+  Affine<F> q;
+  src(q);
+  const F z = acc.z, z1z1 = f_sqr(z);
+  const F u2 = f_mul(q.x, z1z1), s2 = f_mul(f_mul(q.y, z), z1z1);
+  const bool q_inf = q.inf;
+  const F x = acc.x;
+  const F h = f_norm(f_sub(u2, x));
+  const bool ex = (f_is_zero(h) || f_is_zero(z)) && !q_inf;
+  const bool wr = !ex && !q_inf;
+  const F hh = f_sqr(h), i = f_norm(f_dbl(f_dbl(hh)));
+  {
+    const F z3 = f_norm(f_sub(f_sub(f_sqr(f_norm(f_add(z, h))), z1z1), hh));
+    if (wr) acc.z = z3;
+  }
+  const F j = f_mul(h, i);
+  const F y = acc.y;
+  const F rr = f_norm(f_dbl(f_sub(s2, y))), v = f_mul(x, i);
+  const F x3 = f_reduce(f_sub(f_sub(f_sqr(rr), j), f_dbl(v)));
+  const F y3 = f_reduce(f_sub(f_mul(rr, f_norm(f_sub(v, x3))), f_dbl(f_mul(y, j))));
+  if (wr) { acc.x = x3; acc.y = y3; }
+  return ex;
+#endif
 }
 template <class F, class Src> BN_DEV void jac_accumulate_from(Jac<F>& acc, Src src) {
   const bool ex = jac_madd_inplace_from(acc, src);
@@ -423,7 +452,10 @@ BN_DEVN bool g2_in_subgroup(const G2Affine& p) {
 struct G2AffSrc {
   Fp2 x, y;
   bool inf;
-  BN_DEV void operator()(G2Affine& q) const { q.x = x; q.y = y; q.inf = inf; }
+#if defined(__HIPCC__)
+  __device__ __forceinline__
+#endif
+  void operator()(G2Affine& q) const { q.x = x; q.y = y; q.inf = inf; }
 };
 BN_DEVN bool g2_in_subgroup_lds(const G2Affine& p, G2Jac& up) {
   BN_ASSUME_LDS(&up);

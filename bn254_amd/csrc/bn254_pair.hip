@@ -463,9 +463,15 @@ KERNEL_PAIR void k_aggregate_pair(const uint32_t* tuple_msg, const uint64_t* tup
         if (ns1 > 1) t ^= s1[1].p[0] ^ s1[1].p[2 * BN_LIMBS - 1];
         asm volatile("" ::"v"(t));
       }
-      jac_accumulate_from(acc2, k2[0]);
+      if (k == 0) {
+        // the first entries SEED the sums (a load instead of an addition to the identity, which the streamed addition reports as exceptional)
+        { G2Affine e; k2[0](e); jac_from_affine(acc2, e); }
+        if (ns1 > 0) { G1Affine e; s1[0](e); jac_from_affine(acc1, e); }
+      } else {
+        jac_accumulate_from(acc2, k2[0]);
+        if (ns1 > 0) jac_accumulate_from(acc1, s1[0]);
+      }
       if (nk2 > 1) jac_accumulate_from(acc2, k2[1]);
-      if (ns1 > 0) jac_accumulate_from(acc1, s1[0]);
       if (ns1 > 1) jac_accumulate_from(acc1, s1[1]);
     }
     if (__builtin_amdgcn_ballot_w64(dup) != 0) {                          // rare: the tuples with a repeated signer add their keys one by one
