@@ -757,6 +757,19 @@ def test_aggregate_verify_widened_tables_vs_oracle(eng, c):
     for cut in (300, 64):
         got = e2.batch_aggregate_verify(msgs, pk_pool, sig_pool, [t[0] for t in tuples[:cut]], [t[1] for t in tuples[:cut]])
         assert got == want[:cut], cut
+    # pools of ONE group of 8 (a chunk without a second half), of exactly two groups, and of 17 signers (three groups: the last chunk is half empty)
+    for S2 in (5, 16, 17):
+        sks2 = [sk_bytes(950 + s) for s in range(S2)]
+        pk2, _ = eng.batch_g2_mul(None, b"".join(sks2), S2, reduce_scalar=True)
+        sg2, _ = eng.batch_sign([msgs[0]] * S2, b"".join(sks2))
+        tl = [(0, rnd.sample(range(S2), rnd.randrange(0, S2 + 1))) for _ in range(560)]
+        off2, flat2 = [0], []
+        for _, lst in tl:
+            flat2 += lst
+            off2.append(len(flat2))
+        want2 = c.batch_aggregate_verify(msgs[:1], pk2, sg2, [0] * len(tl), off2, flat2, nthreads=8)
+        got2 = e2.batch_aggregate_verify(msgs[:1], pk2, sg2, [0] * len(tl), [t[1] for t in tl])
+        assert got2 == want2, S2
     e2.close()
 
 
