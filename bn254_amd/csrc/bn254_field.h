@@ -361,8 +361,11 @@ BN_DEV Fp fp_lin2_reduce(const Fp& x, int32_t cx, const Fp& y, int32_t cy) {
 // Montgomery product a*b*R^-1 (mod q), product scanning.  Columns are accumulated in a signed
 // 64-bit register; m_k = the balanced digit of (column * -q^-1) makes each column divisible by 2^29.
 #if defined(__HIPCC__)
-typedef int32_t bn_i32x16 __attribute__((vector_size(64)));   // 10 limbs travel in VGPRs across the call
-#define BN_LIMB_VEC bn_i32x16
+// the nine limbs of an operand travel in VGPRs across the call.  (Until round 5 this was a 16-wide vector_size type, a leftover of the
+// 10-limb layout: two of them are 32 dwords, one more than the calling convention has argument registers, so every call of a
+// single-lane product stored a — never read — dword of padding to the stack: 4 B x every Fq product of the hash, G1 and scaling paths.)
+typedef int32_t bn_i32xl __attribute__((ext_vector_type(BN_LIMBS)));
+#define BN_LIMB_VEC bn_i32xl
 #else
 struct bn_limbvec { int32_t e[16]; int32_t& operator[](int i) { return e[i]; } const int32_t& operator[](int i) const { return e[i]; } };
 #define BN_LIMB_VEC bn_limbvec
