@@ -159,6 +159,10 @@ def load():
     L.bn254_mgpu_batch_pairing.argtypes = [vp, vp, vp, sz, sz, u32, vp, vp, ctypes.POINTER(ctypes.c_uint64)]
     L.bn254_mgpu_batch_pairing_device.argtypes = [vp, pp, pp, sz, sz, u32, pp, pp, pp, pp]
     L.bn254_mgpu_batch_hash_to_g1.argtypes = [vp, vp, vp, sz, vp, vp, vp]
+    L.bn254_mgpu_batch_verify_compressed.argtypes = [vp, vp, vp, vp, vp, sz, vp]
+    L.bn254_mgpu_register_keys.argtypes = [vp, vp, sz, u32, vp]
+    L.bn254_mgpu_batch_verify_keyed.argtypes = [vp, vp, vp, vp, vp, sz, u32, vp]
+    L.bn254_mgpu_batch_aggregate_verify.argtypes = [vp, vp, vp, sz, vp, sz, vp, vp, vp, vp, sz, u32, vp]
     _lib = L
     return L
 
@@ -174,5 +178,6 @@ EXPORTED_SYMBOLS = [
     "bn254_mgpu_create", "bn254_mgpu_destroy", "bn254_mgpu_device_count", "bn254_mgpu_ctx", "bn254_mgpu_shard_len", "bn254_mgpu_shard_range",
     "bn254_mgpu_gathered_len", "bn254_mgpu_reserve", "bn254_mgpu_synchronize", "bn254_mgpu_set_option", "bn254_mgpu_last_timing",
     "bn254_mgpu_last_error", "bn254_mgpu_batch_verify", "bn254_mgpu_batch_verify_device", "bn254_mgpu_batch_pairing",
-    "bn254_mgpu_batch_pairing_device", "bn254_mgpu_batch_hash_to_g1",
+    "bn254_mgpu_batch_pairing_device", "bn254_mgpu_batch_hash_to_g1", "bn254_mgpu_batch_verify_compressed", "bn254_mgpu_register_keys",
+    "bn254_mgpu_batch_verify_keyed", "bn254_mgpu_batch_aggregate_verify",
 ]

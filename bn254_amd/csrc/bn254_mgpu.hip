@@ -304,6 +304,51 @@ int job_hash_host(bn254_mgpu* mg, Dev* d, void* p) {
                                 a.tries ? a.tries + lo : nullptr);
 }
 
+struct CompressedHostArgs { const uint8_t* msgs; const uint64_t* off; const uint8_t* sigs33; const uint8_t* pks65; size_t n; uint8_t* status; };
+int job_verify_compressed_host(bn254_mgpu* mg, Dev* d, void* p) {
+  const CompressedHostArgs& a = *(const CompressedHostArgs*)p;
+  HostTimer timer(d);
+  size_t lo, hi;
+  shard_range(mg, a.n, d->index, lo, hi);
+  if (lo == hi) return 0;
+  int rc = rebased_offsets(d, a.off, lo, hi);
+  if (rc) return rc;
+  return bn254_batch_verify_compressed(d->ctx, a.msgs ? a.msgs + a.off[lo] : nullptr, d->off_tmp, a.sigs33 + 33 * lo, a.pks65 + 65 * lo, hi - lo, a.status + lo);
+}
+
+struct RegisterKeysArgs { const uint8_t* pks; size_t n_keys; uint32_t flags; uint8_t* key_status; };
+int job_register_keys(bn254_mgpu*, Dev* d, void* p) {                   // the whole key set on every device; entry 0 reports the statuses
+  const RegisterKeysArgs& a = *(const RegisterKeysArgs*)p;
+  return bn254_ctx_register_keys(d->ctx, a.pks, a.n_keys, a.flags, d->index == 0 ? a.key_status : nullptr);
+}
+struct KeyedHostArgs { const uint8_t* msgs; const uint64_t* off; const uint8_t* sigs; const uint32_t* key_idx; size_t n; uint32_t flags; uint8_t* status; };
+int job_verify_keyed_host(bn254_mgpu* mg, Dev* d, void* p) {
+  const KeyedHostArgs& a = *(const KeyedHostArgs*)p;
+  HostTimer timer(d);
+  size_t lo, hi;
+  shard_range(mg, a.n, d->index, lo, hi);
+  if (lo == hi) return 0;
+  int rc = rebased_offsets(d, a.off, lo, hi);
+  if (rc) return rc;
+  return bn254_batch_verify_keyed(d->ctx, a.msgs ? a.msgs + a.off[lo] : nullptr, d->off_tmp, a.sigs + 64 * lo, a.key_idx + lo, hi - lo, a.flags, a.status + lo);
+}
+
+// aggregate verify: the TUPLES are sharded; messages and pools are what every tuple may name, so every device gets all of them (and builds
+// its own subset tables).  A shard's tuple_off slice is rebased to its first signer entry.
+struct AggregateHostArgs { const uint8_t* msgs; const uint64_t* msg_off; size_t n_msgs; const uint8_t* pk_pool; size_t n_signers; const uint8_t* sig_pool;
+                           const uint32_t* tuple_msg; const uint64_t* tuple_off; const uint32_t* signer_idx; size_t n; uint32_t flags; uint8_t* status; };
+int job_aggregate_host(bn254_mgpu* mg, Dev* d, void* p) {
+  const AggregateHostArgs& a = *(const AggregateHostArgs*)p;
+  HostTimer timer(d);
+  size_t lo, hi;
+  shard_range(mg, a.n, d->index, lo, hi);
+  if (lo == hi) return 0;
+  int rc = rebased_offsets(d, a.tuple_off, lo, hi);
+  if (rc) return rc;
+  return bn254_batch_aggregate_verify(d->ctx, a.msgs, a.msg_off, a.n_msgs, a.pk_pool, a.n_signers, a.sig_pool, a.tuple_msg + lo, d->off_tmp,
+                                      a.signer_idx + a.tuple_off[lo], hi - lo, a.flags, a.status + lo);
+}
+
 struct PairingHostArgs { const uint8_t* g1; const uint8_t* g2; size_t n, k; uint32_t flags; uint8_t* gt; uint8_t* status; uint64_t* partial; };
 int job_pairing_host(bn254_mgpu* mg, Dev* d, void* p) {
   const PairingHostArgs& a = *(const PairingHostArgs*)p;
@@ -545,6 +590,43 @@ int bn254_mgpu_batch_hash_to_g1(bn254_mgpu* mg, const uint8_t* msgs, const uint6
   mg->err[0] = 0;
   HashHostArgs a = {msgs, off, n, points, status, tries};
   return run_all(mg, job_hash_host, &a);
+}
+
+int bn254_mgpu_batch_verify_compressed(bn254_mgpu* mg, const uint8_t* msgs, const uint64_t* off, const uint8_t* sigs33, const uint8_t* pks65, size_t n,
+                                       uint8_t* status) {
+  if (!mg || (n && (!off || !sigs33 || !pks65 || !status))) return BN254_E_BAD_ARGUMENT;
+  if (n == 0) return 0;
+  if (off[n] && !msgs) return BN254_E_BAD_ARGUMENT;
+  mg->err[0] = 0;
+  CompressedHostArgs a = {msgs, off, sigs33, pks65, n, status};
+  return run_all(mg, job_verify_compressed_host, &a);
+}
+
+int bn254_mgpu_register_keys(bn254_mgpu* mg, const uint8_t* pks, size_t n_keys, uint32_t flags, uint8_t* key_status) {
+  if (!mg || (n_keys && !pks)) return BN254_E_BAD_ARGUMENT;
+  mg->err[0] = 0;
+  RegisterKeysArgs a = {pks, n_keys, flags, key_status};
+  return run_all(mg, job_register_keys, &a);
+}
+
+int bn254_mgpu_batch_verify_keyed(bn254_mgpu* mg, const uint8_t* msgs, const uint64_t* off, const uint8_t* sigs, const uint32_t* key_idx, size_t n,
+                                  uint32_t flags, uint8_t* status) {
+  if (!mg || (n && (!off || !sigs || !key_idx || !status))) return BN254_E_BAD_ARGUMENT;
+  if (n == 0) return 0;
+  if (off[n] && !msgs) return BN254_E_BAD_ARGUMENT;
+  mg->err[0] = 0;
+  KeyedHostArgs a = {msgs, off, sigs, key_idx, n, flags, status};
+  return run_all(mg, job_verify_keyed_host, &a);
+}
+
+int bn254_mgpu_batch_aggregate_verify(bn254_mgpu* mg, const uint8_t* msgs, const uint64_t* msg_off, size_t n_msgs, const uint8_t* pk_pool, size_t n_signers,
+                                      const uint8_t* sig_pool, const uint32_t* tuple_msg, const uint64_t* tuple_off, const uint32_t* signer_idx, size_t n,
+                                      uint32_t flags, uint8_t* status) {
+  if (!mg || !n_msgs || !n_signers || (n && (!msg_off || !pk_pool || !sig_pool || !tuple_msg || !tuple_off || !signer_idx || !status))) return BN254_E_BAD_ARGUMENT;
+  if (n == 0) return 0;
+  mg->err[0] = 0;
+  AggregateHostArgs a = {msgs, msg_off, n_msgs, pk_pool, n_signers, sig_pool, tuple_msg, tuple_off, signer_idx, n, flags, status};
+  return run_all(mg, job_aggregate_host, &a);
 }
 
 int bn254_mgpu_batch_pairing(bn254_mgpu* mg, const uint8_t* g1, const uint8_t* g2, size_t n, size_t k, uint32_t flags, uint8_t* gt,

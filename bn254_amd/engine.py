@@ -471,6 +471,51 @@ class MultiEngine:
         self._check("bn254_mgpu_batch_hash_to_g1", self._lib.bn254_mgpu_batch_hash_to_g1(self._h, msgs, off, n, pts, status, tries))
         return pts.raw[:n * G1_BYTES], status.raw[:n], tries.raw[:n]
 
+    def batch_verify_compressed(self, messages, sigs33, pks65):
+        n = len(messages)
+        assert len(sigs33) == n * 33 and len(pks65) == n * 65
+        msgs, off = pack_messages(messages)
+        status = ctypes.create_string_buffer(max(n, 1))
+        self._check("bn254_mgpu_batch_verify_compressed",
+                    self._lib.bn254_mgpu_batch_verify_compressed(self._h, msgs, off, bytes(sigs33), bytes(pks65), n, status))
+        return status.raw[:n]
+
+    def register_keys(self, pks, flags=0):
+        """the whole key set on every device -> per-key status bytes"""
+        n = len(pks) // G2_BYTES
+        st = ctypes.create_string_buffer(max(n, 1))
+        self._check("bn254_mgpu_register_keys", self._lib.bn254_mgpu_register_keys(self._h, bytes(pks), n, flags, st))
+        return st.raw[:n]
+
+    def batch_verify_keyed(self, messages, sigs, key_idx, flags=0):
+        n = len(messages)
+        assert len(sigs) == n * G1_BYTES and len(key_idx) == n
+        msgs, off = pack_messages(messages)
+        idx = (ctypes.c_uint32 * max(n, 1))(*key_idx)
+        status = ctypes.create_string_buffer(max(n, 1))
+        self._check("bn254_mgpu_batch_verify_keyed", self._lib.bn254_mgpu_batch_verify_keyed(self._h, msgs, off, bytes(sigs), idx, n, flags, status))
+        return status.raw[:n]
+
+    def batch_aggregate_verify(self, messages, pk_pool, sig_pool, tuple_msg, signer_lists, flags=0):
+        """as Engine.batch_aggregate_verify, the tuples sharded over the devices"""
+        n, n_msgs = len(tuple_msg), len(messages)
+        n_signers = len(pk_pool) // G2_BYTES
+        assert len(sig_pool) == n_msgs * n_signers * G1_BYTES and len(signer_lists) == n
+        msgs, off = pack_messages(messages)
+        t_off = (ctypes.c_uint64 * (n + 1))()
+        flat = []
+        for i, lst in enumerate(signer_lists):
+            t_off[i] = len(flat)
+            flat.extend(lst)
+        t_off[n] = len(flat)
+        idx = (ctypes.c_uint32 * max(len(flat), 1))(*flat)
+        tm = (ctypes.c_uint32 * max(n, 1))(*tuple_msg)
+        status = ctypes.create_string_buffer(max(n, 1))
+        self._check("bn254_mgpu_batch_aggregate_verify",
+                    self._lib.bn254_mgpu_batch_aggregate_verify(self._h, msgs, off, n_msgs, bytes(pk_pool), n_signers, bytes(sig_pool), tm, t_off, idx, n,
+                                                                flags, status))
+        return status.raw[:n]
+
     def batch_pairing(self, g1s, g2s, n, k=1, flags=0):
         """-> (Gt bytes, status bytes, checksum = sum mod 2^64 of the little-endian 64-bit words of all Gt bytes)"""
         assert len(g1s) == n * k * G1_BYTES and len(g2s) == n * k * G2_BYTES

@@ -372,6 +372,18 @@ int bn254_mgpu_batch_verify(bn254_mgpu *mg, const uint8_t *msgs, const uint64_t 
 int bn254_mgpu_batch_verify_device(bn254_mgpu *mg, const uint8_t *const *d_msgs, const uint64_t *const *d_msg_off,
                                    const uint8_t *const *d_sigs, const uint8_t *const *d_pks, size_t n /* whole batch */, uint32_t flags,
                                    uint8_t *const *d_status_all /* G x gathered_len */, void *const *streams /* G or NULL */);
+/* the other verify-shaped host entry points, sharded the same way (same arguments and status bytes as their single-GPU namesakes):
+ * from the compressed encodings; with REGISTERED keys (bn254_mgpu_register_keys puts the whole key set on every device; key_status as
+ * bn254_ctx_register_keys); the aggregate verify of BASELINE configs[2] — the TUPLES are sharded, messages and pools go to every device,
+ * which builds its own subset tables. */
+int bn254_mgpu_batch_verify_compressed(bn254_mgpu *mg, const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *sigs33, const uint8_t *pks65,
+                                       size_t n, uint8_t *status);
+int bn254_mgpu_register_keys(bn254_mgpu *mg, const uint8_t *pks /* n_keys*128 */, size_t n_keys, uint32_t flags, uint8_t *key_status /* or NULL */);
+int bn254_mgpu_batch_verify_keyed(bn254_mgpu *mg, const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *sigs, const uint32_t *key_idx, size_t n,
+                                  uint32_t flags, uint8_t *status);
+int bn254_mgpu_batch_aggregate_verify(bn254_mgpu *mg, const uint8_t *msgs, const uint64_t *msg_off, size_t n_msgs, const uint8_t *pk_pool,
+                                      size_t n_signers, const uint8_t *sig_pool, const uint32_t *tuple_msg, const uint64_t *tuple_off,
+                                      const uint32_t *signer_idx, size_t n, uint32_t flags, uint8_t *status);
 /* gt[i], status[i] as bn254_batch_pairing (bn::pairing_batch, src/ecdsa.rs:57); *checksum (optional) = the sum mod 2^64 of all
  * little-endian 64-bit words of the n*384 Gt bytes — BASELINE configs[3]'s cross-shard check.  Device form: d_gt[g] = shard g's
  * n_g*384 bytes; d_checksum[g] (the array or NULL) = 8 bytes on every device receiving the all-reduced (ncclAllReduce, sum,

@@ -165,6 +165,58 @@ def test_mgpu_hash_and_pairing_vs_oracle(mg4, eng, c):
     assert cs == sum(words) & 0xFFFFFFFFFFFFFFFF
 
 
+@pytest.mark.gpu
+def test_mgpu_compressed_keyed_and_aggregate_forms_equal_single_gpu(mg4, eng, c, derived):
+    """the other verify-shaped host entry points through the multi-GPU layer give the single-GPU entry point's bytes (which the rest of
+    the suite pins on the oracle), on ragged batches with faults: compressed encodings, registered keys (the set on every device, an index
+    out of range), the aggregate verify of configs[2] (tuples sharded, pools on every device; duplicates, an out-of-range signer)"""
+    from bn254_amd.api import PublicKey, Signature            # compression is byte logic in the host mirror
+    rnd = random.Random(31)
+    n = 203
+    msgs, sigs, pks = _faulty_batch(eng, derived, n, 900)
+    # compressed: re-encode what decodes, keep a malformed encoding for what does not
+    s33, p65 = b"", b""
+    for i in range(n):
+        try:
+            s33 += Signature.from_uncompressed(sigs[64 * i:64 * i + 64]).to_compressed()
+        except Exception:
+            s33 += b"\x02" + sigs[64 * i:64 * i + 32]
+        try:
+            p65 += PublicKey.from_uncompressed(pks[128 * i:128 * i + 128]).to_compressed()
+        except Exception:
+            p65 += b"\x0a" + pks[128 * i:128 * i + 64]
+    assert mg4.batch_verify_compressed(msgs, s33, p65) == eng.batch_verify_compressed(msgs, s33, p65)
+    # keyed
+    keys = b"".join(pks[128 * i:128 * i + 128] for i in range(0, 40))
+    kst = mg4.register_keys(keys)
+    assert kst == eng.register_keys(keys)
+    idx = [rnd.randrange(0, 44) for _ in range(n)]               # 40..43: out of range -> 2
+    assert mg4.batch_verify_keyed(msgs, sigs, idx) == eng.batch_verify_keyed(msgs, sigs, idx)
+    # aggregate
+    from tests.datagen import sk_bytes
+    M, S = 3, 21
+    amsgs = [b"mg-agg-%d" % m for m in range(M)]
+    sks = [sk_bytes(1200 + s) for s in range(S)]
+    pk_pool, _ = eng.batch_g2_mul(None, b"".join(sks), S, reduce_scalar=True)
+    sig_pool, _ = eng.batch_sign([amsgs[m] for m in range(M) for _ in range(S)], b"".join(sks * M))
+    tuples = []
+    for i in range(157):
+        lst = rnd.sample(range(S), rnd.randrange(0, S + 1))
+        if i % 9 == 2 and lst:
+            lst.append(lst[0])
+        if i % 23 == 5:
+            lst.append(S + 3)
+        tuples.append((rnd.randrange(M + (1 if i % 31 == 7 else 0)), lst))
+    got = mg4.batch_aggregate_verify(amsgs, pk_pool, sig_pool, [t[0] for t in tuples], [t[1] for t in tuples])
+    want = eng.batch_aggregate_verify(amsgs, pk_pool, sig_pool, [t[0] for t in tuples], [t[1] for t in tuples])
+    off, flat = [0], []
+    for _, lst in tuples:
+        flat += lst
+        off.append(len(flat))
+    assert got == want == c.batch_aggregate_verify(amsgs, pk_pool, sig_pool, [t[0] for t in tuples], off, flat, nthreads=8)
+    assert {0, 2} <= set(got)
+
+
 def _device_shards(torch, mg, msgs, sigs, pks, n, dev):
     """per entry g: its shard's buffers resident on the device, offsets relative to the shard's own message buffer"""
     G = mg.n_dev
