@@ -532,7 +532,7 @@ int launch_encode_g1(bn254_ctx* c, hipStream_t s, size_t n, int px, int inf_plan
 
 extern "C" {
 
-const char* bn254_version(void) { return "bn254-mi355x 0.6 (gfx950; 9x29-bit balanced Montgomery limbs; verify on lane pairs, batches <= 16384 on lane octets with wave roles)"; }
+const char* bn254_version(void) { return "bn254-mi355x 0.7 (gfx950; 9x29-bit balanced Montgomery limbs; verify on lane pairs, batches <= 16384 on lane octets with wave roles; bn254_mgpu_*: all the GPUs of a node behind one handle)"; }
 
 int bn254_ctx_create(int hip_device, bn254_ctx** out) {
   if (!out) return BN254_E_BAD_ARGUMENT;
@@ -588,7 +588,7 @@ void bn254_ctx_destroy(bn254_ctx* c) {
   if (c->ws.h_cnt) (void)hipFree(c->ws.h_cnt);
   if (c->ws.clk) (void)hipFree(c->ws.clk);
   if (c->pin) (void)hipHostFree(c->pin);
-  for (int i = 0; i < 7; ++i) { if (c->pool[i].planes) (void)hipFree(c->pool[i].planes); if (c->pool[i].st) (void)hipFree(c->pool[i].st); }
+  for (int i = 0; i < 8; ++i) { if (c->pool[i].planes) (void)hipFree(c->pool[i].planes); if (c->pool[i].st) (void)hipFree(c->pool[i].st); }
   for (int i = 0; i < 8; ++i) if (c->stage[i]) (void)hipFree(c->stage[i]);
   if (c->key_lines) (void)hipFree(c->key_lines);
   if (c->key_xy) (void)hipFree(c->key_xy);

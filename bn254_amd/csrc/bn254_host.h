@@ -21,9 +21,9 @@ struct bn254_ctx {
   size_t stage_cap[8];
   int profiling;
   int split_miller;  // A/B knob: one pairing per lane (k_miller_verify_split) instead of the fused 2-pair loop
-  Pool pool[7];       // aggregate verify: pk pool, sig pool, H(m) pool, subset sums of the pk pool and of the signature pool, and their widened
+  Pool pool[8];       // aggregate verify: pk pool, sig pool, H(m) pool, subset sums of the pk pool and of the signature pool, and their widened
                       // forms (16 keys / 8 signatures per entry) for the largest batches (grown on demand)
-  size_t pool_fp[7];  // coordinates per entry: 4, 2, 2, 4, 2, 4, 2
+  size_t pool_fp[8];  // coordinates per entry: 4, 2, 2, 4, 2, 4, 2, 2 ([7]: the pair table the 4-signer signature tables are built from)
   int agg_wide_min_tuples;    // aggregate verify: the widened tables from this many tuples on (0 = never)
   int agg_subset_min_tuples;  // aggregate verify: tabulate subset sums of the pk pool for batches of at least this many tuples (0 = never)
   int agg_sort_by_msg;        // aggregate verify: bucket the tuples by message before the aggregation kernel (default 1; A/B and test knob)
