@@ -348,3 +348,32 @@ def test_mgpu_device_pairing_checksum_by_peer_copies(mg4, eng, c):
         assert bytes(keep[g][2].cpu().numpy()) == want_gt[384 * lo:384 * hi]
         assert bytes(keep[g][3][:n].cpu().numpy()) == want_st
         assert int(keep[g][4].item()) & 0xFFFFFFFFFFFFFFFF == want_cs
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_bench_verify_mgpu_command_line():
+    """`bench.py --workload verify-mgpu` — ONE process, the library's own split — on three contexts of the box's GPU (peer-copy gather)
+    and with one device entry (RCCL gather): the JSON line of the contract, every device's gathered buffer checked against the pattern
+    of every shard, per-device scaling detail, the cost of the layer against the single-GPU entry point"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for extra, G in ((["--gpus", "3", "--mgpu-devices", "0,0,0"], 3), (["--gpus", "1"], 1)):
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "verify-mgpu", "--steps", "3", "--warmup", "1", "--batch", "4096"] + extra,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=840)
+        assert p.returncode == 0, p.stderr[-2000:]
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1
+        r = json.loads(lines[0])
+        assert r["n_gpus"] == G and r["steps"] == 3 and r["warmup"] == 1 and r["scaling"] == "weak" and r["unit"] == "pairings/s"
+        assert r["config"]["bit_exact_vs_expected"] is True and r["config"]["batch_per_gpu"] == 4096
+        assert r["config"]["status_vectors_checked"] == 2 * G * G               # 2 checks x every device's buffer x every shard in it
+        assert abs(r["value"] - 2 * G * 4096 * 3 / (r["ms_per_step"] * 3e-3)) / r["value"] < 1e-6
+        d = r["scaling_detail"]
+        assert len(d["compute_ms_per_step"]["per_device"]) == G and len(d["collective_ms_per_step"]["per_device"]) == G
+        assert all(x > 0 for x in d["compute_ms_per_step"]["per_device"]) and all(x >= 0 for x in d["collective_ms_per_step"]["per_device"])
+        assert ("ncclAllGather" in r["config"]["collective"]) == (G == 1)
+        assert r["single_gpu_direct"]["ms_per_step"] > 0 and "pairings_per_s" in r["host_pointers"]
