@@ -3,7 +3,8 @@ function), 6 / 7 / 4 (the same product mix as 1 / 2 / 4 independent chains in on
 4 chains), 3 / 2 (3 219 dual products called / inlined) at several batch sizes; clocks recorded per run.  Usage: python tools/leaf_chain_probe.py [n ...]"""
 import json
 import sys
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bn254_amd
 from bn254_amd.engine import OPT_CLOCK_PROBE
 from tests.datagen import make_verify_batch
