@@ -84,3 +84,21 @@ def test_option_numbers_of_header_and_python_mirror_agree():
     # the status codes the header names are the reference's Error variants, in order (src/error.rs:6-29)
     codes = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define BN254_ERR_(\w+) (\d+)", text)}
     assert sorted(codes.values()) == [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11] and codes["INDEX_OUT_OF_BOUNDS"] == 2 and codes["VERIFICATION_FAILED"] == 9
+
+
+def test_header_is_plain_c_and_the_dev_hooks_can_be_hidden(tmp_path):
+    """include/bn254_hip.h compiles as C (the FFI of the reference's language binds a C header) and as C++; with BN254_NO_DEV_HOOKS the
+    debug / probe entry points are not declared (they are not part of the drop-in ABI) while everything a binding needs still is"""
+    import subprocess
+    hdr = os.path.join(ROOT, "include", "bn254_hip.h")
+    src = tmp_path / "t.c"
+    src.write_text('#define BN254_NO_DEV_HOOKS 1\n#include "%s"\n'
+                   'int use(bn254_ctx *c, bn254_mgpu *m) {\n'
+                   '  (void)bn254_batch_verify; (void)bn254_mgpu_batch_verify; (void)bn254_mgpu_batch_verify_device; (void)bn254_ctx_reserve_host;\n'
+                   '  return bn254_ctx_synchronize(c) + bn254_mgpu_device_count(m) + BN254_E_RCCL + BN254_ERR_VERIFICATION_FAILED;\n}\n'
+                   '#ifdef TRY_HOOK\nint hook(bn254_ctx *c) { return bn254_debug_fp_op(c, 0, 0, 0, 0, 0, 0); }\n#endif\n' % hdr)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-Wno-unused-function", "-fsyntax-only", str(src)])
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-x", "c++", "-fsyntax-only", str(src)])
+    # with the hooks hidden, naming one is an error (implicit declarations are errors under -Werror=implicit-function-declaration)
+    p = subprocess.run(["gcc", "-std=c99", "-Werror=implicit-function-declaration", "-DTRY_HOOK", "-fsyntax-only", str(src)], capture_output=True, text=True)
+    assert p.returncode != 0 and "bn254_debug_fp_op" in p.stderr
