@@ -357,6 +357,31 @@ BN_DEV Fp fp_lin2_reduce(const Fp& x, int32_t cx, const Fp& y, int32_t cy) {
          bn_set_tight(r, -0.0003 * vv_ - 0.51, 0.0003 * vv_ + 0.51));
   return r;
 }
+// ... and of FOUR terms with per-lane factors (the linear stage of the lane machine, bn254_lmachine.h: every linear output of a level is
+// weak_reduce(sum k_j x_j), so it is tight and within +-(0.51 + 0.0003 sum |k_j| |x_j|) q whatever went in)
+BN_DEV Fp fp_lin4_reduce(const Fp& a, int32_t ca, const Fp& b, int32_t cb, const Fp& c, int32_t cc, const Fp& d, int32_t cd) {
+  const int32_t q[BN_LIMBS] = BN_QL_ARRAY;
+  const int32_t top = a.v[BN_LIMBS - 1] * ca + b.v[BN_LIMBS - 1] * cb + c.v[BN_LIMBS - 1] * cc + d.v[BN_LIMBS - 1] * cd;
+  const int32_t k = (int32_t)(((int64_t)(top + BN_WEAK_HALF) * BN_WEAK_KMUL) >> 32);
+  int64_t carry = 0;
+  Fp r;
+#pragma unroll
+  for (int i = 0; i < BN_LIMBS; ++i) {
+    int64_t acc = carry + (int64_t)a.v[i] * ca + (int64_t)b.v[i] * cb + (int64_t)c.v[i] * cc + (int64_t)d.v[i] * cd - (int64_t)k * q[i];
+    if (i < BN_LIMBS - 1) {
+      r.v[i] = bn_digit((uint32_t)acc);
+      carry = (acc + BN_HALF) >> BN_W;
+    } else {
+      r.v[i] = (int32_t)acc;
+    }
+  }
+  BN_TRK(double fa_ = std::fabs((double)ca); double fb_ = std::fabs((double)cb); double fc_ = std::fabs((double)cc); double fd_ = std::fabs((double)cd);
+         double vv_ = fa_ * bn_vabs(a) + fb_ * bn_vabs(b) + fc_ * bn_vabs(c) + fd_ * bn_vabs(d);
+         if (fa_ * a.bd.top + fb_ * b.bd.top + fc_ * c.bd.top + fd_ * d.bd.top + 4194304.0 >= 2147483648.0 || vv_ > 600.0) bn_bound_fail("lin4_reduce input", vv_);
+         if (fa_ + fb_ + fc_ + fd_ > 64.0) bn_bound_fail("lin4_reduce factors", fa_ + fb_ + fc_ + fd_);
+         bn_set_tight(r, -0.0003 * vv_ - 0.51, 0.0003 * vv_ + 0.51));
+  return r;
+}
 
 // Montgomery product a*b*R^-1 (mod q), product scanning.  Columns are accumulated in a signed
 // 64-bit register; m_k = the balanced digit of (column * -q^-1) makes each column divisible by 2^29.

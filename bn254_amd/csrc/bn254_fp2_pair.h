@@ -103,6 +103,9 @@ BN_DEV Fp2 fp2_reduce_weak(const Fp2& a) { Fp2 r; BN_FOR_ROLES(k) r.c[k] = fp_re
 BN_DEV Fp2 fp2_lin2_reduce(const Fp2& x, int32_t cx, const Fp2& y, int32_t cy) {
   Fp2 r; BN_FOR_ROLES(k) r.c[k] = fp_lin2_reduce(x.c[k], cx, y.c[k], cy); return r;
 }
+BN_DEV Fp2 fp2_lin4_reduce(const Fp2& a, int32_t ca, const Fp2& b, int32_t cb, const Fp2& c, int32_t cc, const Fp2& d, int32_t cd) {
+  Fp2 r; BN_FOR_ROLES(k) r.c[k] = fp_lin4_reduce(a.c[k], ca, b.c[k], cb, c.c[k], cc, d.c[k], cd); return r;
+}
 BN_DEV bool fp2_is_zero(const Fp2& a) { bool z = true; BN_FOR_ROLES(k) z = fp_is_zero(a.c[k]) && z; return bn_pair_and(z); }
 BN_DEV bool fp2_eq(const Fp2& a, const Fp2& b) { return fp2_is_zero(fp2_sub(a, b)); }
 BN_DEV Fp2 fp2_select(bool c, const Fp2& a, const Fp2& b) { Fp2 r; BN_FOR_ROLES(k) r.c[k] = fp_select(c, a.c[k], b.c[k]); return r; }

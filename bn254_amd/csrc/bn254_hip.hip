@@ -560,6 +560,7 @@ int bn254_ctx_create(int hip_device, bn254_ctx** out) {
   if (c->trio_wave_roles == 1 && !c->fits_quad) c->trio_wave_roles = 0;
   if (!c->fits_trio) c->trio_max_batch = 0;
   c->nonet_max_batch = bn254_nonet_fits_device() ? NONET_MAX_BATCH_DEFAULT : 0;
+  c->lm_max_batch = bn254_lm_fits_device() ? LM_MAX_BATCH_DEFAULT : 0;
   c->device = hip_device;
   hipError_t err = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (err == hipSuccess) err = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
@@ -654,6 +655,12 @@ int bn254_ctx_set_option(bn254_ctx* c, int option, int value) {
     c->nonet_max_batch = value;
     return 0;
   }
+  if (option == BN254_OPT_LM_MAX_BATCH) {
+    HIP_TRY(hipSetDevice(c->device));                 // the fits query asks the CURRENT device
+    if (value < 0 || (value > 0 && !bn254_lm_fits_device())) return BN254_E_BAD_ARGUMENT;
+    c->lm_max_batch = value;
+    return 0;
+  }
   if (option == BN254_OPT_PINNED_STAGING) { if (value < 0 || value > 16) return BN254_E_BAD_ARGUMENT; c->pinned_staging = value; return 0; }
   if (option == BN254_OPT_AGG_SORT_BY_MSG) { c->agg_sort_by_msg = value != 0; return 0; }
   if (option == BN254_OPT_AGG_WIDE_MIN_TUPLES) { if (value < 0) return BN254_E_BAD_ARGUMENT; c->agg_wide_min_tuples = value; return 0; }
@@ -715,7 +722,8 @@ int bn254_ctx_last_kernel_ms(bn254_ctx* c, float ms[4]) {
 int launch_pair_or_trio(bn254_ctx* c, hipStream_t s, size_t n, int use_hash, uint8_t* d_status, int mode, bool mark) {
   int rc;
   if (c->trio_max_batch > 0 && n <= (size_t)c->trio_max_batch) {
-    if ((rc = c->trio_wave_roles == 2 ? bn254_w8_miller_verify(n, c->ws, s, mode)
+    if ((rc = c->lm_max_batch > 0 && n <= (size_t)c->lm_max_batch ? bn254_lm_miller_verify(n, c->ws, s, mode)
+              : c->trio_wave_roles == 2 ? bn254_w8_miller_verify(n, c->ws, s, mode)
               : c->trio_wave_roles ? bn254_quad_miller_verify(n, c->ws, s, mode) : bn254_trio_miller_verify(n, c->ws, s, mode))) return rc;
     if (mark) PROF_MARK(3);
     // the smallest batches: nine lane pairs per verify (bn254_nonet.hip) — fewer instructions per lane again, while one pass of 3

@@ -25,6 +25,7 @@ OPT_CLOCK_PROBE = 10
 OPT_AGG_SORT_BY_MSG = 11
 OPT_PINNED_STAGING = 12
 OPT_NONET_MAX_BATCH = 13
+OPT_LM_MAX_BATCH = 15
 OPT_AGG_WIDE_MIN_TUPLES = 14
 
 

@@ -285,6 +285,9 @@ int bn254_ctx_set_profiling(bn254_ctx *ctx, int enabled);
 #define BN254_OPT_NONET_MAX_BATCH 13 /* small batches: up to this many items the final exponentiation runs on NINE lane pairs per item (18 lanes,
                                       three items per wave): the nine squarings of a cyclotomic squaring at once, the 18 products of an Fq12
                                       multiplication in two rounds; same status bytes.  0 = never (octet layout) */
+#define BN254_OPT_LM_MAX_BATCH 15 /* small batches: up to this many items the Miller loop runs as the LANE MACHINE (nine lane pairs in each of four
+                                   waves per item: every product of a dependency level in its own lane pair; twist-point formulas rearranged
+                                   for depth); same status bytes.  0 = never (wave roles / octet layout) */
 #define BN254_OPT_PINNED_STAGING 12 /* bn254_batch_verify (host pointers), batches of >= 8192: T = 1..16 threads copy the caller's (pageable)
                                      buffers through a pinned staging buffer of the context in 1 MB pieces, each piece's DMA enqueued as soon
                                      as it is in place; 0 = hipMemcpyAsync straight from the caller's buffers (the runtime stages them) */

@@ -19,6 +19,7 @@ static struct BnSiteInit { BnSiteInit() { for (int i = 0; i < 1024; ++i) bn_site
 #include "../../bn254_amd/csrc/bn254_pairing.h"
 #include "../../bn254_amd/csrc/bn254_codec_g2.h"
 #include "../../bn254_amd/csrc/bn254_nonet.h"
+#include "../../bn254_amd/csrc/bn254_lmachine.h"
 
 using namespace bn254;
 
@@ -115,6 +116,30 @@ int hp_nonet_check(const uint8_t* h64, const uint8_t* sig64, const uint8_t* pk12
   const bool one_a = fp12_is_one(a), one_b = fp12_is_one(b);
   if (one_a != one_b) return 247;
   return one_b ? 0 : 9;
+}
+// The LANE MACHINE schedule of the Miller loop (bn254_lmiller.hip: one verify on nine lane pairs in each of four waves; bn254_lmachine.h:
+// lm_miller_model — the kernel's stage functions and level tables on a host box, tick by tick): 0 / 9 = the verdict of its Miller value
+// under the final exponentiation, which must be the generic loop's; 246 = the two Gt values differ.  Under -DBN_TRACK_BOUNDS one call is
+// the bound proof of the schedule (every product column, int32 limb and value bound of every level, and of the general Fq12 product on
+// Miller values).
+int hp_lm_verify(const uint8_t* h64, const uint8_t* sig64, const uint8_t* pk128) {
+  G1Affine h, sig;
+  G2Affine pk;
+  load_g1(h, h64); load_g1(sig, sig64); load_g2(pk, pk128);
+  Fp12 f, g, acc;
+  miller_loop<true, true>(f, h, pk, sig);
+  lm_miller_model(g, h, pk, sig);
+  Fp12 a = g, b = g;
+  fe_machine_check(a);                                // the check chain on the lane machine's value (within the chain's bound contract?) ...
+  nn_machine_model(b, C_FE_CHECK);                    // ... and in the nonet schedule, which is what follows the kernel on the device
+  if (fp12_is_one(a) != fp12_is_one(b)) return 244;
+  final_exponentiation(f, f, acc);
+  final_exponentiation(g, g, acc);
+  const Fp2* x[6] = {&f.c0.c0, &f.c0.c1, &f.c0.c2, &f.c1.c0, &f.c1.c1, &f.c1.c2};
+  const Fp2* y[6] = {&g.c0.c0, &g.c0.c1, &g.c0.c2, &g.c1.c0, &g.c1.c1, &g.c1.c2};
+  for (int k = 0; k < 6; ++k) if (!fp2_eq(*x[k], *y[k])) return 246;
+  if (fp12_is_one(a) != fp12_is_one(g)) return 245;
+  return fp12_is_one(g) ? 0 : 9;
 }
 #if defined(BN_TRACK_BOUNDS)
 // What the interval tracker knows about the Miller value a verify hands to its final exponentiation: per coefficient (12, Gt order)

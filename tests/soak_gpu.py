@@ -45,7 +45,7 @@ def soak(args):
     (tests/test_gpu_fullsize.py runs a slice of it in the driver-run suite)"""
     import bn254_amd
     from tests.conftest import ws_default
-    from bn254_amd.engine import OPT_AGG_WIDE_MIN_TUPLES, OPT_AGG_SORT_BY_MSG, OPT_AGG_SUBSET_MIN_TUPLES, OPT_NONET_MAX_BATCH, OPT_PAIR_LANES, OPT_RAND_MIN_BATCH, OPT_TRIO_MAX_BATCH, OPT_TRIO_WAVE_ROLES
+    from bn254_amd.engine import OPT_AGG_WIDE_MIN_TUPLES, OPT_AGG_SORT_BY_MSG, OPT_AGG_SUBSET_MIN_TUPLES, OPT_LM_MAX_BATCH, OPT_NONET_MAX_BATCH, OPT_PAIR_LANES, OPT_RAND_MIN_BATCH, OPT_TRIO_MAX_BATCH, OPT_TRIO_WAVE_ROLES
     from oracle import c_oracle as c
     from tests.datagen import sk_bytes
     eng = bn254_amd.Engine(0)
@@ -117,8 +117,12 @@ def soak(args):
         extra["keyed_tuples"] = extra.get("keyed_tuples", 0) + n
         for flags in (0, 1):
             want, _ = c.batch_verify(msgs, sigs, pks, flags=flags, nthreads=cores)
-            # the small-batch layouts (defaults: eight wave roles up to 16384 items), then the lane pairs for the same batch
-            got = {"roles8": eng.batch_verify(msgs, sigs, pks, flags=flags)}
+            # the small-batch layouts (defaults: the lane machine up to 1536 items, eight wave roles up to 16384), then the lane pairs for the same batch
+            got = {"default": eng.batch_verify(msgs, sigs, pks, flags=flags)}
+            eng.set_option(OPT_LM_MAX_BATCH, 1 << 20)        # the Miller loop as the lane machine whatever the size (several passes above 768)
+            got["lane_machine"] = eng.batch_verify(msgs, sigs, pks, flags=flags)
+            eng.set_option(OPT_LM_MAX_BATCH, 0)              # ... and never: the wave-role / octet kernels at every size below
+            got["roles8"] = eng.batch_verify(msgs, sigs, pks, flags=flags)
             for name, roles in (("roles4", 1), ("octet", 0)):
                 eng.set_option(OPT_TRIO_WAVE_ROLES, roles)
                 got[name] = eng.batch_verify(msgs, sigs, pks, flags=flags)
@@ -134,6 +138,7 @@ def soak(args):
             eng.set_option(OPT_PAIR_LANES, 0)
             got["single"] = eng.batch_verify(msgs, sigs, pks, flags=flags)
             eng.set_option(OPT_PAIR_LANES, 1)
+            eng.set_option(OPT_LM_MAX_BATCH, ws_default("LM_MAX_BATCH_DEFAULT"))
             for name, fl in (("rand128", 0), ("rand_glv", 0x200), ("rand64", 0x100)):
                 got[name] = eng.batch_verify_randomized(msgs, sigs, pks, seed, flags=flags | fl)[0]
             for name, g in got.items():
@@ -228,7 +233,7 @@ def soak(args):
     lib_sha = hashlib.sha256(open(_native.LIB_PATH, "rb").read()).hexdigest()[:16]
     res = {"lib_sha256_16": lib_sha, "rounds": rounds, "tuples": items, "comparisons": items * 2 * 10, "seconds": round(time.time() - t0, 1), "oracle_threads": cores,
            "status_histogram": {str(k): v for k, v in sorted(codes.items())}, "mismatches": 0, "seed": args.seed, "also_compared": extra,
-           "modes": ["keyed (registered keys, once per round with the subgroup check)", "keyed randomised 128-bit / 64-bit / GLV (once per round)", "exact, eight wave roles + final exponentiation on nine lane pairs (default up to 3072)", "... + octet final exponentiation", "... + nine lane pairs at every size", "exact, four wave roles", "exact, lane groups of one wave (octet)", "exact on lane pairs", "exact, one lane per verify", "randomised 128-bit", "randomised GLV", "randomised 64-bit"],
+           "modes": ["keyed (registered keys, once per round with the subgroup check)", "keyed randomised 128-bit / 64-bit / GLV (once per round)", "exact, defaults (lane machine up to 1536, eight wave roles above; final exponentiation on nine lane pairs up to 3072)", "exact, Miller loop as the lane machine at every size", "exact, eight wave roles + final exponentiation on nine lane pairs", "... + octet final exponentiation", "... + nine lane pairs at every size", "exact, four wave roles", "exact, lane groups of one wave (octet)", "exact on lane pairs", "exact, one lane per verify", "randomised 128-bit", "randomised GLV", "randomised 64-bit"],
            "flags": [0, 1]}
     return res
 

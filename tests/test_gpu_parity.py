@@ -439,6 +439,7 @@ def test_pair_lanes_and_single_lane_agree(eng, derived):
 
 from tests.conftest import ws_default  # noqa: E402
 NONET_DEFAULT = ws_default("NONET_MAX_BATCH_DEFAULT")
+LM_DEFAULT = ws_default("LM_MAX_BATCH_DEFAULT")
 TRIO_DEFAULT = ws_default("TRIO_MAX_BATCH_DEFAULT")
 
 
@@ -447,7 +448,7 @@ def test_octet_and_pair_layouts_agree_with_oracle(eng, c, derived, kats):
     with the four lane pairs of a verify as four waves with their own roles, or as lane groups of one wave), larger ones on
     lane pairs: all against the golden cases, the oracle on ragged sizes with faults of every class, and
     check_public_keys; the threshold itself (8192 octet, 8193 pairs) gives the same bytes on either side"""
-    from bn254_amd.engine import OPT_NONET_MAX_BATCH, OPT_TRIO_MAX_BATCH, OPT_TRIO_WAVE_ROLES
+    from bn254_amd.engine import OPT_LM_MAX_BATCH, OPT_NONET_MAX_BATCH, OPT_TRIO_MAX_BATCH, OPT_TRIO_WAVE_ROLES
     from tests.datagen import make_verify_batch
     cs = derived["verify_cases"]
     args = ([H(v["message_hex"]) for v in cs], b"".join(H(v["sig"]) for v in cs), b"".join(H(v["pk"]) for v in cs))
@@ -473,6 +474,8 @@ def test_octet_and_pair_layouts_agree_with_oracle(eng, c, derived, kats):
     edge = make_verify_batch(eng, 8193, corrupt_every=11)
     try:
         # the octet path's Miller loop as eight (default) / four wave roles and as lane groups of one wave; lane pairs; the default threshold
+        # (the lane machine, which takes the smallest batches by default, off: these kernels at every size)
+        eng.set_option(OPT_LM_MAX_BATCH, 0)
         for lim, roles in ((1 << 20, 2), (1 << 20, 1), (1 << 20, 0), (0, 2), (8192, 2)):   # 8192: the edge batch of 8193 on lane pairs, its first 8192 in octets
             eng.set_option(OPT_TRIO_MAX_BATCH, lim)
             eng.set_option(OPT_TRIO_WAVE_ROLES, roles)
@@ -495,10 +498,24 @@ def test_octet_and_pair_layouts_agree_with_oracle(eng, c, derived, kats):
             assert eng.batch_check_public_keys(g2s, g1s, len(cpk) * 3) == cpk_want, ("nonet", lim)
             assert eng.batch_verify(edge[0][:8192], edge[1][:8192 * 64], edge[2][:8192 * 128]) == edge[3][:8192], ("nonet", lim)
             assert eng.batch_verify(edge[0][:3073], edge[1][:3073 * 64], edge[2][:3073 * 128]) == edge[3][:3073], ("nonet", lim)
+        # the Miller loop as the LANE MACHINE (bn254_lmiller.hip; nine lane pairs in each of four waves per verify, 3 verifies per workgroup):
+        # forced on for every small-batch size (1, 2, 7, 9, 65, 1027: not multiples of 3; 8192: eleven passes; identity operands in the
+        # batches and the golden cases: pair A / pair B skipped), with either final exponentiation behind it, then the default threshold on
+        # both sides (1536 | 1537)
+        for lim, nonet in ((1 << 20, NONET_DEFAULT), (1 << 20, 0), (LM_DEFAULT, NONET_DEFAULT)):
+            eng.set_option(OPT_LM_MAX_BATCH, lim)
+            eng.set_option(OPT_NONET_MAX_BATCH, nonet)
+            assert list(eng.batch_verify(*args, flags=1)) == want, ("lane machine", lim)
+            for msgs, sigs, pks, oracle in batches:
+                assert eng.batch_verify(msgs, sigs, pks, flags=1) == oracle, ("lane machine", lim, len(msgs))
+            assert eng.batch_check_public_keys(g2s, g1s, len(cpk) * 3) == cpk_want, ("lane machine", lim)
+            for cut in (8192, LM_DEFAULT, LM_DEFAULT + 1):
+                assert eng.batch_verify(edge[0][:cut], edge[1][:cut * 64], edge[2][:cut * 128]) == edge[3][:cut], ("lane machine", lim, cut)
     finally:
         eng.set_option(OPT_TRIO_MAX_BATCH, TRIO_DEFAULT)               # the defaults
         eng.set_option(OPT_TRIO_WAVE_ROLES, 2)
         eng.set_option(OPT_NONET_MAX_BATCH, NONET_DEFAULT)
+        eng.set_option(OPT_LM_MAX_BATCH, LM_DEFAULT)
     # the default threshold itself: 16384 verifies in two passes of the small-batch kernels, 16385 on lane pairs
     big = make_verify_batch(eng, 16385, corrupt_every=13)
     assert eng.batch_verify(big[0], big[1], big[2]) == big[3]

@@ -165,6 +165,58 @@ def test_nonet_schedule_matches_fe_machine(pair_lib, derived):
     assert set(words) <= {0, 1}
 
 
+def test_lane_machine_schedule_matches_generic_loop(pair_lib, derived):
+    """the Miller loop as the LANE MACHINE (bn254_lmiller.hip, default for batches <= 1 536, i.e. for every single ECDSA::verify,
+    /root/reference/src/ecdsa.rs:49-64): the kernel's own stage functions and level tables (bn254_lmachine.h) on a host box, tick by tick
+    — twist point with w = 3b' z two steps ahead, line product one step ahead, accumulator by the nonet product — give, under the final
+    exponentiation, the generic loop's Gt value coefficient for coefficient (hp_lm_verify returns 246 otherwise) on every verify case, on
+    random signed tuples, and with identity operands (pair A, pair B, both skipped)"""
+    import hashlib
+    pair_lib.hp_lm_verify.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p]
+    n = 0
+    for v in derived["verify_cases"]:
+        if v["status"] not in (0, 9):
+            continue
+        st, h, _ = c.hash_to_g1(H(v["message_hex"]))
+        assert pair_lib.hp_lm_verify(h, H(v["sig"]), H(v["pk"])) == v["status"], v["name"]
+        n += 1
+    assert n >= 10
+    g1, g2 = c.g1_generator(), c.g2_generator()
+    for i in range(3):
+        sk = hashlib.sha256(b"lm-sk%d" % i).digest()
+        _, h, _ = c.hash_to_g1(b"lm-msg-%d" % i)
+        sig, pk = c.g1_mul(h, sk), c.g2_mul(g2, sk)
+        assert pair_lib.hp_lm_verify(h, sig, pk) == 0
+        assert pair_lib.hp_lm_verify(h, sig, c.g2_mul(g2, hashlib.sha256(sk).digest())) == 9
+        assert pair_lib.hp_lm_verify(h, bytes(64), pk) == 9
+        assert pair_lib.hp_lm_verify(h, c.g1_mul(g1, sk), bytes(128)) == 9
+        assert pair_lib.hp_lm_verify(h, bytes(64), bytes(128)) == 0
+
+
+def test_lane_machine_tables_are_well_formed():
+    """the level tables of the lane machine, read from the header: within a level no slot is written twice and no product reads a slot that
+    a product of the same level writes (the stages publish between fences, so a level's reads see the previous level's values); every
+    wave writes only its own slots and the hand-over block of the step's parity"""
+    import re
+    text = open(os.path.join(ROOT, "bn254_amd", "csrc", "bn254_lmachine.h")).read()
+    tables = re.findall(r"LM_TABLE (LM_\w+)\[(\d+)\]\[9\] = \{(.*?)\};", text, re.S)
+    assert {t[0] for t in tables} == {"LM_T_INIT", "LM_T_DBL", "LM_T_ADD", "LM_L_DBL", "LM_L_ADD", "LM_L_PROD"}
+    for name, nlev, body in tables:
+        levels = re.split(r"\},\s*\{", body.strip().strip("{}")) if int(nlev) > 1 else [body]
+        assert len(levels) == int(nlev), name
+        for lvl in levels:
+            muls = re.findall(r"lm_mul\((LS_\w+(?: \+ \d)?), (LS_\w+), (LS_\w+)\)", lvl) + [(m[4], m[0], m[2]) for m in re.findall(r"LmP\{(LS_\w+), (LS_\w+), (LS_\w+), (LS_\w+), (LS_\w+)\}", lvl)]
+            lins = re.findall(r"lm_lin\((LS_\w+(?: \+ \d)?),", lvl)
+            outs = [m[0] for m in muls]
+            assert len(set(outs)) == len(outs) and len(set(lins)) == len(lins), (name, outs, lins)
+            assert not set(outs) & set(lins), (name, "a product and a linear output share a slot")
+            for out, a, b in muls:
+                assert a not in outs and b not in outs, (name, out, "reads a product output of its own level")
+            own = "LS_T" if name.startswith("LM_T") else "LS_L"
+            for o in outs + lins:
+                assert o.startswith(own) or o.startswith("LS_HO") or o.startswith("LS_LP") or (name == "LM_T_INIT" and o in ("LS_Q1X", "LS_Q1Y", "LS_Q2X", "LS_NPKY")), (name, o)
+
+
 DRIVER = r'''
 import ctypes, json, sys
 root = sys.argv[1]
@@ -212,6 +264,31 @@ for v in d["verify_cases"]:
 assert L.hp_nonet_check(g1, bytes(64), H(d["g2_generator"]), None) <= 9
 assert L.hp_nonet_check(g1, g1, bytes(128), None) <= 9
 assert n >= 10
+print("ok")
+'''
+    p = subprocess.run([sys.executable, "-c", drv, ROOT], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and p.stdout.strip() == "ok", (p.stdout[-500:], p.stderr[-2000:])
+
+
+def test_lane_machine_schedule_bounds_hold(pair_lib):
+    """the lane machine's schedule of the Miller loop under the interval tracker: every product column, int32 limb and value bound of every
+    level of waves T and L (fresh formulas: w = 3b' z, the expanded addition), of the general Fq12 product on Miller values (f^2 and f * L
+    through nn_mul_*, whose site modes were searched on the final exponentiation's flows) and of both final-exponentiation schedules on
+    the value it hands over — identity operands included (pair A, pair B, both skipped: data-dependent selects are followed with the
+    union of both sides).  The tracker build ABORTS on a violation."""
+    drv = r'''
+import ctypes, json, sys
+root = sys.argv[1]
+L = ctypes.CDLL(root + "/tests/hostsim/libhostsim_pair_bounds.so")
+d = json.load(open(root + "/tests/golden/derived_vectors.json"))
+H = bytes.fromhex
+g1 = (1).to_bytes(32, "big") + (2).to_bytes(32, "big")
+vs = [v for v in d["verify_cases"] if v["status"] in (0, 9)][:2]       # the bounds depend on the sequence of operations only: one pass per flow is the proof
+for v in vs:
+    assert L.hp_lm_verify(g1, H(v["sig"]), H(v["pk"])) <= 9
+assert L.hp_lm_verify(g1, bytes(64), H(d["g2_generator"])) <= 9
+assert L.hp_lm_verify(g1, g1, bytes(128)) <= 9
+assert L.hp_lm_verify(g1, bytes(64), bytes(128)) <= 9
 print("ok")
 '''
     p = subprocess.run([sys.executable, "-c", drv, ROOT], capture_output=True, text=True, timeout=600)
