@@ -267,11 +267,11 @@ int bn254_debug_hash_candidate(bn254_ctx* c, const uint8_t* h, size_t n, uint8_t
   return 0;
 }
 // layout: 0 one lane per item, exact chain (Gt out) | 1 lane pairs, program C_FE_EXACT (Gt out) | 2 lane pairs, program C_FE_CHECK |
-// 3 octet (straight-line chains below 128 items, accumulator machine from 128 on) | 4 nonet | 5 one lane per item, check chain
+// 3 octet (straight-line chains below 128 items, accumulator machine from 128 on) | 4 nonet | 5 one lane per item, check chain | 6 nonet, wide form (18 lane pairs)
 int bn254_debug_final_exp_limbs(bn254_ctx* c, int layout, const int32_t* limbs, size_t n, uint8_t* gt, uint8_t* status) {
-  if (!c || layout < 0 || layout > 5 || (n && (!limbs || !status)) || (gt && layout > 1)) return BN254_E_BAD_ARGUMENT;
+  if (!c || layout < 0 || layout > 6 || (n && (!limbs || !status)) || (gt && layout > 1)) return BN254_E_BAD_ARGUMENT;
   if (n == 0) return 0;
-  if ((layout == 3 && !c->fits_trio) || (layout == 4 && !bn254_nonet_fits_device())) return BN254_E_BAD_ARGUMENT;
+  if ((layout == 3 && !c->fits_trio) || ((layout == 4 || layout == 6) && !bn254_nonet_fits_device())) return BN254_E_BAD_ARGUMENT;
   HIP_TRY(hipSetDevice(c->device));
   int rc;
   if ((rc = ws_reserve(c, n))) return rc;
@@ -287,6 +287,7 @@ int bn254_debug_final_exp_limbs(bn254_ctx* c, int layout, const int32_t* limbs, 
     case 2: rc = bn254_pair_final_exp(n, c->ws, 0, c->stage[2], nullptr, nullptr, s); break;
     case 3: rc = bn254_trio_final_exp(n, c->ws, 0, c->stage[2], s); break;
     case 4: rc = bn254_nonet_final_exp(n, c->ws, 0, c->stage[2], s); break;
+    case 6: rc = bn254_nonet_final_exp(n, c->ws, 0, c->stage[2], s, 1); break;
     default: { int rc_ = launch_final_exp_lane(c, s, n, 1, 1, 1, 0, nullptr, c->stage[2], 0, 0, nullptr, nullptr); if (rc_) return rc_; } break;
   }
   if (rc) return rc;

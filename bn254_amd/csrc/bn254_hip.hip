@@ -561,6 +561,7 @@ int bn254_ctx_create(int hip_device, bn254_ctx** out) {
   if (!c->fits_trio) c->trio_max_batch = 0;
   c->nonet_max_batch = bn254_nonet_fits_device() ? NONET_MAX_BATCH_DEFAULT : 0;
   c->lm_max_batch = bn254_lm_fits_device() ? LM_MAX_BATCH_DEFAULT : 0;
+  c->nonet_wide = 1;
   c->device = hip_device;
   hipError_t err = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (err == hipSuccess) err = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
@@ -655,6 +656,7 @@ int bn254_ctx_set_option(bn254_ctx* c, int option, int value) {
     c->nonet_max_batch = value;
     return 0;
   }
+  if (option == BN254_OPT_NONET_WIDE) { c->nonet_wide = value != 0; return 0; }
   if (option == BN254_OPT_LM_MAX_BATCH) {
     HIP_TRY(hipSetDevice(c->device));                 // the fits query asks the CURRENT device
     if (value < 0 || (value > 0 && !bn254_lm_fits_device())) return BN254_E_BAD_ARGUMENT;
@@ -728,7 +730,7 @@ int launch_pair_or_trio(bn254_ctx* c, hipStream_t s, size_t n, int use_hash, uin
     if (mark) PROF_MARK(3);
     // the smallest batches: nine lane pairs per verify (bn254_nonet.hip) — fewer instructions per lane again, while one pass of 3
     // verifies per wave still covers the batch
-    if (c->nonet_max_batch > 0 && n <= (size_t)c->nonet_max_batch) return bn254_nonet_final_exp(n, c->ws, use_hash, d_status, s);
+    if (c->nonet_max_batch > 0 && n <= (size_t)c->nonet_max_batch) return bn254_nonet_final_exp(n, c->ws, use_hash, d_status, s, c->nonet_wide && n <= (size_t)NONET_WIDE_MAX_BATCH);
     return bn254_trio_final_exp(n, c->ws, use_hash, d_status, s);
   }
   if ((rc = bn254_pair_miller_verify(n, c->ws, nullptr, nullptr, s, mode))) return rc;

@@ -35,6 +35,7 @@ struct bn254_ctx {
   int hash_direct_width; // small batches: counters tried at once with the square root itself (k_hash_direct); 0 = rounds only
   int trio_max_batch; // verify / check_public_keys batches up to this size run in the octet layout (bn254_trio.hip); 0 = never
   int lm_max_batch;    // ... and up to this size their Miller loop runs as the lane machine (bn254_lmiller.hip); 0 = never
+  int nonet_wide;      // ... on eighteen lane pairs (one verify per wave) while the batch is at most one verify per SIMD (BN254_OPT_NONET_WIDE)
   int nonet_max_batch; // ... and up to this size their final exponentiation runs on nine lane pairs per verify (bn254_nonet.hip); 0 = never
   hipEvent_t ev[5];
   int ev_valid;

@@ -83,21 +83,34 @@ struct NnLdsBox {
   }
 };
 struct NnDevLane : NnLane<NnLdsBox> {
-  unsigned role, vslot;         // real / imaginary part, verify slot within the workgroup (0..11)
+  unsigned role, vslot;         // real / imaginary part, verify slot within the workgroup
+  bool mul_writer;              // publishes its product of a multiplication round (wide form: the lanes of the second nine pairs too)
   NnLdsBox bx;
 };
-__device__ __forceinline__ NnDevLane nn_lane() {
+// WIDE form (batches that leave three quarters of the chip idle anyway: one verify per WAVE): EIGHTEEN lane pairs per verify, so that the 18
+// products of a multiplication are ONE round — pair 9 + p takes product 9 + p, i.e. the second round's entry of pair p, and otherwise
+// follows pair p without publishing anything (same values, same phase functions: the host emulation and its bound proof cover both forms).
+template <bool WIDE> __device__ __forceinline__ NnDevLane nn_lane() {
+  constexpr unsigned LANES = WIDE ? 2 * BN_NONET_LANES : BN_NONET_LANES, PER_WAVE = WIDE ? 1 : BN_NONET_PER_WAVE;
   NnDevLane L;
   const unsigned l = threadIdx.x & (BN_WAVE - 1), w = threadIdx.x / BN_WAVE;
-  const unsigned v = l / BN_NONET_LANES;                       // 0..3
-  const bool writer = v < BN_NONET_PER_WAVE;
+  const unsigned v = l / LANES;
+  const bool in_verify = v < PER_WAVE;
+  const unsigned p = (l % LANES) >> 1;                         // 0..8, wide: 0..17
+  const bool second = p >= BN_NONET_PAIRS;
   L.role = l & 1u;
-  L.vslot = w * BN_NONET_PER_WAVE + (writer ? v : BN_NONET_PER_WAVE - 1);
+  L.vslot = w * PER_WAVE + (in_verify ? v : PER_WAVE - 1);
   L.bx.acc_ = NN_ACC_OFF + (L.vslot * 2 + L.role) * NN_SLOT;
   L.bx.file_ = NN_FILE_OFF + (L.vslot * NN_NSLOTS * 2 + L.role) * NN_SLOT;          // slot k: + k * 2 * NN_SLOT
   L.bx.xp_ = NN_XP_OFF + L.vslot * NN_XP_STRIDE + L.role * BN_LIMBS;
   L.bx.x1_ = NN_X1_OFF + L.vslot * NN_X1_STRIDE + L.role * BN_LIMBS;
-  nn_lane_roles<NnLdsBox>(L, L.bx, (l % BN_NONET_LANES) >> 1, writer);
+  nn_lane_roles<NnLdsBox>(L, L.bx, second ? p - BN_NONET_PAIRS : p, in_verify && !second);
+  L.mul_writer = in_verify;
+  if (WIDE && second) {
+#pragma unroll
+    for (unsigned j = 0; j < 4; ++j) { L.m_rel[0][j] = L.m_rel[1][j]; L.m_zero[0][j] = L.m_zero[1][j]; }
+    L.m_pub[0] = L.m_pub[1];
+  }
   return L;
 }
 // the two distributed operations: phase, publish, phase, publish — between wavefront-scope fences (one wave: its LDS instructions execute
@@ -114,12 +127,12 @@ __device__ __forceinline__ void nn_csqr(NnDevLane& L) {
   if (L.publishes_out) L.bx.put(L.so_coef, o);    // straight into the verify's accumulator
   NN_FENCE();
 }
-__device__ __forceinline__ void nn_mul(NnDevLane& L, unsigned bslot) {     // bslot: word offset of the second operand (a slot of the file), this lane's role
+template <bool WIDE> __device__ __forceinline__ void nn_mul(NnDevLane& L, unsigned bslot) {     // bslot: word offset of the second operand (a slot of the file), this lane's role
 #pragma unroll
-  for (unsigned r = 0; r < 2; ++r) {              // two rounds of nine products
+  for (unsigned r = 0; r < (WIDE ? 1u : 2u); ++r) {  // two rounds of nine products; wide form: one of eighteen
     const Fp2 pr = nn_mul_product(L, L.bx, L.bx.acc_, bslot, r);
     NN_FENCE();
-    if (L.writer) L.bx.put(L.m_pub[r], pr);
+    if (L.mul_writer) L.bx.put(L.m_pub[r], pr);
   }
   NN_FENCE();
   {
@@ -138,7 +151,7 @@ __device__ __forceinline__ void nn_mul(NnDevLane& L, unsigned bslot) {     // bs
 // slot file are the verify's shared copies in LDS.  LOAD / STORE / CONJ / FROB / INV are REPLICATED: every lane of the verify — and the
 // follow-along lanes 54..63 on the wave's last verify — read-modify-writes the shared copy with identical words in lockstep (the
 // invariant stated in bn254_nonet.h); `writer` / `publishes_out` gate only the publish steps of CSQR / MUL.
-__device__ __forceinline__ void nn_machine(NnDevLane& L, const unsigned char (*prog)[2]) {
+template <bool WIDE> __device__ __forceinline__ void nn_machine(NnDevLane& L, const unsigned char (*prog)[2]) {
   Fp12& acc = *(Fp12*)(nn_lds + L.bx.acc_);        // the first 54 words of a slot are an Fp12 in memory order
   BN_ASSUME_LDS(&acc);
 #pragma clang loop unroll(disable)
@@ -153,7 +166,7 @@ __device__ __forceinline__ void nn_machine(NnDevLane& L, const unsigned char (*p
       case FE_LOAD: acc = slot; break;                       // identical words from every pair
       case FE_STORE: slot = acc; break;
       case FE_CSQR: nn_csqr(L); break;
-      case FE_MUL: nn_mul(L, sl); break;
+      case FE_MUL: nn_mul<WIDE>(L, sl); break;
       case FE_CONJ: fp6_neg(acc.c1, acc.c1); break;
       case FE_FROB: fp12_frob_body(acc, acc, arg); break;
       default: fp12_inv(acc, acc); break;
@@ -162,9 +175,10 @@ __device__ __forceinline__ void nn_machine(NnDevLane& L, const unsigned char (*p
   NN_FENCE();
 }
 
-KERNEL_NONET void k_final_exp_nonet(size_t n, Ws ws, int use_hash, uint8_t* status_out) {
-  NnDevLane L = nn_lane();
-  size_t i = (size_t)blockIdx.x * BN_NONET_PER_WG + L.vslot;
+template <bool WIDE> __device__ __forceinline__ void final_exp_nonet_body(size_t n, const Ws& ws, int use_hash, uint8_t* status_out) {
+  constexpr unsigned PER_WG = WIDE ? BN_NONET_WG / BN_WAVE : BN_NONET_PER_WG;
+  NnDevLane L = nn_lane<WIDE>();
+  size_t i = (size_t)blockIdx.x * PER_WG + L.vslot;
   const bool live = L.writer && i < n;
   if (i >= n) i = n - 1;                                 // lanes without a verify of their own follow along on the last one
   if (threadIdx.x < 16) nn_lds[NN_ZERO_OFF + threadIdx.x] = 0;
@@ -176,7 +190,7 @@ KERNEL_NONET void k_final_exp_nonet(size_t n, Ws ws, int use_hash, uint8_t* stat
   uint8_t st = ws_byte(ws, BY_ST_DECODE, i);
   if (st == ST_OK && use_hash) st = ws_byte(ws, BY_ST_HASH, i);
   __syncthreads();                                       // the zero block, the accumulators
-  nn_machine(L, C_FE_CHECK);
+  nn_machine<WIDE>(L, C_FE_CHECK);
   Fp12 f;
   {
     Fp2* c[6] = {&f.c0.c0, &f.c0.c1, &f.c0.c2, &f.c1.c0, &f.c1.c1, &f.c1.c2};
@@ -186,6 +200,8 @@ KERNEL_NONET void k_final_exp_nonet(size_t n, Ws ws, int use_hash, uint8_t* stat
   const bool one = fp12_is_one(f);                       // combined over the pair
   if (live && L.pair == 0 && L.role == 0) status_out[i] = st != ST_OK ? st : (one ? (uint8_t)ST_OK : (uint8_t)ST_VERIFICATION_FAILED);
 }
+KERNEL_NONET void k_final_exp_nonet(size_t n, Ws ws, int use_hash, uint8_t* status_out) { final_exp_nonet_body<false>(n, ws, use_hash, status_out); }
+KERNEL_NONET void k_final_exp_nonet_wide(size_t n, Ws ws, int use_hash, uint8_t* status_out) { final_exp_nonet_body<true>(n, ws, use_hash, status_out); }
 
 bool bn254_nonet_fits_device() {
   int blocks = 0;
@@ -193,9 +209,15 @@ bool bn254_nonet_fits_device() {
   if (e != hipSuccess) { (void)hipGetLastError(); return true; }
   return blocks > 0;
 }
-int bn254_nonet_final_exp(size_t n, Ws ws, int use_hash, uint8_t* status_out, hipStream_t s) {
-  const unsigned grid = (unsigned)((n + BN_NONET_PER_WG - 1) / BN_NONET_PER_WG);
-  k_final_exp_nonet<<<grid, BN_NONET_WG, NN_LDS_WORDS * sizeof(int32_t), s>>>(n, ws, use_hash, status_out);
+// `wide`: one verify per wave on eighteen lane pairs (a multiplication's products in one round) — for batches of up to one verify per SIMD
+int bn254_nonet_final_exp(size_t n, Ws ws, int use_hash, uint8_t* status_out, hipStream_t s, int wide) {
+  if (wide) {
+    const unsigned per_wg = BN_NONET_WG / BN_WAVE;
+    k_final_exp_nonet_wide<<<(unsigned)((n + per_wg - 1) / per_wg), BN_NONET_WG, NN_LDS_WORDS * sizeof(int32_t), s>>>(n, ws, use_hash, status_out);
+  } else {
+    const unsigned grid = (unsigned)((n + BN_NONET_PER_WG - 1) / BN_NONET_PER_WG);
+    k_final_exp_nonet<<<grid, BN_NONET_WG, NN_LDS_WORDS * sizeof(int32_t), s>>>(n, ws, use_hash, status_out);
+  }
   HIP_TRY(hipGetLastError());
   return 0;
 }

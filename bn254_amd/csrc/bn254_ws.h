@@ -5,6 +5,7 @@
 #define BN_WAVE 64
 #define BN_SPLIT_MAX_N ((size_t)98304)   // <= 1.5 waves per SIMD with one lane per verify
 #define TRIO_MAX_BATCH_DEFAULT 16384               // octet layout up to TWO passes of one wave per SIMD (1024 SIMDs x 8 verifies): 3.5 ms at 8192, 6.5 ms at 16384 (lane pairs: 7.1 / 7.9 ms)
+#define NONET_WIDE_MAX_BATCH 1024                  // ... and up to this size on EIGHTEEN lane pairs, one verify per wave: the 18 products of a multiplication in one round (0.63 -> 0.56 ms)
 #define NONET_MAX_BATCH_DEFAULT 3072               // final exponentiation on nine lane pairs per verify up to this batch size: ONE pass of 3 verifies per wave on 1024 SIMDs (0.64 ms against the octet layout's 1.09; a second pass would cost 1.3)
 #define LM_MAX_BATCH_DEFAULT 1536                   // Miller loop as the lane machine (bn254_lmiller.hip: nine lane pairs in each of four waves per verify, 3 verifies per workgroup, one workgroup per CU) up to this batch size: two passes over 256 CUs (0.43 ms one pass, 0.86 two; eight wave roles: 1.0); 0 = never
 #define TRIO_WAVE_ROLES_DEFAULT 2                  // ... with the Miller loop as wave roles: 2 = eight waves per 32 verifies (k_miller_verify_w8), 1 = four
@@ -166,4 +167,4 @@ __attribute__((visibility("hidden"))) bool bn254_lm_fits_device();
 __attribute__((visibility("hidden"))) int bn254_lm_miller_verify(size_t n, Ws ws, hipStream_t s, int mode = 0);
 // entry points of bn254_nonet.hip (final exponentiation of the smallest batches on nine lane pairs per verify)
 __attribute__((visibility("hidden"))) bool bn254_nonet_fits_device();
-__attribute__((visibility("hidden"))) int bn254_nonet_final_exp(size_t n, Ws ws, int use_hash, uint8_t* status_out, hipStream_t s);
+__attribute__((visibility("hidden"))) int bn254_nonet_final_exp(size_t n, Ws ws, int use_hash, uint8_t* status_out, hipStream_t s, int wide = 0);

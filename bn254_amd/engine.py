@@ -26,6 +26,7 @@ OPT_AGG_SORT_BY_MSG = 11
 OPT_PINNED_STAGING = 12
 OPT_NONET_MAX_BATCH = 13
 OPT_LM_MAX_BATCH = 15
+OPT_NONET_WIDE = 16
 OPT_AGG_WIDE_MIN_TUPLES = 14
 
 
@@ -281,7 +282,7 @@ class Engine:
         return out.raw[:n * GT_BYTES]
 
     def debug_final_exp_limbs(self, layout, limbs, n, want_gt=False):
-        """final exponentiation of layout 0..5 on n x 108 int32 limbs (include/bn254_hip.h) -> (Gt bytes or None, status bytes)"""
+        """final exponentiation of layout 0..6 on n x 108 int32 limbs (include/bn254_hip.h) -> (Gt bytes or None, status bytes)"""
         assert len(limbs) == n * 108
         arr = (ctypes.c_int32 * max(len(limbs), 1))(*limbs)
         gt = ctypes.create_string_buffer(max(n, 1) * GT_BYTES) if want_gt else None

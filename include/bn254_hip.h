@@ -288,6 +288,8 @@ int bn254_ctx_set_profiling(bn254_ctx *ctx, int enabled);
 #define BN254_OPT_LM_MAX_BATCH 15 /* small batches: up to this many items the Miller loop runs as the LANE MACHINE (nine lane pairs in each of four
                                    waves per item: every product of a dependency level in its own lane pair; twist-point formulas rearranged
                                    for depth); same status bytes.  0 = never (wave roles / octet layout) */
+#define BN254_OPT_NONET_WIDE 16 /* ... and, while the batch is at most one item per SIMD (1 024), on EIGHTEEN lane pairs, one item per wave: the 18
+                                 products of a multiplication in one round (default 1; 0 = nine lane pairs at every size) */
 #define BN254_OPT_PINNED_STAGING 12 /* bn254_batch_verify (host pointers), batches of >= 8192: T = 1..16 threads copy the caller's (pageable)
                                      buffers through a pinned staging buffer of the context in 1 MB pieces, each piece's DMA enqueued as soon
                                      as it is in place; 0 = hipMemcpyAsync straight from the caller's buffers (the runtime stages them) */
@@ -417,7 +419,7 @@ int bn254_debug_fp12_op(bn254_ctx *ctx, int op, const uint8_t *a, const uint8_t 
 /* the final exponentiation of ECDSA::verify / bn::pairing_batch (src/ecdsa.rs:57-59) on caller-supplied LIMB vectors — n x 12 coefficients
  * (Gt order) x 9 int32 limbs, value = sum limb_k 2^(29 k) in Montgomery form (R = 2^261) — in the layout named: 0 one lane per item, exact
  * exponent, gt = canonical Gt bytes | 1 lane pairs, exact, gt | 2 lane pairs, the == one chain | 3 lane octets (straight-line chains below
- * 128 items, accumulator machine from 128 on) | 4 nine lane pairs per item | 5 one lane, the == one chain.  status[i] = 0 (the value is one) or 9.
+ * 128 items, accumulator machine from 128 on) | 4 nine lane pairs per item | 5 one lane, the == one chain | 6 eighteen lane pairs per item (one per wave).  status[i] = 0 (the value is one) or 9.
  * Exists so that the parity tests can hand every layout NON-CANONICAL representatives with extreme balanced digits — what the interval
  * tracker's contract for a Miller value allows (limbs 0..7 in [-2^28, 2^28], |value| <= 0.5215 q) but no byte decoder produces. */
 int bn254_debug_final_exp_limbs(bn254_ctx *ctx, int layout, const int32_t *limbs /* n*108 */, size_t n, uint8_t *gt /* n*384, layouts 0 / 1, or NULL */,

@@ -45,7 +45,7 @@ def soak(args):
     (tests/test_gpu_fullsize.py runs a slice of it in the driver-run suite)"""
     import bn254_amd
     from tests.conftest import ws_default
-    from bn254_amd.engine import OPT_AGG_WIDE_MIN_TUPLES, OPT_AGG_SORT_BY_MSG, OPT_AGG_SUBSET_MIN_TUPLES, OPT_LM_MAX_BATCH, OPT_NONET_MAX_BATCH, OPT_PAIR_LANES, OPT_RAND_MIN_BATCH, OPT_TRIO_MAX_BATCH, OPT_TRIO_WAVE_ROLES
+    from bn254_amd.engine import OPT_AGG_WIDE_MIN_TUPLES, OPT_AGG_SORT_BY_MSG, OPT_AGG_SUBSET_MIN_TUPLES, OPT_LM_MAX_BATCH, OPT_NONET_MAX_BATCH, OPT_NONET_WIDE, OPT_PAIR_LANES, OPT_RAND_MIN_BATCH, OPT_TRIO_MAX_BATCH, OPT_TRIO_WAVE_ROLES
     from oracle import c_oracle as c
     from tests.datagen import sk_bytes
     eng = bn254_amd.Engine(0)
@@ -121,6 +121,9 @@ def soak(args):
             got = {"default": eng.batch_verify(msgs, sigs, pks, flags=flags)}
             eng.set_option(OPT_LM_MAX_BATCH, 1 << 20)        # the Miller loop as the lane machine whatever the size (several passes above 768)
             got["lane_machine"] = eng.batch_verify(msgs, sigs, pks, flags=flags)
+            eng.set_option(OPT_NONET_WIDE, 0)                # ... with the final exponentiation on nine lane pairs also up to 1024 items (default there: eighteen)
+            got["lane_machine_nonet9"] = eng.batch_verify(msgs, sigs, pks, flags=flags)
+            eng.set_option(OPT_NONET_WIDE, 1)
             eng.set_option(OPT_LM_MAX_BATCH, 0)              # ... and never: the wave-role / octet kernels at every size below
             got["roles8"] = eng.batch_verify(msgs, sigs, pks, flags=flags)
             for name, roles in (("roles4", 1), ("octet", 0)):

@@ -106,7 +106,7 @@ def test_fp12_ops(eng, c):
 def test_adversarial_limbs_in_every_final_exponentiation_layout(eng):
     """Every layout of the final exponentiation of ECDSA::verify (/root/reference/src/ecdsa.rs:57-59) — one lane (exact and == one chains),
     lane pairs (both programs of the accumulator machine), lane octets (straight-line chains below 128 items, machine from 128 on), nine
-    lane pairs (the default for every single verify) — on LIMB vectors at the edge of the interval tracker's contract for a Miller value:
+    lane pairs and eighteen (one verify per wave: the default for every single verify) — on LIMB vectors at the edge of the interval tracker's contract for a Miller value:
     non-canonical representatives, extreme balanced digits and top limbs (tests/golden/adversarial_fe_vectors.json; expected results
     from the independent big-integer model).  Family "full" (all 12 coefficients adversarial): canonical Gt bytes where a layout writes
     them, status 9 everywhere; family "one" (f = g^r s, s in Fq6 forcing six adversarial coefficients): status 0 from every layout — a
@@ -125,14 +125,14 @@ def test_adversarial_limbs_in_every_final_exponentiation_layout(eng):
         gt, st = eng.debug_final_exp_limbs(layout, limbs, n, want_gt=True)
         assert st == want_st, (layout, st, want_st)
         assert gt == want_gt, layout
-    for layout in (2, 3, 4, 5):
+    for layout in (2, 3, 4, 5, 6):
         _, st = eng.debug_final_exp_limbs(layout, limbs, n)
         assert st == want_st, (layout, st, want_st)
     # sizes that change the kernels' own arrangement: the octet layout's accumulator machine (>= 128 items), several workgroups of the
     # nonet kernel (12 verifies each) incl. a ragged last one, lane pairs over several waves
     reps = 5
     big = limbs * reps + limbs[:108 * 7]
-    for layout in (1, 2, 3, 4):
+    for layout in (1, 2, 3, 4, 6):
         gt, st = eng.debug_final_exp_limbs(layout, big, reps * n + 7, want_gt=(layout == 1))
         assert st == want_st * reps + want_st[:7], layout
         if gt is not None:
@@ -141,7 +141,7 @@ def test_adversarial_limbs_in_every_final_exponentiation_layout(eng):
     import ctypes
     arr = (ctypes.c_int32 * 108)()
     out = ctypes.create_string_buffer(384)
-    assert eng._lib.bn254_debug_final_exp_limbs(eng._h, 6, arr, 1, None, out) == -10001
+    assert eng._lib.bn254_debug_final_exp_limbs(eng._h, 7, arr, 1, None, out) == -10001
     assert eng._lib.bn254_debug_final_exp_limbs(eng._h, 4, arr, 1, out, out) == -10001      # Gt bytes only from layouts 0 and 1
 
 
@@ -448,7 +448,7 @@ def test_octet_and_pair_layouts_agree_with_oracle(eng, c, derived, kats):
     with the four lane pairs of a verify as four waves with their own roles, or as lane groups of one wave), larger ones on
     lane pairs: all against the golden cases, the oracle on ragged sizes with faults of every class, and
     check_public_keys; the threshold itself (8192 octet, 8193 pairs) gives the same bytes on either side"""
-    from bn254_amd.engine import OPT_LM_MAX_BATCH, OPT_NONET_MAX_BATCH, OPT_TRIO_MAX_BATCH, OPT_TRIO_WAVE_ROLES
+    from bn254_amd.engine import OPT_LM_MAX_BATCH, OPT_NONET_MAX_BATCH, OPT_NONET_WIDE, OPT_TRIO_MAX_BATCH, OPT_TRIO_WAVE_ROLES
     from tests.datagen import make_verify_batch
     cs = derived["verify_cases"]
     args = ([H(v["message_hex"]) for v in cs], b"".join(H(v["sig"]) for v in cs), b"".join(H(v["pk"]) for v in cs))
@@ -502,20 +502,22 @@ def test_octet_and_pair_layouts_agree_with_oracle(eng, c, derived, kats):
         # forced on for every small-batch size (1, 2, 7, 9, 65, 1027: not multiples of 3; 8192: eleven passes; identity operands in the
         # batches and the golden cases: pair A / pair B skipped), with either final exponentiation behind it, then the default threshold on
         # both sides (1536 | 1537)
-        for lim, nonet in ((1 << 20, NONET_DEFAULT), (1 << 20, 0), (LM_DEFAULT, NONET_DEFAULT)):
+        for lim, nonet, wide in ((1 << 20, NONET_DEFAULT, 1), (1 << 20, NONET_DEFAULT, 0), (1 << 20, 0, 1), (LM_DEFAULT, NONET_DEFAULT, 1)):
             eng.set_option(OPT_LM_MAX_BATCH, lim)
             eng.set_option(OPT_NONET_MAX_BATCH, nonet)
+            eng.set_option(OPT_NONET_WIDE, wide)                  # final exponentiation on eighteen lane pairs up to 1 024 verifies (default) / nine at every size
             assert list(eng.batch_verify(*args, flags=1)) == want, ("lane machine", lim)
             for msgs, sigs, pks, oracle in batches:
                 assert eng.batch_verify(msgs, sigs, pks, flags=1) == oracle, ("lane machine", lim, len(msgs))
             assert eng.batch_check_public_keys(g2s, g1s, len(cpk) * 3) == cpk_want, ("lane machine", lim)
-            for cut in (8192, LM_DEFAULT, LM_DEFAULT + 1):
+            for cut in (8192, LM_DEFAULT, LM_DEFAULT + 1, 1024, 1025):
                 assert eng.batch_verify(edge[0][:cut], edge[1][:cut * 64], edge[2][:cut * 128]) == edge[3][:cut], ("lane machine", lim, cut)
     finally:
         eng.set_option(OPT_TRIO_MAX_BATCH, TRIO_DEFAULT)               # the defaults
         eng.set_option(OPT_TRIO_WAVE_ROLES, 2)
         eng.set_option(OPT_NONET_MAX_BATCH, NONET_DEFAULT)
         eng.set_option(OPT_LM_MAX_BATCH, LM_DEFAULT)
+        eng.set_option(OPT_NONET_WIDE, 1)
     # the default threshold itself: 16384 verifies in two passes of the small-batch kernels, 16385 on lane pairs
     big = make_verify_batch(eng, 16385, corrupt_every=13)
     assert eng.batch_verify(big[0], big[1], big[2]) == big[3]
