@@ -1016,6 +1016,24 @@ def run_verify(args, R):
                         best = dt if best is None or dt < best else best
                     assert got == expected_for(0, last, m), "small-batch statuses differ from the expected pattern"
                     lat["verifies_%d_ms" % m] = 1e3 * best
+                # the same single verify on round 4's small-batch kernels (eight wave roles, nine lane pairs) — what the lane machine and the
+                # eighteen-pair final exponentiation are measured against
+                import re
+                from bn254_amd.engine import OPT_LM_MAX_BATCH, OPT_NONET_WIDE
+                with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "bn254_amd", "csrc", "bn254_ws.h")) as fh:
+                    lm_default = int(re.search(r"#define\s+LM_MAX_BATCH_DEFAULT\s+(\d+)", fh.read()).group(1))
+                eng.set_option(OPT_LM_MAX_BATCH, 0); eng.set_option(OPT_NONET_WIDE, 0)
+                try:
+                    best = None
+                    for _ in range(5):
+                        t1 = time.perf_counter()
+                        got = eng.batch_verify(msgs[:1], sig_sets[last & 1][:64], pks[:128], flags=0)
+                        dt = time.perf_counter() - t1
+                        best = dt if best is None or dt < best else best
+                    assert got == expected_for(0, last, 1), "small-batch statuses differ from the expected pattern"
+                    lat["verifies_1_ms_wave_roles_and_nine_pairs"] = 1e3 * best
+                finally:
+                    eng.set_option(OPT_LM_MAX_BATCH, lm_default); eng.set_option(OPT_NONET_WIDE, 1)
                 result["small_batch_latency"] = lat
             except AssertionError:
                 raise

@@ -15,6 +15,8 @@ if [ "$part" = a ]; then
   python $R/bench.py --workload verify-keyed-randomized --steps 3 --warmup 1 2>/dev/null | tail -1 > $O/keyed_randomized_1m.json; echo keyedrand done
   python $R/bench.py --workload verify-mgpu --gpus 1 --steps 25 --warmup 3 2>/dev/null | tail -1 > $O/bench_verify_mgpu_g1.json; echo mgpu1 done
   python $R/bench.py --workload verify-mgpu --gpus 4 --mgpu-devices 0,0,0,0 --steps 10 --warmup 2 2>/dev/null | tail -1 > $O/bench_verify_mgpu_4ctx_one_gpu.json; echo mgpu4 done
+  python $R/tools/lm_check.py 2>/dev/null | grep "^{" > $O/small_batch_lane_machine_vs_wave_roles.jsonl; echo lm_check done
+  bash $R/tools/small_trace.sh 1 20 > $O/single_verify_kernel_timeline.txt 2>&1; echo timeline done
   rm -f $O/batch_sweep.jsonl
   for b in 1 64 1024 4096 8192 16384 32768 65536 131072 262144 1048576; do python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --batch $b 2>/dev/null | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; fl=r.get('product_leaf_floor') or {}
