@@ -721,6 +721,12 @@ int bn254_ctx_last_kernel_ms(bn254_ctx* c, float ms[4]) {
 // Miller loop + final exponentiation of a verify-shaped batch on lane pairs, or — for batches that cannot fill the chip —
 // in the octet layout (three lane pairs share the Fq6 products of every Fq12 operation: fewer instructions per lane,
 // which is what latency is made of when a wave has its SIMD to itself).  Same status bytes either way.
+// final exponentiation of a small batch: the smallest on nine lane pairs per verify (bn254_nonet.hip; eighteen while one verify per wave
+// still covers the batch) — fewer instructions per lane again —, the others in the octet layout
+int launch_small_final_exp(bn254_ctx* c, hipStream_t s, size_t n, int use_hash, uint8_t* d_status) {
+  if (c->nonet_max_batch > 0 && n <= (size_t)c->nonet_max_batch) return bn254_nonet_final_exp(n, c->ws, use_hash, d_status, s, c->nonet_wide && n <= (size_t)NONET_WIDE_MAX_BATCH);
+  return bn254_trio_final_exp(n, c->ws, use_hash, d_status, s);
+}
 int launch_pair_or_trio(bn254_ctx* c, hipStream_t s, size_t n, int use_hash, uint8_t* d_status, int mode, bool mark) {
   int rc;
   if (c->trio_max_batch > 0 && n <= (size_t)c->trio_max_batch) {
@@ -728,10 +734,7 @@ int launch_pair_or_trio(bn254_ctx* c, hipStream_t s, size_t n, int use_hash, uin
               : c->trio_wave_roles == 2 ? bn254_w8_miller_verify(n, c->ws, s, mode)
               : c->trio_wave_roles ? bn254_quad_miller_verify(n, c->ws, s, mode) : bn254_trio_miller_verify(n, c->ws, s, mode))) return rc;
     if (mark) PROF_MARK(3);
-    // the smallest batches: nine lane pairs per verify (bn254_nonet.hip) — fewer instructions per lane again, while one pass of 3
-    // verifies per wave still covers the batch
-    if (c->nonet_max_batch > 0 && n <= (size_t)c->nonet_max_batch) return bn254_nonet_final_exp(n, c->ws, use_hash, d_status, s, c->nonet_wide && n <= (size_t)NONET_WIDE_MAX_BATCH);
-    return bn254_trio_final_exp(n, c->ws, use_hash, d_status, s);
+    return launch_small_final_exp(c, s, n, use_hash, d_status);
   }
   if ((rc = bn254_pair_miller_verify(n, c->ws, nullptr, nullptr, s, mode))) return rc;
   if (mark) PROF_MARK(3);

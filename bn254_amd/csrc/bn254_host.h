@@ -112,6 +112,7 @@ BN_HIDDEN int launch_decode_g1(bn254_ctx* c, hipStream_t s, const uint8_t* d_pts
 BN_HIDDEN int launch_decode_g2(bn254_ctx* c, hipStream_t s, const uint8_t* d_pts, size_t n, uint32_t flags, int accumulate);
 BN_HIDDEN int launch_hash_rounds(bn254_ctx* c, hipStream_t s, const uint8_t* d_msgs, const uint64_t* d_off, size_t n, int px, int inf_plane,
                                  uint8_t* d_tries, int mark_finish = -1);
+BN_HIDDEN int launch_small_final_exp(bn254_ctx* c, hipStream_t s, size_t n, int use_hash, uint8_t* d_status);
 BN_HIDDEN int launch_pair_or_trio(bn254_ctx* c, hipStream_t s, size_t n, int use_hash, uint8_t* d_status, int mode, bool mark);
 // one lane per item: k_miller_verify (map / count: a device-side queue of items, or null) and k_final_exp (the arguments of the kernel)
 BN_HIDDEN int launch_miller_verify_lane(bn254_ctx* c, hipStream_t s, size_t n, const uint32_t* map, const uint32_t* count);

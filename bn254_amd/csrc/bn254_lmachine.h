@@ -37,14 +37,15 @@ enum LmSlot {
   LS_TB, LS_TE, LS_TXY, LS_TX2, LS_TYW, LS_TYZ, LS_TH3, LS_TBF, LS_TBMF, LS_TXY2, LS_TOZ, LS_TOW, LS_TOY2, LS_TE2,
   LS_T1, LS_T2, LS_TC, LS_TD, LS_TMX, LS_TMZ, LS_TMY, LS_TTM, LS_TTHZ, LS_TMW, LS_TDD, LS_TPA, LS_TPB, LS_TPC, LS_TPD, LS_TPE, LS_TPF,
   // wave L: the point of the addition step it evaluates, the table line's constants, temporaries
-  LS_LQX, LS_LQY, LS_MC0, LS_MC1,
+  LS_LQX, LS_LQY, LS_MC0, LS_MC1, LS_KC0, LS_KC1, LS_XI,
   LS_LL0, LS_LL1, LS_LM0, LS_LM1, LS_LCA, LS_LCB, LS_LL0S, LS_LL1S, LS_LL2S, LS_LW3, LS_LW4, LS_LV0, LS_LV1, LS_LX01,
   // waves F: accumulator (six coefficients), products (two buffers of 18, by parity of the product), Fq6 coefficients (9)
   LS_ACC, LS_XP0 = LS_ACC + 6, LS_XP1 = LS_XP0 + 18, LS_X1 = LS_XP1 + 18,
-  // by parity of the step: what wave T hands wave L (doubling: h, -3 x^2, l2 = b - e; addition: theta, mu), the line product (6)
+  // by parity of the step: what wave T hands wave L (doubling: h, -3 x^2, l2 = b - e; addition: theta, mu; keyed form: the two scaled
+  // table lines l0, l1, m0, m1), the line product (6)
   LS_REL0 = LS_X1 + 9,
-  LS_HOA = LS_REL0, LS_HOB, LS_HOC, LS_LP,
-  LS_REL_N = 3 + 6,
+  LS_HOA = LS_REL0, LS_HOB, LS_HOC, LS_HOD, LS_LP,
+  LS_REL_N = 4 + 6,
   LS_COUNT = LS_REL0 + 2 * LS_REL_N
 };
 static_assert(LS_COUNT <= 255, "slot ids are bytes");
@@ -54,23 +55,26 @@ static_assert(LS_COUNT <= 255, "slot ids are bytes");
 //   w[1]  product: out
 //   w[2]  linear:  x0 | x1 << 8 | x2 << 16 | x3 << 24
 //   w[3]  linear:  k0 .. k3, signed bytes
-//   w[4]  linear:  out | flags << 8 | alt << 16               flags: 1 = xi on term 2; 2 / 4 = S[alt] instead when pair A / pair B is skipped
+//   w[4]  linear:  out | flags << 8 | alt << 16 | za << 24 | zb << 28
+//                  flags: 1 = xi on term 2; 2 / 4 = S[alt] instead when pair A / pair B is skipped; za / zb: bit j = term j dropped when pair
+//                  A / pair B is skipped
 struct LmEntry { uint32_t w[5]; };
 enum { LM_XI = 1, LM_SKIP_A = 2, LM_SKIP_B = 4 };
 constexpr uint32_t lm_b4(int a, int b, int c, int d) { return (uint32_t)(a & 255) | (uint32_t)(b & 255) << 8 | (uint32_t)(c & 255) << 16 | (uint32_t)(d & 255) << 24; }
 struct LmP { int a1, a2, b1, b2, out; };
-struct LmL { int out, x0, k0, x1, k1, x2, k2, x3, k3, flags, alt; };
+struct LmL { int out, x0, k0, x1, k1, x2, k2, x3, k3, flags, alt, za, zb; };
 constexpr LmP LM_NOP_P = {LS_ZERO, LS_ZERO, LS_ZERO, LS_ZERO, LS_DUMMY};
-constexpr LmL LM_NOP_L = {LS_DUMMY, LS_ZERO, 0, LS_ZERO, 0, LS_ZERO, 0, LS_ZERO, 0, 0, LS_ZERO};
+constexpr LmL LM_NOP_L = {LS_DUMMY, LS_ZERO, 0, LS_ZERO, 0, LS_ZERO, 0, LS_ZERO, 0, 0, LS_ZERO, 0, 0};
 constexpr LmEntry lm_entry(const LmP& p, const LmL& l) {
   return LmEntry{{lm_b4(p.a1, p.a2, p.b1, p.b2), (uint32_t)p.out, lm_b4(l.x0, l.x1, l.x2, l.x3), lm_b4(l.k0, l.k1, l.k2, l.k3),
-                  (uint32_t)l.out | (uint32_t)l.flags << 8 | (uint32_t)l.alt << 16}};
+                  (uint32_t)l.out | (uint32_t)l.flags << 8 | (uint32_t)l.alt << 16 | (uint32_t)l.za << 24 | (uint32_t)l.zb << 28}};
 }
 constexpr LmP lm_mul(int out, int a, int b) { return LmP{a, LS_ZERO, b, LS_ZERO, out}; }
 constexpr LmL lm_lin(int out, int x0, int k0, int x1 = LS_ZERO, int k1 = 0, int x2 = LS_ZERO, int k2 = 0, int x3 = LS_ZERO, int k3 = 0) {
-  return LmL{out, x0, k0, x1, k1, x2, k2, x3, k3, 0, LS_ZERO};
+  return LmL{out, x0, k0, x1, k1, x2, k2, x3, k3, 0, LS_ZERO, 0, 0};
 }
-constexpr LmL lm_lin_skip(int flag, int alt, const LmL& l) { return LmL{l.out, l.x0, l.k0, l.x1, l.k1, l.x2, l.k2, l.x3, l.k3, l.flags | flag, alt}; }
+constexpr LmL lm_lin_skip(int flag, int alt, const LmL& l) { return LmL{l.out, l.x0, l.k0, l.x1, l.k1, l.x2, l.k2, l.x3, l.k3, l.flags | flag, alt, l.za, l.zb}; }
+constexpr LmL lm_lin_drop(int za, int zb, const LmL& l) { return LmL{l.out, l.x0, l.k0, l.x1, l.k1, l.x2, l.k2, l.x3, l.k3, l.flags, l.alt, za, zb}; }
 #define LM_E(P, L) lm_entry(P, L)
 
 #if defined(__HIPCC__)
@@ -160,6 +164,24 @@ LM_TABLE LM_L_PROD[1][9] = {{
     LM_E((LmP{LS_LL0S, LS_LL1S, LS_LM0, LS_LM1, LS_LX01}), LM_L_SKIP_B(LS_LL2S, lm_lin(LS_LP + 4, LS_LL0S, 1, LS_LW3, 1))),
     LM_E(LM_NOP_P, LM_NOP_L), LM_E(LM_NOP_P, LM_NOP_L), LM_E(LM_NOP_P, LM_NOP_L), LM_E(LM_NOP_P, LM_NOP_L)}};
 
+// KEYED form (registered public keys: the lines of pair A tabulated in the c2 = 1 form like those of the fixed pair; no twist-point wave):
+// wave LA, two steps ahead: both table lines scaled by their G1 points, a skipped pair's line replaced by 1 = (1, 0, c2 = 0) ...
+LM_TABLE LM_K_EVAL[1][9] = {{
+    LM_E(lm_mul(LS_LL0, LS_KC0, LS_PAY), LM_L_SKIP_A(LS_ONE, lm_lin(LS_HOA, LS_LL0, 1))),
+    LM_E(lm_mul(LS_LL1, LS_KC1, LS_PAX), LM_L_SKIP_A(LS_ZERO, lm_lin(LS_HOB, LS_LL1, 1))),
+    LM_E(lm_mul(LS_LM0, LS_MC0, LS_PBY), LM_L_SKIP_B(LS_ONE, lm_lin(LS_HOC, LS_LM0, 1))),
+    LM_E(lm_mul(LS_LM1, LS_MC1, LS_PBX), LM_L_SKIP_B(LS_ZERO, lm_lin(LS_HOD, LS_LM1, 1))),
+    LM_E(LM_NOP_P, LM_NOP_L), LM_E(LM_NOP_P, LM_NOP_L), LM_E(LM_NOP_P, LM_NOP_L), LM_E(LM_NOP_P, LM_NOP_L), LM_E(LM_NOP_P, LM_NOP_L)}};
+// ... wave LB, one step ahead: (l0 + l1 w + ca w^3)(m0 + m1 w + cb w^3), ca / cb = 0 for a skipped pair (bn254_pairing.h: mul_by_two_table_lines):
+//   b00 = l0 m0 + ca cb xi, b01 = l1 m1, b02 = cb l1 + ca m1, b10 = (l0 + l1)(m0 + m1) - l0 m0 - l1 m1, b11 = cb l0 + ca m0
+LM_TABLE LM_K_PROD[1][9] = {{
+    LM_E(lm_mul(LS_LV0, LS_HOA, LS_HOC), lm_lin_drop(2, 2, lm_lin(LS_LP + 0, LS_LV0, 1, LS_XI, 1))),
+    LM_E(lm_mul(LS_LV1, LS_HOB, LS_HOD), lm_lin(LS_LP + 1, LS_LV1, 1)),
+    LM_E((LmP{LS_HOA, LS_HOB, LS_HOC, LS_HOD, LS_LX01}), lm_lin_drop(2, 1, lm_lin(LS_LP + 2, LS_HOB, 1, LS_HOD, 1))),
+    LM_E(LM_NOP_P, lm_lin(LS_LP + 3, LS_LX01, 1, LS_LV0, -1, LS_LV1, -1)),
+    LM_E(LM_NOP_P, lm_lin_drop(2, 1, lm_lin(LS_LP + 4, LS_HOA, 1, LS_HOC, 1))),
+    LM_E(LM_NOP_P, LM_NOP_L), LM_E(LM_NOP_P, LM_NOP_L), LM_E(LM_NOP_P, LM_NOP_L), LM_E(LM_NOP_P, LM_NOP_L)}};
+
 // ---- the two stages of a level, for one lane pair.  `par`: parity of the step the wave is working on (relocates slots >= LS_REL0).
 template <class Box> BN_DEV typename Box::Ref lm_ref(Box& bx, uint32_t id, unsigned par) { return bx.slot(id + (id >= (uint32_t)LS_REL0 ? par * (unsigned)LS_REL_N : 0u)); }
 template <class Box> BN_DEV Fp2 lm_stage_product(const LmEntry& e, Box& bx, unsigned par) {
@@ -174,7 +196,9 @@ template <class Box> BN_DEV Fp2 lm_stage_linear(const LmEntry& e, Box& bx, unsig
   const Fp2 x2 = bx.get(lm_ref(bx, (e.w[2] >> 16) & 255u, par)), x3 = bx.get(lm_ref(bx, e.w[2] >> 24, par));
   const uint32_t flags = (e.w[4] >> 8) & 255u;
   const Fp2 x2x = fp2_select_pos((flags & LM_XI) != 0, fp2_mul_xi(x2), x2);
-  const Fp2 r = fp2_lin4_reduce(x0, lm_k(e.w[3], 0), x1, lm_k(e.w[3], 1), x2x, lm_k(e.w[3], 2), x3, lm_k(e.w[3], 3));
+  const uint32_t drop = (skip_a ? (e.w[4] >> 24) & 15u : 0u) | (skip_b ? e.w[4] >> 28 : 0u);      // terms that fall away with a skipped pair
+  const Fp2 r = fp2_lin4_reduce(x0, (drop & 1u) ? 0 : lm_k(e.w[3], 0), x1, (drop & 2u) ? 0 : lm_k(e.w[3], 1), x2x, (drop & 4u) ? 0 : lm_k(e.w[3], 2),
+                                x3, (drop & 8u) ? 0 : lm_k(e.w[3], 3));
   const bool replace = ((flags & LM_SKIP_A) != 0 && skip_a) || ((flags & LM_SKIP_B) != 0 && skip_b);
   return fp2_select(replace, bx.get(lm_ref(bx, (e.w[4] >> 16) & 255u, par)), r);
 }
@@ -277,6 +301,41 @@ inline void lm_miller_model(Fp12& f, const G1Affine& pa, const G2Affine& qa, con
         Fp2* lp = &bx.s[LS_LP + par_f * LS_REL_N];
         if (ty_f == 0) { if (tick == 0) lm_host_mul(bx, L, &bx.s[LS_ACC]); else if (tick == 1) lm_host_mul(bx, L, lp); }
         else if (tick == 0) lm_host_mul(bx, L, lp);
+      }
+    }
+  }
+  f.c0.c0 = bx.s[LS_ACC]; f.c0.c1 = bx.s[LS_ACC + 1]; f.c0.c2 = bx.s[LS_ACC + 2];
+  f.c1.c0 = bx.s[LS_ACC + 3]; f.c1.c1 = bx.s[LS_ACC + 4]; f.c1.c2 = bx.s[LS_ACC + 5];
+}
+// the Miller value of e(pa, key) e(pb, -G2) in the KEYED schedule: `tab` = the key's 87 x (c0, c1) (bn254_pairing.h: miller_loop_keyed).
+// Global step g: wave LA works on step g + 2, wave LB on step g + 1, waves F on step g; two ticks for a doubling step, one for an addition.
+inline void lm_miller_keyed_model(Fp12& f, const G1Affine& pa, bool key_inf, const int32_t (*tab)[2][2][BN_LIMBS], const G1Affine& pb) {
+  static LmHostBox bx;
+  static NnLane<LmHostBox> L[9];
+  for (int i = 0; i < LS_COUNT; ++i) bx.s[i] = fp2_zero();
+  for (unsigned p = 0; p < 9; ++p) nn_lane_roles(L[p], bx, p, true);
+  const bool skip_a = pa.inf || key_inf, skip_b = pb.inf;
+  bx.s[LS_ONE] = fp2_one();
+  bx.s[LS_XI] = fp2_load_const(C_XI_MONT);
+  bx.s[LS_PAX] = fp2_from_fp(pa.x); bx.s[LS_PAY] = fp2_from_fp(pa.y); bx.s[LS_PBX] = fp2_from_fp(pb.x); bx.s[LS_PBY] = fp2_from_fp(pb.y);
+  bx.s[LS_ACC] = fp2_one();
+  signed char ty[BN_N_FIXED_LINES + 2];
+  lm_step_types(ty);
+  for (int g = -2; g < BN_N_FIXED_LINES; ++g) {
+    const int ty_f = g >= 0 ? ty[g] : 4;
+    const int ticks = ty_f == 0 ? 2 : 1;
+    for (int tick = 0; tick < ticks; ++tick) {
+      if (tick == 0 && g + 2 < BN_N_FIXED_LINES) {                     // wave LA
+        const int k = g + 2;
+        bx.s[LS_KC0] = fp2_load_const(tab[k][0]); bx.s[LS_KC1] = fp2_load_const(tab[k][1]);
+        bx.s[LS_MC0] = fp2_load_const(C_NEG_G2_LINES[k][0]); bx.s[LS_MC1] = fp2_load_const(C_NEG_G2_LINES[k][1]);
+        lm_host_level(bx, LM_K_EVAL[0], (unsigned)k & 1u, skip_a, skip_b);
+      }
+      if (tick == 0 && g + 1 >= 0 && g + 1 < BN_N_FIXED_LINES) lm_host_level(bx, LM_K_PROD[0], (unsigned)(g + 1) & 1u, skip_a, skip_b);   // wave LB
+      if (ty_f != 4) {                                                   // waves F
+        Fp2* lp = &bx.s[LS_LP + ((unsigned)g & 1u) * LS_REL_N];
+        if (ty_f == 0) { if (tick == 0) lm_host_mul(bx, L, &bx.s[LS_ACC]); else lm_host_mul(bx, L, lp); }
+        else lm_host_mul(bx, L, lp);
       }
     }
   }

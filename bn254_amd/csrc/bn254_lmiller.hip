@@ -129,6 +129,7 @@ __device__ __noinline__ void lm_wave_t(const LmLane ln) {
   }
 }
 // ---- wave L: the step's line at pair A's G1 point times the table line at pair B's, one step ahead
+// (measured: the tables copied into LDS once per workgroup instead of a fetch a step ahead — neutral for the keyed form, +8 us for this one)
 __device__ __forceinline__ Fp2 lm_table_const(int k, int j) { return fp2_load_const(C_NEG_G2_LINES[k < BN_N_FIXED_LINES ? k : 0][j]); }
 __device__ __noinline__ void lm_wave_l(const LmLane ln) {
   const LmEntry e_d = lm_load_entry(LM_L_DBL[0], ln.pair), e_a = lm_load_entry(LM_L_ADD[0], ln.pair), e_p = lm_load_entry(LM_L_PROD[0], ln.pair);
@@ -181,7 +182,7 @@ __device__ __forceinline__ void lm_f_finish(const LmLane& ln, const NnLane<LmLds
   if (L.publishes_out) bx.put(L.out_coef, o);
   LM_FENCE();
 }
-template <int R> __device__ __noinline__ void lm_wave_f(const LmLane ln) {
+template <int R, bool KEYED> __device__ __noinline__ void lm_wave_f(const LmLane ln) {
   LmLdsBox bx = ln.bx;
   NnLane<LmLdsBox> L0, L1;
   nn_lane_roles<LmLdsBox>(L0, bx, ln.pair, ln.writer);
@@ -192,8 +193,8 @@ template <int R> __device__ __noinline__ void lm_wave_f(const LmLane ln) {
   LM_TICK();
 #pragma clang loop unroll(disable)
   for (int g = LM_GLOBAL_STEPS_BEGIN; g < BN_N_FIXED_LINES; ++g) {
-    const int ticks = lm_ticks(lm_ty(g + 2));
     const int ty = g >= 0 ? lm_ty(g) : 4;
+    const int ticks = KEYED ? (ty == 0 ? 2 : 1) : lm_ticks(lm_ty(g + 2));
     const unsigned lp = bx.slot((unsigned)LS_LP + ((unsigned)g & 1u) * (unsigned)LS_REL_N);
 #pragma clang loop unroll(disable)
     for (int tick = 0; tick < ticks; ++tick) {
@@ -264,13 +265,112 @@ KERNEL_LM void k_miller_verify_lm(size_t n, Ws ws, int mode) {
   }
   __syncthreads();
   switch (w) {
-    case 0: lm_wave_f<0>(ln); break;
-    case 1: lm_wave_f<1>(ln); break;
+    case 0: lm_wave_f<0, false>(ln); break;
+    case 1: lm_wave_f<1, false>(ln); break;
     case 2: lm_wave_t(ln); break;
     default: lm_wave_l(ln); break;
   }
   if (w != 0 || !live || ln.pair >= 6) return;           // wave F0 writes the Miller value out: pair k coefficient k
   ws_store_fp(ws, PL_F0 + 2 * (int)ln.pair + (int)role, i, ln.bx.get(ln.bx.slot(LS_ACC + ln.pair)).c[0]);
+}
+
+// ---- KEYED form (registered public keys, bn254_ctx_register_keys: the 87 lines of a key's Miller loop tabulated in the c2 = 1 form): no
+// twist point to walk — the waves are F0, F1, LA (both table lines scaled by their G1 points, two steps ahead) and LB (their product, one
+// step ahead); every wave has at most one level per tick, so an addition step is ONE tick: 153 ticks instead of 201.
+__device__ __forceinline__ Fp2 lm_key_const(const int32_t* key_lines, int k, int coef) {
+  Fp2 r;
+  const int32_t* w = key_lines + ((size_t)(k < BN_N_FIXED_LINES ? k : 0) * 2 + (size_t)coef) * 2 * BN_LIMBS + (threadIdx.x & 1u) * BN_LIMBS;
+#pragma unroll
+  for (int i = 0; i < BN_LIMBS; ++i) r.c[0].v[i] = w[i];
+  return r;
+}
+__device__ __noinline__ void lm_wave_ka(const LmLane ln, const int32_t* key_lines) {
+  const LmEntry e_ev = lm_load_entry(LM_K_EVAL[0], ln.pair);
+  Fp2 kc0 = lm_key_const(key_lines, 0, 0), kc1 = lm_key_const(key_lines, 0, 1), mc0 = lm_table_const(0, 0), mc1 = lm_table_const(0, 1);
+  LM_TICK();
+#pragma clang loop unroll(disable)
+  for (int g = LM_GLOBAL_STEPS_BEGIN; g < BN_N_FIXED_LINES; ++g) {
+    const int k = g + 2;
+    if (k < BN_N_FIXED_LINES) {
+      if (ln.writer) { ln.bx.put(ln.bx.slot(LS_KC0), kc0); ln.bx.put(ln.bx.slot(LS_KC1), kc1); ln.bx.put(ln.bx.slot(LS_MC0), mc0); ln.bx.put(ln.bx.slot(LS_MC1), mc1); }
+      LM_FENCE();
+      kc0 = lm_key_const(key_lines, k + 1, 0); kc1 = lm_key_const(key_lines, k + 1, 1); mc0 = lm_table_const(k + 1, 0); mc1 = lm_table_const(k + 1, 1);
+      lm_level(ln, e_ev, (unsigned)k & 1u);
+    }
+    LM_TICK();
+    if (g >= 0 && lm_ty(g) == 0) LM_TICK();
+  }
+}
+__device__ __noinline__ void lm_wave_kb(const LmLane ln) {
+  const LmEntry e_pr = lm_load_entry(LM_K_PROD[0], ln.pair);
+  LM_TICK();
+#pragma clang loop unroll(disable)
+  for (int g = LM_GLOBAL_STEPS_BEGIN; g < BN_N_FIXED_LINES; ++g) {
+    const int k = g + 1;
+    if (k >= 0 && k < BN_N_FIXED_LINES) lm_level(ln, e_pr, (unsigned)k & 1u);
+    LM_TICK();
+    if (g >= 0 && lm_ty(g) == 0) LM_TICK();
+  }
+}
+KERNEL_LM void k_miller_verify_lmk(size_t n, Ws ws, const uint32_t* key_idx, KeyTable kt) {
+  const unsigned w = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // the wave's role: F0, F1, LA, LB
+  const unsigned l = threadIdx.x & (BN_WAVE - 1);
+  const unsigned v = l / BN_LM_LANES;
+  LmLane ln;
+  ln.writer = v < BN_LM_PER_WG;
+  const unsigned vslot = ln.writer ? v : BN_LM_PER_WG - 1;
+  ln.pair = (l % BN_LM_LANES) >> 1;
+  const unsigned role = l & 1u;
+  size_t i = (size_t)blockIdx.x * BN_LM_PER_WG + vslot;
+  const bool live = ln.writer && i < n;
+  if (i >= n) i = n - 1;
+  ln.bx.base = vslot * LM_VERIFY_STRIDE + role * LM_ROLE_STRIDE;
+  for (unsigned k = threadIdx.x; k < LM_LDS_WORDS; k += BN_LM_WG) lm_lds[k] = 0;
+  __syncthreads();
+  // the key (as k_miller_verify_keyed_pair: an index out of range or a refused key sets the tuple's status and walks the loop as a skipped pair)
+  uint32_t key = key_idx[i];
+  uint8_t kst = ST_OK;
+  if (key >= kt.n_keys) { kst = ST_INDEX_OOB; key = 0; }
+  else kst = kt.st[key];
+  const bool key_inf = kst != ST_OK || kt.inf[key] != 0;
+  G1Affine sig, h;
+  ws_load_g1(ws, PL_P1X, BY_P1_INF, i, sig);
+  ws_load_g1(ws, PL_P2X, BY_P2_INF, i, h);
+  ln.skip_a = h.inf || key_inf; ln.skip_b = sig.inf;
+  if (w == 0) {
+    if (live && ln.pair == 0 && role == 0) {
+      const uint8_t prev = ws_byte(ws, BY_ST_DECODE, i);
+      ws_byte(ws, BY_ST_DECODE, i) = prev != ST_OK ? prev : kst;
+    }
+    if (ln.writer) { ln.bx.put(ln.bx.slot(LS_ONE), fp2_one()); ln.bx.put(ln.bx.slot(LS_ACC), fp2_one()); ln.bx.put(ln.bx.slot(LS_XI), fp2_load_const(C_XI_MONT)); }
+    const int dg = (int)C_ATE_NAF[l];
+    const unsigned long long nz = __builtin_amdgcn_ballot_w64(dg != 0);
+    const int at = (int)l + __builtin_popcountll(nz & ((1ull << l) - 1ull));
+    signed char* ty = (signed char*)(lm_lds + LM_TY_OFF);
+    ty[at] = 0;
+    if (dg != 0) ty[at + 1] = (signed char)dg;
+    if (l == 0) { ty[BN_N_FIXED_LINES - 2] = 2; ty[BN_N_FIXED_LINES - 1] = 3; ty[BN_N_FIXED_LINES] = 4; ty[BN_N_FIXED_LINES + 1] = 4; }
+  } else if (w == 3) {
+    if (ln.writer) {
+      ln.bx.put(ln.bx.slot(LS_PAX), fp2_from_fp(h.x)); ln.bx.put(ln.bx.slot(LS_PAY), fp2_from_fp(h.y));
+      ln.bx.put(ln.bx.slot(LS_PBX), fp2_from_fp(sig.x)); ln.bx.put(ln.bx.slot(LS_PBY), fp2_from_fp(sig.y));
+    }
+  }
+  __syncthreads();
+  switch (w) {
+    case 0: lm_wave_f<0, true>(ln); break;
+    case 1: lm_wave_f<1, true>(ln); break;
+    case 2: lm_wave_ka(ln, kt.lines + (size_t)key * BN_N_FIXED_LINES * BN_KEY_LINE_WORDS); break;
+    default: lm_wave_kb(ln); break;
+  }
+  if (w != 0 || !live || ln.pair >= 6) return;
+  ws_store_fp(ws, PL_F0 + 2 * (int)ln.pair + (int)role, i, ln.bx.get(ln.bx.slot(LS_ACC + ln.pair)).c[0]);
+}
+int bn254_lm_miller_verify_keyed(size_t n, Ws ws, const uint32_t* key_idx, KeyTable kt, hipStream_t s) {
+  const unsigned grid = (unsigned)((n + BN_LM_PER_WG - 1) / BN_LM_PER_WG);
+  k_miller_verify_lmk<<<grid, BN_LM_WG, LM_LDS_WORDS * sizeof(int32_t), s>>>(n, ws, key_idx, kt);
+  HIP_TRY(hipGetLastError());
+  return 0;
 }
 
 bool bn254_lm_fits_device() {

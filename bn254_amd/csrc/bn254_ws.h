@@ -149,6 +149,7 @@ __attribute__((visibility("hidden"))) int bn254_pair_decompress_g2(const uint8_t
 // lines[key][line][coefficient c0 / c1][re / im][limb] (canonical limbs; 12.5 KB per key), its decode status and identity flag
 #define BN_KEY_LINE_WORDS (2 * 2 * BN_LIMBS)
 struct KeyTable { const int32_t* lines; const uint8_t* st; const uint8_t* inf; uint32_t n_keys; };
+__attribute__((visibility("hidden"))) int bn254_lm_miller_verify_keyed(size_t n, Ws ws, const uint32_t* key_idx, KeyTable kt, hipStream_t s);   // bn254_lmiller.hip: the smallest batches
 __attribute__((visibility("hidden"))) int bn254_pair_miller_verify_keyed(size_t n, Ws ws, const uint32_t* key_idx, KeyTable kt, hipStream_t s, size_t base = 0,
                                                                          const uint32_t* map = nullptr, const uint32_t* count = nullptr);
 

@@ -141,6 +141,34 @@ int hp_lm_verify(const uint8_t* h64, const uint8_t* sig64, const uint8_t* pk128)
   if (fp12_is_one(a) != fp12_is_one(g)) return 245;
   return fp12_is_one(g) ? 0 : 9;
 }
+// ... and its KEYED form (k_miller_verify_lmk: the key's lines tabulated, no twist-point wave; lm_miller_keyed_model): 0 / 9, 243 = its Gt
+// value differs from the keyed pair loop's, 249 = the table could not be built (the identity key: the loop then skips pair A anyway)
+int hp_lm_verify_keyed(const uint8_t* h64, const uint8_t* sig64, const uint8_t* pk128) {
+  G1Affine h, sig;
+  G2Affine pk;
+  load_g1(h, h64); load_g1(sig, sig64); load_g2(pk, pk128);
+  static int32_t tab[BN_N_FIXED_LINES][2][2][BN_LIMBS];
+  const bool ok = g2_line_table(pk, [&](int idx, const KeyLine& kl) {
+    const Fp2* c[2] = {&kl.c0, &kl.c1};
+    for (int e = 0; e < 2; ++e)
+      for (int r = 0; r < 2; ++r) { Fp x = fp_canon(c[e]->c[r]); for (int k = 0; k < BN_LIMBS; ++k) tab[idx][e][r][k] = x.v[k]; }
+  });
+  if (!ok) return 249;
+  Fp12 f, g;
+  miller_loop_keyed(f, h, pk.inf, tab, sig);
+  lm_miller_keyed_model(g, h, pk.inf, tab, sig);
+  Fp12 a = g, b = g;
+  fe_machine_check(a);
+  nn_machine_model(b, C_FE_CHECK);
+  if (fp12_is_one(a) != fp12_is_one(b)) return 244;
+  fe_machine_exact(f);
+  fe_machine_exact(g);
+  const Fp2* x[6] = {&f.c0.c0, &f.c0.c1, &f.c0.c2, &f.c1.c0, &f.c1.c1, &f.c1.c2};
+  const Fp2* y[6] = {&g.c0.c0, &g.c0.c1, &g.c0.c2, &g.c1.c0, &g.c1.c1, &g.c1.c2};
+  for (int k = 0; k < 6; ++k) if (!fp2_eq(*x[k], *y[k])) return 243;
+  if (fp12_is_one(a) != fp12_is_one(g)) return 245;
+  return fp12_is_one(g) ? 0 : 9;
+}
 #if defined(BN_TRACK_BOUNDS)
 // What the interval tracker knows about the Miller value a verify hands to its final exponentiation: per coefficient (12, Gt order)
 // {limb lo, limb hi, |top limb| max, value/q lo, value/q hi} — the contract an adversarial-limb test may fill to the brim

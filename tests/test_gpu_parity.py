@@ -1115,7 +1115,7 @@ def test_keyed_verify_vs_oracle(eng, c, derived):
     for j in range(K):
         assert kst[j] == (want_kst[j] if want_kst[j] in (3, 4, 6) else 0), (j, kst[j], want_kst[j])
     assert kst[5] == 4 and kst[6] == 6 and kst[7] == 4 and kst[8] == 0
-    for n in (50, 20011):
+    for n in (50, 4099, 20011):
         msgs = [D("keyed", i) for i in range(n)]
         kidx = [rnd.randrange(K) for _ in range(n)]
         sigs, st = eng.batch_sign(msgs, b"".join(sks[k] for k in kidx))
@@ -1139,6 +1139,18 @@ def test_keyed_verify_vs_oracle(eng, c, derived):
         diff = [(i, got[i], want[i], kidx[i]) for i in range(n) if got[i] != want[i]]
         assert not diff, diff[:10]
         assert n < 1000 or {0, 2, 4, 6, 9} <= set(got)
+        # the smallest batches (<= 1 536) take the KEYED lane machine (k_miller_verify_lmk: the key's line table, no twist-point wave); off: the
+        # keys are expanded and the generic small-batch kernels run; forced on at the larger size too (several passes of 256 workgroups)
+        from bn254_amd.engine import OPT_LM_MAX_BATCH
+        for lim in (0, 1 << 20):
+            eng.set_option(OPT_LM_MAX_BATCH, lim)
+            try:
+                if n <= TRIO_DEFAULT or lim == 0:
+                    got_l = eng.batch_verify_keyed(msgs, bytes(sigs), idx_call)
+                    diff = [(i, got_l[i], want[i], kidx[i]) for i in range(n) if got_l[i] != want[i]]
+                    assert not diff, (lim, diff[:10])
+            finally:
+                eng.set_option(OPT_LM_MAX_BATCH, LM_DEFAULT)
         # the device entry point on the caller's stream
         dev = torch.device("cuda", 0)
         t8 = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)   # noqa: E731

@@ -193,6 +193,22 @@ def test_lane_machine_schedule_matches_generic_loop(pair_lib, derived):
         assert pair_lib.hp_lm_verify(h, bytes(64), bytes(128)) == 0
 
 
+def test_lane_machine_keyed_schedule_matches_keyed_loop(pair_lib, derived):
+    """the KEYED form of the lane machine (k_miller_verify_lmk; registered public keys, include/bn254_hip.h: bn254_batch_verify_keyed for
+    batches <= 1 536): both table lines scaled two steps ahead, their product one step ahead, an addition step in ONE tick — the host
+    emulation gives, under the final exponentiation, the Gt value of the keyed pair loop (miller_loop_keyed) on every verify case and with
+    skipped pairs (identity signature, identity key, both)"""
+    pair_lib.hp_lm_verify_keyed.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p]
+    n = 0
+    for v in derived["verify_cases"]:
+        if v["status"] not in (0, 9):
+            continue
+        st, h, _ = c.hash_to_g1(H(v["message_hex"]))
+        assert pair_lib.hp_lm_verify_keyed(h, H(v["sig"]), H(v["pk"])) == v["status"], v["name"]
+        n += 1
+    assert n >= 10
+
+
 def test_lane_machine_tables_are_well_formed():
     """the level tables of the lane machine, read from the header: within a level no slot is written twice and no product reads a slot that
     a product of the same level writes (the stages publish between fences, so a level's reads see the previous level's values); every
@@ -200,7 +216,7 @@ def test_lane_machine_tables_are_well_formed():
     import re
     text = open(os.path.join(ROOT, "bn254_amd", "csrc", "bn254_lmachine.h")).read()
     tables = re.findall(r"LM_TABLE (LM_\w+)\[(\d+)\]\[9\] = \{(.*?)\};", text, re.S)
-    assert {t[0] for t in tables} == {"LM_T_INIT", "LM_T_DBL", "LM_T_ADD", "LM_L_DBL", "LM_L_ADD", "LM_L_PROD"}
+    assert {t[0] for t in tables} == {"LM_T_INIT", "LM_T_DBL", "LM_T_ADD", "LM_L_DBL", "LM_L_ADD", "LM_L_PROD", "LM_K_EVAL", "LM_K_PROD"}
     for name, nlev, body in tables:
         levels = re.split(r"\},\s*\{", body.strip().strip("{}")) if int(nlev) > 1 else [body]
         assert len(levels) == int(nlev), name
@@ -212,7 +228,7 @@ def test_lane_machine_tables_are_well_formed():
             assert not set(outs) & set(lins), (name, "a product and a linear output share a slot")
             for out, a, b in muls:
                 assert a not in outs and b not in outs, (name, out, "reads a product output of its own level")
-            own = "LS_T" if name.startswith("LM_T") else "LS_L"
+            own = "LS_T" if name.startswith("LM_T") else "LS_L"                     # (the keyed waves LA / LB use wave L's temporaries)
             for o in outs + lins:
                 assert o.startswith(own) or o.startswith("LS_HO") or o.startswith("LS_LP") or (name == "LM_T_INIT" and o in ("LS_Q1X", "LS_Q1Y", "LS_Q2X", "LS_NPKY")), (name, o)
 
@@ -289,6 +305,11 @@ for v in vs:
 assert L.hp_lm_verify(g1, bytes(64), H(d["g2_generator"])) <= 9
 assert L.hp_lm_verify(g1, g1, bytes(128)) <= 9
 assert L.hp_lm_verify(g1, bytes(64), bytes(128)) <= 9
+for v in vs:                                                              # the keyed form: table lines of both pairs, one tick per addition step
+    assert L.hp_lm_verify_keyed(g1, H(v["sig"]), H(v["pk"])) <= 9
+assert L.hp_lm_verify_keyed(g1, bytes(64), H(d["g2_generator"])) <= 9
+assert L.hp_lm_verify_keyed(g1, g1, bytes(128)) <= 9
+assert L.hp_lm_verify_keyed(g1, bytes(64), bytes(128)) <= 9
 print("ok")
 '''
     p = subprocess.run([sys.executable, "-c", drv, ROOT], capture_output=True, text=True, timeout=600)
