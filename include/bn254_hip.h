@@ -140,8 +140,9 @@ int bn254_batch_verify_compressed_device(bn254_ctx *ctx, const uint8_t *d_msgs, 
  * bn254_batch_verify_keyed[_device]: as bn254_batch_verify with key_idx[i] (uint32) in place of the i-th public key.
  * status[i] = the signature's decode error, else 2 (IndexOutOfBounds) if key_idx[i] >= n_keys, else the key's registration
  * status, else what verify gives.  Same result bytes as bn254_batch_verify(flags | BN254_FLAG_G2_SUBGROUP_CHECK) on the
- * expanded keys.  Batches of up to BN254_OPT_TRIO_MAX_BATCH tuples take the small-batch kernels on the expanded keys (latency); the line
- * tables serve the larger ones (throughput). */
+ * expanded keys.  Batches of up to BN254_OPT_LM_MAX_BATCH tuples run the lane machine's keyed form on the line tables (latency: no twist
+ * point to walk), batches of up to BN254_OPT_TRIO_MAX_BATCH the small-batch kernels on the expanded keys; the line tables serve the larger
+ * ones too (throughput). */
 int bn254_ctx_register_keys(bn254_ctx *ctx, const uint8_t *pks /* n_keys*128 */, size_t n_keys, uint32_t flags, uint8_t *key_status /* n_keys or NULL */);
 int bn254_batch_verify_keyed(bn254_ctx *ctx, const uint8_t *msgs, const uint64_t *msg_off /* n+1 */, const uint8_t *sigs /* n*64 */,
                              const uint32_t *key_idx /* n */, size_t n, uint32_t flags, uint8_t *status /* n */);
@@ -287,7 +288,8 @@ int bn254_ctx_set_profiling(bn254_ctx *ctx, int enabled);
                                       multiplication in two rounds; same status bytes.  0 = never (octet layout) */
 #define BN254_OPT_LM_MAX_BATCH 15 /* small batches: up to this many items the Miller loop runs as the LANE MACHINE (nine lane pairs in each of four
                                    waves per item: every product of a dependency level in its own lane pair; twist-point formulas rearranged
-                                   for depth); same status bytes.  0 = never (wave roles / octet layout) */
+                                   for depth; bn254_batch_verify_keyed: its keyed form on the registered keys' line tables); same status
+                                   bytes.  0 = never (wave roles / octet layout) */
 #define BN254_OPT_NONET_WIDE 16 /* ... and, while the batch is at most one item per SIMD (1 024), on EIGHTEEN lane pairs, one item per wave: the 18
                                  products of a multiplication in one round (default 1; 0 = nine lane pairs at every size) */
 #define BN254_OPT_PINNED_STAGING 12 /* bn254_batch_verify (host pointers), batches of >= 8192: T = 1..16 threads copy the caller's (pageable)
