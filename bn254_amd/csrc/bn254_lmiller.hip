@@ -8,8 +8,13 @@
 // are ordered by wavefront-scope fences (a wave's LDS instructions execute in order), between waves by the tick's workgroup barrier, and
 // everything one wave hands another is double-buffered by the parity of the step it belongs to.
 //
-// Proof and parity: the same stage functions and tables run on a host box in tests/hostsim (hp_lm_verify), under the interval tracker too
-// (tests/test_pair_layout.py::test_lane_machine_*); on the device: tests/test_gpu_parity.py (every small-batch test with this layout on).
+// k_miller_verify_lmk is the KEYED form (bn254_batch_verify_keyed: the key's lines come from its table, waves LA / LB instead of T / L, an
+// addition step in one tick).  Measured (profiles/r05_k_lane_machine_wave_shares.jsonl): the loop is bound by the accumulator waves — 2.25 us
+// per Fq12 product, 1.0 of it the product leaf — not by the twist point (197 levels, 0.33 ms alone) or the barriers (0.3 us per tick).
+//
+// Proof and parity: the same stage functions and tables run on a host box in tests/hostsim (hp_lm_verify, hp_lm_verify_keyed), under the
+// interval tracker too (tests/test_pair_layout.py::test_lane_machine_*); on the device: tests/test_gpu_parity.py (every small-batch test with
+// this layout on and off, test_keyed_verify_vs_oracle), tests/soak_gpu.py.
 #include <hip/hip_runtime.h>
 
 #define BN_SPLIT_FP2 1
