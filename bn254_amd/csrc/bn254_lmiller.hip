@@ -239,7 +239,8 @@ KERNEL_LM void k_miller_verify_lm(size_t n, Ws ws, int mode) {
   if (mode == 1) { h.x = fp_load_const(C_G1_GEN[0]); h.y = fp_load_const(C_G1_GEN[1]); h.inf = false; }   // uniform
   else ws_load_g1(ws, PL_P2X, BY_P2_INF, i, h);
   const bool pk_inf = ws_byte(ws, BY_Q_INF, i) != 0;
-  ln.skip_a = h.inf || pk_inf; ln.skip_b = sig.inf;
+  if (mode == 2) h = sig;                                // a single pair e(P1, Q) (bn254_batch_pairing*): the fixed pair is skipped
+  ln.skip_a = h.inf || pk_inf; ln.skip_b = sig.inf || mode == 2;
   if (w == 0) {
     if (ln.writer) { ln.bx.put(ln.bx.slot(LS_ONE), fp2_one()); ln.bx.put(ln.bx.slot(LS_ACC), fp2_one()); ln.bx.put(ln.bx.slot(LS_B3), fp2_load_const(C_TWIST_3B)); }
     // step types: doubling d sits behind the d doublings and the additions before it

@@ -175,33 +175,58 @@ template <bool WIDE> __device__ __forceinline__ void nn_machine(NnDevLane& L, co
   NN_FENCE();
 }
 
-template <bool WIDE> __device__ __forceinline__ void final_exp_nonet_body(size_t n, const Ws& ws, int use_hash, uint8_t* status_out) {
+// 32 big-endian bytes of the canonical value (4-byte aligned destination)
+__device__ __forceinline__ void nn_store_fp_be(uint8_t* b, const Fp& a) {
+  U256 x = fp_to_u256(a);
+  uint32_t* w = (uint32_t*)b;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) w[k] = __builtin_bswap32(x.w[7 - k]);
+}
+// item i: (PRODUCT: the product of the k Miller values at workspace indices i k .. i k + k - 1, then) the final exponentiation — program
+// C_FE_CHECK for a status alone, C_FE_EXACT when canonical Gt bytes are wanted (bn254_batch_pairing*: same contract as k_final_exp_pair)
+template <bool WIDE, bool PRODUCT> __device__ __forceinline__ void final_exp_nonet_body(size_t n, size_t k, const Ws& ws, int use_hash, uint8_t* gt_out, uint8_t* status_out) {
   constexpr unsigned PER_WG = WIDE ? BN_NONET_WG / BN_WAVE : BN_NONET_PER_WG;
   NnDevLane L = nn_lane<WIDE>();
   size_t i = (size_t)blockIdx.x * PER_WG + L.vslot;
   const bool live = L.writer && i < n;
   if (i >= n) i = n - 1;                                 // lanes without a verify of their own follow along on the last one
+  const size_t first = PRODUCT ? i * k : i;
   if (threadIdx.x < 16) nn_lds[NN_ZERO_OFF + threadIdx.x] = 0;
   if (L.publishes_out) {                                 // pair k < 6 brings in coefficient k of the Miller value
-    const Fp c = ws_load_fp(ws, PL_F0 + 2 * (int)L.pair + (int)L.role, i);
+    const Fp c = ws_load_fp(ws, PL_F0 + 2 * (int)L.pair + (int)L.role, first);
 #pragma unroll
     for (int j = 0; j < BN_LIMBS; ++j) nn_lds[L.bx.acc_ + L.pair * BN_LIMBS + j] = c.v[j];
   }
-  uint8_t st = ws_byte(ws, BY_ST_DECODE, i);
+  uint8_t st = ws_byte(ws, BY_ST_DECODE, first);
   if (st == ST_OK && use_hash) st = ws_byte(ws, BY_ST_HASH, i);
   __syncthreads();                                       // the zero block, the accumulators
-  nn_machine<WIDE>(L, C_FE_CHECK);
+  if (PRODUCT) {
+    for (size_t j = 1; j < k; ++j) {                     // the other Miller values of the item through slot 0 (every program stores a slot before it reads it)
+      if (L.publishes_out) {
+        const Fp c = ws_load_fp(ws, PL_F0 + 2 * (int)L.pair + (int)L.role, first + j);
+#pragma unroll
+        for (int q = 0; q < BN_LIMBS; ++q) nn_lds[L.bx.file_ + L.pair * BN_LIMBS + q] = c.v[q];
+      }
+      NN_FENCE();
+      nn_mul<WIDE>(L, L.bx.file_);
+      const uint8_t sj = ws_byte(ws, BY_ST_DECODE, first + j);
+      if (st == ST_OK) st = sj;
+    }
+  }
+  nn_machine<WIDE>(L, (PRODUCT && gt_out) ? C_FE_EXACT : C_FE_CHECK);
   Fp12 f;
   {
     Fp2* c[6] = {&f.c0.c0, &f.c0.c1, &f.c0.c2, &f.c1.c0, &f.c1.c1, &f.c1.c2};
 #pragma unroll
-    for (int k = 0; k < 6; ++k) *c[k] = L.bx.get(L.bx.acc_ + k * BN_LIMBS);
+    for (int q = 0; q < 6; ++q) *c[q] = L.bx.get(L.bx.acc_ + q * BN_LIMBS);
   }
+  if (PRODUCT && gt_out && live && L.publishes_out) nn_store_fp_be(gt_out + 384 * i + 64 * L.pair + 32 * L.role, L.bx.get(L.bx.acc_ + L.pair * BN_LIMBS).c[0]);
   const bool one = fp12_is_one(f);                       // combined over the pair
-  if (live && L.pair == 0 && L.role == 0) status_out[i] = st != ST_OK ? st : (one ? (uint8_t)ST_OK : (uint8_t)ST_VERIFICATION_FAILED);
+  if (status_out && live && L.pair == 0 && L.role == 0) status_out[i] = st != ST_OK ? st : (one ? (uint8_t)ST_OK : (uint8_t)ST_VERIFICATION_FAILED);
 }
-KERNEL_NONET void k_final_exp_nonet(size_t n, Ws ws, int use_hash, uint8_t* status_out) { final_exp_nonet_body<false>(n, ws, use_hash, status_out); }
-KERNEL_NONET void k_final_exp_nonet_wide(size_t n, Ws ws, int use_hash, uint8_t* status_out) { final_exp_nonet_body<true>(n, ws, use_hash, status_out); }
+KERNEL_NONET void k_final_exp_nonet(size_t n, Ws ws, int use_hash, uint8_t* status_out) { final_exp_nonet_body<false, false>(n, 1, ws, use_hash, nullptr, status_out); }
+KERNEL_NONET void k_final_exp_nonet_wide(size_t n, Ws ws, int use_hash, uint8_t* status_out) { final_exp_nonet_body<true, false>(n, 1, ws, use_hash, nullptr, status_out); }
+KERNEL_NONET void k_final_exp_nonet_product(size_t n, size_t k, Ws ws, uint8_t* gt_out, uint8_t* status_out) { final_exp_nonet_body<true, true>(n, k, ws, 0, gt_out, status_out); }
 
 bool bn254_nonet_fits_device() {
   int blocks = 0;
@@ -218,6 +243,13 @@ int bn254_nonet_final_exp(size_t n, Ws ws, int use_hash, uint8_t* status_out, hi
     const unsigned grid = (unsigned)((n + BN_NONET_PER_WG - 1) / BN_NONET_PER_WG);
     k_final_exp_nonet<<<grid, BN_NONET_WG, NN_LDS_WORDS * sizeof(int32_t), s>>>(n, ws, use_hash, status_out);
   }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+// bn254_batch_pairing* for small batches: items of k pairs each, eighteen lane pairs per item (n <= NONET_WIDE_MAX_BATCH)
+int bn254_nonet_final_exp_product(size_t n, size_t k, Ws ws, uint8_t* gt_out, uint8_t* status_out, hipStream_t s) {
+  const unsigned per_wg = BN_NONET_WG / BN_WAVE;
+  k_final_exp_nonet_product<<<(unsigned)((n + per_wg - 1) / per_wg), BN_NONET_WG, NN_LDS_WORDS * sizeof(int32_t), s>>>(n, k, ws, gt_out, status_out);
   HIP_TRY(hipGetLastError());
   return 0;
 }

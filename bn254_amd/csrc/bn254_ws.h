@@ -169,3 +169,4 @@ __attribute__((visibility("hidden"))) int bn254_lm_miller_verify(size_t n, Ws ws
 // entry points of bn254_nonet.hip (final exponentiation of the smallest batches on nine lane pairs per verify)
 __attribute__((visibility("hidden"))) bool bn254_nonet_fits_device();
 __attribute__((visibility("hidden"))) int bn254_nonet_final_exp(size_t n, Ws ws, int use_hash, uint8_t* status_out, hipStream_t s, int wide = 0);
+__attribute__((visibility("hidden"))) int bn254_nonet_final_exp_product(size_t n, size_t k, Ws ws, uint8_t* gt_out, uint8_t* status_out, hipStream_t s);   // bn254_batch_pairing*, n <= NONET_WIDE_MAX_BATCH

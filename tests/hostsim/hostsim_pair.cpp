@@ -306,6 +306,20 @@ void hp_pairing(const uint8_t* g1, const uint8_t* g2, uint8_t* gt384) {
   for (int k = 0; k < 6; ++k) { fp_to_be32(gt384 + 64 * k, c[k]->c[0]); fp_to_be32(gt384 + 64 * k + 32, c[k]->c[1]); }
 }
 // two variable pairs sharing f (k_miller_rand2_pair), product of two such values (the LDS tree), final exponentiation
+// ... and as the small-batch kernels compute it (bn254_batch_pairing* for batches that cannot fill the chip): the lane machine's schedule with
+// the fixed pair skipped (lm_miller_model, pb = identity), then program C_FE_EXACT in the nonet schedule; under -DBN_TRACK_BOUNDS the bound
+// proof of that flow.  The caller compares the bytes with hp_pairing's.
+void hp_pairing_small_batch(const uint8_t* g1, const uint8_t* g2, uint8_t* gt384) {
+  G1Affine p, none;
+  G2Affine q;
+  load_g1(p, g1); load_g2(q, g2);
+  none = p; none.inf = true;
+  Fp12 f;
+  lm_miller_model(f, p, q, none);
+  nn_machine_model(f, C_FE_EXACT);
+  const Fp2* c[6] = {&f.c0.c0, &f.c0.c1, &f.c0.c2, &f.c1.c0, &f.c1.c1, &f.c1.c2};
+  for (int k = 0; k < 6; ++k) { fp_to_be32(gt384 + 64 * k, c[k]->c[0]); fp_to_be32(gt384 + 64 * k + 32, c[k]->c[1]); }
+}
 void hp_pairing_product4(const uint8_t* g1x4, const uint8_t* g2x4, uint8_t* gt384) {
   G1Affine p[4];
   G2Affine q[4];

@@ -582,6 +582,49 @@ def test_pairing_check_k_pairs(eng, c):
     assert gt == c.pairing(g1[128:320], g2[256:640], k=3)
 
 
+def test_pairing_small_batches_take_the_small_batch_kernels(eng, c, derived):
+    """bn254_batch_pairing / _check for batches that cannot fill the chip (n k <= 1 536 pairs, n <= 1 024 items): the lane machine with the
+    fixed pair skipped + the final exponentiation (exact program) on eighteen lane pairs — canonical Gt bytes and statuses equal the
+    lane-pair path's (BN254_OPT_LM_MAX_BATCH = 0) and the oracle's, for k = 1, 2, 3 pairs per item, sizes that are no multiples of the
+    kernels' 3 / 4 items per workgroup, identity operands (the pair contributes one), an undecodable point (its status, Gt untouched
+    semantics as on lane pairs), and on both sides of the routing limits"""
+    from bn254_amd.engine import OPT_LM_MAX_BATCH
+    ps, qs = _rand_points(c, 23, b"sbp")
+    neg = lambda p: p[:32] + ((Q - int.from_bytes(p[32:], "big")) % Q).to_bytes(32, "big")   # noqa: E731
+    for n, k in ((1, 1), (7, 1), (5, 2), (3, 3), (23, 1), (11, 2)):
+        g1 = bytearray(b"".join(ps[(i * 3 + j) % 23] for i in range(n) for j in range(k)))
+        g2 = bytearray(b"".join(qs[(i * 5 + 2 * j) % 23] for i in range(n) for j in range(k)))
+        if n >= 5:
+            g1[64 * (2 * k):64 * (2 * k) + 64] = bytes(64)                     # identity G1 operand in item 2
+            g2[128 * (3 * k):128 * (3 * k) + 128] = bytes(128)                 # identity G2 operand in item 3
+            g1[64 * (4 * k) + 63] ^= 1                                         # off-curve point in item 4 -> its status
+        if k == 2 and n >= 2:                                                   # item 1: e(P, Q) e(-P, Q) = 1
+            g1[64 * 2:64 * 4] = ps[0] + neg(ps[0]); g2[128 * 2:128 * 4] = qs[0] + qs[0]
+        g1, g2 = bytes(g1), bytes(g2)
+        eng.set_option(OPT_LM_MAX_BATCH, 0)
+        try:
+            gt_pair, st_pair = eng.batch_pairing(g1, g2, n, k)
+            ck_pair = eng.batch_pairing_check(g1, g2, n, k)
+        finally:
+            eng.set_option(OPT_LM_MAX_BATCH, LM_DEFAULT)
+        gt, st = eng.batch_pairing(g1, g2, n, k)
+        assert st == st_pair and eng.batch_pairing_check(g1, g2, n, k) == ck_pair == st, (n, k, st, st_pair)
+        for i in range(n):
+            if st[i] in (0, 9):
+                assert gt[384 * i:384 * i + 384] == gt_pair[384 * i:384 * i + 384], (n, k, i)
+                assert gt[384 * i:384 * i + 384] == c.pairing(g1[64 * k * i:64 * k * (i + 1)], g2[128 * k * i:128 * k * (i + 1)], k=k), (n, k, i)
+        if n >= 5:
+            assert st[4] == 4 and gt[384 * 2:384 * 3] == gt_pair[384 * 2:384 * 3]
+        if k == 2 and n >= 2:
+            assert st[1] == 0 and gt[384:768].hex() == derived["gt_one"]
+    # the routing limits: 1 024 items of one pair (small-batch kernels) and 1 025 (lane pairs) give the same bytes on the common prefix
+    n = 1025
+    g1 = b"".join(ps[i % 23] for i in range(n)); g2 = b"".join(qs[(7 * i) % 23] for i in range(n))
+    gt_a, st_a = eng.batch_pairing(g1[:64 * 1024], g2[:128 * 1024], 1024)
+    gt_b, st_b = eng.batch_pairing(g1, g2, n)
+    assert gt_a == gt_b[:384 * 1024] and st_a == st_b[:1024]
+
+
 def test_group_ops_vs_oracle(eng, c):
     ps, qs = _rand_points(c, 40, b"grp")
     n = 40

@@ -209,6 +209,23 @@ def test_lane_machine_keyed_schedule_matches_keyed_loop(pair_lib, derived):
     assert n >= 10
 
 
+def test_small_batch_pairing_schedule_gives_the_pairing(pair_lib, derived):
+    """bn254_batch_pairing* for batches that cannot fill the chip (include/bn254_hip.h; the reference's pairing(), /root/reference/src/lib.rs
+    re-export of bn::pairing): the lane machine's schedule with the fixed pair skipped, then the EXACT final-exponentiation program in the
+    nonet schedule — canonical Gt bytes equal the fixtures' (independent big-integer model) and the lane-pair path's, identity operands
+    give one"""
+    for v in derived["pairing_gt"]:
+        o = ctypes.create_string_buffer(384)
+        pair_lib.hp_pairing_small_batch(H(v["g1"]), H(v["g2"]), o)
+        assert o.raw.hex() == v["gt"]
+    g1, g2 = c.g1_generator(), c.g2_generator()
+    a, b = ctypes.create_string_buffer(384), ctypes.create_string_buffer(384)
+    for p1, q2 in ((c.g1_mul(g1, (77).to_bytes(32, "big")), c.g2_mul(g2, (91).to_bytes(32, "big"))), (bytes(64), g2), (g1, bytes(128))):
+        pair_lib.hp_pairing(p1, q2, a)
+        pair_lib.hp_pairing_small_batch(p1, q2, b)
+        assert a.raw == b.raw
+
+
 def test_lane_machine_tables_are_well_formed():
     """the level tables of the lane machine, read from the header: within a level no slot is written twice and no product reads a slot that
     a product of the same level writes (the stages publish between fences, so a level's reads see the previous level's values); every
@@ -310,6 +327,8 @@ for v in vs:                                                              # the 
 assert L.hp_lm_verify_keyed(g1, bytes(64), H(d["g2_generator"])) <= 9
 assert L.hp_lm_verify_keyed(g1, g1, bytes(128)) <= 9
 assert L.hp_lm_verify_keyed(g1, bytes(64), bytes(128)) <= 9
+o = ctypes.create_string_buffer(384)                                       # one pairing: fixed pair skipped, EXACT program in the nonet schedule
+v = d["pairing_gt"][1]; L.hp_pairing_small_batch(H(v["g1"]), H(v["g2"]), o); assert o.raw.hex() == v["gt"]
 print("ok")
 '''
     p = subprocess.run([sys.executable, "-c", drv, ROOT], capture_output=True, text=True, timeout=600)
