@@ -151,14 +151,19 @@ def soak(args):
             for b in want:
                 codes[b] = codes.get(b, 0) + 1
         if rounds % 8 == 0:
-            # pairing API (canonical Gt bytes) and check_public_keys on lane pairs vs the oracle
+            # pairing API (canonical Gt bytes; both kernel families) and check_public_keys vs the oracle
             m = 24
             ks = [rnd.randrange(1, 1 << 250).to_bytes(32, "big") for _ in range(2 * m)]
             g1 = (1).to_bytes(32, "big") + (2).to_bytes(32, "big")
             ps, st1 = eng.batch_g1_mul(g1 * m, b"".join(ks[:m]), m)
             qs, st2 = eng.batch_g2_mul(None, b"".join(ks[m:]), m)
             assert st1 == bytes(m) and st2 == bytes(m)
-            gt, stg = eng.batch_pairing(ps, qs, m, 1)
+            gt, stg = eng.batch_pairing(ps, qs, m, 1)          # a small batch: the small-batch kernels (lane machine, eighteen lane pairs) ...
+            eng.set_option(OPT_LM_MAX_BATCH, 0)
+            gt_lp, stg_lp = eng.batch_pairing(ps, qs, m, 1)    # ... and the lane-pair kernels
+            eng.set_option(OPT_LM_MAX_BATCH, ws_default("LM_MAX_BATCH_DEFAULT"))
+            if gt != gt_lp or stg != stg_lp:
+                raise SoakMismatch("MISMATCH pairing small-batch kernels vs lane pairs round %d" % rounds)
             for j in range(m):
                 want_gt = c.pairing(ps[64 * j:64 * j + 64], qs[128 * j:128 * j + 128])
                 if gt[384 * j:384 * j + 384] != want_gt:
