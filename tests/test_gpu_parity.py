@@ -676,6 +676,15 @@ def test_aggregate_verify_vs_oracle(eng, c):
     tuples = [(0, [0]), (1, list(range(S))), (2, [1, 3, 5, 7]), (0, []), (1, [4, 4]), (2, [8, 0, 2]), (0, [2, 99]), (1, [6])]
     tuples += [(m % M, [s for s in range(S) if (m * 37 + s * 11) % 3]) for m in range(70)]
     got = eng.batch_aggregate_verify(msgs, pk_pool, sig_pool, [t[0] for t in tuples], [t[1] for t in tuples])
+    # 78 tuples: the pairing part runs on the small-batch kernels (lane machine, eighteen lane pairs); the same bytes from the eight wave roles
+    # (lane machine off) and from the lane-pair kernels (small-batch kernels off)
+    from bn254_amd.engine import OPT_LM_MAX_BATCH, OPT_TRIO_MAX_BATCH
+    for opt, off, dflt in ((OPT_LM_MAX_BATCH, 0, LM_DEFAULT), (OPT_TRIO_MAX_BATCH, 0, TRIO_DEFAULT)):
+        eng.set_option(opt, off)
+        try:
+            assert eng.batch_aggregate_verify(msgs, pk_pool, sig_pool, [t[0] for t in tuples], [t[1] for t in tuples]) == got
+        finally:
+            eng.set_option(opt, dflt)
     for i, (m, lst) in enumerate(tuples):
         if any(s >= S for s in lst):
             assert got[i] == 2
