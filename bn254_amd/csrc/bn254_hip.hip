@@ -458,7 +458,14 @@ int pool_reserve(bn254_ctx* c, int which, size_t n_fp, size_t entries) {
 
 // G2 decoding: with the subgroup test requested (one 63-bit ladder on the twist per point) it runs on lane pairs
 int launch_decode_g2(bn254_ctx* c, hipStream_t s, const uint8_t* d_pts, size_t n, uint32_t flags, int accumulate) {
-  if (c->pair_lanes && (flags & FLAG_G2_SUBGROUP_CHECK)) return bn254_pair_decode_g2(d_pts, n, flags, c->ws, accumulate, s);
+  if (c->pair_lanes && (flags & FLAG_G2_SUBGROUP_CHECK)) {
+    if (c->lm_max_batch > 0 && n <= (size_t)c->lm_max_batch) {
+      // the smallest batches: decode without the test, then the test with its ladder in the lane machine's level tables
+      k_decode_g2<<<grid_for(n), BN_WAVE, 0, s>>>(d_pts, n, flags & ~(uint32_t)FLAG_G2_SUBGROUP_CHECK, c->ws, accumulate);
+      return bn254_lm_g2_subgroup(n, c->ws, s);
+    }
+    return bn254_pair_decode_g2(d_pts, n, flags, c->ws, accumulate, s);
+  }
   k_decode_g2<<<grid_for(n), BN_WAVE, 0, s>>>(d_pts, n, flags, c->ws, accumulate);
   return 0;
 }

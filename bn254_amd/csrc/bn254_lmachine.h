@@ -344,4 +344,40 @@ inline void lm_miller_keyed_model(Fp12& f, const G1Affine& pa, bool key_inf, con
 }
 #endif
 
+// ---- the G2 subgroup test of a decode (bn254_curve.h: g2_in_subgroup; what AffineG2::new enforces, /root/reference/src/utils.rs:113) with
+// its ladder [u]P in wave T's level tables (k_g2_subgroup_lm): 62 doublings of two levels, 22 additions of three, then the tail of the
+// test in ordinary pair-layout code on the Jacobian form of the result.  The addition formulas are the incomplete ones of the Miller loop: they
+// degenerate exactly when the running point meets +-P, i.e. when [k]P = +-P for some 1 < k < u — impossible for a point of order r (k +- 1
+// < r is no multiple of r), so P is then outside the subgroup; a degenerate step leaves Z = 0 (T = -P: (0, Y, 0); T = P: (0, 0, 0)), Z = 0
+// survives every later level, and the tail answers "outside" for [u]P = identity and P != identity: the verdict is right on every input.
+template <class Box> BN_DEV void lm_subgroup_init(Box& bx, const G2Affine& p) {
+  bx.put(bx.slot(LS_ONE), fp2_one()); bx.put(bx.slot(LS_B3), fp2_load_const(C_TWIST_3B));
+  bx.put(bx.slot(LS_PKX), p.x); bx.put(bx.slot(LS_PKY), p.y); bx.put(bx.slot(LS_NPKY), fp2_neg(p.y));
+  bx.put(bx.slot(LS_TX), p.x); bx.put(bx.slot(LS_TY), p.y); bx.put(bx.slot(LS_TZ), fp2_one()); bx.put(bx.slot(LS_TW), fp2_load_const(C_TWIST_3B));
+}
+// the verdict from the ladder's result (projective x = X / Z, y = Y / Z -> Jacobian (X Z, Y Z^2, Z))
+BN_DEV bool lm_subgroup_verdict(const G2Affine& p, const Fp2& X, const Fp2& Y, const Fp2& Z) {
+  G2Jac up;
+  const Fp2 z2 = fp2_sqr(Z);
+  up.x = fp2_mul(X, Z); up.y = fp2_mul(Y, z2); up.z = Z;
+  return g2_in_subgroup_tail(p, up);
+}
+#if !defined(__HIPCC__)
+inline bool lm_g2_subgroup_model(const G2Affine& p) {
+  static LmHostBox bx;
+  for (int i = 0; i < LS_COUNT; ++i) bx.s[i] = fp2_zero();
+  lm_subgroup_init(bx, p);
+  for (int i = 0; i < BN_U_NAF_LEN; ++i) {
+    lm_host_level(bx, LM_T_DBL[0], 0, false, false);
+    lm_host_level(bx, LM_T_DBL[1], 0, false, false);
+    const int d = C_U_NAF[i];
+    if (d != 0) {
+      bx.s[LS_TQX] = bx.s[LS_PKX]; bx.s[LS_TQY] = bx.s[d > 0 ? LS_PKY : LS_NPKY];
+      for (int l = 0; l < 3; ++l) lm_host_level(bx, LM_T_ADD[l], 0, false, false);
+    }
+  }
+  return lm_subgroup_verdict(p, bx.s[LS_TX], bx.s[LS_TY], bx.s[LS_TZ]);
+}
+#endif
+
 }  // namespace bn254

@@ -379,6 +379,62 @@ int bn254_lm_miller_verify_keyed(size_t n, Ws ws, const uint32_t* key_idx, KeyTa
   return 0;
 }
 
+// ---- the G2 subgroup test of a decode for the smallest batches (flag bit 0; bn254_curve.h: g2_in_subgroup — [u + 1]P + psi([u]P) +
+// psi^2([u]P) == psi^3([2u]P)): its ladder [u]P runs wave T's level tables — 62 doublings of two levels, 22 additions of three, 0.66 ->
+// 0.4 ms for one point — in ONE wave per three points (no other wave to meet: fences only); the tail of the test is the lane-pair code.
+// Why the incomplete additions cannot give a wrong verdict: bn254_lmachine.h (lm_g2_subgroup_model).  Reads the point k_decode_g2 left in the
+// Q planes; a point outside the subgroup gets the decoder's status and is replaced by the generator, as in k_decode_g2_pair.
+#define KERNEL_LMS __global__ __launch_bounds__(BN_WAVE) __attribute__((amdgpu_waves_per_eu(1, 2)))
+KERNEL_LMS void k_g2_subgroup_lm(size_t n, Ws ws) {
+  const unsigned l = threadIdx.x & (BN_WAVE - 1);
+  const unsigned v = l / BN_LM_LANES;
+  LmLane ln;
+  ln.writer = v < BN_LM_PER_WG;
+  const unsigned vslot = ln.writer ? v : BN_LM_PER_WG - 1;
+  ln.pair = (l % BN_LM_LANES) >> 1;
+  ln.skip_a = false; ln.skip_b = false;
+  const unsigned role = l & 1u;
+  size_t i = (size_t)blockIdx.x * BN_LM_PER_WG + vslot;
+  const bool live = ln.writer && i < n;
+  if (i >= n) i = n - 1;
+  ln.bx.base = vslot * LM_VERIFY_STRIDE + role * LM_ROLE_STRIDE;
+  for (unsigned k = threadIdx.x; k < LM_LDS_WORDS; k += BN_WAVE) lm_lds[k] = 0;
+  __syncthreads();
+  G2Affine q;
+  q.x.c[0] = ws_load_fp(ws, PL_QX0 + (int)role, i); q.y.c[0] = ws_load_fp(ws, PL_QY0 + (int)role, i);
+  q.inf = ws_byte(ws, BY_Q_INF, i) != 0;
+  if (ln.writer) lm_subgroup_init(ln.bx, q);             // identical words from every pair of the point
+  LM_FENCE();
+  const LmEntry e_d0 = lm_load_entry(LM_T_DBL[0], ln.pair), e_d1 = lm_load_entry(LM_T_DBL[1], ln.pair);
+  const LmEntry e_a0 = lm_load_entry(LM_T_ADD[0], ln.pair), e_a1 = lm_load_entry(LM_T_ADD[1], ln.pair), e_a2 = lm_load_entry(LM_T_ADD[2], ln.pair);
+#pragma clang loop unroll(disable)
+  for (int k = 0; k < BN_U_NAF_LEN; ++k) {
+    lm_level(ln, e_d0, 0);
+    lm_level(ln, e_d1, 0);
+    const int d = C_U_NAF[k];                              // wave-uniform: u is a public constant
+    if (d != 0) {
+      lm_copy(ln, LS_TQX, LS_PKX); lm_copy(ln, LS_TQY, d > 0 ? (unsigned)LS_PKY : (unsigned)LS_NPKY);
+      LM_FENCE();
+      lm_level(ln, e_a0, 0);
+      lm_level(ln, e_a1, 0);
+      lm_level(ln, e_a2, 0);
+    }
+  }
+  const bool in = lm_subgroup_verdict(q, ln.bx.get(ln.bx.slot(LS_TX)), ln.bx.get(ln.bx.slot(LS_TY)), ln.bx.get(ln.bx.slot(LS_TZ)));
+  if (!live || ln.pair != 0 || in) return;
+  ws_store_fp(ws, PL_QX0 + (int)role, i, fp2_load_const(C_G2_GEN[0]).c[0]);
+  ws_store_fp(ws, PL_QY0 + (int)role, i, fp2_load_const(C_G2_GEN[1]).c[0]);
+  if (role == 0) {
+    ws_byte(ws, BY_Q_INF, i) = 0;
+    if (ws_byte(ws, BY_ST_DECODE, i) == ST_OK) ws_byte(ws, BY_ST_DECODE, i) = ST_INVALID_GROUP_POINT;
+  }
+}
+int bn254_lm_g2_subgroup(size_t n, Ws ws, hipStream_t s) {
+  k_g2_subgroup_lm<<<(unsigned)((n + BN_LM_PER_WG - 1) / BN_LM_PER_WG), BN_WAVE, LM_LDS_WORDS * sizeof(int32_t), s>>>(n, ws);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 bool bn254_lm_fits_device() {
   int blocks = 0;
   hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_miller_verify_lm, BN_LM_WG, LM_LDS_WORDS * sizeof(int32_t));

@@ -166,6 +166,7 @@ __attribute__((visibility("hidden"))) int bn254_trio_final_exp(size_t n, Ws ws, 
 // entry points of bn254_lmiller.hip (Miller loop of the smallest batches as the lane machine: nine lane pairs in each of four waves per verify)
 __attribute__((visibility("hidden"))) bool bn254_lm_fits_device();
 __attribute__((visibility("hidden"))) int bn254_lm_miller_verify(size_t n, Ws ws, hipStream_t s, int mode = 0);
+__attribute__((visibility("hidden"))) int bn254_lm_g2_subgroup(size_t n, Ws ws, hipStream_t s);   // the G2 subgroup test of points already decoded into the Q planes
 // entry points of bn254_nonet.hip (final exponentiation of the smallest batches on nine lane pairs per verify)
 __attribute__((visibility("hidden"))) bool bn254_nonet_fits_device();
 __attribute__((visibility("hidden"))) int bn254_nonet_final_exp(size_t n, Ws ws, int use_hash, uint8_t* status_out, hipStream_t s, int wide = 0);

@@ -306,6 +306,13 @@ void hp_pairing(const uint8_t* g1, const uint8_t* g2, uint8_t* gt384) {
   for (int k = 0; k < 6; ++k) { fp_to_be32(gt384 + 64 * k, c[k]->c[0]); fp_to_be32(gt384 + 64 * k + 32, c[k]->c[1]); }
 }
 // two variable pairs sharing f (k_miller_rand2_pair), product of two such values (the LDS tree), final exponentiation
+// the G2 subgroup test with its ladder in the lane machine's level tables (k_g2_subgroup_lm; bn254_lmachine.h: lm_g2_subgroup_model) beside
+// the lane-pair form (g2_in_subgroup): returns both verdicts as bits 0 (machine) and 1 (lane pairs); the input must be on the twist
+int hp_g2_subgroup_both(const uint8_t* pk128) {
+  G2Affine q;
+  load_g2(q, pk128);
+  return (lm_g2_subgroup_model(q) ? 1 : 0) | (g2_in_subgroup(q) ? 2 : 0);
+}
 // ... and as the small-batch kernels compute it (bn254_batch_pairing* for batches that cannot fill the chip): the lane machine's schedule with
 // the fixed pair skipped (lm_miller_model, pb = identity), then program C_FE_EXACT in the nonet schedule; under -DBN_TRACK_BOUNDS the bound
 // proof of that flow.  The caller compares the bytes with hp_pairing's.

@@ -462,7 +462,8 @@ def test_octet_and_pair_layouts_agree_with_oracle(eng, c, derived, kats):
             sigs[64 * 8 + 40] ^= 2                            # off-curve y
         if n >= 65:
             sigs[64 * 20:64 * 20 + 32] = b"\xff" * 32          # x >= q
-            pks = bytearray(pks); pks[128 * 11:128 * 12] = bytes(128); pks[128 * 13 + 3] ^= 1; pks = bytes(pks)   # identity / off-twist keys
+            pks = bytearray(pks); pks[128 * 11:128 * 12] = bytes(128); pks[128 * 13 + 3] ^= 1                        # identity / off-twist keys
+            pks[128 * 17:128 * 18] = H(derived["g2_not_in_subgroup"]); pks = bytes(pks)                              # on the twist, outside the order-r subgroup (flag bit 0: status 4)
         sigs = bytes(sigs)
         oracle, _ = c.batch_verify(msgs, sigs, pks, flags=1, nthreads=8)
         batches.append((msgs, sigs, pks, oracle))

@@ -226,6 +226,39 @@ def test_small_batch_pairing_schedule_gives_the_pairing(pair_lib, derived):
         assert a.raw == b.raw
 
 
+def test_lane_machine_subgroup_ladder_agrees_with_lane_pairs(pair_lib, derived):
+    """the G2 subgroup test of a decode (AffineG2::new, /root/reference/src/utils.rs:113) with its ladder [u]P in the lane machine's level
+    tables (k_g2_subgroup_lm, batches <= 1 536) gives the lane-pair form's verdict — and the definition's ([r]P == O, big-integer model) —
+    on points of G2, on random twist points outside it, on their cofactor-cleared and mixed forms, on a point of the twist's small
+    order 10 069 (2q - r = 10 069 x a 241-bit number), and on the identity"""
+    import random
+    from oracle import bn254_model as m
+    rnd = random.Random(77)
+
+    def enc(p):
+        return b"".join(v.to_bytes(32, "big") for v in (p[0][0], p[0][1], p[1][0], p[1][1]))
+    pts = [(m.g2_mul(m.G2_GEN, rnd.randrange(1, m.R)), True) for _ in range(2)]
+    n = 0
+    while n < 3:
+        x = (rnd.randrange(m.Q), rnd.randrange(m.Q))
+        y = m.f2_sqrt(m.f2_add(m.f2_mul(m.f2_mul(x, x), x), m.B2))
+        if y is None:
+            continue
+        n += 1
+        p = (x, y)
+        cleared = m.g2_mul(p, 2 * m.Q - m.R)
+        pts += [(p, m.g2_in_subgroup(p)), (cleared, True), (m.g2_add(cleared, m.g2_mul(p, m.R)), False)]
+        small = m.g2_mul(p, (2 * m.Q - m.R) // 10069 * m.R)
+        if small is not None:
+            assert m.g2_mul(small, 10069) is None
+            pts.append((small, False))
+    assert any(not w for _, w in pts) and len(pts) >= 12
+    for p, want in pts:
+        assert pair_lib.hp_g2_subgroup_both(enc(p)) == (3 if want else 0), want
+    assert pair_lib.hp_g2_subgroup_both(H(derived["g2_not_in_subgroup"])) == 0
+    assert pair_lib.hp_g2_subgroup_both(bytes(128)) == 3
+
+
 def test_lane_machine_tables_are_well_formed():
     """the level tables of the lane machine, read from the header: within a level no slot is written twice and no product reads a slot that
     a product of the same level writes (the stages publish between fences, so a level's reads see the previous level's values); every
@@ -329,6 +362,7 @@ assert L.hp_lm_verify_keyed(g1, g1, bytes(128)) <= 9
 assert L.hp_lm_verify_keyed(g1, bytes(64), bytes(128)) <= 9
 o = ctypes.create_string_buffer(384)                                       # one pairing: fixed pair skipped, EXACT program in the nonet schedule
 v = d["pairing_gt"][1]; L.hp_pairing_small_batch(H(v["g1"]), H(v["g2"]), o); assert o.raw.hex() == v["gt"]
+assert L.hp_g2_subgroup_both(H(d["g2_generator"])) == 3 and L.hp_g2_subgroup_both(H(d["g2_not_in_subgroup"])) == 0 and L.hp_g2_subgroup_both(bytes(128)) == 3   # the subgroup ladder in wave T's tables
 print("ok")
 '''
     p = subprocess.run([sys.executable, "-c", drv, ROOT], capture_output=True, text=True, timeout=600)
