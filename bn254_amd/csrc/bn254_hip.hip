@@ -809,7 +809,11 @@ int bn254_batch_verify_compressed_device(bn254_ctx* c, const uint8_t* d_msgs, co
   c->last_stream = s;
   PROF_MARK(0);
   k_decompress_g1_ws<<<grid_for(n), BN_WAVE, 0, s>>>(d_sigs33, n, c->ws);
-  if (c->pair_lanes) { if ((rc = bn254_pair_decompress_g2(d_pks65, n, c->ws, s))) return rc; }
+  if (c->pair_lanes && c->lm_max_batch > 0 && n <= (size_t)c->lm_max_batch) {
+    // the smallest batches: the subgroup test of the decompressed keys with its ladder in the lane machine's level tables
+    if ((rc = bn254_pair_decompress_g2(d_pks65, n, c->ws, s, 1))) return rc;
+    if ((rc = bn254_lm_g2_subgroup(n, c->ws, s, ST_NOT_MEMBER))) return rc;
+  } else if (c->pair_lanes) { if ((rc = bn254_pair_decompress_g2(d_pks65, n, c->ws, s))) return rc; }
   else k_decompress_g2_ws<<<grid_for(n), BN_WAVE, 0, s>>>(d_pks65, n, c->ws);
   return verify_after_decode(c, s, d_msgs, d_off, n, d_status, false);
 }

@@ -385,7 +385,7 @@ int bn254_lm_miller_verify_keyed(size_t n, Ws ws, const uint32_t* key_idx, KeyTa
 // Why the incomplete additions cannot give a wrong verdict: bn254_lmachine.h (lm_g2_subgroup_model).  Reads the point k_decode_g2 left in the
 // Q planes; a point outside the subgroup gets the decoder's status and is replaced by the generator, as in k_decode_g2_pair.
 #define KERNEL_LMS __global__ __launch_bounds__(BN_WAVE) __attribute__((amdgpu_waves_per_eu(1, 2)))
-KERNEL_LMS void k_g2_subgroup_lm(size_t n, Ws ws) {
+KERNEL_LMS void k_g2_subgroup_lm(size_t n, Ws ws, int fail_status) {
   const unsigned l = threadIdx.x & (BN_WAVE - 1);
   const unsigned v = l / BN_LM_LANES;
   LmLane ln;
@@ -426,11 +426,11 @@ KERNEL_LMS void k_g2_subgroup_lm(size_t n, Ws ws) {
   ws_store_fp(ws, PL_QY0 + (int)role, i, fp2_load_const(C_G2_GEN[1]).c[0]);
   if (role == 0) {
     ws_byte(ws, BY_Q_INF, i) = 0;
-    if (ws_byte(ws, BY_ST_DECODE, i) == ST_OK) ws_byte(ws, BY_ST_DECODE, i) = ST_INVALID_GROUP_POINT;
+    if (ws_byte(ws, BY_ST_DECODE, i) == ST_OK) ws_byte(ws, BY_ST_DECODE, i) = (uint8_t)fail_status;   // uncompressed decode: InvalidGroupPoint; compressed: NotMember
   }
 }
-int bn254_lm_g2_subgroup(size_t n, Ws ws, hipStream_t s) {
-  k_g2_subgroup_lm<<<(unsigned)((n + BN_LM_PER_WG - 1) / BN_LM_PER_WG), BN_WAVE, LM_LDS_WORDS * sizeof(int32_t), s>>>(n, ws);
+int bn254_lm_g2_subgroup(size_t n, Ws ws, hipStream_t s, int fail_status) {
+  k_g2_subgroup_lm<<<(unsigned)((n + BN_LM_PER_WG - 1) / BN_LM_PER_WG), BN_WAVE, LM_LDS_WORDS * sizeof(int32_t), s>>>(n, ws, fail_status);
   HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -122,7 +122,7 @@ KERNEL_PAIR void k_decode_g2_pair(const uint8_t* pts, size_t n, uint32_t flags, 
 }
 // Compressed public keys (65 B, bn::G2::from_compressed: Fq2 square root + subgroup test) into the Q planes of a
 // verify, on lane pairs; same statuses as k_decompress_g2_ws.
-KERNEL_PAIR void k_decompress_g2_pair(const uint8_t* in, size_t n, Ws ws) {
+KERNEL_PAIR void k_decompress_g2_pair(const uint8_t* in, size_t n, Ws ws, int skip_subgroup_test) {     // skip_subgroup_test: the caller runs it (bn254_lm_g2_subgroup)
   const unsigned role = threadIdx.x & 1u;
   size_t i = ((size_t)blockIdx.x * BN_PAIR_WG + threadIdx.x) >> 1;
   const bool live = i < n;                          // no early return: the subgroup ladder votes across the wave
@@ -133,11 +133,14 @@ KERNEL_PAIR void k_decompress_g2_pair(const uint8_t* in, size_t n, Ws ws) {
   gen.x = fp2_load_const(C_G2_GEN[0]); gen.y = fp2_load_const(C_G2_GEN[1]); gen.inf = false;
   if (st != ST_OK) q = gen;
   __shared__ G2Jac lds_up[BN_PAIR_WG];               // the subgroup ladder's accumulator, 27 words per lane
+  bool in_sub = true;
+  if (!skip_subgroup_test) {                         // wave-uniform
 #if defined(BN_SUBGROUP_PRIVATE)
-  bool in_sub = g2_in_subgroup(q);
+  in_sub = g2_in_subgroup(q);
 #else
-  bool in_sub = g2_in_subgroup_lds(q, lds_up[threadIdx.x]);
+  in_sub = g2_in_subgroup_lds(q, lds_up[threadIdx.x]);
 #endif
+  }
   if (st == ST_OK && !in_sub) { st = ST_NOT_MEMBER; q = gen; }
   if (!live) return;
   ws_store_fp(ws, PL_QX0 + (int)role, i, q.x.c[0]);
@@ -148,8 +151,8 @@ KERNEL_PAIR void k_decompress_g2_pair(const uint8_t* in, size_t n, Ws ws) {
     ws_byte(ws, BY_ST_DECODE, i) = prev != ST_OK ? prev : st;
   }
 }
-int bn254_pair_decompress_g2(const uint8_t* in, size_t n, Ws ws, hipStream_t s) {
-  k_decompress_g2_pair<<<(unsigned)((2 * n + BN_PAIR_WG - 1) / BN_PAIR_WG), BN_PAIR_WG, 0, s>>>(in, n, ws);
+int bn254_pair_decompress_g2(const uint8_t* in, size_t n, Ws ws, hipStream_t s, int skip_subgroup_test) {
+  k_decompress_g2_pair<<<(unsigned)((2 * n + BN_PAIR_WG - 1) / BN_PAIR_WG), BN_PAIR_WG, 0, s>>>(in, n, ws, skip_subgroup_test);
   HIP_TRY(hipGetLastError());
   return 0;
 }

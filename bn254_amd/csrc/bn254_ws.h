@@ -143,7 +143,7 @@ __attribute__((visibility("hidden"))) int bn254_pair_aggregate(const uint32_t* t
                                                                const uint32_t* perm = nullptr, const Pool* wide2_pool = nullptr,
                                                                const Pool* wide1_pool = nullptr);
 __attribute__((visibility("hidden"))) int bn254_pair_decode_g2(const uint8_t* pts, size_t n, uint32_t flags, Ws ws, int accumulate, hipStream_t s);
-__attribute__((visibility("hidden"))) int bn254_pair_decompress_g2(const uint8_t* in, size_t n, Ws ws, hipStream_t s);
+__attribute__((visibility("hidden"))) int bn254_pair_decompress_g2(const uint8_t* in, size_t n, Ws ws, hipStream_t s, int skip_subgroup_test = 0);
 
 // keyed verify: the registered keys of a context — per key the 87 lines of its Miller loop in the c2 = 1 form,
 // lines[key][line][coefficient c0 / c1][re / im][limb] (canonical limbs; 12.5 KB per key), its decode status and identity flag
@@ -166,7 +166,7 @@ __attribute__((visibility("hidden"))) int bn254_trio_final_exp(size_t n, Ws ws, 
 // entry points of bn254_lmiller.hip (Miller loop of the smallest batches as the lane machine: nine lane pairs in each of four waves per verify)
 __attribute__((visibility("hidden"))) bool bn254_lm_fits_device();
 __attribute__((visibility("hidden"))) int bn254_lm_miller_verify(size_t n, Ws ws, hipStream_t s, int mode = 0);
-__attribute__((visibility("hidden"))) int bn254_lm_g2_subgroup(size_t n, Ws ws, hipStream_t s);   // the G2 subgroup test of points already decoded into the Q planes
+__attribute__((visibility("hidden"))) int bn254_lm_g2_subgroup(size_t n, Ws ws, hipStream_t s, int fail_status = 4 /* ST_INVALID_GROUP_POINT; the compressed decoders report ST_NOT_MEMBER */);   // the G2 subgroup test of points already decoded into the Q planes
 // entry points of bn254_nonet.hip (final exponentiation of the smallest batches on nine lane pairs per verify)
 __attribute__((visibility("hidden"))) bool bn254_nonet_fits_device();
 __attribute__((visibility("hidden"))) int bn254_nonet_final_exp(size_t n, Ws ws, int use_hash, uint8_t* status_out, hipStream_t s, int wide = 0);
