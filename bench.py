@@ -177,6 +177,26 @@ FP_MUL_AGG_TAIL = 7 + 18 + 27                      # G1 / G2 to affine, the fina
 HASH_MEAN_TRIES = 2.116                            # counters tested per message on average (p = 0.4726 per try)
 
 
+def cpu_baseline_verify(msgs, sigs, pks, expected, sample_cap=8192):
+    """`cpu_baseline` of a verify line: the oracle (oracle/bn254_oracle.c, the CPU restatement of the reference path — `kind: port`) on the
+    first `sample_cap` tuples of the SAME batch, on every core the cgroup grants and on one; statuses compared with the expected pattern"""
+    from oracle import c_oracle
+    cores = effective_cores()
+    sample = min(len(msgs), sample_cap)                  # ~11 CPU-seconds of work in total (1.4 ms per verify)
+    t1 = time.perf_counter()
+    st_cpu, _ = c_oracle.batch_verify(msgs[:sample], sigs[:64 * sample], pks[:128 * sample], flags=0, nthreads=cores)
+    dt_all = time.perf_counter() - t1
+    assert st_cpu == expected[:sample], "oracle disagrees with the expected pattern"
+    one = min(sample, 256)
+    t1 = time.perf_counter()
+    c_oracle.batch_verify(msgs[:one], sigs[:64 * one], pks[:128 * one], flags=0, nthreads=1)
+    dt_one = time.perf_counter() - t1
+    return {"value": 2.0 * sample / dt_all, "unit": "pairings/s", "cores": cores, "kind": "port",
+            "sample": "first %d tuples of the same batch, oracle/bn254_oracle.c (C restatement of the reference path, "
+                      "4x64-bit Montgomery limbs, pthreads, gcc -O2); statuses equal the GPU's" % sample,
+            "single_thread_value": 2.0 * one / dt_one}
+
+
 def kernel_roofline(kernel, fp_mul_per_launch, kernel_ms, note=None):
     """roofline object of one kernel: algorithmic MAC32 per launch / its HIP-event duration in THIS run, against the
     VALU integer-multiply peak; `traffic` from the committed PMC pass of the same command when there is one"""
@@ -837,8 +857,12 @@ def run_verify(args, R):
     # the clock the chip sustains DURING the timed steps: the lane-pair kernels accumulate, per workgroup, shader-clock cycles and
     # constant-rate ticks between entry and exit (two scalar clock reads per workgroup); read and cleared after the warm-up, read again
     # after the last timed step (include/bn254_hip.h: BN254_OPT_CLOCK_PROBE, bn254_ctx_last_clocks)
+    # Default (--clock-probe after): the timed steps run WITHOUT the probe — the headline binary path is stamp-free — and the clock is taken
+    # over four more steps right after the timed region.  --clock-probe timed keeps the probe on inside the timed steps (the round-5 form);
+    # the same-box A/B of the two is profiles/r06_*_ab_clock_probe.jsonl.
     clock_probe = False
-    if pair and n > 16384:
+    clock_capable = pair and n > 16384
+    if clock_capable and args.clock_probe == "timed":
         try:
             eng.set_option(bn254_amd.engine.OPT_CLOCK_PROBE, 1)
             clock_probe = True
@@ -860,6 +884,19 @@ def run_verify(args, R):
     timed_clocks = eng.last_clocks() if clock_probe else None   # accumulated over the K timed steps, nothing else
     ok_last = check(args.warmup + args.steps - 1)            # the LAST step's pattern (differs from the one before)
     assert ok_last, "GPU status bytes of the last timed step differ from the expected pattern"
+    clock_steps_after = 0
+    if clock_capable and not clock_probe and args.clock_probe == "after":
+        try:                                                 # four more steps, back to back, OUTSIDE the timed region, with the probe on
+            eng.set_option(bn254_amd.engine.OPT_CLOCK_PROBE, 1)
+            eng.last_clocks()
+            clock_steps_after = 4
+            for k in range(clock_steps_after):
+                step(args.warmup + args.steps + k)
+            torch.cuda.synchronize()
+            timed_clocks = eng.last_clocks()
+            eng.set_option(bn254_amd.engine.OPT_CLOCK_PROBE, 0)
+        except Exception:
+            timed_clocks = None
 
     detail = R.scaling_detail(args.steps, sum(kernel_ms.values()))      # a collective: every rank takes part
     verifies = n * world * args.steps
@@ -908,7 +945,11 @@ def run_verify(args, R):
                     sclk["issue_probe"] = round(eng.last_clocks()["issue_probe"], 1)
                 sclk["nominal"] = 2400.0
                 sclk["method"] = ("sum over workgroups and launches of s_memtime cycles / s_memrealtime ticks x hipDeviceAttributeWallClockRate, accumulated "
-                                  "over the %d TIMED steps themselves (BN254_OPT_CLOCK_PROBE on from before the warm-up; counters cleared after it)" % args.steps)
+                                  + ("over the %d TIMED steps themselves (BN254_OPT_CLOCK_PROBE on from before the warm-up; counters cleared after it)" % args.steps
+                                     if clock_probe else
+                                     "over %d steps run back to back right AFTER the timed region (the timed steps themselves run without the probe: "
+                                     "--clock-probe after, the default)" % clock_steps_after))
+                sclk["probe_inside_timed_region"] = bool(clock_probe)
             except Exception as exc:                               # never lose the bench line over the extra
                 sclk = {"error": repr(exc)}
         leaf_floor = None
@@ -993,6 +1034,7 @@ def run_verify(args, R):
             "frac_of_measured_peak": achieved / (probe["peak_mac32_measured"] / 1e12) if probe else None,
             "issue_probe": probe,
             "traffic": (traffic or {}).get("bytes_per_launch"),   # HBM bytes per launch (PMC), private-segment traffic
+            "traffic_over_algorithmic": ((traffic or {}).get("bytes_per_launch") / io_bytes) if (traffic or {}).get("bytes_per_launch") else None,
             "traffic_detail": traffic,
             "valu_issue": measured_valu_issue(kname, lane_products, probe, k_avg[dom] * 1e-3),
             "kernel_ms": k_avg,
@@ -1001,6 +1043,24 @@ def run_verify(args, R):
             "hbm": {"algorithmic_bytes_per_step": io_bytes, "achieved_GBps": io_bytes / (1e-3 * 1e3 * elapsed / args.steps) / 1e9,
                     "peak_GBps": HBM_PEAK_GBPS, "note": "evidence that the path is not memory-bound"},
         }
+        # the OTHER hot kernel of the step priced the same way (the dominant one is `roofline` itself): its own algorithmic MAC32 per launch
+        # over its own HIP-event duration in this run, its own PMC traffic against the algorithmic bytes
+        try:
+            other = "final_exp" if dom == "miller_loop" else "miller_loop"
+            okname = {("miller_loop", True): "k_miller_verify_pair", ("miller_loop", False): "k_miller_verify",
+                      ("final_exp", True): "k_final_exp_pair", ("final_exp", False): "k_final_exp"}[(other, pair)]
+            ofp = FP_MUL_MILLER if other == "miller_loop" else FP_MUL_FINAL_EXP
+            oach = ofp * MAC32_PER_FP_MUL * n / (k_avg[other] * 1e-3) / 1e12
+            otr = measured_traffic(okname)
+            result["roofline"]["second_kernel"] = {
+                "kernel": okname, "achieved": oach, "peak": PEAK_MAC32_THEORETICAL / 1e12, "unit": "TMAC32/s", "frac": oach / (PEAK_MAC32_THEORETICAL / 1e12),
+                "frac_at_effective_sclk": (oach / (PEAK_MAC32_THEORETICAL / 1e12 * sclk[other] / 2400.0)) if sclk and sclk.get(other) else None,
+                "kernel_ms": k_avg[other], "traffic": (otr or {}).get("bytes_per_launch"),
+                "traffic_over_algorithmic": ((otr or {}).get("bytes_per_launch") / (432.0 * n)) if (otr or {}).get("bytes_per_launch") else None,
+                "algorithmic_bytes_per_launch": 432.0 * n,
+                "note": "algorithmic bytes of this kernel alone: one Fq12 Miller value per verify (12 x 9 words) between the two kernels"}
+        except Exception as exc:
+            result["roofline"]["second_kernel"] = {"error": repr(exc)}
         if world == 1 and n >= 1024:
             # informational, outside the timed region: latency of a SMALL call through the host-pointer entry point (H2D, kernels,
             # D2H, sync) — batches of up to 16 384 verifies take the small-batch kernels
@@ -1040,24 +1100,8 @@ def run_verify(args, R):
             except Exception as exc:                             # never lose the bench line over the extra
                 result["small_batch_latency"] = {"error": repr(exc)}
         if world == 1 and not args.no_cpu_baseline:
-            from oracle import c_oracle
-            cores = effective_cores()
-            sample = min(n, 8192)                            # ~11 CPU-seconds of work in total (1.4 ms per verify)
             last = args.warmup + args.steps - 1
-            t1 = time.perf_counter()
-            st_cpu, _ = c_oracle.batch_verify(msgs[:sample], sig_sets[last & 1][:64 * sample], pks[:128 * sample], flags=0, nthreads=cores)
-            dt_all = time.perf_counter() - t1
-            assert st_cpu == expected_for(0, last, sample), "oracle disagrees with the expected pattern"
-            one = min(sample, 256)
-            t1 = time.perf_counter()
-            c_oracle.batch_verify(msgs[:one], sig_sets[last & 1][:64 * one], pks[:128 * one], flags=0, nthreads=1)
-            dt_one = time.perf_counter() - t1
-            result["cpu_baseline"] = {
-                "value": 2.0 * sample / dt_all, "unit": "pairings/s", "cores": cores, "kind": "port",
-                "sample": "first %d tuples of the same batch, oracle/bn254_oracle.c (C restatement of the reference path, "
-                          "4x64-bit Montgomery limbs, pthreads, gcc -O2); statuses equal the GPU's" % sample,
-                "single_thread_value": 2.0 * one / dt_one,
-            }
+            result["cpu_baseline"] = cpu_baseline_verify(msgs, sig_sets[last & 1], pks, expected_for(0, last))
         result["pmc_as_of"] = pmc_as_of()
         print(json.dumps(result))
     R.finish()
@@ -1071,7 +1115,7 @@ def run_verify_mgpu(args):
     verify`; torch is used only to hold the device buffers."""
     import torch
     import bn254_amd
-    from bn254_amd.engine import MGPU_OPT_TIMING
+    from bn254_amd.engine import MGPU_OPT_GATHER, MGPU_OPT_TIMING
     from tests.datagen import KEY_POOL, sk_bytes
     if int(os.environ.get("WORLD_SIZE", "1")) != 1:
         raise SystemExit("--workload verify-mgpu is ONE process driving all devices: start it without torchrun")
@@ -1082,8 +1126,13 @@ def run_verify_mgpu(args):
     n = args.batch or BATCH
     N = n * G
     mg = bn254_amd.MultiEngine(devices)
+    gather_mode = {"auto": 0, "rccl": 1, "copy": 2}[args.mgpu_gather]
+    if gather_mode:
+        mg.set_option(MGPU_OPT_GATHER, gather_mode)
+    uses_rccl = gather_mode == 1 or (gather_mode == 0 and len(set(devices)) == G and G > 1)
     mg.reserve(2 * N, init_collectives=True)
     mg.set_option(MGPU_OPT_TIMING, 1)
+    mg.engine(0).set_profiling(True)                     # entry 0's kernels by HIP events on its stream: the roofline of the line
 
     def corrupted(good, phase):
         sigs = bytearray(good)
@@ -1149,6 +1198,7 @@ def run_verify_mgpu(args):
         step(k)
     assert args.warmup == 0 or check(args.warmup - 1), "GPU status bytes differ from the expected pattern"
     comp_ms, coll_ms = [0.0] * G, [0.0] * G
+    kernel_ms = {"decode": 0.0, "hash_to_g1": 0.0, "miller_loop": 0.0, "final_exp": 0.0}
     sync_all()
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -1156,6 +1206,9 @@ def run_verify_mgpu(args):
         a, b = mg.last_timing()                              # HIP events on every device's stream (synchronises them), as run_verify's per_step
         comp_ms = [x + y for x, y in zip(comp_ms, a)]
         coll_ms = [x + y for x, y in zip(coll_ms, b)]
+        ms0 = mg.engine(0).last_kernel_ms()                  # entry 0's own kernels (HIP events on the stream they were launched on)
+        for key in kernel_ms:
+            kernel_ms[key] += ms0[key]
     sync_all()
     elapsed = time.perf_counter() - t0
     assert check(args.warmup + args.steps - 1), "GPU status bytes of the last timed step differ from the expected pattern"
@@ -1171,12 +1224,30 @@ def run_verify_mgpu(args):
                    "batch_per_gpu": n, "verifies_per_s": verifies_per_s, "bit_exact_vs_expected": checks["mismatches"] == 0,
                    "status_vectors_checked": checks["steps_checked"] * G * G,
                    "collective": ("ncclAllGather (RCCL C API, ncclCommInitAll, in place) of %d status bytes per device and step" % n)
-                   if len(set(devices)) == G else "peer copies (a device is listed twice: RCCL refuses two ranks on one device)"},
+                   if uses_rccl else ("peer copies (--mgpu-gather %s; a one-device handle has nothing to gather, and RCCL refuses two ranks "
+                                      "on one device)" % args.mgpu_gather)},
         "scaling_detail": {"compute_ms_per_step": {"per_device": [x / args.steps for x in comp_ms]},
                            "collective_ms_per_step": {"per_device": [x / args.steps for x in coll_ms]},
                            "timed_by": "HIP events on each device's stream: before its shard's first kernel, after its last, after the gather",
                            "note": "one process: ms_per_step is the host clock over K steps between synchronisations of every device"},
     }
+    # roofline of the dominant kernel — per DEVICE (entry 0's launch: its shard of n verifies), HIP events in this run; cpu_baseline on shard 0
+    k_avg = {k: v / args.steps for k, v in kernel_ms.items()}
+    small = n <= 16384                                       # such shards take the small-batch kernels (other code, other counters)
+    dom = max(("miller_loop", "final_exp"), key=lambda k: k_avg[k])
+    kname = {"miller_loop": "k_miller_verify_pair", "final_exp": "k_final_exp_pair"}[dom] if not small else {"miller_loop": "small-batch Miller kernel", "final_exp": "small-batch final exponentiation"}[dom]
+    fp_mul = FP_MUL_MILLER if dom == "miller_loop" else FP_MUL_FINAL_EXP
+    if k_avg[dom] > 0:
+        result["roofline"] = kernel_roofline(kname, fp_mul * n, k_avg[dom],
+                                             note="per device: entry 0's launch over its shard of %d verifies, HIP events on its stream; %d device "
+                                                  "entries run such a launch side by side (on distinct GPUs each at this rate; entries that share a GPU "
+                                                  "share its VALUs and this figure with it)" % (n, G))
+        result["roofline"]["kernel_ms"] = k_avg
+        if result["roofline"].get("traffic"):
+            result["roofline"]["traffic_over_algorithmic"] = result["roofline"]["traffic"] / (BYTES_PER_VERIFY_IO * n)
+    if not args.no_cpu_baseline:
+        last = args.warmup + args.steps - 1
+        result["cpu_baseline"] = cpu_baseline_verify(host[0], host[1][last & 1], host[2], expected_for(0, last))
     # what the layer costs: the same shard through the single-GPU entry point on device entry 0 alone, same process, same steps
     eng0 = mg.engine(0)
     torch.cuda.synchronize(devices[0])
@@ -1343,6 +1414,12 @@ def main():
                          "other entry points on one GPU (informational — see DESIGN.md §4b)")
     ap.add_argument("--mgpu-devices", default="", help="--workload verify-mgpu: comma-separated HIP device list (default 0..gpus-1); a device "
                                                        "may be listed more than once (one-GPU rehearsal, gather by peer copies)")
+    ap.add_argument("--clock-probe", default="after", choices=["after", "timed", "off"],
+                    help="--workload verify: where the shader clock under load is measured — after = over four extra steps behind the timed region "
+                         "(default: nothing rides in the timed kernels), timed = inside the timed steps (two scalar clock reads per workgroup), off")
+    ap.add_argument("--mgpu-gather", default="auto", choices=["auto", "rccl", "copy"],
+                    help="--workload verify-mgpu: auto = RCCL for two or more distinct devices, else peer copies; rccl with ONE device = the one-rank "
+                         "rehearsal of the RCCL calls")
     args = ap.parse_args()
     global PMC_WORKLOAD
     PMC_WORKLOAD = "verify" if args.workload in ("verify-host", "verify-compressed") else args.workload   # same kernels, same batch as the headline command

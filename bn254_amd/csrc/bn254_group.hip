@@ -484,7 +484,7 @@ int bn254_batch_g1_mul_device(bn254_ctx* c, const uint8_t* d_p, const uint8_t* d
   if (misaligned(d_p) || misaligned(d_k) || misaligned(d_out)) return BN254_E_MISALIGNED;
   HIP_TRY(hipSetDevice(c->device));
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
-  c->last_stream = s;
+  CallDone call_done(c, s);
   k_g1_mul<<<grid_for(n), BN_WAVE, 0, s>>>(d_p, d_k, n, reduce, c->ws, d_out, d_status);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -495,7 +495,7 @@ int bn254_batch_g2_mul_device(bn254_ctx* c, const uint8_t* d_p, const uint8_t* d
   if ((d_p && misaligned(d_p)) || misaligned(d_k) || misaligned(d_out)) return BN254_E_MISALIGNED;
   HIP_TRY(hipSetDevice(c->device));
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
-  c->last_stream = s;
+  CallDone call_done(c, s);
   k_g2_mul<<<grid_for(n), BN_WAVE, 0, s>>>(d_p, d_k, n, reduce, d_out, d_status);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -531,7 +531,7 @@ int bn254_batch_sign_device(bn254_ctx* c, const uint8_t* d_msgs, const uint64_t*
   int rc = ws_reserve(c, n);
   if (rc) return rc;
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
-  c->last_stream = s;
+  CallDone call_done(c, s);
   if ((rc = launch_hash_rounds(c, s, d_msgs, d_off, n, PL_P1X, BY_P1_INF, nullptr))) return rc;             // ecdsa.rs:28
   k_g1_mul<<<grid_for(n), BN_WAVE, 0, s>>>(nullptr, d_sks, n, 1, c->ws, d_sigs, d_status);              // ecdsa.rs:31
   HIP_TRY(hipGetLastError());
@@ -596,7 +596,7 @@ int bn254_batch_aggregate_verify_device(bn254_ctx* c, const uint8_t* d_msgs, con
   if ((rc = pool_reserve(c, 1, 2, n_msgs * n_signers))) return rc;
   if ((rc = pool_reserve(c, 2, 2, n_msgs))) return rc;
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
-  c->last_stream = s;
+  CallDone call_done(c, s);
   PROF_MARK(0);                                        // ms[0] = pools (decode, hash of the messages, subset-sum table), ms[1] = the aggregation kernel
   k_pool_decode_g2<<<grid_for(n_signers), BN_WAVE, 0, s>>>(d_pk_pool, n_signers, flags, c->pool[0]);
   k_pool_decode_g1<<<grid_for(n_msgs * n_signers), BN_WAVE, 0, s>>>(d_sig_pool, n_msgs * n_signers, flags, c->pool[1]);

@@ -392,10 +392,9 @@ KERNEL_SMALL void k_encode_g1(size_t n, Ws ws, int px, int inf_plane, uint8_t* o
 int ctx_quiesce(bn254_ctx* c) {
   HIP_TRY(hipStreamSynchronize(c->stream));
   HIP_TRY(hipStreamSynchronize(c->copy_stream));
-  if (c->last_stream && c->last_stream != c->stream) {
-    // a caller's stream; if the caller has destroyed it since, everything it carried has completed: not an error
-    if (hipStreamSynchronize(c->last_stream) != hipSuccess) (void)hipGetLastError();
-    c->last_stream = nullptr;
+  if (c->last_done_armed) {                         // the last *_device call ran on a caller's stream: wait for the event recorded behind it
+    c->last_done_armed = false;
+    HIP_TRY(hipEventSynchronize(c->last_done));
   }
   return 0;
 }
@@ -573,8 +572,10 @@ int bn254_ctx_create(int hip_device, bn254_ctx** out) {
   hipError_t err = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (err == hipSuccess) err = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
   if (err == hipSuccess) err = hipEventCreateWithFlags(&c->copy_done, hipEventDisableTiming);
+  if (err == hipSuccess) err = hipEventCreateWithFlags(&c->last_done, hipEventDisableTiming);
   for (int i = 0; i < 5 && err == hipSuccess; ++i) err = hipEventCreate(&c->ev[i]);
   if (err != hipSuccess) {
+    if (c->last_done) (void)hipEventDestroy(c->last_done);
     for (int i = 0; i < 5; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->copy_done) (void)hipEventDestroy(c->copy_done);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
@@ -588,7 +589,7 @@ int bn254_ctx_create(int hip_device, bn254_ctx** out) {
 void bn254_ctx_destroy(bn254_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  (void)hipStreamSynchronize(c->stream);
+  (void)ctx_quiesce(c);                               // own streams + the end of the last call on a caller's stream
   if (c->ws.planes) (void)hipFree(c->ws.planes);
   if (c->ws.bytes) (void)hipFree(c->ws.bytes);
   if (c->ws.h_best) (void)hipFree(c->ws.h_best);
@@ -605,6 +606,7 @@ void bn254_ctx_destroy(bn254_ctx* c) {
   if (c->key_inf) (void)hipFree(c->key_inf);
   for (int i = 0; i < 5; ++i) (void)hipEventDestroy(c->ev[i]);
   (void)hipEventDestroy(c->copy_done);
+  (void)hipEventDestroy(c->last_done);
   (void)hipStreamSynchronize(c->copy_stream);
   (void)hipStreamDestroy(c->copy_stream);
   (void)hipStreamDestroy(c->stream);
@@ -787,7 +789,7 @@ int bn254_batch_verify_device(bn254_ctx* c, const uint8_t* d_msgs, const uint64_
   int rc = ws_reserve(c, split ? 2 * n : n);
   if (rc) return rc;
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
-  c->last_stream = s;
+  CallDone call_done(c, s);
   PROF_MARK(0);
   k_decode_g1<<<grid_for(n), BN_WAVE, 0, s>>>(d_sigs, n, flags, c->ws, PL_P1X, BY_P1_INF, 0);
   if ((rc = launch_decode_g2(c, s, d_pks, n, flags, 1))) return rc;
@@ -806,7 +808,7 @@ int bn254_batch_verify_compressed_device(bn254_ctx* c, const uint8_t* d_msgs, co
   int rc = ws_reserve(c, n);
   if (rc) return rc;
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
-  c->last_stream = s;
+  CallDone call_done(c, s);
   PROF_MARK(0);
   k_decompress_g1_ws<<<grid_for(n), BN_WAVE, 0, s>>>(d_sigs33, n, c->ws);
   if (c->pair_lanes && c->lm_max_batch > 0 && n <= (size_t)c->lm_max_batch) {
@@ -979,7 +981,7 @@ int bn254_batch_hash_to_g1_device(bn254_ctx* c, const uint8_t* d_msgs, const uin
   int rc = ws_reserve(c, n);
   if (rc) return rc;
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
-  c->last_stream = s;
+  CallDone call_done(c, s);
   unsigned g = grid_for(n);
   PROF_MARK(0);                                        // ms[0] = the filter rounds (init / round / resolve), ms[1] = k_hash_finish (the square roots),
   if ((rc = launch_hash_rounds(c, s, d_msgs, d_off, n, PL_P1X, BY_P1_INF, d_tries, 1))) return rc;     // ms[2] = encoding the points, ms[3] = 0
@@ -1022,7 +1024,7 @@ static int pairing_device(bn254_ctx* c, const uint8_t* d_g1, const uint8_t* d_g2
   int rc = ws_reserve(c, lanes);
   if (rc) return rc;
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
-  c->last_stream = s;
+  CallDone call_done(c, s);
   PROF_MARK(0);
   k_decode_g1<<<grid_for(lanes), BN_WAVE, 0, s>>>(d_g1, lanes, flags, c->ws, PL_P1X, BY_P1_INF, 0);
   if ((rc = launch_decode_g2(c, s, d_g2, lanes, flags, 1))) return rc;

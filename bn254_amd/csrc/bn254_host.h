@@ -54,7 +54,8 @@ struct bn254_ctx {
   uint8_t* key_st;
   uint8_t* key_inf;
   size_t n_keys, key_cap;
-  hipStream_t last_stream;   // the stream of the most recent *_device call (a context carries ONE call in flight: what must drain before a buffer goes)
+  hipEvent_t last_done;      // recorded on the CALLER's stream when a *_device call on such a stream returns (CallDone below): what ctx_quiesce
+  bool last_done_armed;      // waits for.  The context keeps no handle of a stream it does not own — the caller may destroy its stream any time.
   bool fits_w8, fits_quad, fits_trio;   // the device can hold a workgroup of the small-batch kernels (LDS), asked at creation
 };
 
@@ -71,9 +72,25 @@ struct ScopedEvents {
 };
 static inline unsigned grid_for(size_t n) { return (unsigned)((n + BN_WAVE - 1) / BN_WAVE); }
 
-// before a buffer of the context is freed or rewritten: wait for the context's own streams and for the stream of its last *_device call —
-// not for the whole device (other contexts, other streams and a stream capture running elsewhere in the process are left alone)
+// before a buffer of the context is freed or rewritten: wait for the context's own streams and for the END of its last *_device call on a
+// caller's stream (an event the context owns) — not for the whole device (other contexts, other streams and a stream capture running
+// elsewhere in the process are left alone)
 BN_HIDDEN int ctx_quiesce(bn254_ctx* c);
+// Opened by every *_device entry point once it knows its stream: on every exit path (errors included — kernels may have been enqueued)
+// the context's own event is recorded behind whatever the call put on a caller's stream.  Nothing is recorded for the context's own stream
+// (ctx_quiesce synchronises that one directly), so the default path pays nothing.
+struct CallDone {
+  bn254_ctx* c;
+  hipStream_t s;
+  CallDone(bn254_ctx* ctx, hipStream_t stream) : c(ctx), s(stream) {}
+  ~CallDone() {
+    if (s == c->stream) return;
+    if (hipEventRecord(c->last_done, s) == hipSuccess) c->last_done_armed = true;
+    else (void)hipGetLastError();                    // e.g. a stream under capture: nothing of this call can outlive the capture's owner
+  }
+  CallDone(const CallDone&) = delete;
+  CallDone& operator=(const CallDone&) = delete;
+};
 BN_HIDDEN int ws_reserve(bn254_ctx* c, size_t n);
 BN_HIDDEN int stage_reserve(bn254_ctx* c, int slot, size_t bytes);
 BN_HIDDEN int stage_in(bn254_ctx* c, int slot, const void* host, size_t bytes);

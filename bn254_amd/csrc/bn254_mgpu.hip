@@ -12,7 +12,6 @@
 //
 // librccl.so.1 is loaded with dlopen at the first call that needs it: the single-GPU user never pays for it.
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
 
 #include <dlfcn.h>
 
@@ -36,6 +35,15 @@
 namespace {
 
 // ---- RCCL through dlopen ------------------------------------------------------------------------------------------------
+// The handful of RCCL names this file uses, declared here so that the library builds without the RCCL development headers
+// (the values are those of rccl.h / nccl.h, a stable ABI: ncclSuccess = 0, ncclUint8 = 1, ncclUint64 = 5, ncclSum = 0).
+typedef struct ncclComm* ncclComm_t;
+typedef int ncclResult_t;
+typedef int ncclDataType_t;
+typedef int ncclRedOp_t;
+constexpr ncclResult_t ncclSuccess = 0;
+constexpr ncclDataType_t ncclUint8 = 1, ncclUint64 = 5;
+constexpr ncclRedOp_t ncclSum = 0;
 struct Rccl {
   void* so;
   ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*);
@@ -45,6 +53,8 @@ struct Rccl {
   ncclResult_t (*GroupStart)();
   ncclResult_t (*GroupEnd)();
   const char* (*GetErrorString)(ncclResult_t);
+  bool shared_devices_ok;       // the loaded library accepts several ranks on ONE device: only the test stub does (tests/rccl_stub), it says
+                                // so by exporting bn254_rccl_stub_shared_devices; RCCL itself refuses, and then so does this layer
 };
 
 struct Dev;
@@ -54,12 +64,13 @@ struct Dev {
   int index, device;
   bn254_ctx* ctx;
   hipStream_t stream;
-  hipEvent_t ev_done, ev_pulled, t0, t1, t2;
+  hipEvent_t ev_done, ev_pulled, ev_end, t0, t1, t2;
   ncclComm_t comm;
   uint64_t* off_tmp;            // host: the shard's message offsets rebased to its first byte
   size_t off_cap;
   unsigned long long* d_sum;    // device: [0] this shard's Gt checksum, [1 .. G] the partials pulled from every device (copy mode)
-  hipStream_t used_stream;      // the stream the last *_device call ran on
+  bool end_armed;               // ev_end was recorded behind the last *_device call's gather (what destroy waits for: the handle keeps no
+                                // handle of a caller's stream, which the caller may have destroyed since)
   float host_ms;                // host entry points: the worker's wall clock
   bool timed;                   // t0/t1/t2 were recorded by the last call
   // worker thread
@@ -154,6 +165,20 @@ inline hipStream_t stream_of(Dev* d, void* const* streams) {
   return (streams && streams[d->index]) ? (hipStream_t)streams[d->index] : d->stream;
 }
 
+// The whole offsets array is checked ONCE on the calling thread before any shard starts (as the single-GPU entry points do): a
+// shard-local check would let shard 0 follow a span that only a later shard's slice shows to be malformed.
+inline bool offsets_ok(const uint64_t* off, size_t n) {
+  for (size_t i = 0; i < n; ++i) if (off[i] > off[i + 1]) return false;
+  return true;
+}
+// the caller's current HIP device is restored on every exit path of an entry point (the layer calls hipSetDevice on the caller's thread)
+struct DeviceGuard {
+  int dev;
+  bool ok;
+  DeviceGuard() : dev(0), ok(hipGetDevice(&dev) == hipSuccess) {}
+  ~DeviceGuard() { if (ok) (void)hipSetDevice(dev); }
+};
+
 int rebased_offsets(Dev* d, const uint64_t* off, size_t lo, size_t hi) {
   const size_t need = hi - lo + 1;
   if (need > d->off_cap) {
@@ -162,7 +187,7 @@ int rebased_offsets(Dev* d, const uint64_t* off, size_t lo, size_t hi) {
     d->off_tmp = p; d->off_cap = need;
   }
   const uint64_t base = off[lo];
-  for (size_t i = 0; i + 1 < need; ++i) if (off[lo + i] > off[lo + i + 1]) return BN254_E_BAD_ARGUMENT;   // as the single-GPU entry point: refused, never followed
+  for (size_t i = 0; i + 1 < need; ++i) if (off[lo + i] > off[lo + i + 1]) return BN254_E_BAD_ARGUMENT;   // backstop: the entry points have checked the whole array
   for (size_t i = 0; i < need; ++i) d->off_tmp[i] = off[lo + i] - base;
   return 0;
 }
@@ -196,16 +221,19 @@ int rccl_load(bn254_mgpu* mg) {
     dlclose(so);
     return BN254_E_RCCL;
   }
+  R.shared_devices_ok = dlsym(so, "bn254_rccl_stub_shared_devices") != nullptr;
   R.so = so;
   return 0;
 }
-bool use_rccl(const bn254_mgpu* mg) { return mg->gather_opt == 1 || (mg->gather_opt == 0 && mg->distinct); }
+// A one-device handle has nothing to gather: it takes the (empty) copy branch and never loads librccl — unless the caller asks for
+// the collective explicitly (BN254_MGPU_OPT_GATHER = 1: the one-rank rehearsal of the RCCL calls).
+bool use_rccl(const bn254_mgpu* mg) { return mg->gather_opt == 1 || (mg->gather_opt == 0 && mg->distinct && mg->G > 1); }
 
 int comm_init(bn254_mgpu* mg) {
   if (mg->comm_ready) return 0;
-  if (!mg->distinct) { snprintf(mg->err, sizeof mg->err, "RCCL needs distinct devices: this handle lists one twice"); return BN254_E_RCCL; }
   int rc = rccl_load(mg);
   if (rc) return rc;
+  if (!mg->distinct && !mg->rccl.shared_devices_ok) { snprintf(mg->err, sizeof mg->err, "RCCL needs distinct devices: this handle lists one twice"); return BN254_E_RCCL; }
   ncclComm_t comms[64];
   int devs[64];
   for (int g = 0; g < mg->G; ++g) devs[g] = mg->dev[g].device;
@@ -261,12 +289,13 @@ int gather(bn254_mgpu* mg, uint8_t* const* all, size_t S, void* const* streams, 
         if (h != g) MG_HIP(hipStreamWaitEvent(sg, mg->dev[h].ev_pulled, 0));
     }
   }
-  if (mg->timing)
-    for (int g = 0; g < G; ++g) {
-      Dev* d = &mg->dev[g];
-      MG_HIP(hipSetDevice(d->device));
-      MG_HIP(hipEventRecord(d->t2, stream_of(d, streams)));
-    }
+  for (int g = 0; g < G; ++g) {
+    Dev* d = &mg->dev[g];
+    MG_HIP(hipSetDevice(d->device));
+    if (mg->timing) MG_HIP(hipEventRecord(d->t2, stream_of(d, streams)));
+    MG_HIP(hipEventRecord(d->ev_end, stream_of(d, streams)));
+    d->end_armed = true;
+  }
   return 0;
 }
 
@@ -378,7 +407,6 @@ int job_verify_dev(bn254_mgpu* mg, Dev* d, void* p) {
   shard_range(mg, a.n, g, lo, hi);
   const size_t S = shard_len(mg, a.n);
   hipStream_t s = stream_of(d, a.streams);
-  d->used_stream = s;
   MG_HIP(hipSetDevice(d->device));
   d->timed = mg->timing != 0;
   if (mg->timing) MG_HIP(hipEventRecord(d->t0, s));
@@ -400,7 +428,6 @@ int job_pairing_dev(bn254_mgpu* mg, Dev* d, void* p) {
   shard_range(mg, a.n, g, lo, hi);
   const size_t S = shard_len(mg, a.n);
   hipStream_t s = stream_of(d, a.streams);
-  d->used_stream = s;
   MG_HIP(hipSetDevice(d->device));
   d->timed = mg->timing != 0;
   if (mg->timing) MG_HIP(hipEventRecord(d->t0, s));
@@ -440,7 +467,7 @@ void destroy_dev(Dev* d) {
   if (d->stream) (void)hipStreamSynchronize(d->stream);
   if (d->ctx) bn254_ctx_destroy(d->ctx);
   if (d->d_sum) (void)hipFree(d->d_sum);
-  hipEvent_t* evs[5] = {&d->ev_done, &d->ev_pulled, &d->t0, &d->t1, &d->t2};
+  hipEvent_t* evs[6] = {&d->ev_done, &d->ev_pulled, &d->ev_end, &d->t0, &d->t1, &d->t2};
   for (hipEvent_t* e : evs) if (*e) (void)hipEventDestroy(*e);
   if (d->stream) (void)hipStreamDestroy(d->stream);
   free(d->off_tmp);
@@ -455,6 +482,7 @@ int bn254_mgpu_create(const int* devices, int n_dev, bn254_mgpu** out) {
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return BN254_E_NO_DEVICE;   // no CPU fallback, by design
   for (int g = 0; g < n_dev; ++g) if (devices[g] < 0 || devices[g] >= count) return BN254_E_BAD_ARGUMENT;
+  DeviceGuard guard;
   bn254_mgpu* mg = new (std::nothrow) bn254_mgpu();
   if (!mg) return BN254_E_NO_MEMORY;
   mg->G = n_dev;
@@ -471,6 +499,7 @@ int bn254_mgpu_create(const int* devices, int n_dev, bn254_mgpu** out) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&d->ev_done, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&d->ev_pulled, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&d->ev_end, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreate(&d->t0);
     if (e == hipSuccess) e = hipEventCreate(&d->t1);
     if (e == hipSuccess) e = hipEventCreate(&d->t2);
@@ -508,10 +537,11 @@ int bn254_mgpu_create(const int* devices, int n_dev, bn254_mgpu** out) {
 
 void bn254_mgpu_destroy(bn254_mgpu* mg) {
   if (!mg) return;
+  DeviceGuard guard;
   for (int g = 0; g < mg->G; ++g) {                   // nothing of a collective may still be in flight when its communicator goes
     Dev* d = &mg->dev[g];
     (void)hipSetDevice(d->device);
-    if (d->used_stream) (void)hipStreamSynchronize(d->used_stream);
+    if (d->end_armed) (void)hipEventSynchronize(d->ev_end);
     (void)hipStreamSynchronize(d->stream);
   }
   if (mg->comm_ready)
@@ -536,7 +566,8 @@ const char* bn254_mgpu_last_error(const bn254_mgpu* mg) { return mg ? mg->err : 
 int bn254_mgpu_set_option(bn254_mgpu* mg, int option, int value) {
   if (!mg) return BN254_E_BAD_ARGUMENT;
   if (option == BN254_MGPU_OPT_GATHER) {
-    if (value < 0 || value > 2 || (value == 1 && !mg->distinct)) return BN254_E_BAD_ARGUMENT;
+    if (value < 0 || value > 2) return BN254_E_BAD_ARGUMENT;
+    if (value == 1 && !mg->distinct && (rccl_load(mg) != 0 || !mg->rccl.shared_devices_ok)) return BN254_E_BAD_ARGUMENT;   // RCCL refuses two ranks on one device
     mg->gather_opt = value;
     return 0;
   }
@@ -546,6 +577,7 @@ int bn254_mgpu_set_option(bn254_mgpu* mg, int option, int value) {
 
 int bn254_mgpu_reserve(bn254_mgpu* mg, size_t n_total, int init_collectives) {
   if (!mg) return BN254_E_BAD_ARGUMENT;
+  DeviceGuard guard;
   mg->err[0] = 0;
   ReserveArgs a = {shard_len(mg, n_total)};
   int rc = run_all(mg, job_reserve, &a);
@@ -556,11 +588,13 @@ int bn254_mgpu_reserve(bn254_mgpu* mg, size_t n_total, int init_collectives) {
 
 int bn254_mgpu_synchronize(bn254_mgpu* mg) {
   if (!mg) return BN254_E_BAD_ARGUMENT;
+  DeviceGuard guard;
   return run_all(mg, job_sync, nullptr);
 }
 
 int bn254_mgpu_last_timing(bn254_mgpu* mg, float* compute_ms, float* collective_ms) {
   if (!mg || !mg->timing || !compute_ms || !collective_ms) return BN254_E_BAD_ARGUMENT;
+  DeviceGuard guard;
   for (int g = 0; g < mg->G; ++g) {
     Dev* d = &mg->dev[g];
     if (!d->timed) { compute_ms[g] = d->host_ms; collective_ms[g] = 0.0f; continue; }
@@ -576,7 +610,9 @@ int bn254_mgpu_batch_verify(bn254_mgpu* mg, const uint8_t* msgs, const uint64_t*
                             uint32_t flags, uint8_t* status) {
   if (!mg || (n && (!off || !sigs || !pks || !status))) return BN254_E_BAD_ARGUMENT;
   if (n == 0) return 0;
+  if (!offsets_ok(off, n)) return BN254_E_BAD_ARGUMENT;      // the WHOLE array, before any shard starts
   if (off[n] && !msgs) return BN254_E_BAD_ARGUMENT;
+  DeviceGuard guard;
   mg->err[0] = 0;
   VerifyHostArgs a = {msgs, off, sigs, pks, n, flags, status};
   return run_all(mg, job_verify_host, &a);
@@ -586,7 +622,9 @@ int bn254_mgpu_batch_hash_to_g1(bn254_mgpu* mg, const uint8_t* msgs, const uint6
                                 uint8_t* tries) {
   if (!mg || (n && (!off || !points || !status))) return BN254_E_BAD_ARGUMENT;
   if (n == 0) return 0;
+  if (!offsets_ok(off, n)) return BN254_E_BAD_ARGUMENT;      // the WHOLE array, before any shard starts
   if (off[n] && !msgs) return BN254_E_BAD_ARGUMENT;
+  DeviceGuard guard;
   mg->err[0] = 0;
   HashHostArgs a = {msgs, off, n, points, status, tries};
   return run_all(mg, job_hash_host, &a);
@@ -596,7 +634,9 @@ int bn254_mgpu_batch_verify_compressed(bn254_mgpu* mg, const uint8_t* msgs, cons
                                        uint8_t* status) {
   if (!mg || (n && (!off || !sigs33 || !pks65 || !status))) return BN254_E_BAD_ARGUMENT;
   if (n == 0) return 0;
+  if (!offsets_ok(off, n)) return BN254_E_BAD_ARGUMENT;      // the WHOLE array, before any shard starts
   if (off[n] && !msgs) return BN254_E_BAD_ARGUMENT;
+  DeviceGuard guard;
   mg->err[0] = 0;
   CompressedHostArgs a = {msgs, off, sigs33, pks65, n, status};
   return run_all(mg, job_verify_compressed_host, &a);
@@ -604,6 +644,7 @@ int bn254_mgpu_batch_verify_compressed(bn254_mgpu* mg, const uint8_t* msgs, cons
 
 int bn254_mgpu_register_keys(bn254_mgpu* mg, const uint8_t* pks, size_t n_keys, uint32_t flags, uint8_t* key_status) {
   if (!mg || (n_keys && !pks)) return BN254_E_BAD_ARGUMENT;
+  DeviceGuard guard;
   mg->err[0] = 0;
   RegisterKeysArgs a = {pks, n_keys, flags, key_status};
   return run_all(mg, job_register_keys, &a);
@@ -613,7 +654,9 @@ int bn254_mgpu_batch_verify_keyed(bn254_mgpu* mg, const uint8_t* msgs, const uin
                                   uint32_t flags, uint8_t* status) {
   if (!mg || (n && (!off || !sigs || !key_idx || !status))) return BN254_E_BAD_ARGUMENT;
   if (n == 0) return 0;
+  if (!offsets_ok(off, n)) return BN254_E_BAD_ARGUMENT;      // the WHOLE array, before any shard starts
   if (off[n] && !msgs) return BN254_E_BAD_ARGUMENT;
+  DeviceGuard guard;
   mg->err[0] = 0;
   KeyedHostArgs a = {msgs, off, sigs, key_idx, n, flags, status};
   return run_all(mg, job_verify_keyed_host, &a);
@@ -624,6 +667,11 @@ int bn254_mgpu_batch_aggregate_verify(bn254_mgpu* mg, const uint8_t* msgs, const
                                       uint32_t flags, uint8_t* status) {
   if (!mg || !n_msgs || !n_signers || (n && (!msg_off || !pk_pool || !sig_pool || !tuple_msg || !tuple_off || !signer_idx || !status))) return BN254_E_BAD_ARGUMENT;
   if (n == 0) return 0;
+  // as the single-GPU entry point (bn254_group.hip): both offset arrays non-decreasing, or nothing is touched.  Every shard's signer slice
+  // signer_idx + tuple_off[lo] of length tuple_off[hi] - tuple_off[lo] then lies inside the caller's signer_idx[0 .. tuple_off[n]).
+  if (!offsets_ok(tuple_off, n) || !offsets_ok(msg_off, n_msgs)) return BN254_E_BAD_ARGUMENT;
+  if (msg_off[n_msgs] && !msgs) return BN254_E_BAD_ARGUMENT;
+  DeviceGuard guard;
   mg->err[0] = 0;
   AggregateHostArgs a = {msgs, msg_off, n_msgs, pk_pool, n_signers, sig_pool, tuple_msg, tuple_off, signer_idx, n, flags, status};
   return run_all(mg, job_aggregate_host, &a);
@@ -634,6 +682,7 @@ int bn254_mgpu_batch_pairing(bn254_mgpu* mg, const uint8_t* g1, const uint8_t* g
   if (!mg || k == 0 || (n && (!g1 || !g2 || !gt))) return BN254_E_BAD_ARGUMENT;
   if (checksum) *checksum = 0;
   if (n == 0) return 0;
+  DeviceGuard guard;
   mg->err[0] = 0;
   uint64_t partial[64];
   PairingHostArgs a = {g1, g2, n, k, flags, gt, status, checksum ? partial : nullptr};
@@ -652,6 +701,7 @@ int bn254_mgpu_batch_verify_device(bn254_mgpu* mg, const uint8_t* const* d_msgs,
     shard_range(mg, n, g, lo, hi);
     if (!d_status_all[g] || (hi > lo && (!d_msgs[g] || !d_off[g] || !d_sigs[g] || !d_pks[g]))) return BN254_E_BAD_ARGUMENT;
   }
+  DeviceGuard guard;
   mg->err[0] = 0;
   if (use_rccl(mg)) { int rc = comm_init(mg); if (rc) return rc; }     // before anything is enqueued: a failure leaves nothing in flight
   VerifyDevArgs a = {d_msgs, d_off, d_sigs, d_pks, n, flags, d_status_all, streams};
@@ -670,6 +720,7 @@ int bn254_mgpu_batch_pairing_device(bn254_mgpu* mg, const uint8_t* const* d_g1, 
     if (!d_status_all[g] || (d_checksum && !d_checksum[g]) || (hi > lo && (!d_g1[g] || !d_g2[g] || (d_gt && !d_gt[g])))) return BN254_E_BAD_ARGUMENT;
     if (d_gt && d_gt[g] && ((uintptr_t)d_gt[g] & 7u)) return BN254_E_MISALIGNED;
   }
+  DeviceGuard guard;
   mg->err[0] = 0;
   if (use_rccl(mg)) { int rc = comm_init(mg); if (rc) return rc; }
   PairingDevArgs a = {d_g1, d_g2, n, k, flags, d_gt, d_status_all, d_checksum != nullptr, streams};

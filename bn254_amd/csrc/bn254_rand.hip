@@ -369,7 +369,7 @@ int bn254_batch_verify_keyed_device(bn254_ctx* c, const uint8_t* d_msgs, const u
   int rc = ws_reserve(c, n);
   if (rc) return rc;
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
-  c->last_stream = s;
+  CallDone call_done(c, s);
   KeyTable kt = {c->key_lines, c->key_st, c->key_inf, (uint32_t)c->n_keys};
   PROF_MARK(0);
   { int rc_ = launch_decode_g1(c, s, d_sigs, n, flags, PL_P1X, BY_P1_INF, 0); if (rc_) return rc_; }
@@ -451,7 +451,7 @@ int bn254_batch_verify_keyed_randomized_device(bn254_ctx* c, const uint8_t* d_ms
   uint32_t *start = cnt + K, *meta = start + K, *gkey = meta + 2, *perm = gkey + groups_max;
   uint8_t* d_group_st = c->stage[7];
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
-  c->last_stream = s;
+  CallDone call_done(c, s);
   Seed seed;
   for (int j = 0; j < 8; ++j)
     seed.w[j] = ((uint32_t)seed32[4 * j] << 24) | ((uint32_t)seed32[4 * j + 1] << 16) | ((uint32_t)seed32[4 * j + 2] << 8) | seed32[4 * j + 3];
@@ -527,7 +527,7 @@ int bn254_batch_verify_randomized_device(bn254_ctx* c, const uint8_t* d_msgs, co
   int rc = ws_reserve(c, gbase + n_groups);
   if (rc) return rc;
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
-  c->last_stream = s;
+  CallDone call_done(c, s);
   Seed seed;
   for (int j = 0; j < 8; ++j)
     seed.w[j] = ((uint32_t)seed32[4 * j] << 24) | ((uint32_t)seed32[4 * j + 1] << 16) | ((uint32_t)seed32[4 * j + 2] << 8) | seed32[4 * j + 3];

@@ -364,8 +364,9 @@ size_t bn254_mgpu_gathered_len(const bn254_mgpu *mg, size_t n);
  * init_collectives != 0, create the RCCL communicators now instead of inside the first *_device call */
 int bn254_mgpu_reserve(bn254_mgpu *mg, size_t n_total, int init_collectives);
 int bn254_mgpu_synchronize(bn254_mgpu *mg); /* waits for the handle's own streams */
-#define BN254_MGPU_OPT_GATHER 1 /* 0 (default) = RCCL when the devices are distinct, peer copies otherwise; 1 = RCCL (an error for
-                                   duplicate devices); 2 = peer copies */
+#define BN254_MGPU_OPT_GATHER 1 /* 0 (default) = RCCL when the handle has two or more DISTINCT devices, else peer copies (a one-device handle has
+                                   nothing to gather and never loads librccl); 1 = RCCL (an error for duplicate devices — RCCL refuses two
+                                   ranks on one device; with one device: the one-rank rehearsal of the RCCL calls); 2 = peer copies */
 #define BN254_MGPU_OPT_TIMING 2 /* 1 = record per device the time of its shard's compute and of the collective (bn254_mgpu_last_timing) */
 int bn254_mgpu_set_option(bn254_mgpu *mg, int option, int value);
 /* per device g of the last call, in ms: compute_ms[g] = its shard's kernels (device entry points: HIP events on its stream; host

@@ -361,7 +361,7 @@ def test_bench_verify_mgpu_command_line():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for extra, G in ((["--gpus", "3", "--mgpu-devices", "0,0,0"], 3), (["--gpus", "1"], 1)):
+    for extra, G in ((["--gpus", "3", "--mgpu-devices", "0,0,0"], 3), (["--gpus", "1", "--mgpu-gather", "rccl"], 1)):
         p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "verify-mgpu", "--steps", "3", "--warmup", "1", "--batch", "4096"] + extra,
                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=840)
         assert p.returncode == 0, p.stderr[-2000:]
@@ -377,3 +377,5 @@ def test_bench_verify_mgpu_command_line():
         assert all(x > 0 for x in d["compute_ms_per_step"]["per_device"]) and all(x >= 0 for x in d["collective_ms_per_step"]["per_device"])
         assert ("ncclAllGather" in r["config"]["collective"]) == (G == 1)
         assert r["single_gpu_direct"]["ms_per_step"] > 0 and "pairings_per_s" in r["host_pointers"]
+        assert r["roofline"]["bound"] == "valu" and 0 < r["roofline"]["frac"] < 1 and r["roofline"]["kernel_ms"]["miller_loop"] > 0
+        assert r["cpu_baseline"]["kind"] == "port" and r["cpu_baseline"]["value"] > 0 and r["cpu_baseline"]["cores"] >= 1
