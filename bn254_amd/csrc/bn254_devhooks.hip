@@ -146,6 +146,16 @@ __global__ void __launch_bounds__(256) k_issue_probe(uint32_t* out, uint32_t see
 
 extern "C" {
 
+// the routing table of the context (bn254_ws.h: bn_route_table) — tests iterate its boundaries
+int bn254_debug_route_table(bn254_ctx* c, uint64_t* max_n, int* miller, int* fe, int cap) {
+  if (!c || !max_n || !miller || !fe || cap < 5) return BN254_E_BAD_ARGUMENT;
+  size_t m[5];
+  BnRoute r[5];
+  const int rows = bn_route_table(route_limits(c), m, r, 5);
+  for (int i = 0; i < rows; ++i) { max_n[i] = m[i] == (size_t)-1 ? UINT64_MAX : (uint64_t)m[i]; miller[i] = r[i].miller; fe[i] = r[i].fe; }
+  return rows;
+}
+
 // issue-rate probe: wave-instructions per second of `op` with `waves_per_simd` waves on every SIMD, timed with HIP events
 int bn254_probe_issue_rate(bn254_ctx* c, int op, int waves_per_simd, double* wave_inst_per_s, int* n_simd) {
   if (!c || !wave_inst_per_s || op < 0 || op > 2 || waves_per_simd < 1 || waves_per_simd > 8) return BN254_E_BAD_ARGUMENT;

@@ -418,6 +418,24 @@ int ws_reserve(bn254_ctx* c, size_t n) {
   c->ws.stride = cap;
   return 0;
 }
+#define WS_BYTES_PER_ITEM ((size_t)N_PLANES * BN_LIMBS * sizeof(int32_t) + N_BYTE_PLANES + sizeof(uint32_t) + 1 + 2 * sizeof(uint32_t))
+size_t ws_chunk_for(bn254_ctx* c, size_t n) {
+  if (c->max_chunk > 0) return n > (size_t)c->max_chunk ? (size_t)c->max_chunk : 0;
+  if (n <= c->ws.stride) return 0;                   // already reserved
+  size_t avail;
+  if (c->assume_free_mb > 0) avail = (size_t)c->assume_free_mb << 20;
+  else {
+    size_t fr = 0, total = 0;
+    if (hipSetDevice(c->device) != hipSuccess || hipMemGetInfo(&fr, &total) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    avail = fr + c->ws.stride * WS_BYTES_PER_ITEM;   // growing frees the present workspace first
+  }
+  const size_t need = ((n + 255) & ~(size_t)255) * WS_BYTES_PER_ITEM;
+  if (need <= avail / 10 * 9) return 0;
+  size_t chunk = (avail / 10 * 8) / WS_BYTES_PER_ITEM;
+  chunk &= ~(size_t)65535;
+  if (chunk == 0) chunk = (avail / 10 * 8) / WS_BYTES_PER_ITEM & ~(size_t)255;   // a very small device share: whatever fits (a failure to allocate is then reported as before)
+  return chunk && chunk < n ? chunk : 0;
+}
 int stage_reserve(bn254_ctx* c, int slot, size_t bytes) {
   if (bytes <= c->stage_cap[slot]) return 0;
   HIP_TRY(hipSetDevice(c->device));
@@ -458,7 +476,7 @@ int pool_reserve(bn254_ctx* c, int which, size_t n_fp, size_t entries) {
 // G2 decoding: with the subgroup test requested (one 63-bit ladder on the twist per point) it runs on lane pairs
 int launch_decode_g2(bn254_ctx* c, hipStream_t s, const uint8_t* d_pts, size_t n, uint32_t flags, int accumulate) {
   if (c->pair_lanes && (flags & FLAG_G2_SUBGROUP_CHECK)) {
-    if (c->lm_max_batch > 0 && n <= (size_t)c->lm_max_batch) {
+    if (route_lane_machine_helpers(c, n)) {
       // the smallest batches: decode without the test, then the test with its ladder in the lane machine's level tables
       k_decode_g2<<<grid_for(n), BN_WAVE, 0, s>>>(d_pts, n, flags & ~(uint32_t)FLAG_G2_SUBGROUP_CHECK, c->ws, accumulate);
       return bn254_lm_g2_subgroup(n, c->ws, s);
@@ -688,6 +706,8 @@ int bn254_ctx_set_option(bn254_ctx* c, int option, int value) {
     return 0;
   }
   if (option == BN254_OPT_HASH_MAX_TRIES) { if (value < 0 || value > 255) return BN254_E_BAD_ARGUMENT; c->hash_max_tries = value; return 0; }
+  if (option == BN254_OPT_MAX_CHUNK) { if (value < 0) return BN254_E_BAD_ARGUMENT; c->max_chunk = value; return 0; }
+  if (option == BN254_OPT_ASSUME_FREE_MB) { if (value < 0) return BN254_E_BAD_ARGUMENT; c->assume_free_mb = value; return 0; }
   return BN254_E_BAD_ARGUMENT;
 }
 // clock probe (BN254_OPT_CLOCK_PROBE): the clock the chip ran the last Miller kernel [0], final exponentiation [1] and issue probe [2]
@@ -732,22 +752,34 @@ int bn254_ctx_last_kernel_ms(bn254_ctx* c, float ms[4]) {
 // which is what latency is made of when a wave has its SIMD to itself).  Same status bytes either way.
 // final exponentiation of a small batch: the smallest on nine lane pairs per verify (bn254_nonet.hip; eighteen while one verify per wave
 // still covers the batch) — fewer instructions per lane again —, the others in the octet layout
+// (the layouts come from the routing table, bn254_ws.h: bn_route; a caller that has ALREADY chosen a small-batch Miller kernel — the keyed lane
+// machine — asks for the small-batch final exponentiation of the same row)
+static int launch_final_exp_layout(bn254_ctx* c, hipStream_t s, size_t n, int use_hash, uint8_t* d_status, int fe) {
+  switch (fe) {
+    case BN_FE_NONET_WIDE: return bn254_nonet_final_exp(n, c->ws, use_hash, d_status, s, 1);
+    case BN_FE_NONET: return bn254_nonet_final_exp(n, c->ws, use_hash, d_status, s, 0);
+    case BN_FE_OCTET: return bn254_trio_final_exp(n, c->ws, use_hash, d_status, s);
+    default: return bn254_pair_final_exp(n, c->ws, use_hash, d_status, nullptr, nullptr, s);
+  }
+}
 int launch_small_final_exp(bn254_ctx* c, hipStream_t s, size_t n, int use_hash, uint8_t* d_status) {
-  if (c->nonet_max_batch > 0 && n <= (size_t)c->nonet_max_batch) return bn254_nonet_final_exp(n, c->ws, use_hash, d_status, s, c->nonet_wide && n <= (size_t)NONET_WIDE_MAX_BATCH);
-  return bn254_trio_final_exp(n, c->ws, use_hash, d_status, s);
+  const BnRoute r = route_for(c, n);
+  return launch_final_exp_layout(c, s, n, use_hash, d_status, r.fe == BN_FE_LANE_PAIRS ? BN_FE_OCTET : r.fe);
 }
 int launch_pair_or_trio(bn254_ctx* c, hipStream_t s, size_t n, int use_hash, uint8_t* d_status, int mode, bool mark) {
+  const BnRoute r = route_for(c, n);
   int rc;
-  if (c->trio_max_batch > 0 && n <= (size_t)c->trio_max_batch) {
-    if ((rc = c->lm_max_batch > 0 && n <= (size_t)c->lm_max_batch ? bn254_lm_miller_verify(n, c->ws, s, mode)
-              : c->trio_wave_roles == 2 ? bn254_w8_miller_verify(n, c->ws, s, mode)
-              : c->trio_wave_roles ? bn254_quad_miller_verify(n, c->ws, s, mode) : bn254_trio_miller_verify(n, c->ws, s, mode))) return rc;
-    if (mark) PROF_MARK(3);
-    return launch_small_final_exp(c, s, n, use_hash, d_status);
+  switch (r.miller) {
+    case BN_ML_LANE_MACHINE: rc = bn254_lm_miller_verify(n, c->ws, s, mode); break;
+    case BN_ML_WAVE_ROLES:         // BN254_OPT_TRIO_WAVE_ROLES (developer knob): eight waves (default), four, or the lane groups of one wave
+      rc = c->trio_wave_roles == 2 ? bn254_w8_miller_verify(n, c->ws, s, mode)
+           : c->trio_wave_roles ? bn254_quad_miller_verify(n, c->ws, s, mode) : bn254_trio_miller_verify(n, c->ws, s, mode);
+      break;
+    default: rc = bn254_pair_miller_verify(n, c->ws, nullptr, nullptr, s, mode); break;
   }
-  if ((rc = bn254_pair_miller_verify(n, c->ws, nullptr, nullptr, s, mode))) return rc;
+  if (rc) return rc;
   if (mark) PROF_MARK(3);
-  return bn254_pair_final_exp(n, c->ws, use_hash, d_status, nullptr, nullptr, s);
+  return launch_final_exp_layout(c, s, n, use_hash, d_status, r.fe);
 }
 
 extern "C" {
@@ -786,6 +818,16 @@ int bn254_batch_verify_device(bn254_ctx* c, const uint8_t* d_msgs, const uint64_
   // loop; BN254_OPT_SPLIT_MILLER additionally runs one pairing per lane (two waves per verify) — both kept for A/B
   // runs, see profiles/r01_c_ab_occupancy.log and DESIGN.md section 4
   bool split = c->split_miller && n <= BN_SPLIT_MAX_N;
+  if (const size_t chunk = ws_chunk_for(c, n)) {
+    // an oversized batch: slices of `chunk` items through this same entry point, one after the other on the caller's stream — the offsets are
+    // absolute into d_msgs, so a slice is the same arrays further in; statuses land at the items' own positions (profiling: the last slice's)
+    for (size_t lo = 0; lo < n; lo += chunk) {
+      const size_t len = n - lo < chunk ? n - lo : chunk;
+      const int rc_ = bn254_batch_verify_device(c, d_msgs, d_off + lo, d_sigs + 64 * lo, d_pks + 128 * lo, len, flags, d_status + lo, stream);
+      if (rc_) return rc_;
+    }
+    return 0;
+  }
   int rc = ws_reserve(c, split ? 2 * n : n);
   if (rc) return rc;
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
@@ -805,13 +847,21 @@ int bn254_batch_verify_compressed_device(bn254_ctx* c, const uint8_t* d_msgs, co
   if (n == 0) return 0;
   if ((uintptr_t)d_off & 7u) return BN254_E_MISALIGNED;
   HIP_TRY(hipSetDevice(c->device));
+  if (const size_t chunk = ws_chunk_for(c, n)) {       // an oversized batch in slices (see bn254_batch_verify_device)
+    for (size_t lo = 0; lo < n; lo += chunk) {
+      const size_t len = n - lo < chunk ? n - lo : chunk;
+      const int rc_ = bn254_batch_verify_compressed_device(c, d_msgs, d_off + lo, d_sigs33 + 33 * lo, d_pks65 + 65 * lo, len, d_status + lo, stream);
+      if (rc_) return rc_;
+    }
+    return 0;
+  }
   int rc = ws_reserve(c, n);
   if (rc) return rc;
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
   CallDone call_done(c, s);
   PROF_MARK(0);
   k_decompress_g1_ws<<<grid_for(n), BN_WAVE, 0, s>>>(d_sigs33, n, c->ws);
-  if (c->pair_lanes && c->lm_max_batch > 0 && n <= (size_t)c->lm_max_batch) {
+  if (route_lane_machine_helpers(c, n)) {
     // the smallest batches: the subgroup test of the decompressed keys with its ladder in the lane machine's level tables
     if ((rc = bn254_pair_decompress_g2(d_pks65, n, c->ws, s, 1))) return rc;
     if ((rc = bn254_lm_g2_subgroup(n, c->ws, s, ST_NOT_MEMBER))) return rc;
@@ -827,6 +877,18 @@ int bn254_batch_verify_compressed(bn254_ctx* c, const uint8_t* msgs, const uint6
   HIP_TRY(hipSetDevice(c->device));
   int rc;
   if (!offsets_ok(off, n)) return BN254_E_BAD_ARGUMENT;
+  if (const size_t chunk = ws_chunk_for(c, n)) {       // an oversized batch in slices, offsets rebased per slice (see bn254_batch_verify)
+    uint64_t* tmp = (uint64_t*)malloc((chunk + 1) * sizeof(uint64_t));
+    if (!tmp) return BN254_E_NO_MEMORY;
+    rc = 0;
+    for (size_t lo = 0; lo < n && !rc; lo += chunk) {
+      const size_t len = n - lo < chunk ? n - lo : chunk;
+      for (size_t i = 0; i <= len; ++i) tmp[i] = off[lo + i] - off[lo];
+      rc = bn254_batch_verify_compressed(c, msgs ? msgs + off[lo] : nullptr, tmp, sigs33 + 33 * lo, pks65 + 65 * lo, len, status + lo);
+    }
+    free(tmp);
+    return rc;
+  }
   if ((rc = stage_in(c, 0, msgs, (size_t)off[n]))) return rc;
   if ((rc = stage_in(c, 1, off, (n + 1) * sizeof(uint64_t)))) return rc;
   if ((rc = stage_in(c, 2, sigs33, n * 33))) return rc;
@@ -961,6 +1023,19 @@ int bn254_batch_verify(bn254_ctx* c, const uint8_t* msgs, const uint64_t* off, c
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
   }
+  if (const size_t chunk = ws_chunk_for(c, n)) {
+    // an oversized batch: slices through this same entry point, each with its offsets rebased to its own first message byte
+    uint64_t* tmp = (uint64_t*)malloc((chunk + 1) * sizeof(uint64_t));
+    if (!tmp) return BN254_E_NO_MEMORY;
+    rc = 0;
+    for (size_t lo = 0; lo < n && !rc; lo += chunk) {
+      const size_t len = n - lo < chunk ? n - lo : chunk;
+      for (size_t i = 0; i <= len; ++i) tmp[i] = off[lo + i] - off[lo];
+      rc = bn254_batch_verify(c, msgs ? msgs + off[lo] : nullptr, tmp, sigs + 64 * lo, pks + 128 * lo, len, flags, status + lo);
+    }
+    free(tmp);
+    return rc;
+  }
   rc = verify_host_overlapped(c, msgs, off, sigs, pks, n, flags, status, msg_bytes);
   if (rc) {
     // a failure after the first asynchronous enqueue: the copies and kernels already in flight still read the caller's
@@ -1030,8 +1105,7 @@ static int pairing_device(bn254_ctx* c, const uint8_t* d_g1, const uint8_t* d_g2
   if ((rc = launch_decode_g2(c, s, d_g2, lanes, flags, 1))) return rc;
   PROF_MARK(1);
   PROF_MARK(2);                                      // no hash in a pairing: ms[1] = 0
-  if (c->pair_lanes && !raw_only && c->lm_max_batch > 0 && lanes <= (size_t)c->lm_max_batch && c->nonet_max_batch > 0 && c->nonet_wide &&
-      n <= (size_t)NONET_WIDE_MAX_BATCH) {
+  if (!raw_only && route_lane_machine_helpers(c, lanes) && route_for(c, n).fe == BN_FE_NONET_WIDE) {
     // a batch that cannot fill the chip: the small-batch kernels of a verify — the lane machine with the fixed
     // pair skipped, the final exponentiation (exact program, Gt bytes) on eighteen lane pairs per item: 5.7 -> 1.3 ms for one pairing
     if ((rc = bn254_lm_miller_verify(lanes, c->ws, s, 2))) return rc;

@@ -56,6 +56,8 @@ struct bn254_ctx {
   size_t n_keys, key_cap;
   hipEvent_t last_done;      // recorded on the CALLER's stream when a *_device call on such a stream returns (CallDone below): what ctx_quiesce
   bool last_done_armed;      // waits for.  The context keeps no handle of a stream it does not own — the caller may destroy its stream any time.
+  int max_chunk;             // BN254_OPT_MAX_CHUNK: verify-shaped batches above this size are processed in slices (0 = only when the workspace would not fit)
+  int assume_free_mb;        // test knob (BN254_OPT_ASSUME_FREE_MB): the automatic rule prices the workspace against this much free memory instead of hipMemGetInfo
   bool fits_w8, fits_quad, fits_trio;   // the device can hold a workgroup of the small-batch kernels (LDS), asked at creation
 };
 
@@ -70,6 +72,19 @@ struct ScopedEvents {
   ScopedEvents(const ScopedEvents&) = delete;
   ScopedEvents& operator=(const ScopedEvents&) = delete;
 };
+// the context's thresholds as the routing table's limits (bn254_ws.h: bn_route) — every size-dependent choice of layout goes through here
+static inline BnRouteLimits route_limits(const bn254_ctx* c) {
+  BnRouteLimits L;
+  L.small_max = c->pair_lanes && c->trio_max_batch > 0 ? (size_t)c->trio_max_batch : 0;
+  L.lm_max = c->lm_max_batch > 0 ? (size_t)c->lm_max_batch : 0;
+  L.nonet_max = c->nonet_max_batch > 0 ? (size_t)c->nonet_max_batch : 0;
+  L.nonet_wide_max = c->nonet_wide ? (size_t)NONET_WIDE_MAX_BATCH : 0;
+  return L;
+}
+static inline BnRoute route_for(const bn254_ctx* c, size_t n) { return bn_route(route_limits(c), n); }
+// the decode-time helpers of the smallest batches (G2 subgroup ladder on the lane machine's level tables; the pairing API's small-batch
+// kernels) follow the lane machine's own threshold, whatever the size of the small-batch family
+static inline bool route_lane_machine_helpers(const bn254_ctx* c, size_t n) { return c->pair_lanes && c->lm_max_batch > 0 && n <= (size_t)c->lm_max_batch; }
 static inline unsigned grid_for(size_t n) { return (unsigned)((n + BN_WAVE - 1) / BN_WAVE); }
 
 // before a buffer of the context is freed or rewritten: wait for the context's own streams and for the END of its last *_device call on a
@@ -92,6 +107,10 @@ struct CallDone {
   CallDone& operator=(const CallDone&) = delete;
 };
 BN_HIDDEN int ws_reserve(bn254_ctx* c, size_t n);
+// Oversized batches: the slice length the verify-shaped entry points cut a batch of n items into, or 0 = one piece.  BN254_OPT_MAX_CHUNK when
+// set; otherwise only when the workspace of the whole batch (WS_BYTES_PER_ITEM each) would not fit what the device has free (+ what the
+// context's present workspace would give back): then the largest multiple of 65 536 items that fits in 80 % of it.
+BN_HIDDEN size_t ws_chunk_for(bn254_ctx* c, size_t n);
 BN_HIDDEN int stage_reserve(bn254_ctx* c, int slot, size_t bytes);
 BN_HIDDEN int stage_in(bn254_ctx* c, int slot, const void* host, size_t bytes);
 BN_HIDDEN int stage_out(bn254_ctx* c, int slot, void* host, size_t bytes);

@@ -366,6 +366,14 @@ int bn254_batch_verify_keyed_device(bn254_ctx* c, const uint8_t* d_msgs, const u
   if (n == 0) return 0;
   if (misaligned(d_sigs) || misaligned(d_key_idx) || ((uintptr_t)d_off & 7u)) return BN254_E_MISALIGNED;
   HIP_TRY(hipSetDevice(c->device));
+  if (const size_t chunk = ws_chunk_for(c, n)) {       // an oversized batch in slices (see bn254_batch_verify_device)
+    for (size_t lo = 0; lo < n; lo += chunk) {
+      const size_t len = n - lo < chunk ? n - lo : chunk;
+      const int rc_ = bn254_batch_verify_keyed_device(c, d_msgs, d_off + lo, d_sigs + 64 * lo, d_key_idx + lo, len, flags, d_status + lo, stream);
+      if (rc_) return rc_;
+    }
+    return 0;
+  }
   int rc = ws_reserve(c, n);
   if (rc) return rc;
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
@@ -381,10 +389,10 @@ int bn254_batch_verify_keyed_device(bn254_ctx* c, const uint8_t* d_msgs, const u
   PROF_MARK(1);
   if ((rc = launch_hash_rounds(c, s, d_msgs, d_off, n, PL_P2X, BY_P2_INF, nullptr))) return rc;
   PROF_MARK(2);
-  if (c->pair_lanes && c->trio_max_batch > 0 && n <= (size_t)c->trio_max_batch) {
+  if (route_for(c, n).miller != BN_ML_LANE_PAIRS) {
     // a batch that cannot fill the chip: latency counts — expand the keys and take the small-batch kernels (2.3 ms instead of the
     // 6 ms of the lane-pair layout; the line tables pay off only where throughput binds)
-    if (c->lm_max_batch > 0 && n <= (size_t)c->lm_max_batch) {
+    if (route_for(c, n).miller == BN_ML_LANE_MACHINE) {
       // the smallest: the lane machine's keyed form on the line tables themselves (no twist point to walk: 0.32 ms against 0.43)
       if ((rc = bn254_lm_miller_verify_keyed(n, c->ws, d_key_idx, kt, s))) return rc;
       PROF_MARK(3);

@@ -1,6 +1,7 @@
 // Workspace layout shared by the two device translation units of libbn254hip.so (bn254_hip.hip: one item per
 // lane; bn254_pair.hip: one verify per lane PAIR).  Device-side only; include after the field headers.
 #pragma once
+#include <stddef.h>
 
 #define BN_WAVE 64
 #define BN_SPLIT_MAX_N ((size_t)98304)   // <= 1.5 waves per SIMD with one lane per verify
@@ -8,6 +9,43 @@
 #define NONET_WIDE_MAX_BATCH 1024                  // ... and up to this size on EIGHTEEN lane pairs, one verify per wave: the 18 products of a multiplication in one round (0.63 -> 0.56 ms)
 #define NONET_MAX_BATCH_DEFAULT 3072               // final exponentiation on nine lane pairs per verify up to this batch size: ONE pass of 3 verifies per wave on 1024 SIMDs (0.64 ms against the octet layout's 1.09; a second pass would cost 1.3)
 #define LM_MAX_BATCH_DEFAULT 1536                   // Miller loop as the lane machine (bn254_lmiller.hip: nine lane pairs in each of four waves per verify, 3 verifies per workgroup, one workgroup per CU) up to this batch size: two passes over 256 CUs (0.43 ms one pass, 0.86 two; eight wave roles: 1.0); 0 = never
+// ---- batch size -> kernel layout: the ONE routing table of the verify-shaped entry points ---------------------------------------------
+// (verify, verify from compressed encodings, check_public_keys, aggregate verify's pairing part, keyed verify below its table route.)
+// Four thresholds — the *_DEFAULT values above, overridden per context by BN254_OPT_LM_MAX_BATCH / _NONET_MAX_BATCH / _NONET_WIDE /
+// _TRIO_MAX_BATCH — span the table; bn_route() is the only place that turns a batch size into layouts, bn_route_table() lists its rows
+// (what bn254_debug_route_table hands to the tests, which generate every boundary +-1 from it instead of listing sizes by hand).
+//   default rows:  n <=  1 024  lane machine      + eighteen lane pairs      (one verify per SIMD)
+//                  n <=  1 536  lane machine      + nine lane pairs
+//                  n <=  3 072  eight wave roles  + nine lane pairs
+//                  n <= 16 384  eight wave roles  + octets
+//                  above        lane pairs        + lane pairs               (two waves per SIMD: throughput)
+enum BnMillerLayout { BN_ML_LANE_MACHINE = 0, BN_ML_WAVE_ROLES = 1, BN_ML_LANE_PAIRS = 2 };
+enum BnFeLayout { BN_FE_NONET_WIDE = 0, BN_FE_NONET = 1, BN_FE_OCTET = 2, BN_FE_LANE_PAIRS = 3 };
+struct BnRouteLimits { size_t lm_max, nonet_wide_max, nonet_max, small_max; };   // 0 = that layout is off; small_max bounds the whole small-batch family
+struct BnRoute { int miller, fe; };
+static inline BnRoute bn_route(const BnRouteLimits& L, size_t n) {
+  BnRoute r = {BN_ML_LANE_PAIRS, BN_FE_LANE_PAIRS};
+  if (n > L.small_max) return r;
+  r.miller = n <= L.lm_max ? BN_ML_LANE_MACHINE : BN_ML_WAVE_ROLES;
+  r.fe = n <= L.nonet_max ? (n <= L.nonet_wide_max ? BN_FE_NONET_WIDE : BN_FE_NONET) : BN_FE_OCTET;
+  return r;
+}
+// rows (max_n[i], route[i]) in ascending order of max_n, the last one max_n = SIZE_MAX; returns the number of rows (<= 5)
+static inline int bn_route_table(const BnRouteLimits& L, size_t* max_n, BnRoute* route, int cap) {
+  size_t b[4] = {L.lm_max, L.nonet_wide_max, L.nonet_max, L.small_max};
+  for (int i = 0; i < 4; ++i) if (b[i] > L.small_max) b[i] = L.small_max;
+  for (int i = 0; i < 4; ++i) for (int j = i + 1; j < 4; ++j) if (b[j] < b[i]) { size_t t = b[i]; b[i] = b[j]; b[j] = t; }
+  int rows = 0;
+  for (int i = 0; i < 4 && rows < cap - 1; ++i) {
+    if (b[i] == 0 || (i && b[i] == b[i - 1])) continue;
+    const BnRoute r = bn_route(L, b[i]);
+    if (rows && route[rows - 1].miller == r.miller && route[rows - 1].fe == r.fe) { max_n[rows - 1] = b[i]; continue; }
+    max_n[rows] = b[i]; route[rows] = r; ++rows;
+  }
+  max_n[rows] = (size_t)-1; route[rows] = bn_route(L, (size_t)-1); ++rows;
+  return rows;
+}
+#ifndef BN_WS_ROUTE_ONLY      /* (a host-side test includes the part above alone: tests/test_abi.py::test_routing_table_rows) */
 #define TRIO_WAVE_ROLES_DEFAULT 2                  // ... with the Miller loop as wave roles: 2 = eight waves per 32 verifies (k_miller_verify_w8), 1 = four
 #define AGG_SUBSET_MIN_TUPLES_DEFAULT 4096       // aggregate verify: subset-sum table of the key pool from this many tuples on (the table costs ~0.3 ms)
 #define AGG_SUBSET_MAX_SIGNERS ((size_t)2048)     // ... one mask byte per group of 8 keys and tuple in LDS: 256 groups at most
@@ -171,3 +209,4 @@ __attribute__((visibility("hidden"))) int bn254_lm_g2_subgroup(size_t n, Ws ws, 
 __attribute__((visibility("hidden"))) bool bn254_nonet_fits_device();
 __attribute__((visibility("hidden"))) int bn254_nonet_final_exp(size_t n, Ws ws, int use_hash, uint8_t* status_out, hipStream_t s, int wide = 0);
 __attribute__((visibility("hidden"))) int bn254_nonet_final_exp_product(size_t n, size_t k, Ws ws, uint8_t* gt_out, uint8_t* status_out, hipStream_t s);   // bn254_batch_pairing*, n <= NONET_WIDE_MAX_BATCH
+#endif  // BN_WS_ROUTE_ONLY

@@ -28,6 +28,8 @@ OPT_NONET_MAX_BATCH = 13
 OPT_LM_MAX_BATCH = 15
 OPT_NONET_WIDE = 16
 OPT_AGG_WIDE_MIN_TUPLES = 14
+OPT_MAX_CHUNK = 17          # verify-shaped batches above this size are processed in slices (0 = only when the workspace would not fit)
+OPT_ASSUME_FREE_MB = 18     # test knob of the automatic slicing rule
 
 
 class NativeError(RuntimeError):
@@ -105,6 +107,15 @@ class Engine:
         rate, simds = ctypes.c_double(0), ctypes.c_int(0)
         _check("bn254_probe_issue_rate", self._lib.bn254_probe_issue_rate(self._h, op, waves_per_simd, ctypes.byref(rate), ctypes.byref(simds)))
         return rate.value, simds.value
+
+    def route_table(self):
+        """developer hook: the context's batch-size -> layout routing table as it stands: [(max_n, miller, fe)], last row max_n = 2**64 - 1
+        (miller: 0 lane machine, 1 wave roles, 2 lane pairs; fe: 0 eighteen lane pairs, 1 nine, 2 octets, 3 lane pairs)"""
+        m, a, b = (ctypes.c_uint64 * 8)(), (ctypes.c_int * 8)(), (ctypes.c_int * 8)()
+        rows = self._lib.bn254_debug_route_table(self._h, m, a, b, 8)
+        if rows < 0:
+            _check("bn254_debug_route_table", rows)
+        return [(int(m[i]), int(a[i]), int(b[i])) for i in range(rows)]
 
     def last_kernel_ms(self):
         ms = (ctypes.c_float * 4)()

@@ -262,29 +262,16 @@ int bn254_batch_g2_decompress(bn254_ctx *ctx, const uint8_t *in /* n*65 */, size
  * launch stream around each kernel: ms[0] decode, ms[1] hash-to-G1, ms[2] Miller loop,
  * ms[3] final exponentiation.  Synchronises the stream.  Requires bn254_ctx_set_profiling(ctx, 1). */
 int bn254_ctx_set_profiling(bn254_ctx *ctx, int enabled);
-/* tuning/test knobs.  BN254_OPT_SPLIT_MILLER: 1 = run the two Miller loops of a verify in two lanes of
- * different waves (one pairing per lane) instead of one lane sharing f^2 (default 0).  Results are
- * identical either way. */
-#define BN254_OPT_SPLIT_MILLER 1
-#define BN254_OPT_RAND_MIN_BATCH 5 /* randomised verify: batches with fewer items run the exact kernels instead (same statuses; group_ok = no item of the
-                                     group failed the pairing check).  Default 131072, the measured break-even on an MI355X; 0 = always randomised */
-#define BN254_OPT_PAIR_LANES 4 /* verify: Miller loop + final exponentiation on lane pairs, two waves per SIMD (default 1); 0 = one lane per verify */
-#define BN254_OPT_RAND_ITEMS_PER_LANE 3 /* randomised verify: items per lane in the Miller kernel; 0 = by batch size (default), 1, 2 */
+/* Options a CALLER may want to touch: the batch-size thresholds of the routing table (which kernel layout serves which batch size — ONE
+ * table, bn254_amd/csrc/bn254_ws.h: bn_route; defaults measured on an MI355X), the thresholds of the aggregate / randomised paths, and the
+ * staging mode of the host-pointer verify.  Every setting returns the same status bytes; they trade latency against throughput.
+ * (The A/B layouts of earlier rounds — one lane per verify, one pairing per lane, four wave roles, lane groups — and the test / measurement
+ * knobs are developer options: section BN254_DEV_HOOKS at the end of this header.) */
 #define BN254_OPT_TRIO_MAX_BATCH 6 /* verify / check_public_keys batches of up to this many items run in the OCTET layout (eight lanes per item: the
                                      three Fq6 products of every Fq12 operation in three lane pairs) — fewer instructions per lane, i.e. lower
                                      latency when the batch cannot fill the chip anyway; same status bytes.  Default 16384 (two passes of one wave
                                      on each of the 1024 SIMDs: 2.3 ms for 1 verify, 3.3 ms for 8192, 6.3 ms for 16384, against 6.4 / 7.1 /
                                      7.9 ms on lane pairs); 0 = never */
-#define BN254_OPT_TRIO_WAVE_ROLES 8 /* octet path, Miller loop: the lane pairs of a verify as WAVES of a workgroup, each with its own instruction
-                                     stream (twist point / line product / the halves of f), values exchanged through LDS between barriers:
-                                     2 (default) = eight waves per 32 verifies (every Fq6 product split over two waves), 1 = four waves,
-                                     0 = four lane pairs of one wave (every pair runs all the linear work).  Same status bytes. */
-#define BN254_OPT_HASH_DIRECT_WIDTH 7 /* hash-to-G1 of batches of up to 4096 messages: this many counters of every message are tried at once, in
-                                       lanes of one wave, with the square root itself (latency 0.17 ms instead of 0.25); a power of two <= 32,
-                                       default 32; 0 = always the filter rounds.  Same points and try counts either way. */
-#define BN254_OPT_AGG_SUBSET_MIN_TUPLES 9 /* aggregate verify: from this many tuples on (default 4096) the sums of all subsets of every 8 consecutive
-                                            keys of the pool are tabulated once per call and a tuple adds one table entry per group instead of one
-                                            key per signer (pools of up to 2048 signers, lists longer than n_signers / 8); 0 = never.  Same statuses. */
 #define BN254_OPT_NONET_MAX_BATCH 13 /* small batches: up to this many items the final exponentiation runs on NINE lane pairs per item (18 lanes,
                                       three items per wave): the nine squarings of a cyclotomic squaring at once, the 18 products of an Fq12
                                       multiplication in two rounds; same status bytes.  0 = never (octet layout) */
@@ -292,23 +279,22 @@ int bn254_ctx_set_profiling(bn254_ctx *ctx, int enabled);
                                    waves per item: every product of a dependency level in its own lane pair; twist-point formulas rearranged
                                    for depth; bn254_batch_verify_keyed: its keyed form on the registered keys' line tables); same status
                                    bytes.  0 = never (wave roles / octet layout) */
-#define BN254_OPT_NONET_WIDE 16 /* ... and, while the batch is at most one item per SIMD (1 024), on EIGHTEEN lane pairs, one item per wave: the 18
-                                 products of a multiplication in one round (default 1; 0 = nine lane pairs at every size) */
-#define BN254_OPT_PINNED_STAGING 12 /* bn254_batch_verify (host pointers), batches of >= 8192: T = 1..16 threads copy the caller's (pageable)
-                                     buffers through a pinned staging buffer of the context in 1 MB pieces, each piece's DMA enqueued as soon
-                                     as it is in place; 0 = hipMemcpyAsync straight from the caller's buffers (the runtime stages them) */
-#define BN254_OPT_AGG_SORT_BY_MSG 11 /* aggregate verify, batches that use the per-message signature tables: bucket the tuples by message on the
-                                      device (counting sort into an index map) so that a workgroup of the aggregation kernel gathers from ONE
-                                      message's table; statuses land at the tuples' own indices either way.  Default 1; 0 = the caller's order */
+#define BN254_OPT_RAND_MIN_BATCH 5 /* randomised verify: batches with fewer items run the exact kernels instead (same statuses; group_ok = no item of the
+                                     group failed the pairing check).  Default 131072, the measured break-even on an MI355X; 0 = always randomised */
+#define BN254_OPT_AGG_SUBSET_MIN_TUPLES 9 /* aggregate verify: from this many tuples on (default 4096) the sums of all subsets of every 8 consecutive
+                                            keys of the pool are tabulated once per call and a tuple adds one table entry per group instead of one
+                                            key per signer (pools of up to 2048 signers, lists longer than n_signers / 8); 0 = never.  Same statuses. */
 #define BN254_OPT_AGG_WIDE_MIN_TUPLES 14 /* aggregate verify: from this many tuples on (default 262144) the subset-sum tables are WIDENED once more —
                                           keys: the sums of all subsets of every 16 consecutive signers (n_signers / 16 x 65536 entries, 671 MB
                                           for 1024 signers), signatures per message: of every 8 — by one batched affine addition per entry, so
                                           that a tuple adds half as many entries; 0 = never.  Same statuses. */
-#define BN254_OPT_CLOCK_PROBE 10 /* measurement: 1 = the lane-pair Miller / final-exponentiation kernels and the issue probe record, per workgroup,
-                                  shader-clock cycles (s_memtime) and constant-rate ticks (s_memrealtime) between entry and exit, read back by
-                                  bn254_ctx_last_clocks: the clock the chip actually sustains under this load (power-limited parts run below
-                                  their nominal 2.4 GHz).  Costs two scalar clock reads per workgroup; default 0 */
-#define BN254_OPT_HASH_MAX_TRIES 2 /* test knob: counters tried before HashToPointError; 0 = 255 as in src/hash.rs:40 */
+#define BN254_OPT_PINNED_STAGING 12 /* bn254_batch_verify (host pointers), batches of >= 8192: T = 1..16 threads copy the caller's (pageable)
+                                     buffers through a pinned staging buffer of the context in 1 MB pieces, each piece's DMA enqueued as soon
+                                     as it is in place; 0 = hipMemcpyAsync straight from the caller's buffers (the runtime stages them) */
+#define BN254_OPT_MAX_CHUNK 17 /* *_device and host entry points of verify / verify_compressed / verify_keyed: a batch of more than this many items
+                                is processed in slices of this size (the 792 B/item workspace of a slice is reused; statuses land at the items'
+                                own positions, so the result is that of one call).  0 (default) = automatic: slice only when the workspace of
+                                the whole batch does not fit the device's free memory */
 int bn254_ctx_set_option(bn254_ctx *ctx, int option, int value);
 /* per-kernel times of the last verify-shaped call with profiling on (HIP events on the call's stream):
  * ms[0] decode, ms[1] hash-to-G1, ms[2] Miller loop, ms[3] final exponentiation.  The host-pointer bn254_batch_verify runs
@@ -414,6 +400,35 @@ int bn254_mgpu_batch_hash_to_g1(bn254_mgpu *mg, const uint8_t *msgs, const uint6
  * BN254_NO_DEV_HOOKS before including this header to hide the declarations.
  * ===================================================================================================================== */
 #ifndef BN254_NO_DEV_HOOKS
+/* developer options of bn254_ctx_set_option: A/B layouts kept for measurements and for the randomised path's re-check queue, test and
+ * measurement knobs.  Same status bytes with every setting; none of them is something a caller of the drop-in ABI should set. */
+#define BN254_OPT_SPLIT_MILLER 1 /* 1 = the two Miller loops of a verify in two lanes of different waves (one pairing per lane, one-lane layout only;
+                                 default 0) */
+#define BN254_OPT_PAIR_LANES 4 /* verify: Miller loop + final exponentiation on lane pairs, two waves per SIMD (default 1); 0 = one lane per verify */
+#define BN254_OPT_RAND_ITEMS_PER_LANE 3 /* randomised verify: items per lane in the Miller kernel; 0 = by batch size (default), 1, 2 */
+#define BN254_OPT_TRIO_WAVE_ROLES 8 /* octet path, Miller loop: the lane pairs of a verify as WAVES of a workgroup, each with its own instruction
+                                     stream (twist point / line product / the halves of f), values exchanged through LDS between barriers:
+                                     2 (default) = eight waves per 32 verifies (every Fq6 product split over two waves), 1 = four waves,
+                                     0 = four lane pairs of one wave (every pair runs all the linear work).  Same status bytes. */
+#define BN254_OPT_HASH_DIRECT_WIDTH 7 /* hash-to-G1 of batches of up to 4096 messages: this many counters of every message are tried at once, in
+                                       lanes of one wave, with the square root itself (latency 0.17 ms instead of 0.25); a power of two <= 32,
+                                       default 32; 0 = always the filter rounds.  Same points and try counts either way. */
+#define BN254_OPT_NONET_WIDE 16 /* ... and, while the batch is at most one item per SIMD (1 024), on EIGHTEEN lane pairs, one item per wave: the 18
+                                 products of a multiplication in one round (default 1; 0 = nine lane pairs at every size) */
+#define BN254_OPT_AGG_SORT_BY_MSG 11 /* aggregate verify, batches that use the per-message signature tables: bucket the tuples by message on the
+                                      device (counting sort into an index map) so that a workgroup of the aggregation kernel gathers from ONE
+                                      message's table; statuses land at the tuples' own indices either way.  Default 1; 0 = the caller's order */
+#define BN254_OPT_CLOCK_PROBE 10 /* measurement: 1 = the lane-pair Miller / final-exponentiation kernels and the issue probe record, per workgroup,
+                                  shader-clock cycles (s_memtime) and constant-rate ticks (s_memrealtime) between entry and exit, read back by
+                                  bn254_ctx_last_clocks: the clock the chip actually sustains under this load (power-limited parts run below
+                                  their nominal 2.4 GHz).  Costs two scalar clock reads per workgroup; default 0 */
+#define BN254_OPT_HASH_MAX_TRIES 2 /* test knob: counters tried before HashToPointError; 0 = 255 as in src/hash.rs:40 */
+#define BN254_OPT_ASSUME_FREE_MB 18 /* test knob for the automatic slicing rule (BN254_OPT_MAX_CHUNK = 0): price the workspace of a batch against this many MB
+                                    of free device memory instead of what hipMemGetInfo reports; 0 = ask the runtime */
+/* the routing table of this context as it stands (defaults + options): rows (max_n[i], miller[i], fe[i]) in ascending order of max_n, the last
+ * row max_n = UINT64_MAX; miller: 0 lane machine, 1 wave roles, 2 lane pairs; fe: 0 eighteen lane pairs, 1 nine lane pairs, 2 octets, 3 lane
+ * pairs.  Returns the number of rows (<= cap) or a negative error.  The parity tests generate every boundary +-1 from it. */
+int bn254_debug_route_table(bn254_ctx *ctx, uint64_t *max_n, int *miller, int *fe, int cap);
 /* test hooks: element-wise field/tower operations on byte-encoded operands, used by the parity
  * tests to compare each layer of the HIP arithmetic with the oracle.
  *   op: 0 mul, 1 add, 2 sub, 3 inverse(a), 4 square(a), 5 sqrt(a) (status 6 if none)   [Fq, 32 B]

@@ -102,3 +102,43 @@ def test_header_is_plain_c_and_the_dev_hooks_can_be_hidden(tmp_path):
     # with the hooks hidden, naming one is an error (implicit declarations are errors under -Werror=implicit-function-declaration)
     p = subprocess.run(["gcc", "-std=c99", "-Werror=implicit-function-declaration", "-DTRY_HOOK", "-fsyntax-only", str(src)], capture_output=True, text=True)
     assert p.returncode != 0 and "bn254_debug_fp_op" in p.stderr
+
+
+def test_routing_table_rows(tmp_path):
+    """The batch-size -> layout routing is ONE table (bn254_amd/csrc/bn254_ws.h: bn_route / bn_route_table): its default rows are the documented
+    ones, bn_route agrees with the rows on both sides of every boundary, and overriding a threshold moves exactly that boundary."""
+    import subprocess
+    src = tmp_path / "route.cpp"
+    src.write_text(r'''
+#define BN_WS_ROUTE_ONLY 1
+#include "bn254_ws.h"
+#include <cstdio>
+static void dump(BnRouteLimits L) {
+  size_t m[5]; BnRoute r[5];
+  int rows = bn_route_table(L, m, r, 5);
+  for (int i = 0; i < rows; ++i) printf("%zu:%d:%d ", m[i], r[i].miller, r[i].fe);
+  // bn_route itself on both sides of every boundary
+  for (int i = 0; i + 1 < rows; ++i) {
+    BnRoute a = bn_route(L, m[i]), b = bn_route(L, m[i] + 1);
+    if (a.miller != r[i].miller || a.fe != r[i].fe || b.miller != r[i + 1].miller || b.fe != r[i + 1].fe) printf("MISMATCH ");
+  }
+  printf("\n");
+}
+int main() {
+  dump(BnRouteLimits{LM_MAX_BATCH_DEFAULT, NONET_WIDE_MAX_BATCH, NONET_MAX_BATCH_DEFAULT, TRIO_MAX_BATCH_DEFAULT});
+  dump(BnRouteLimits{0, NONET_WIDE_MAX_BATCH, NONET_MAX_BATCH_DEFAULT, TRIO_MAX_BATCH_DEFAULT});      // lane machine off
+  dump(BnRouteLimits{1u << 20, 0, 0, 1u << 20});                                                     // lane machine + octets at every small size
+  dump(BnRouteLimits{LM_MAX_BATCH_DEFAULT, NONET_WIDE_MAX_BATCH, NONET_MAX_BATCH_DEFAULT, 0});        // small-batch family off
+  dump(BnRouteLimits{1u << 20, NONET_WIDE_MAX_BATCH, 1u << 20, 8192});                                // everything clipped at the family's end
+  return 0;
+}''')
+    exe = tmp_path / "route"
+    subprocess.check_call(["g++", "-std=c++17", "-I", os.path.join(ROOT, "bn254_amd", "csrc"), "-o", str(exe), str(src)])
+    out = subprocess.check_output([str(exe)], text=True).splitlines()
+    big = str(2 ** 64 - 1)
+    assert out[0].split() == ["1024:0:0", "1536:0:1", "3072:1:1", "16384:1:2", big + ":2:3"]
+    assert out[1].split() == ["1024:1:0", "3072:1:1", "16384:1:2", big + ":2:3"]
+    assert out[2].split() == ["1048576:0:2", big + ":2:3"]
+    assert out[3].split() == [big + ":2:3"]
+    assert out[4].split() == ["1024:0:0", "8192:0:1", big + ":2:3"]
+    assert not any("MISMATCH" in ln for ln in out)

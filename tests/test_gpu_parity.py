@@ -525,6 +525,100 @@ def test_octet_and_pair_layouts_agree_with_oracle(eng, c, derived, kats):
     assert eng.batch_verify(big[0][:16384], big[1][:16384 * 64], big[2][:16384 * 128]) == big[3][:16384]
 
 
+def test_every_boundary_of_the_routing_table_vs_expected(eng, c):
+    """The batch size -> layout routing is ONE table (bn254_amd/csrc/bn254_ws.h: bn_route; bn254_debug_route_table hands out the rows of this
+    context): every boundary of it, on both sides, is generated FROM the table — for the defaults and for three other settings of the
+    thresholds — and must give the expected status bytes (one batch, checked once against the oracle, cut at every size needed); the keyed
+    verify and check_public_keys take the same table and are cut at the same sizes."""
+    from bn254_amd.engine import OPT_LM_MAX_BATCH, OPT_NONET_MAX_BATCH, OPT_NONET_WIDE, OPT_TRIO_MAX_BATCH
+    from tests.datagen import make_verify_batch
+    big = make_verify_batch(eng, 16386, corrupt_every=13)
+    oracle, _ = c.batch_verify(big[0][:3100], big[1][:3100 * 64], big[2][:3100 * 128], flags=0, nthreads=8)
+    assert oracle == big[3][:3100]                          # the expected pattern IS the oracle's (checked where the oracle is quick)
+    default = eng.route_table()
+    assert default == [(1024, 0, 0), (LM_DEFAULT, 0, 1), (NONET_DEFAULT, 1, 1), (TRIO_DEFAULT, 1, 2), (2 ** 64 - 1, 2, 3)], default
+    seen_routes = set()
+    settings = ((LM_DEFAULT, NONET_DEFAULT, 1, TRIO_DEFAULT), (0, NONET_DEFAULT, 1, TRIO_DEFAULT), (2048, 1500, 0, 4096), (700, 5000, 1, 5000))
+    try:
+        for lm, nonet, wide, trio in settings:
+            eng.set_option(OPT_LM_MAX_BATCH, lm); eng.set_option(OPT_NONET_MAX_BATCH, nonet)
+            eng.set_option(OPT_NONET_WIDE, wide); eng.set_option(OPT_TRIO_MAX_BATCH, trio)
+            table = eng.route_table()
+            assert table[-1] == (2 ** 64 - 1, 2, 3) and [r[0] for r in table] == sorted(r[0] for r in table)
+            for (max_n, miller, fe), nxt in zip(table[:-1], table[1:]):
+                assert (miller, fe) != (nxt[1], nxt[2])        # a row per distinct route
+                seen_routes |= {(miller, fe), (nxt[1], nxt[2])}
+                for n in (max_n - 1, max_n, max_n + 1):        # both sides of the boundary, generated from the table
+                    assert eng.batch_verify(big[0][:n], big[1][:n * 64], big[2][:n * 128]) == big[3][:n], ((lm, nonet, wide, trio), n)
+    finally:
+        eng.set_option(OPT_LM_MAX_BATCH, LM_DEFAULT); eng.set_option(OPT_NONET_MAX_BATCH, NONET_DEFAULT)
+        eng.set_option(OPT_NONET_WIDE, 1); eng.set_option(OPT_TRIO_MAX_BATCH, TRIO_DEFAULT)
+    assert seen_routes >= {(0, 0), (0, 1), (1, 1), (1, 2), (2, 3), (0, 2)}, seen_routes
+    assert eng.route_table() == default
+
+
+def test_oversized_batches_are_sliced_inside_the_library(eng, c, derived):
+    """A batch whose workspace does not fit is cut into slices inside the library instead of failing with an out-of-memory error: forced
+    by BN254_OPT_MAX_CHUNK (a cap that is no multiple of anything) and by the automatic rule priced against a pretended 3 MB of free device
+    memory (BN254_OPT_ASSUME_FREE_MB); host and device entry points of verify, verify from compressed encodings and keyed verify; ragged
+    messages with faults of every class — the statuses are those of the oracle, i.e. of the one-piece call."""
+    import ctypes
+    import torch
+    from bn254_amd.engine import OPT_ASSUME_FREE_MB, OPT_MAX_CHUNK
+    from tests.test_mgpu import _faulty_batch
+    n = 4099
+    msgs, sigs, pks = _faulty_batch(eng, derived, n, 4242)
+    want, _ = c.batch_verify(msgs, sigs, pks, flags=1, nthreads=8)
+    assert len(set(want)) >= 4
+    dev = torch.device("cuda", 0)
+    blob = b"".join(msgs)
+    offs = [0]
+    for m in msgs:
+        offs.append(offs[-1] + len(m))
+    d_msgs = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+    d_off = torch.tensor(offs, dtype=torch.int64, device=dev)
+    d_sigs = torch.frombuffer(bytearray(sigs), dtype=torch.uint8).to(dev)
+    d_pks = torch.frombuffer(bytearray(pks), dtype=torch.uint8).to(dev)
+    fresh = __import__("bn254_amd").Engine(0)                 # its own context: the workspace starts EMPTY, so the automatic rule has something to decide
+    try:
+        for opt, val in ((OPT_MAX_CHUNK, 1000), (OPT_MAX_CHUNK, 4098), (OPT_ASSUME_FREE_MB, 3), (OPT_MAX_CHUNK, 0)):
+            fresh.set_option(OPT_MAX_CHUNK, 0); fresh.set_option(OPT_ASSUME_FREE_MB, 0)
+            fresh.set_option(opt, val)
+            assert fresh.batch_verify(msgs, sigs, pks, flags=1) == want, (opt, val)
+            d_st = torch.full((n,), 0xEE, dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()
+            fresh.batch_verify_device(d_msgs.data_ptr(), d_off.data_ptr(), d_sigs.data_ptr(), d_pks.data_ptr(), n, d_st.data_ptr(), flags=1)
+            fresh.synchronize()
+            assert bytes(d_st.cpu().numpy()) == want, (opt, val)
+        # 3 MB priced against 811 B per item: slices of 2 816 items (the largest multiple of 256 that fits 80 % of it) — the workspace never grew beyond
+        fresh2 = __import__("bn254_amd").Engine(0)
+        fresh2.set_option(OPT_ASSUME_FREE_MB, 3)
+        assert fresh2.batch_verify(msgs, sigs, pks, flags=1) == want
+        # compressed encodings and registered keys through the same rule
+        good = [i for i in range(n) if want[i] in (0, 9) and sigs[64 * i:64 * i + 64] != bytes(64) and pks[128 * i:128 * i + 128] != bytes(128)][:1500]
+        gm = [msgs[i] for i in good]
+        gs = b"".join(sigs[64 * i:64 * i + 64] for i in good)
+        gp = b"".join(pks[128 * i:128 * i + 128] for i in good)
+        gw = bytes(want[i] for i in good)
+        from bn254_amd.api import PublicKey, Signature
+        s33 = b"".join(Signature(gs[64 * i:64 * i + 64]).to_compressed() for i in range(len(good)))       # byte logic only (utils.rs:84-104, :130-158)
+        p65 = b"".join(PublicKey(gp[128 * i:128 * i + 128]).to_compressed() for i in range(len(good)))
+        fresh.set_option(OPT_MAX_CHUNK, 0); fresh.set_option(OPT_ASSUME_FREE_MB, 0)
+        one_piece = fresh.batch_verify_compressed(gm, s33, p65)
+        assert one_piece == gw
+        fresh.set_option(OPT_MAX_CHUNK, 333)
+        assert fresh.batch_verify_compressed(gm, s33, p65) == gw
+        keys = sorted(set(gp[128 * i:128 * i + 128] for i in range(len(good))))
+        st = fresh.register_keys(b"".join(keys))
+        assert st == bytes(len(keys))
+        idx = [keys.index(gp[128 * i:128 * i + 128]) for i in range(len(good))]
+        assert fresh.batch_verify_keyed(gm, gs, idx) == gw
+        fresh.set_option(OPT_MAX_CHUNK, 0)
+        assert fresh.batch_verify_keyed(gm, gs, idx) == gw
+    finally:
+        fresh.close()
+
+
 def test_malformed_inputs_fuzz_vs_oracle(eng, c, derived):
     """3000 verifies whose signature / public key bytes are valid, mutated (bit flips, coordinate >= q,
     swapped coordinates, zeros) or random: every status byte must equal the oracle's, with and without the
