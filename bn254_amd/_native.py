@@ -126,6 +126,10 @@ def load():
     L.bn254_batch_g2_sum.argtypes = [vp, vp, vp, sz, vp, vp]
     L.bn254_batch_aggregate_verify.argtypes = [vp, vp, vp, sz, vp, sz, vp, vp, vp, vp, sz, u32, vp]
     L.bn254_batch_aggregate_verify_device.argtypes = [vp, vp, vp, sz, vp, sz, vp, vp, vp, vp, sz, u32, vp, vp]
+    L.bn254_ctx_register_pools.argtypes = [vp, vp, vp, sz, vp, sz, vp, u32, sz]
+    L.bn254_ctx_register_pools_device.argtypes = [vp, vp, vp, sz, vp, sz, vp, u32, sz, vp]
+    L.bn254_batch_aggregate_verify_registered.argtypes = [vp, vp, vp, vp, sz, vp]
+    L.bn254_batch_aggregate_verify_registered_device.argtypes = [vp, vp, vp, vp, sz, vp, vp]
     L.bn254_batch_g1_decompress.argtypes = [vp, vp, sz, vp, vp]
     L.bn254_batch_g2_decompress.argtypes = [vp, vp, sz, vp, vp]
     L.bn254_debug_fp_op.argtypes = [vp, i32, vp, vp, sz, vp, vp]
@@ -175,7 +179,8 @@ EXPORTED_SYMBOLS = [
     "bn254_batch_pairing_check", "bn254_batch_pairing", "bn254_batch_pairing_device", "bn254_batch_check_public_keys",
     "bn254_batch_g1_add", "bn254_batch_g2_add", "bn254_batch_g1_mul", "bn254_batch_g2_mul", "bn254_batch_g1_mul_device",
     "bn254_batch_g2_mul_device", "bn254_batch_sign", "bn254_batch_sign_device", "bn254_batch_g1_sum", "bn254_batch_g2_sum",
-    "bn254_batch_aggregate_verify", "bn254_batch_aggregate_verify_device", "bn254_batch_g1_decompress", "bn254_batch_g2_decompress", "bn254_debug_fp_op", "bn254_debug_fp12_op", "bn254_debug_final_exp_limbs", "bn254_debug_miller_loop", "bn254_debug_hash_candidate", "bn254_debug_route_table", "bn254_probe_issue_rate", "bn254_probe_leaf_floor", "bn254_probe_fe_program", "bn254_ctx_set_profiling", "bn254_ctx_last_kernel_ms", "bn254_ctx_set_option", "bn254_ctx_last_clocks", "bn254_ctx_expect_msgs_len", "bn254_ctx_register_keys", "bn254_batch_verify_keyed", "bn254_batch_verify_keyed_device", "bn254_batch_verify_keyed_randomized", "bn254_batch_verify_keyed_randomized_device",
+    "bn254_batch_aggregate_verify", "bn254_batch_aggregate_verify_device", "bn254_ctx_register_pools", "bn254_ctx_register_pools_device",
+    "bn254_batch_aggregate_verify_registered", "bn254_batch_aggregate_verify_registered_device", "bn254_batch_g1_decompress", "bn254_batch_g2_decompress", "bn254_debug_fp_op", "bn254_debug_fp12_op", "bn254_debug_final_exp_limbs", "bn254_debug_miller_loop", "bn254_debug_hash_candidate", "bn254_debug_route_table", "bn254_probe_issue_rate", "bn254_probe_leaf_floor", "bn254_probe_fe_program", "bn254_ctx_set_profiling", "bn254_ctx_last_kernel_ms", "bn254_ctx_set_option", "bn254_ctx_last_clocks", "bn254_ctx_expect_msgs_len", "bn254_ctx_register_keys", "bn254_batch_verify_keyed", "bn254_batch_verify_keyed_device", "bn254_batch_verify_keyed_randomized", "bn254_batch_verify_keyed_randomized_device",
     "bn254_mgpu_create", "bn254_mgpu_destroy", "bn254_mgpu_device_count", "bn254_mgpu_ctx", "bn254_mgpu_shard_len", "bn254_mgpu_shard_range",
     "bn254_mgpu_gathered_len", "bn254_mgpu_reserve", "bn254_mgpu_synchronize", "bn254_mgpu_set_option", "bn254_mgpu_last_timing",
     "bn254_mgpu_last_error", "bn254_mgpu_batch_verify", "bn254_mgpu_batch_verify_device", "bn254_mgpu_batch_pairing",

@@ -613,7 +613,13 @@ BN_DEV bool fp_limbs_all_zero(const Fp& a) {
   for (int i = 0; i < BN_LIMBS; ++i) o |= a.v[i];
   return o == 0;
 }
-BN_DEV bool fp_is_zero(const Fp& a) { return fp_limbs_all_zero(fp_canon(a)); }
+// a == 0 (mod q).  Round 6: by the WEAK reduction instead of fp_canon.  fp_reduce_weak leaves the value inside (-0.7 q, 0.7 q) for any input of
+// up to 600 q (its contract, which the bound tracker enforces at every call) with tight limbs — and in that interval the only multiple of q is 0,
+// whose balanced-digit representation is unique (a digit in [-2^28, 2^28) that is 0 mod 2^29 is 0, limb by limb): all limbs zero.  ~60 32-bit
+// instructions (one v_mul_hi, nine multiply-adds) where fp_canon — a Montgomery product by one and two conditional corrections — took ~400: the
+// mixed additions of k_aggregate_pair test h and z per addition (two of these against their 11 products), the complete additions of the
+// ladders four.  Same truth value on every input fp_canon accepted (|value| <= 80 q).
+BN_DEV bool fp_is_zero(const Fp& a) { return fp_limbs_all_zero(fp_reduce_weak(a)); }
 BN_DEV bool fp_eq(const Fp& a, const Fp& b) { return fp_is_zero(fp_sub(a, b)); }
 
 // plain U256 (< 2^256) -> limbs (not yet Montgomery)

@@ -579,25 +579,19 @@ static int sum_host(bn254_ctx* c, int g2, const uint8_t* pts, const uint64_t* se
 int bn254_batch_g1_sum(bn254_ctx* c, const uint8_t* pts, const uint64_t* seg, size_t n, uint8_t* out, uint8_t* status) { return sum_host(c, 0, pts, seg, n, out, status); }
 int bn254_batch_g2_sum(bn254_ctx* c, const uint8_t* pts, const uint64_t* seg, size_t n, uint8_t* out, uint8_t* status) { return sum_host(c, 1, pts, seg, n, out, status); }
 
-int bn254_batch_aggregate_verify_device(bn254_ctx* c, const uint8_t* d_msgs, const uint64_t* d_msg_off, size_t n_msgs, const uint8_t* d_pk_pool,
-                                        size_t n_signers, const uint8_t* d_sig_pool, const uint32_t* d_tuple_msg, const uint64_t* d_tuple_off,
-                                        const uint32_t* d_signer_idx, size_t n, uint32_t flags, uint8_t* d_status, void* stream) {
-  MsgsLenScope msgs_len_scope(c);
-  if (!c || !n_msgs || !n_signers || (n && (!d_msgs || !d_msg_off || !d_pk_pool || !d_sig_pool || !d_tuple_msg || !d_tuple_off || !d_signer_idx || !d_status)))
-    return BN254_E_BAD_ARGUMENT;
-  if (n == 0) return 0;
-  if (misaligned(d_pk_pool) || misaligned(d_sig_pool) || misaligned(d_tuple_msg) || misaligned(d_signer_idx) || ((uintptr_t)d_msg_off & 7u) ||
-      ((uintptr_t)d_tuple_off & 7u))
-    return BN254_E_MISALIGNED;
-  HIP_TRY(hipSetDevice(c->device));
+// ---- aggregate verify: the pools' side (decode, H(m), subset-sum tables) and the tuples' side, apart -------------------------------------
+// The tables depend on the POOLS and on how many tuples they are built for (thresholds of bn254_ws.h) — not on the tuples themselves.  A call
+// with raw pools builds them and runs; bn254_ctx_register_pools builds them ONCE for a caller whose pools are fixed (a validator set signing
+// a stream of messages' worth of tuples), and bn254_batch_aggregate_verify_registered only walks tuples — what bn254_ctx_register_keys is to
+// the verify path (/root/reference/src/types.rs:126-132, :264-270: the sums; src/ecdsa.rs:49-64: the check).
+static int agg_build_tables(bn254_ctx* c, hipStream_t s, const uint8_t* d_msgs, const uint64_t* d_msg_off, size_t n_msgs, const uint8_t* d_pk_pool,
+                            size_t n_signers, const uint8_t* d_sig_pool, uint32_t flags, size_t n, AggTables* t) {
   int rc;
+  t->valid = 0; t->n_msgs = n_msgs; t->n_signers = n_signers; t->n_groups = 0; t->groups4 = 0; t->wide2 = 0; t->wide1 = 0; t->built_for = n;
   if ((rc = ws_reserve(c, n > n_msgs ? n : n_msgs))) return rc;
   if ((rc = pool_reserve(c, 0, 4, n_signers))) return rc;
   if ((rc = pool_reserve(c, 1, 2, n_msgs * n_signers))) return rc;
   if ((rc = pool_reserve(c, 2, 2, n_msgs))) return rc;
-  hipStream_t s = stream ? (hipStream_t)stream : c->stream;
-  CallDone call_done(c, s);
-  PROF_MARK(0);                                        // ms[0] = pools (decode, hash of the messages, subset-sum table), ms[1] = the aggregation kernel
   k_pool_decode_g2<<<grid_for(n_signers), BN_WAVE, 0, s>>>(d_pk_pool, n_signers, flags, c->pool[0]);
   k_pool_decode_g1<<<grid_for(n_msgs * n_signers), BN_WAVE, 0, s>>>(d_sig_pool, n_msgs * n_signers, flags, c->pool[1]);
   if ((rc = launch_hash_rounds(c, s, d_msgs, d_msg_off, n_msgs, PL_P2X, BY_P2_INF, nullptr))) return rc;
@@ -631,10 +625,45 @@ int bn254_batch_aggregate_verify_device(bn254_ctx* c, const uint8_t* d_msgs, con
         }
       }
     }
+    // the largest batches: tables of twice the window, built from the ones above by one batched affine addition per entry
+    // (k_pool_widen_*): half the additions per tuple.  A table that does not fit its budget (or HBM) is simply not used.
+    if (n_groups != 0 && c->agg_wide_min_tuples > 0 && n >= (size_t)c->agg_wide_min_tuples) {
+      const size_t n_chunks = (n_groups + 1) / 2;
+      const size_t e2 = n_chunks * 65536, bytes2 = e2 * (2 * BN_POOL_HALF_WORDS * sizeof(int32_t) + 1);
+      if (bytes2 <= AGG_WIDE_G2_MAX_BYTES) {
+        if (pool_reserve(c, 5, 4, e2) == 0) {
+          k_pool_widen_g2<<<grid_for(n_chunks * 256 * (256 / BN_WIDEN_G2_NLO)), BN_WAVE, 0, s>>>(c->pool[3], n_groups, n_chunks, c->pool[5]);
+          t->wide2 = 1;
+        } else {
+          (void)hipGetLastError();
+        }
+      }
+      const size_t e1 = n_msgs * n_groups * 256, bytes1 = ((e1 + 255) & ~(size_t)255) * (BN_POOL_HALF_WORDS * sizeof(int32_t) + 1);
+      if (groups4 != 0 && n >= AGG_WIDE_G1_TUPLES_PER_MSG * n_msgs && bytes1 <= AGG_SUBSET_G1_MAX_BYTES) {
+        if (pool_reserve(c, 6, 2, e1) == 0) {
+          k_pool_widen_g1<<<grid_for(n_msgs * n_groups * 16), BN_WAVE, 0, s>>>(c->pool[4], groups4, n_groups, n_msgs, c->pool[6]);
+          t->wide1 = 1;
+        } else {
+          (void)hipGetLastError();
+        }
+      }
+    }
+    t->n_groups = n_groups; t->groups4 = groups4;
+  }
+  HIP_TRY(hipGetLastError());
+  t->valid = 1;
+  return 0;
+}
+// the tuples' side: (optionally) bucket them by message, the aggregation kernel on the tables named by `t`, then the verify kernels
+static int agg_run(bn254_ctx* c, hipStream_t s, const AggTables& t, const uint32_t* d_tuple_msg, const uint64_t* d_tuple_off, const uint32_t* d_signer_idx,
+                   size_t n, uint8_t* d_status) {
+  int rc;
+  const size_t n_msgs = t.n_msgs, n_signers = t.n_signers;
+  if (c->pair_lanes) {
     // with the per-message signature tables in use: bucket the tuples by message (see k_agg_sort_count).  The hash rounds of the
     // messages are done with ws.h_list (2 x stride words): its first n words take the index map, the counters sit behind.
     const uint32_t* perm = nullptr;
-    if (groups4 != 0 && c->agg_sort_by_msg && n >= 4 * n_msgs && n <= 0xFFFFFFFFull && n_msgs < 0xFFFFFFFFull && c->ws.stride >= 2 * (n_msgs + 1)) {
+    if (t.groups4 != 0 && c->agg_sort_by_msg && n >= 4 * n_msgs && n <= 0xFFFFFFFFull && n_msgs < 0xFFFFFFFFull && c->ws.stride >= 2 * (n_msgs + 1)) {
       uint32_t* map = c->ws.h_list;
       uint32_t* cnt = c->ws.h_list + c->ws.stride;
       uint32_t* cursor = cnt + (n_msgs + 1);
@@ -644,34 +673,9 @@ int bn254_batch_aggregate_verify_device(bn254_ctx* c, const uint8_t* d_msgs, con
       k_agg_sort_scatter<<<grid_for(n), BN_WAVE, 0, s>>>(d_tuple_msg, n, (uint32_t)n_msgs, cursor, map);
       perm = map;
     }
-    // the largest batches: tables of twice the window, built from the ones above by one batched affine addition per entry
-    // (k_pool_widen_*): half the additions per tuple.  A table that does not fit its budget (or HBM) is simply not used.
-    const Pool* wide2 = nullptr;
-    const Pool* wide1 = nullptr;
-    if (n_groups != 0 && c->agg_wide_min_tuples > 0 && n >= (size_t)c->agg_wide_min_tuples) {
-      const size_t n_chunks = (n_groups + 1) / 2;
-      const size_t e2 = n_chunks * 65536, bytes2 = e2 * (2 * BN_POOL_HALF_WORDS * sizeof(int32_t) + 1);
-      if (bytes2 <= AGG_WIDE_G2_MAX_BYTES) {
-        if (pool_reserve(c, 5, 4, e2) == 0) {
-          k_pool_widen_g2<<<grid_for(n_chunks * 256 * (256 / BN_WIDEN_G2_NLO)), BN_WAVE, 0, s>>>(c->pool[3], n_groups, n_chunks, c->pool[5]);
-          wide2 = &c->pool[5];
-        } else {
-          (void)hipGetLastError();
-        }
-      }
-      const size_t e1 = n_msgs * n_groups * 256, bytes1 = ((e1 + 255) & ~(size_t)255) * (BN_POOL_HALF_WORDS * sizeof(int32_t) + 1);
-      if (groups4 != 0 && n >= AGG_WIDE_G1_TUPLES_PER_MSG * n_msgs && bytes1 <= AGG_SUBSET_G1_MAX_BYTES) {
-        if (pool_reserve(c, 6, 2, e1) == 0) {
-          k_pool_widen_g1<<<grid_for(n_msgs * n_groups * 16), BN_WAVE, 0, s>>>(c->pool[4], groups4, n_groups, n_msgs, c->pool[6]);
-          wide1 = &c->pool[6];
-        } else {
-          (void)hipGetLastError();
-        }
-      }
-    }
     PROF_MARK(1);
-    if ((rc = bn254_pair_aggregate(d_tuple_msg, d_tuple_off, d_signer_idx, n, n_signers, n_msgs, c->pool[0], c->pool[1], c->pool[2], c->pool[3], n_groups,
-                                   c->pool[4], groups4, c->ws, s, perm, wide2, wide1))) return rc;
+    if ((rc = bn254_pair_aggregate(d_tuple_msg, d_tuple_off, d_signer_idx, n, n_signers, n_msgs, c->pool[0], c->pool[1], c->pool[2], c->pool[3], t.n_groups,
+                                   c->pool[4], t.groups4, c->ws, s, perm, t.wide2 ? &c->pool[5] : nullptr, t.wide1 ? &c->pool[6] : nullptr))) return rc;
   } else {
     PROF_MARK(1);
     k_aggregate<<<grid_for(n), BN_WAVE, 0, s>>>(d_tuple_msg, d_tuple_off, d_signer_idx, n, n_signers, n_msgs, c->pool[0], c->pool[1], c->pool[2], c->ws);
@@ -690,6 +694,87 @@ int bn254_batch_aggregate_verify_device(bn254_ctx* c, const uint8_t* d_msgs, con
   if (c->profiling) { c->ev_valid = 1; c->ev_hash_first = 0; }
   HIP_TRY(hipGetLastError());
   return 0;
+}
+
+int bn254_batch_aggregate_verify_device(bn254_ctx* c, const uint8_t* d_msgs, const uint64_t* d_msg_off, size_t n_msgs, const uint8_t* d_pk_pool,
+                                        size_t n_signers, const uint8_t* d_sig_pool, const uint32_t* d_tuple_msg, const uint64_t* d_tuple_off,
+                                        const uint32_t* d_signer_idx, size_t n, uint32_t flags, uint8_t* d_status, void* stream) {
+  MsgsLenScope msgs_len_scope(c);
+  if (!c || !n_msgs || !n_signers || (n && (!d_msgs || !d_msg_off || !d_pk_pool || !d_sig_pool || !d_tuple_msg || !d_tuple_off || !d_signer_idx || !d_status)))
+    return BN254_E_BAD_ARGUMENT;
+  if (n == 0) return 0;
+  if (misaligned(d_pk_pool) || misaligned(d_sig_pool) || misaligned(d_tuple_msg) || misaligned(d_signer_idx) || ((uintptr_t)d_msg_off & 7u) ||
+      ((uintptr_t)d_tuple_off & 7u))
+    return BN254_E_MISALIGNED;
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  c->reg_pools.valid = 0;                              // raw pools overwrite the context's pool buffers: a registration does not survive them
+  AggTables t;
+  int rc = ws_reserve(c, n > n_msgs ? n : n_msgs);
+  if (rc) return rc;
+  CallDone call_done(c, s);
+  PROF_MARK(0);                                        // ms[0] = pools (decode, hash of the messages, subset-sum tables), ms[1] = the aggregation kernel
+  if ((rc = agg_build_tables(c, s, d_msgs, d_msg_off, n_msgs, d_pk_pool, n_signers, d_sig_pool, flags, n, &t))) return rc;
+  return agg_run(c, s, t, d_tuple_msg, d_tuple_off, d_signer_idx, n, d_status);
+}
+// Registered pools: decode, H(m) and every subset-sum table built ONCE, for batches of about `expect_tuples` tuples (the table thresholds of
+// bn254_ws.h are applied to that figure); the tables stay in the context until the next registration or the next call with raw pools.
+int bn254_ctx_register_pools_device(bn254_ctx* c, const uint8_t* d_msgs, const uint64_t* d_msg_off, size_t n_msgs, const uint8_t* d_pk_pool, size_t n_signers,
+                                    const uint8_t* d_sig_pool, uint32_t flags, size_t expect_tuples, void* stream) {
+  MsgsLenScope msgs_len_scope(c);
+  if (!c || !n_msgs || !n_signers || !d_msgs || !d_msg_off || !d_pk_pool || !d_sig_pool) return BN254_E_BAD_ARGUMENT;
+  if (misaligned(d_pk_pool) || misaligned(d_sig_pool) || ((uintptr_t)d_msg_off & 7u)) return BN254_E_MISALIGNED;
+  HIP_TRY(hipSetDevice(c->device));
+  { int rc_ = ctx_quiesce(c); if (rc_) return rc_; }   // no aggregate verify may still be reading the previous tables
+  hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  c->reg_pools.valid = 0;
+  CallDone call_done(c, s);
+  return agg_build_tables(c, s, d_msgs, d_msg_off, n_msgs, d_pk_pool, n_signers, d_sig_pool, flags, expect_tuples ? expect_tuples : 1, &c->reg_pools);
+}
+int bn254_ctx_register_pools(bn254_ctx* c, const uint8_t* msgs, const uint64_t* msg_off, size_t n_msgs, const uint8_t* pk_pool, size_t n_signers,
+                             const uint8_t* sig_pool, uint32_t flags, size_t expect_tuples) {
+  MsgsLenScope msgs_len_scope(c);
+  if (!c || !n_msgs || !n_signers || !msg_off || !pk_pool || !sig_pool) return BN254_E_BAD_ARGUMENT;
+  if (!offsets_ok(msg_off, n_msgs) || (msg_off[n_msgs] && !msgs)) return BN254_E_BAD_ARGUMENT;
+  HIP_TRY(hipSetDevice(c->device));
+  int rc;
+  if ((rc = stage_in(c, 0, msgs, (size_t)msg_off[n_msgs]))) return rc;
+  if ((rc = stage_in(c, 1, msg_off, (n_msgs + 1) * sizeof(uint64_t)))) return rc;
+  if ((rc = stage_in(c, 2, pk_pool, n_signers * 128))) return rc;
+  if ((rc = stage_in(c, 3, sig_pool, n_msgs * n_signers * 64))) return rc;
+  rc = bn254_ctx_register_pools_device(c, c->stage[0], (const uint64_t*)c->stage[1], n_msgs, c->stage[2], n_signers, c->stage[3], flags, expect_tuples, nullptr);
+  hipError_t e = hipStreamSynchronize(c->stream);     // also on failure: the staged copies read the caller's buffers
+  return rc ? rc : -(int)e;
+}
+int bn254_batch_aggregate_verify_registered_device(bn254_ctx* c, const uint32_t* d_tuple_msg, const uint64_t* d_tuple_off, const uint32_t* d_signer_idx, size_t n,
+                                                   uint8_t* d_status, void* stream) {
+  if (!c || (n && (!d_tuple_msg || !d_tuple_off || !d_signer_idx || !d_status))) return BN254_E_BAD_ARGUMENT;
+  if (!c->reg_pools.valid) return BN254_E_BAD_ARGUMENT;        // nothing registered (or a call with raw pools has replaced the tables since)
+  if (n == 0) return 0;
+  if (misaligned(d_tuple_msg) || misaligned(d_signer_idx) || ((uintptr_t)d_tuple_off & 7u)) return BN254_E_MISALIGNED;
+  HIP_TRY(hipSetDevice(c->device));
+  int rc = ws_reserve(c, n > c->reg_pools.n_msgs ? n : c->reg_pools.n_msgs);
+  if (rc) return rc;
+  hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  CallDone call_done(c, s);
+  PROF_MARK(0);                                        // ms[0] = 0: the pools' side was paid at registration
+  return agg_run(c, s, c->reg_pools, d_tuple_msg, d_tuple_off, d_signer_idx, n, d_status);
+}
+int bn254_batch_aggregate_verify_registered(bn254_ctx* c, const uint32_t* tuple_msg, const uint64_t* tuple_off, const uint32_t* signer_idx, size_t n, uint8_t* status) {
+  if (!c || (n && (!tuple_msg || !tuple_off || !signer_idx || !status))) return BN254_E_BAD_ARGUMENT;
+  if (!c->reg_pools.valid) return BN254_E_BAD_ARGUMENT;
+  if (n == 0) return 0;
+  if (!offsets_ok(tuple_off, n)) return BN254_E_BAD_ARGUMENT;
+  HIP_TRY(hipSetDevice(c->device));
+  int rc;
+  if ((rc = stage_in(c, 4, tuple_msg, n * sizeof(uint32_t)))) return rc;
+  if ((rc = stage_in(c, 5, tuple_off, (n + 1) * sizeof(uint64_t)))) return rc;
+  if ((rc = stage_in(c, 6, signer_idx, (size_t)tuple_off[n] * sizeof(uint32_t)))) return rc;
+  if ((rc = stage_reserve(c, 7, n))) return rc;
+  rc = bn254_batch_aggregate_verify_registered_device(c, (const uint32_t*)c->stage[4], (const uint64_t*)c->stage[5], (const uint32_t*)c->stage[6], n, c->stage[7], nullptr);
+  if (!rc) rc = stage_out(c, 7, status, n);
+  hipError_t e = hipStreamSynchronize(c->stream);
+  return rc ? rc : -(int)e;
 }
 int bn254_batch_aggregate_verify(bn254_ctx* c, const uint8_t* msgs, const uint64_t* msg_off, size_t n_msgs, const uint8_t* pk_pool, size_t n_signers,
                                  const uint8_t* sig_pool, const uint32_t* tuple_msg, const uint64_t* tuple_off, const uint32_t* signer_idx, size_t n,

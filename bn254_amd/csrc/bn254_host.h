@@ -12,6 +12,9 @@
 
 #define BN_HIDDEN __attribute__((visibility("hidden")))
 
+// aggregate verify: which of the context's pool buffers hold valid tables, and for which pools (bn254_group.hip: agg_build_tables)
+struct AggTables { int valid; size_t n_msgs, n_signers, n_groups, groups4, built_for; int wide2, wide1; };
+
 struct bn254_ctx {
   int device;
   hipStream_t stream;
@@ -56,6 +59,7 @@ struct bn254_ctx {
   size_t n_keys, key_cap;
   hipEvent_t last_done;      // recorded on the CALLER's stream when a *_device call on such a stream returns (CallDone below): what ctx_quiesce
   bool last_done_armed;      // waits for.  The context keeps no handle of a stream it does not own — the caller may destroy its stream any time.
+  AggTables reg_pools;       // bn254_ctx_register_pools: the tables of the registered pools (valid until the next registration or raw-pool call)
   int max_chunk;             // BN254_OPT_MAX_CHUNK: verify-shaped batches above this size are processed in slices (0 = only when the workspace would not fit)
   int assume_free_mb;        // test knob (BN254_OPT_ASSUME_FREE_MB): the automatic rule prices the workspace against this much free memory instead of hipMemGetInfo
   bool fits_w8, fits_quad, fits_trio;   // the device can hold a workgroup of the small-batch kernels (LDS), asked at creation

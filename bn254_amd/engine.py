@@ -268,6 +268,40 @@ class Engine:
                self._lib.bn254_batch_aggregate_verify(self._h, msgs, off, n_msgs, bytes(pk_pool), n_signers, bytes(sig_pool), tm, t_off, idx, n, flags, status))
         return status.raw[:n]
 
+    def register_pools(self, messages, pk_pool, sig_pool, expect_tuples, flags=0):
+        """the pools of an aggregate verify decoded, hashed and tabulated ONCE (bn254_ctx_register_pools): for a fixed validator set / message
+        set whose tuples keep arriving; `expect_tuples` = the batch size the subset-sum tables are chosen for"""
+        n_msgs = len(messages)
+        n_signers = len(pk_pool) // G2_BYTES
+        assert len(sig_pool) == n_msgs * n_signers * G1_BYTES
+        msgs, off = pack_messages(messages)
+        _check("bn254_ctx_register_pools",
+               self._lib.bn254_ctx_register_pools(self._h, msgs, off, n_msgs, bytes(pk_pool), n_signers, bytes(sig_pool), flags, expect_tuples))
+
+    def batch_aggregate_verify_registered(self, tuple_msg, signer_lists):
+        """as batch_aggregate_verify on the registered pools: only the tuples cross the boundary"""
+        n = len(tuple_msg)
+        assert len(signer_lists) == n
+        t_off = (ctypes.c_uint64 * (n + 1))()
+        flat = []
+        for i, lst in enumerate(signer_lists):
+            t_off[i] = len(flat)
+            flat.extend(lst)
+        t_off[n] = len(flat)
+        idx = (ctypes.c_uint32 * max(len(flat), 1))(*flat)
+        tm = (ctypes.c_uint32 * max(n, 1))(*tuple_msg)
+        status = ctypes.create_string_buffer(max(n, 1))
+        _check("bn254_batch_aggregate_verify_registered", self._lib.bn254_batch_aggregate_verify_registered(self._h, tm, t_off, idx, n, status))
+        return status.raw[:n]
+
+    def register_pools_device(self, d_msgs, d_msg_off, n_msgs, d_pk_pool, n_signers, d_sig_pool, expect_tuples, flags=0, stream=None):
+        _check("bn254_ctx_register_pools_device",
+               self._lib.bn254_ctx_register_pools_device(self._h, d_msgs, d_msg_off, n_msgs, d_pk_pool, n_signers, d_sig_pool, flags, expect_tuples, stream))
+
+    def batch_aggregate_verify_registered_device(self, d_tuple_msg, d_tuple_off, d_signer_idx, n, d_status, stream=None):
+        _check("bn254_batch_aggregate_verify_registered_device",
+               self._lib.bn254_batch_aggregate_verify_registered_device(self._h, d_tuple_msg, d_tuple_off, d_signer_idx, n, d_status, stream))
+
     def batch_g1_decompress(self, data, n):
         out = ctypes.create_string_buffer(max(n, 1) * G1_BYTES)
         status = ctypes.create_string_buffer(max(n, 1))

@@ -245,6 +245,23 @@ int bn254_batch_aggregate_verify(bn254_ctx *ctx, const uint8_t *msgs, const uint
 int bn254_batch_aggregate_verify_device(bn254_ctx *ctx, const uint8_t *d_msgs, const uint64_t *d_msg_off, size_t n_msgs, const uint8_t *d_pk_pool,
                                         size_t n_signers, const uint8_t *d_sig_pool, const uint32_t *d_tuple_msg, const uint64_t *d_tuple_off,
                                         const uint32_t *d_signer_idx, size_t n, uint32_t flags, uint8_t *d_status, void *stream);
+/* REGISTERED POOLS — the aggregate counterpart of bn254_ctx_register_keys, for a caller whose pools are fixed (a validator set and the
+ * messages it has signed) while tuples keep arriving: everything that depends on the pools alone — decoding, H(m) of every message, the
+ * subset-sum tables of both pools (8 / 16 keys and 4 / 8 signatures per entry; ~8 ms per call for 1 024 x 1 024 pools) — is done ONCE.
+ * expect_tuples = the batch size the tables are chosen for (the thresholds BN254_OPT_AGG_SUBSET_MIN_TUPLES / _AGG_WIDE_MIN_TUPLES are applied
+ * to it; 0 = no tables).  bn254_batch_aggregate_verify_registered[_device] then takes only the tuples: same status bytes as
+ * bn254_batch_aggregate_verify on the same pools (pool-entry decode statuses included; flags as given at registration).  The tables live in
+ * the context until the next registration OR the next bn254_batch_aggregate_verify* call with raw pools (which reuses the same buffers):
+ * after either, the registered call returns BN254_E_BAD_ARGUMENT until pools are registered again.  Reference: the sums are
+ * `Add for PublicKey / Signature` (src/types.rs:126-132, :264-270), the check ECDSA::verify (src/ecdsa.rs:49-64). */
+int bn254_ctx_register_pools(bn254_ctx *ctx, const uint8_t *msgs, const uint64_t *msg_off /* n_msgs+1 */, size_t n_msgs, const uint8_t *pk_pool /* n_signers*128 */,
+                             size_t n_signers, const uint8_t *sig_pool /* n_msgs*n_signers*64 */, uint32_t flags, size_t expect_tuples);
+int bn254_ctx_register_pools_device(bn254_ctx *ctx, const uint8_t *d_msgs, const uint64_t *d_msg_off, size_t n_msgs, const uint8_t *d_pk_pool, size_t n_signers,
+                                    const uint8_t *d_sig_pool, uint32_t flags, size_t expect_tuples, void *stream);
+int bn254_batch_aggregate_verify_registered(bn254_ctx *ctx, const uint32_t *tuple_msg /* n */, const uint64_t *tuple_off /* n+1 */, const uint32_t *signer_idx,
+                                            size_t n, uint8_t *status /* n */);
+int bn254_batch_aggregate_verify_registered_device(bn254_ctx *ctx, const uint32_t *d_tuple_msg, const uint64_t *d_tuple_off, const uint32_t *d_signer_idx,
+                                                   size_t n, uint8_t *d_status, void *stream);
 
 /* compressed wire formats (src/utils.rs:84-104, :130-158): out = uncompressed point, status as
  * bn::G1::from_compressed / bn::G2::from_compressed report through src/types.rs:91-93, :233-237, checked in the order

@@ -845,7 +845,33 @@ def test_aggregate_verify_subset_sum_table_vs_oracle(eng, c):
         got = eng.batch_aggregate_verify(msgs, pk_pool, sig_pool, [t[0] for t in tuples], [t[1] for t in tuples])
         diff = [(i, got[i], want[i], tuples[i]) for i in range(len(tuples)) if got[i] != want[i]]
         assert not diff, (knob, diff[:5])
-    eng.set_option(OPT_AGG_SUBSET_MIN_TUPLES, ws_default("AGG_SUBSET_MIN_TUPLES_DEFAULT"))
+    # REGISTERED POOLS (bn254_ctx_register_pools): the same pools decoded, hashed and tabulated once, then only tuples per call — the
+    # oracle's statuses for the whole list and for slices of it in another order (calls back to back on the same tables), with tables
+    # chosen for a large batch (subset sums on), for a tiny one (none), and with the widened tables forced on; a raw-pool call in between
+    # replaces the tables and the registered call says so instead of reading them
+    import pytest as _pytest
+    from bn254_amd.engine import NativeError, OPT_AGG_WIDE_MIN_TUPLES
+    try:
+        for expect, wide_min in ((1 << 20, ws_default("AGG_WIDE_MIN_TUPLES_DEFAULT")), (1, ws_default("AGG_WIDE_MIN_TUPLES_DEFAULT")), (1 << 20, 1)):
+            eng.set_option(OPT_AGG_SUBSET_MIN_TUPLES, 1 if expect > 1 else ws_default("AGG_SUBSET_MIN_TUPLES_DEFAULT"))
+            eng.set_option(OPT_AGG_WIDE_MIN_TUPLES, wide_min)
+            eng.register_pools(msgs, pk_pool, sig_pool, expect_tuples=expect)
+            got = eng.batch_aggregate_verify_registered([t[0] for t in tuples], [t[1] for t in tuples])
+            diff = [(i, got[i], want[i], tuples[i]) for i in range(len(tuples)) if got[i] != want[i]]
+            assert not diff, ("registered", expect, wide_min, diff[:5])
+            order = list(range(len(tuples)))
+            rnd.shuffle(order)
+            for part in (order[:64], order[64:], order[:1], []):
+                got = eng.batch_aggregate_verify_registered([tuples[i][0] for i in part], [tuples[i][1] for i in part])
+                assert got == bytes(want[i] for i in part), ("registered slice", expect, len(part))
+        assert eng.batch_aggregate_verify(msgs, pk_pool, sig_pool, [0], [[1, 2]]) == bytes([want_small := c.batch_aggregate_verify(msgs, pk_pool, sig_pool, [0], [0, 2], [1, 2])[0]])
+        with _pytest.raises(NativeError):
+            eng.batch_aggregate_verify_registered([0], [[1, 2]])          # raw pools have replaced the tables: refused, not followed
+        eng.register_pools(msgs, pk_pool, sig_pool, expect_tuples=64)
+        assert eng.batch_aggregate_verify_registered([0], [[1, 2]]) == bytes([want_small])
+    finally:
+        eng.set_option(OPT_AGG_SUBSET_MIN_TUPLES, ws_default("AGG_SUBSET_MIN_TUPLES_DEFAULT"))
+        eng.set_option(OPT_AGG_WIDE_MIN_TUPLES, ws_default("AGG_WIDE_MIN_TUPLES_DEFAULT"))
 
 
 def test_aggregate_verify_widened_tables_vs_oracle(eng, c):
