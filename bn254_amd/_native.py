@@ -21,7 +21,7 @@ def translation_units():
 
 def _dependencies():
     return translation_units() + sorted(glob.glob(os.path.join(_CSRC, "*.h"))) + sorted(glob.glob(os.path.join(_CSRC, "*.inc"))) + [
-        os.path.join(_CSRC, "gen_constants.py"), os.path.join(os.path.dirname(_PKG), "include", "bn254_hip.h")]
+        os.path.join(_CSRC, "gen_constants.py"), os.path.join(_CSRC, "gen_step_asm.py"), os.path.join(os.path.dirname(_PKG), "include", "bn254_hip.h")]
 
 # max-ilp: the AMDGPU machine scheduler's ILP-first strategy — these kernels are VALU-issue bound at a fixed occupancy
 # (amdgpu_waves_per_eu), so the default strategy's occupancy-driven choices buy nothing; same-box A/B +1.3 % on the verify step
@@ -46,6 +46,11 @@ def build(force=False, verbose=False, jobs=None):
     gen = os.path.join(_CSRC, "gen_constants.py")
     if not os.path.exists(const_h) or os.path.getmtime(const_h) < os.path.getmtime(gen):
         subprocess.check_call(["python3", gen], stdout=None if verbose else subprocess.DEVNULL)
+    asm_h, asm_gen = os.path.join(_CSRC, "bn254_csqr_asm.h"), os.path.join(_CSRC, "gen_step_asm.py")
+    if not os.path.exists(asm_h) or os.path.getmtime(asm_h) < os.path.getmtime(asm_gen):
+        subprocess.check_call(["python3", asm_gen, "selftest"], stdout=None if verbose else subprocess.DEVNULL)   # simulated before it is assembled
+        with open(asm_h, "w") as f:
+            subprocess.check_call(["python3", asm_gen, "header"], stdout=f)
     if force or _stale():
         import time
         from concurrent.futures import ThreadPoolExecutor

@@ -1059,6 +1059,23 @@ BN_DEVN void final_exponentiation_check(Fp12& r, const Fp12& fin, Fp12& acc) {
 #ifndef BN_FE_PRIO_SHIFT
 #define BN_FE_PRIO_SHIFT 2     // the wave-priority cycle advances every 2^shift program steps (x the kernel's own BN_PRIO_SHIFT); 0..5 measured: profiles/r03_x_ab_fe_priority_period.log
 #endif
+// Round 6: in the translation units that run this machine on the LANE-PAIR layout with the accumulator in LDS (bn254_fe.hip,
+// bn254_probe.hip: they define BN_ASM_CSQR_UNIT unless built with -DBN_NO_ASM_CSQR) the CSQR opcode — 189 of the 326 steps of a verify's
+// program — is the generated straight-line assembly block of gen_step_asm.py (bn254_csqr_asm.h): explicit VGPR + LDS map, the nine squaring
+// leaves inlined with the registers their operands already sit in, no v_mov between operations, nothing through the private segment; the
+// same formulas and carry sites as fp12_cyclotomic_sqr_body<170> (so the same int32 limb values and the same bound proof), executed by
+// the generator's own four-lane simulator against a big-integer model before it is assembled (tests/test_abi.py).  Same box, alternating:
+// final exponentiation 3.98-4.02 -> 3.91-3.92 ms per 65 536 (profiles/r06_d_ab_asm_csqr.log).
+#if defined(BN_ASM_CSQR_UNIT) && defined(__HIP_DEVICE_COMPILE__)
+#include "bn254_csqr_asm.h"
+#define BN_FE_CSQR(acc)                                                                                              \
+  do {                                                                                                               \
+    const uint32_t lds_addr_ = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&(acc);                 \
+    asm volatile(BN_CSQR_ASM_TEXT : : "v"(lds_addr_) : BN_CSQR_ASM_CLOBBERS);                                        \
+  } while (0)
+#else
+#define BN_FE_CSQR(acc) fp12_cyclotomic_sqr_body<170>(acc, acc)
+#endif
 enum FeOpcode : int { FE_END = 0, FE_LOAD = 1, FE_STORE = 2, FE_CSQR = 3, FE_MUL = 4, FE_CONJ = 5, FE_FROB = 6, FE_INV = 7 };
 template <int NSLOTS>
 BN_DEV void fe_machine(Fp12& acc, Fp12 (&slot)[NSLOTS], const unsigned char (*prog)[2]) {
@@ -1072,7 +1089,7 @@ BN_DEV void fe_machine(Fp12& acc, Fp12 (&slot)[NSLOTS], const unsigned char (*pr
     switch (op) {
       case FE_LOAD: acc = slot[arg]; break;
       case FE_STORE: slot[arg] = acc; break;
-      case FE_CSQR: fp12_cyclotomic_sqr_body<170>(acc, acc); break;
+      case FE_CSQR: BN_FE_CSQR(acc); break;
       case FE_MUL: fp12_mul_body(acc, acc, slot[arg]); break;
       case FE_CONJ: fp6_neg(acc.c1, acc.c1); break;        // balanced digits stay balanced: no carry
       case FE_FROB: fp12_frob_body(acc, acc, arg); break;

@@ -3,6 +3,9 @@
 #include <hip/hip_runtime.h>
 
 #define BN_SPLIT_FP2 1
+#if !defined(BN_NO_ASM_CSQR)
+#define BN_ASM_CSQR_UNIT 1          // the accumulator machine of this unit runs on lane pairs with its accumulator in LDS (bn254_pairing.h: BN_FE_CSQR)
+#endif
 #define BN_PAIR_SQR_DPP_ASM 1
 #define BN_PRIO_SHIFT 1
 #define BN_SET_STEP_PRIORITY(step)                                                        \
