@@ -45,7 +45,7 @@ def soak(args):
     (tests/test_gpu_fullsize.py runs a slice of it in the driver-run suite)"""
     import bn254_amd
     from tests.conftest import ws_default
-    from bn254_amd.engine import OPT_AGG_WIDE_MIN_TUPLES, OPT_AGG_SORT_BY_MSG, OPT_AGG_SUBSET_MIN_TUPLES, OPT_LM_MAX_BATCH, OPT_NONET_MAX_BATCH, OPT_NONET_WIDE, OPT_PAIR_LANES, OPT_RAND_MIN_BATCH, OPT_TRIO_MAX_BATCH, OPT_TRIO_WAVE_ROLES
+    from bn254_amd.engine import OPT_MAX_CHUNK, OPT_AGG_WIDE_MIN_TUPLES, OPT_AGG_SORT_BY_MSG, OPT_AGG_SUBSET_MIN_TUPLES, OPT_LM_MAX_BATCH, OPT_NONET_MAX_BATCH, OPT_NONET_WIDE, OPT_PAIR_LANES, OPT_RAND_MIN_BATCH, OPT_TRIO_MAX_BATCH, OPT_TRIO_WAVE_ROLES
     from oracle import c_oracle as c
     from tests.datagen import sk_bytes
     eng = bn254_amd.Engine(0)
@@ -119,6 +119,9 @@ def soak(args):
             want, _ = c.batch_verify(msgs, sigs, pks, flags=flags, nthreads=cores)
             # the small-batch layouts (defaults: the lane machine up to 1536 items, eight wave roles up to 16384), then the lane pairs for the same batch
             got = {"default": eng.batch_verify(msgs, sigs, pks, flags=flags)}
+            eng.set_option(OPT_MAX_CHUNK, max(1, n // 3 + 1))  # round 6: the same batch in three slices inside the library (oversized-batch route)
+            got["sliced"] = eng.batch_verify(msgs, sigs, pks, flags=flags)
+            eng.set_option(OPT_MAX_CHUNK, 0)
             eng.set_option(OPT_LM_MAX_BATCH, 1 << 20)        # the Miller loop as the lane machine whatever the size (several passes above 768)
             got["lane_machine"] = eng.batch_verify(msgs, sigs, pks, flags=flags)
             eng.set_option(OPT_NONET_WIDE, 0)                # ... with the final exponentiation on nine lane pairs also up to 1024 items (default there: eighteen)
@@ -206,6 +209,14 @@ def soak(args):
             got_ww = eng.batch_aggregate_verify(amsgs, apk_pool, asig_pool, [t[0] for t in one_msg], [t[1] for t in one_msg])
             eng.set_option(OPT_AGG_WIDE_MIN_TUPLES, 0)
             got_wn = eng.batch_aggregate_verify(amsgs, apk_pool, asig_pool, [t[0] for t in one_msg], [t[1] for t in one_msg])
+            # REGISTERED pools (round 6): the tables built once (subset sums forced on, the widened ones off), then the tuples alone, twice in two orders
+            eng.set_option(OPT_AGG_WIDE_MIN_TUPLES, 0)
+            eng.register_pools(amsgs, apk_pool, asig_pool, expect_tuples=len(tuples))
+            got_r = eng.batch_aggregate_verify_registered([t[0] for t in tuples], [t[1] for t in tuples])
+            rev = list(range(len(tuples)))[::-1]
+            got_rr = eng.batch_aggregate_verify_registered([tuples[j][0] for j in rev], [tuples[j][1] for j in rev])
+            if got_r != got_b or got_rr != bytes(got_b[j] for j in rev):
+                raise SoakMismatch("MISMATCH aggregate registered pools round %d %r %r" % (rounds, list(got_b), list(got_r)))
             eng.set_option(OPT_AGG_WIDE_MIN_TUPLES, ws_default("AGG_WIDE_MIN_TUPLES_DEFAULT"))
             eng.set_option(OPT_AGG_SUBSET_MIN_TUPLES, ws_default("AGG_SUBSET_MIN_TUPLES_DEFAULT"))
             if got_w != got_b or got_ww != got_wn:
@@ -241,7 +252,7 @@ def soak(args):
     lib_sha = hashlib.sha256(open(_native.LIB_PATH, "rb").read()).hexdigest()[:16]
     res = {"lib_sha256_16": lib_sha, "rounds": rounds, "tuples": items, "comparisons": items * 2 * 10, "seconds": round(time.time() - t0, 1), "oracle_threads": cores,
            "status_histogram": {str(k): v for k, v in sorted(codes.items())}, "mismatches": 0, "seed": args.seed, "also_compared": extra,
-           "modes": ["keyed (registered keys, once per round with the subgroup check)", "keyed randomised 128-bit / 64-bit / GLV (once per round)", "exact, defaults (lane machine up to 1536, eight wave roles above; final exponentiation on nine lane pairs up to 3072)", "exact, Miller loop as the lane machine at every size", "exact, eight wave roles + final exponentiation on nine lane pairs", "... + octet final exponentiation", "... + nine lane pairs at every size", "exact, four wave roles", "exact, lane groups of one wave (octet)", "exact on lane pairs", "exact, one lane per verify", "randomised 128-bit", "randomised GLV", "randomised 64-bit"],
+           "modes": ["exact, the batch in three slices inside the library (BN254_OPT_MAX_CHUNK)", "aggregate verify on registered pools (every eighth round)", "keyed (registered keys, once per round with the subgroup check)", "keyed randomised 128-bit / 64-bit / GLV (once per round)", "exact, defaults (lane machine up to 1536, eight wave roles above; final exponentiation on nine lane pairs up to 3072)", "exact, Miller loop as the lane machine at every size", "exact, eight wave roles + final exponentiation on nine lane pairs", "... + octet final exponentiation", "... + nine lane pairs at every size", "exact, four wave roles", "exact, lane groups of one wave (octet)", "exact on lane pairs", "exact, one lane per verify", "randomised 128-bit", "randomised GLV", "randomised 64-bit"],
            "flags": [0, 1]}
     return res
 
