@@ -429,6 +429,9 @@ KERNEL_PAIR void k_aggregate_pair(const uint32_t* tuple_msg, const uint64_t* tup
     // went through the private segment.  One word at either end of each record is touched first, all together, so that the fetches of an
     // iteration overlap (a real function waits for every outstanding load at its entry: the records then sit in the L1 when it reads them).
     const unsigned n_chunks = (n_groups + 1) / 2;
+    // (Round 6, measured and not kept: this loop SOFTWARE-PIPELINED for the route of the largest batches — the records of chunk k + 1 loaded into
+    // registers while chunk k is added, the additions reading registers — 35.85-35.92 against 35.48-35.53 ms per 1 Mi tuples same box,
+    // profiles/r06_f_ab_agg_pipeline.log: the 36 more live registers cost more than the round trips they were meant to hide.)
     for (unsigned k = 0; k < n_chunks; ++k) {                              // wave-uniform
       const uint32_t m16 = dup ? 0u : (my_masks[k >> 1] >> (16u * (k & 1u))) & 0xFFFFu;
       const uint32_t byte0 = m16 & 255u, byte1 = m16 >> 8;

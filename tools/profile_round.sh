@@ -37,7 +37,8 @@ elif [ "$part" = c ]; then
   for spec in "verify-keyed:65536" "pairing:524288" "hash:16777216" "aggregate:1048576"; do
     w=${spec%%:*}; b=${spec##*:}
     OUTJ=$R/gpurun_out/pmc_${ROUND:-r04}_${tag}_$w.json; [ -f $O/pmc.json ] && cp $O/pmc.json $OUTJ
-    bash $R/tests/pmc_profile.sh ${ROUND:-r04}_${tag}_$w "--workload $w" $w $b "$SHORT" > $O/pmc_$w.log 2>&1; cp $OUTJ $O/pmc.json; echo pmc $w done
+    EXTRA=""; [ "$w" = aggregate ] && EXTRA=" --agg-main-only"     # only the default route: the bench's side runs (direct additions, narrow tables) launch the same kernel
+    bash $R/tests/pmc_profile.sh ${ROUND:-r04}_${tag}_$w "--workload $w$EXTRA" $w $b "$SHORT" > $O/pmc_$w.log 2>&1; cp $OUTJ $O/pmc.json; echo pmc $w done
     cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$w -- python3 $R/bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_${w}_under_rocprof.json 2> $O/stats_$w.err; echo stats $w done
   done
 fi
