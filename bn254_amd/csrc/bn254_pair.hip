@@ -380,6 +380,58 @@ KERNEL_PAIR void k_aggregate_pair(const uint32_t* tuple_msg, const uint64_t* tup
     for (unsigned w = role; w < mask_stride; w += 2) my_masks[w] = 0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   }
+#if !defined(BN_AGG_NO_BATCHED_WALK)
+  if (use_sub1) {                          // wave-uniform: keys AND signatures come from tables — the walk only checks entries and sets mask bits
+    // Round 6: the walk in BATCHES.  The old loop below took two entries per iteration, every lane loading both, each load's result needed
+    // at once: index -> status bytes -> mask bit is a chain of dependent round trips, ~256 times per lane with nothing in flight beside it
+    // (there are no product calls on this path, so loads CAN stay in flight).  Here a lane takes only ITS entries (list position = role mod 2),
+    // eight at a time: eight index loads together, then sixteen status bytes together, then the bookkeeping (k_aggregate_pair 35.6 -> 30.8 ms
+    // per 1 Mi tuples same box, profiles/r06_g_ab_agg_batched_walk.log).  The tuple's status is that of the
+    // FIRST failing entry in list order: each lane keeps the position of its first failure and the pair takes the smaller of the two.
+#ifndef BN_AGG_WALK_BATCH
+#define BN_AGG_WALK_BATCH 8       // 2 / 4 / 8 measured: 31.0 / 30.9 / 30.7 ms (profiles/r06_g_ab_agg_walk_batch_size.log) — halving the loads per lane is what pays, not the depth
+#endif
+    constexpr int WB = BN_AGG_WALK_BATCH;
+    uint64_t bad_pos = ~(uint64_t)0;
+    uint32_t bad_st = ST_OK;
+    for (uint64_t t = 0; t < longest; t += 2 * WB) {
+      uint32_t sgn[WB];
+      bool act[WB], valid[WB];
+      uint8_t s1[WB], s2[WB];
+#pragma unroll
+      for (int j = 0; j < WB; ++j) {
+        const uint64_t pos = lo + t + 2 * j + role;
+        act[j] = pos < hi;
+        sgn[j] = act[j] ? signer_idx[pos] : 0u;
+      }
+#pragma unroll
+      for (int j = 0; j < WB; ++j) {
+        valid[j] = act[j] && sgn[j] < n_signers;
+        const uint32_t g = valid[j] ? sgn[j] : 0u;
+        s1[j] = sig_pool.st[(size_t)m * n_signers + g];
+        s2[j] = pk_pool.st[g];
+      }
+#pragma unroll
+      for (int j = 0; j < WB; ++j) {
+        uint32_t e_st = ST_OK;
+        if (act[j] && !valid[j]) e_st = ST_INDEX_OOB;                         // IndexOutOfBounds
+        else if (valid[j] && (s1[j] & 0x7f)) e_st = s1[j] & 0x7f;             // the signature's decode status first, then the key's
+        else if (valid[j] && (s2[j] & 0x7f)) e_st = s2[j] & 0x7f;
+        const uint64_t pos = lo + t + 2 * j + role;
+        if (e_st != ST_OK && pos < bad_pos) { bad_pos = pos; bad_st = e_st; }
+        if (valid[j]) {
+          const uint32_t bit = 1u << (8u * ((sgn[j] >> 3) & 3u) + (sgn[j] & 7u));
+          const uint32_t old = atomicOr(&my_masks[sgn[j] >> 5], bit);
+          dup = dup || (old & bit) != 0;
+        }
+      }
+    }
+    const uint32_t p_lo = (uint32_t)bn_partner_word((int32_t)(uint32_t)bad_pos), p_hi = (uint32_t)bn_partner_word((int32_t)(uint32_t)(bad_pos >> 32));
+    const uint32_t p_st = (uint32_t)bn_partner_word((int32_t)bad_st);
+    const uint64_t p_pos = ((uint64_t)p_hi << 32) | p_lo;
+    if (st == ST_OK) st = (uint8_t)(p_pos < bad_pos ? p_st : bad_st);
+  } else
+#endif
   for (uint64_t t = 0; t < longest; t += 2) {
     G2Affine pp[2];
     G1Affine sp;
