@@ -489,12 +489,62 @@ int bn254_batch_g1_mul_device(bn254_ctx* c, const uint8_t* d_p, const uint8_t* d
   HIP_TRY(hipGetLastError());
   return 0;
 }
+// The comb table of the generator for key derivation (k_g2_mul_fixed_pair, bn254_pair.hip): records j * 8 + (d - 1) = d 16^j G2::one() for
+// j = 0 .. 64, d = 1 .. 8, and record 520 = the blinding point.  Built once per context with the library's own ladder (k_g2_mul on the 521
+// scalars, reduced mod r on the host) and decoder; ~6 ms, on the context's own stream, waited for before the first use.
+static int g2_comb_build(bn254_ctx* c) {
+  if (c->g2_comb_ready) return 0;
+  const size_t N = BN_G2_COMB_RECORDS;
+  uint8_t* h = (uint8_t*)malloc(N * 32);
+  if (!h) return BN254_E_NO_MEMORY;
+  // 256-bit arithmetic mod r on little-endian words: x -> 2x mod r, x + y mod r
+  const uint32_t* R = nullptr;
+  static const uint32_t r_words[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+  R = r_words;
+  auto geq = [&](const uint32_t* a) { for (int i = 7; i >= 0; --i) { if (a[i] != R[i]) return a[i] > R[i]; } return true; };
+  auto sub_r = [&](uint32_t* a) { uint64_t bw = 0; for (int i = 0; i < 8; ++i) { uint64_t d = (uint64_t)a[i] - R[i] - bw; a[i] = (uint32_t)d; bw = (d >> 63) & 1; } };
+  auto add = [&](uint32_t* a, const uint32_t* b) {         // a, b < r < 2^254: the sum fits 256 bits
+    uint64_t cy = 0; for (int i = 0; i < 8; ++i) { uint64_t t = (uint64_t)a[i] + b[i] + cy; a[i] = (uint32_t)t; cy = t >> 32; }
+    if (geq(a)) sub_r(a);
+  };
+  auto put = [&](size_t idx, const uint32_t* a) { for (int i = 0; i < 8; ++i) { uint32_t w = a[7 - i]; h[32 * idx + 4 * i] = (uint8_t)(w >> 24); h[32 * idx + 4 * i + 1] = (uint8_t)(w >> 16); h[32 * idx + 4 * i + 2] = (uint8_t)(w >> 8); h[32 * idx + 4 * i + 3] = (uint8_t)w; } };
+  uint32_t base[8] = {1, 0, 0, 0, 0, 0, 0, 0};              // 16^j mod r
+  for (int j = 0; j < 65; ++j) {
+    uint32_t acc[8] = {0};
+    for (int d = 1; d <= 8; ++d) { add(acc, base); put((size_t)j * 8 + (d - 1), acc); }
+    for (int t = 0; t < 4; ++t) { uint32_t dbl[8]; memcpy(dbl, base, sizeof dbl); add(base, dbl); }
+  }
+  // the blinding point: a fixed scalar nobody's key is related to (SHA-256("bn254-mi355x g2 comb blinding point"), reduced once)
+  static const uint32_t blind[8] = {0x6b2f1c9du, 0x0f3a7e55u, 0x9c4d21a7u, 0x5be0cd19u, 0x1f83d9abu, 0x3c6ef372u, 0xa54ff53au, 0x2b67ae85u};
+  { uint32_t b[8]; memcpy(b, blind, sizeof b); if (geq(b)) sub_r(b); put(N - 1, b); }
+  int rc;
+  if ((rc = pool_reserve_one(c, &c->g2_comb, 4, N))) { free(h); return rc; }
+  // staging slots 5 .. 7: a host-pointer caller (mul_host) has ITS scalars in slots 0 .. 3 when this runs
+  if ((rc = stage_in(c, 5, h, N * 32))) { free(h); return rc; }
+  if ((rc = stage_reserve(c, 6, N * 128))) { free(h); return rc; }
+  if ((rc = stage_reserve(c, 7, N))) { free(h); return rc; }
+  k_g2_mul<<<grid_for(N), BN_WAVE, 0, c->stream>>>(nullptr, c->stage[5], N, 0, c->stage[6], c->stage[7]);
+  k_pool_decode_g2<<<grid_for(N), BN_WAVE, 0, c->stream>>>(c->stage[6], N, 0, c->g2_comb);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);      // the staged scalars are read from `h`; the table is complete before any stream uses it
+  free(h);
+  if (e != hipSuccess) return -(int)e;
+  c->g2_comb_ready = 1;
+  return 0;
+}
 int bn254_batch_g2_mul_device(bn254_ctx* c, const uint8_t* d_p, const uint8_t* d_k, size_t n, int reduce, uint8_t* d_out, uint8_t* d_status, void* stream) {
   if (!c || (n && (!d_k || !d_out || !d_status))) return BN254_E_BAD_ARGUMENT;   // d_p == NULL: generator
   if (n == 0) return 0;
   if ((d_p && misaligned(d_p)) || misaligned(d_k) || misaligned(d_out)) return BN254_E_MISALIGNED;
   HIP_TRY(hipSetDevice(c->device));
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  if (!d_p && c->pair_lanes && c->g2_fixed_base) {
+    // key derivation multiplies the FIXED generator: 65 table additions on a lane pair instead of the 256-step ladder on one lane
+    int rc = g2_comb_build(c);
+    if (rc) return rc;
+    CallDone call_done(c, s);
+    return bn254_pair_g2_mul_fixed(d_k, n, reduce, c->g2_comb, d_out, d_status, s);
+  }
   CallDone call_done(c, s);
   k_g2_mul<<<grid_for(n), BN_WAVE, 0, s>>>(d_p, d_k, n, reduce, d_out, d_status);
   HIP_TRY(hipGetLastError());

@@ -456,6 +456,21 @@ int stage_out(bn254_ctx* c, int slot, void* host, size_t bytes) {
   if (bytes) HIP_TRY(hipMemcpyAsync(host, c->stage[slot], bytes, hipMemcpyDeviceToHost, c->stream));
   return 0;
 }
+// a pool outside the numbered slots (the comb table of the G2 generator): allocated once, never resized in practice
+int pool_reserve_one(bn254_ctx* c, Pool* p, size_t n_fp, size_t entries) {
+  if (entries <= p->stride) return 0;
+  HIP_TRY(hipSetDevice(c->device));
+  { int rc_ = ctx_quiesce(c); if (rc_) return rc_; }
+  if (p->planes) { HIP_TRY(hipFree(p->planes)); p->planes = nullptr; }
+  if (p->st) { HIP_TRY(hipFree(p->st)); p->st = nullptr; }
+  p->stride = 0;
+  const size_t cap = (entries + 255) & ~(size_t)255;
+  p->g2 = n_fp == 4 ? 1u : 0u;
+  HIP_TRY(hipMalloc((void**)&p->planes, (n_fp / 2) * BN_POOL_HALF_WORDS * sizeof(int32_t) * cap));
+  HIP_TRY(hipMalloc((void**)&p->st, cap));
+  p->stride = cap;
+  return 0;
+}
 int pool_reserve(bn254_ctx* c, int which, size_t n_fp, size_t entries) {
   Pool& p = c->pool[which];
   if (entries <= p.stride && c->pool_fp[which] == n_fp) return 0;
@@ -586,6 +601,7 @@ int bn254_ctx_create(int hip_device, bn254_ctx** out) {
   c->nonet_max_batch = bn254_nonet_fits_device() ? NONET_MAX_BATCH_DEFAULT : 0;
   c->lm_max_batch = bn254_lm_fits_device() ? LM_MAX_BATCH_DEFAULT : 0;
   c->nonet_wide = 1;
+  c->g2_fixed_base = 1;
   c->device = hip_device;
   hipError_t err = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (err == hipSuccess) err = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
@@ -617,6 +633,8 @@ void bn254_ctx_destroy(bn254_ctx* c) {
   if (c->ws.clk) (void)hipFree(c->ws.clk);
   if (c->pin) (void)hipHostFree(c->pin);
   for (int i = 0; i < 8; ++i) { if (c->pool[i].planes) (void)hipFree(c->pool[i].planes); if (c->pool[i].st) (void)hipFree(c->pool[i].st); }
+  if (c->g2_comb.planes) (void)hipFree(c->g2_comb.planes);
+  if (c->g2_comb.st) (void)hipFree(c->g2_comb.st);
   for (int i = 0; i < 8; ++i) if (c->stage[i]) (void)hipFree(c->stage[i]);
   if (c->key_lines) (void)hipFree(c->key_lines);
   if (c->key_xy) (void)hipFree(c->key_xy);
@@ -706,6 +724,7 @@ int bn254_ctx_set_option(bn254_ctx* c, int option, int value) {
     return 0;
   }
   if (option == BN254_OPT_HASH_MAX_TRIES) { if (value < 0 || value > 255) return BN254_E_BAD_ARGUMENT; c->hash_max_tries = value; return 0; }
+  if (option == BN254_OPT_G2_FIXED_BASE) { c->g2_fixed_base = value != 0; return 0; }
   if (option == BN254_OPT_MAX_CHUNK) { if (value < 0) return BN254_E_BAD_ARGUMENT; c->max_chunk = value; return 0; }
   if (option == BN254_OPT_ASSUME_FREE_MB) { if (value < 0) return BN254_E_BAD_ARGUMENT; c->assume_free_mb = value; return 0; }
   return BN254_E_BAD_ARGUMENT;

@@ -59,6 +59,9 @@ struct bn254_ctx {
   size_t n_keys, key_cap;
   hipEvent_t last_done;      // recorded on the CALLER's stream when a *_device call on such a stream returns (CallDone below): what ctx_quiesce
   bool last_done_armed;      // waits for.  The context keeps no handle of a stream it does not own — the caller may destroy its stream any time.
+  Pool g2_comb;              // fixed-base table of the G2 generator for key derivation (bn254_group.hip: g2_comb_build), built at the first keygen call
+  int g2_comb_ready;
+  int g2_fixed_base;         // BN254_OPT_G2_FIXED_BASE (developer option, default 1): key derivation through the comb table; 0 = the 256-step ladder
   AggTables reg_pools;       // bn254_ctx_register_pools: the tables of the registered pools (valid until the next registration or raw-pool call)
   int max_chunk;             // BN254_OPT_MAX_CHUNK: verify-shaped batches above this size are processed in slices (0 = only when the workspace would not fit)
   int assume_free_mb;        // test knob (BN254_OPT_ASSUME_FREE_MB): the automatic rule prices the workspace against this much free memory instead of hipMemGetInfo
@@ -119,6 +122,7 @@ BN_HIDDEN int stage_reserve(bn254_ctx* c, int slot, size_t bytes);
 BN_HIDDEN int stage_in(bn254_ctx* c, int slot, const void* host, size_t bytes);
 BN_HIDDEN int stage_out(bn254_ctx* c, int slot, void* host, size_t bytes);
 BN_HIDDEN int pool_reserve(bn254_ctx* c, int which, size_t n_fp, size_t entries);
+BN_HIDDEN int pool_reserve_one(bn254_ctx* c, Pool* p, size_t n_fp, size_t entries);
 static inline bool misaligned(const void* p) { return ((uintptr_t)p & 3u) != 0; }
 // host-pointer entry points: an offsets array (n + 1 entries) must be non-decreasing — a kernel computes lengths as
 // off[i+1] - off[i], and a wrapped length walks far outside the staged buffer.  O(n) on memory the host already has.

@@ -594,6 +594,103 @@ int bn254_pair_aggregate(const uint32_t* tuple_msg, const uint64_t* tuple_off, c
   HIP_TRY(hipGetLastError());
   return 0;
 }
+// ---- fixed-base scalar multiplication sk * G2::one() on lane pairs (PublicKey::from_private_key, /root/reference/src/types.rs:85-87) ----------
+// Key derivation multiplies the FIXED generator, so the doublings can be tabulated: sk = sum d_j 16^j with signed digits d_j in [-8, 8]
+// (65 of them) and sk * G = sum d_j (16^j G) — 65 mixed additions from the table T[j][d - 1] = d 16^j G (bn254_group.hip: g2_comb_build,
+// once per context) where the 256-step ladder of k_g2_mul spends 256 doublings + 65 complete additions: 0.7 k Fq2 products per key instead of
+// 3 k, on TWO lanes instead of one.  The scalar is a private key: a window's entry is found by reading all eight records of the window and
+// keeping one by selects (no address and no branch depends on a digit), the digit's sign is a conditional negation, a zero digit adds the
+// identity.  The accumulator starts at a fixed BLINDING point B (record 520) that is subtracted at the end, so that it is never the identity
+// and never +- a table entry for any scalar an honest caller holds — the in-place addition's exceptional route (P = +-Q, handled by the
+// complete formula behind a wave vote) then never runs, which keeps the schedule independent of the key; it still gives the right point if
+// it ever does.
+#define BN_G2_COMB_WINDOWS 65
+#define BN_G2_COMB_BLIND (BN_G2_COMB_WINDOWS * 8)
+template <class A> struct AffineValue {
+  A v;
+  __device__ __forceinline__ void operator()(A& q) const { q = v; }
+};
+__device__ __forceinline__ void store_fp_be_pair(uint8_t* b, const Fp& a) {
+  U256 x = fp_to_u256(a);
+  uint32_t* w = (uint32_t*)b;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) w[k] = __builtin_bswap32(x.w[7 - k]);
+}
+KERNEL_PAIR void k_g2_mul_fixed_pair(const uint8_t* scalars, size_t n, int reduce, Pool comb, uint8_t* out, uint8_t* status) {
+  const unsigned role = threadIdx.x & 1u;
+  size_t i = ((size_t)blockIdx.x * BN_PAIR_WG + threadIdx.x) >> 1;
+  const bool live = i < n;                         // no early return: the additions vote across the wave
+  const size_t ii = live ? i : n - 1;
+  uint32_t k[8];
+  {
+    const uint32_t* w = (const uint32_t*)(scalars + 32 * ii);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) k[7 - j] = __builtin_bswap32(w[j]);
+    if (reduce) {
+      for (int it = 0; it < 6; ++it) {             // 2^256 / r < 6; the subtraction is applied by selects
+        const bool ge = u256_geq(k, C_ORDER_R);
+        uint32_t bw = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const uint64_t d = (uint64_t)k[j] - C_ORDER_R[j] - bw;
+          bw = (uint32_t)(d >> 63);
+          k[j] = ge ? (uint32_t)d : k[j];
+        }
+      }
+    }
+  }
+  __shared__ G2Jac lds_acc[BN_PAIR_WG];
+  G2Jac& acc = lds_acc[threadIdx.x];
+  {
+    G2Affine b;
+    PoolRec{comb.planes + pool_word(comb, (int)role, BN_G2_COMB_BLIND), false}(b);
+    jac_from_affine(acc, b);
+  }
+  int carry = 0;
+#pragma unroll 1
+  for (int j = 0; j < BN_G2_COMB_WINDOWS; ++j) {
+    int v = (j < 64 ? (int)((k[j >> 3] >> (4 * (j & 7))) & 15u) : 0) + carry;
+    carry = v > 8;
+    const int d = v - 16 * carry, m = d < 0 ? -d : d;
+    G2Affine q;
+    PoolRec{comb.planes + pool_word(comb, (int)role, (size_t)j * 8), false}(q);
+#pragma unroll 1
+    for (int e = 1; e < 8; ++e) {                  // every record of the window is read; the wanted one is kept by selects
+      G2Affine t;
+      PoolRec{comb.planes + pool_word(comb, (int)role, (size_t)j * 8 + e), false}(t);
+      q.x = fp2_select(m == e + 1, t.x, q.x);
+      q.y = fp2_select(m == e + 1, t.y, q.y);
+    }
+    q.y = fp2_select(d < 0, fp2_neg(q.y), q.y);
+    q.inf = m == 0;
+    jac_accumulate_from(acc, AffineValue<G2Affine>{q});
+  }
+  {
+    G2Affine b;
+    PoolRec{comb.planes + pool_word(comb, (int)role, BN_G2_COMB_BLIND), false}(b);
+    b.y = fp2_neg(b.y);
+    jac_accumulate_from(acc, AffineValue<G2Affine>{b});
+  }
+  G2Affine r;
+  jac_to_affine(r, acc);
+  if (!live) return;
+  uint8_t* o = out + 128 * i;
+  if (r.inf) {
+    uint32_t* w = (uint32_t*)(o + 32 * role);
+    uint32_t* w2 = (uint32_t*)(o + 64 + 32 * role);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) { w[t] = 0; w2[t] = 0; }
+  } else {
+    store_fp_be_pair(o + 32 * role, r.x.c[0]);
+    store_fp_be_pair(o + 64 + 32 * role, r.y.c[0]);
+  }
+  if (role == 0) status[i] = ST_OK;
+}
+int bn254_pair_g2_mul_fixed(const uint8_t* d_scalars, size_t n, int reduce, Pool comb, uint8_t* d_out, uint8_t* d_status, hipStream_t s) {
+  k_g2_mul_fixed_pair<<<(unsigned)((2 * n + BN_PAIR_WG - 1) / BN_PAIR_WG), BN_PAIR_WG, 0, s>>>(d_scalars, n, reduce, comb, d_out, d_status);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
 int bn254_pair_miller_verify(size_t n, Ws ws, const uint32_t* map, const uint32_t* count, hipStream_t s, int mode) {
   k_miller_verify_pair<<<(unsigned)((2 * n + BN_PAIR_WG - 1) / BN_PAIR_WG), BN_PAIR_WG, 0, s>>>(n, ws, map, count, mode);
   HIP_TRY(hipGetLastError());

@@ -29,7 +29,8 @@ OPT_LM_MAX_BATCH = 15
 OPT_NONET_WIDE = 16
 OPT_AGG_WIDE_MIN_TUPLES = 14
 OPT_MAX_CHUNK = 17          # verify-shaped batches above this size are processed in slices (0 = only when the workspace would not fit)
-OPT_ASSUME_FREE_MB = 18     # test knob of the automatic slicing rule
+OPT_ASSUME_FREE_MB = 18
+OPT_G2_FIXED_BASE = 19      # developer option: key derivation through the comb table of the generator (default 1)     # test knob of the automatic slicing rule
 
 
 class NativeError(RuntimeError):

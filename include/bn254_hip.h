@@ -440,6 +440,8 @@ int bn254_mgpu_batch_hash_to_g1(bn254_mgpu *mg, const uint8_t *msgs, const uint6
                                   bn254_ctx_last_clocks: the clock the chip actually sustains under this load (power-limited parts run below
                                   their nominal 2.4 GHz).  Costs two scalar clock reads per workgroup; default 0 */
 #define BN254_OPT_HASH_MAX_TRIES 2 /* test knob: counters tried before HashToPointError; 0 = 255 as in src/hash.rs:40 */
+#define BN254_OPT_G2_FIXED_BASE 19 /* key derivation (bn254_batch_g2_mul with points = NULL: sk * G2::one()): 1 (default) = 65 additions from a table of the
+                                   generator's multiples, built once per context, on a lane pair; 0 = the general 256-step ladder on one lane.  Same bytes. */
 #define BN254_OPT_ASSUME_FREE_MB 18 /* test knob for the automatic slicing rule (BN254_OPT_MAX_CHUNK = 0): price the workspace of a batch against this many MB
                                     of free device memory instead of what hipMemGetInfo reports; 0 = ask the runtime */
 /* the routing table of this context as it stands (defaults + options): rows (max_n[i], miller[i], fe[i]) in ascending order of max_n, the last

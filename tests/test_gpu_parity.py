@@ -720,6 +720,42 @@ def test_pairing_small_batches_take_the_small_batch_kernels(eng, c, derived):
     assert gt_a == gt_b[:384 * 1024] and st_a == st_b[:1024]
 
 
+def test_key_derivation_from_the_comb_table_vs_oracle_and_ladder(eng, c, kats):
+    """sk * G2::one() (PublicKey::from_private_key, /root/reference/src/types.rs:85-87) through the fixed-base comb of round 6 (65 table additions on a
+    lane pair, window entries found by constant-time scans, blinded accumulator) against the oracle's scalar multiplication AND the general
+    256-step ladder it replaces (BN254_OPT_G2_FIXED_BASE = 0): scalars that put every digit pattern on the table's edges — 0, 1, 7, 8, 9, 15,
+    16, 2^k and 2^k - 1, all-8 / all-9 nibbles (every window carries), r - 1, r, r + 1, 2^256 - 1 (raw: used as they are; reduced: Fr::from_slice),
+    random ones, a batch that is no multiple of the workgroup, and the four sk * G2 known answers of the reference (src/types_test.rs:71-129)."""
+    from bn254_amd.engine import OPT_G2_FIXED_BASE
+    R = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+    rnd = random.Random(99)
+    vals = [0, 1, 7, 8, 9, 15, 16, 17, 2 ** 64, 2 ** 64 - 1, 2 ** 128 + 1, 2 ** 252, 2 ** 253 - 1, int("8" * 64, 16), int("9" * 64, 16) % 2 ** 256, int("7" * 64, 16),
+            R - 1, R, R + 1, 2 * R, 2 ** 256 - 1, 2 ** 256 - 2 ** 4]
+    vals += [rnd.randrange(2 ** 256) for _ in range(175)] + [rnd.randrange(R) for _ in range(70)]
+    n = len(vals)
+    assert n % 128 != 0
+    scal = b"".join(v.to_bytes(32, "big") for v in vals)
+    g2 = c.g2_generator()
+    for reduce in (False, True):
+        want = b"".join(c.g2_mul(g2, ((v % R) if reduce else v).to_bytes(32, "big")) for v in vals)
+        eng.set_option(OPT_G2_FIXED_BASE, 1)
+        got, st = eng.batch_g2_mul(None, scal, n, reduce_scalar=reduce)
+        eng.set_option(OPT_G2_FIXED_BASE, 0)
+        ladder, st_l = eng.batch_g2_mul(None, scal, n, reduce_scalar=reduce)
+        eng.set_option(OPT_G2_FIXED_BASE, 1)
+        assert st == st_l == bytes(n)
+        bad = [i for i in range(n) if got[128 * i:128 * i + 128] != want[128 * i:128 * i + 128]]
+        assert not bad, (reduce, [hex(vals[i]) for i in bad[:4]])
+        assert ladder == want
+        assert got[:128] == bytes(128)                       # 0 * G = the identity = all-zero bytes
+    # one key, and the reference's own known answers, through the mirror of the reference API
+    one, st = eng.batch_g2_mul(None, (5).to_bytes(32, "big"), 1)
+    assert one == c.g2_mul(g2, (5).to_bytes(32, "big")) and st == b"\0"
+    for v in kats["public_key_from_private_key"]:
+        out, st = eng.batch_g2_mul(None, H(v["private_key"]), 1, reduce_scalar=True)
+        assert out == H(v["uncompressed"]) and st == b"\0"
+
+
 def test_group_ops_vs_oracle(eng, c):
     ps, qs = _rand_points(c, 40, b"grp")
     n = 40
