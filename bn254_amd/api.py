@@ -155,8 +155,7 @@ class PublicKeyG1(_G1Point):
 
     @classmethod
     def from_private_key(cls, private_key):
-        gen = (1).to_bytes(32, "big") + (2).to_bytes(32, "big")
-        out, st = _eng().batch_g1_mul(gen, private_key.to_bytes(), 1, reduce_scalar=True)
+        out, st = _eng().batch_g1_mul(None, private_key.to_bytes(), 1, reduce_scalar=True)      # None = G1::one(): the fixed-base table
         _raise(st[0])
         return cls(out)
 

@@ -478,12 +478,26 @@ static int binop_host(bn254_ctx* c, int g2, const uint8_t* a, const uint8_t* b, 
 int bn254_batch_g1_add(bn254_ctx* c, const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out, uint8_t* status) { return binop_host(c, 0, a, b, n, out, status); }
 int bn254_batch_g2_add(bn254_ctx* c, const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out, uint8_t* status) { return binop_host(c, 1, a, b, n, out, status); }
 
+static int comb_build(bn254_ctx* c, int g2);
+KERNEL void k_g1_gen_mul_reduce(const uint8_t* scalars, size_t n, int reduce, uint8_t* out, uint8_t* status);
 int bn254_batch_g1_mul_device(bn254_ctx* c, const uint8_t* d_p, const uint8_t* d_k, size_t n, int reduce, uint8_t* d_out, uint8_t* d_status, void* stream) {
-  if (!c || (n && (!d_p || !d_k || !d_out || !d_status))) return BN254_E_BAD_ARGUMENT;
+  if (!c || (n && (!d_k || !d_out || !d_status))) return BN254_E_BAD_ARGUMENT;    // d_p == NULL: the generator (PublicKeyG1::from_private_key)
   if (n == 0) return 0;
-  if (misaligned(d_p) || misaligned(d_k) || misaligned(d_out)) return BN254_E_MISALIGNED;
+  if ((d_p && misaligned(d_p)) || misaligned(d_k) || misaligned(d_out)) return BN254_E_MISALIGNED;
   HIP_TRY(hipSetDevice(c->device));
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  if (!d_p) {
+    if (c->pair_lanes && c->g2_fixed_base) {           // the fixed generator: 65 table additions split over the two lanes of a pair
+      int rc = comb_build(c, 0);
+      if (rc) return rc;
+      CallDone call_done(c, s);
+      return bn254_pair_g1_mul_fixed(d_k, n, reduce, c->g1_comb, d_out, d_status, s);
+    }
+    CallDone call_done(c, s);
+    k_g1_gen_mul_reduce<<<grid_for(n), BN_WAVE, 0, s>>>(d_k, n, reduce, d_out, d_status);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   CallDone call_done(c, s);
   k_g1_mul<<<grid_for(n), BN_WAVE, 0, s>>>(d_p, d_k, n, reduce, c->ws, d_out, d_status);
   HIP_TRY(hipGetLastError());
@@ -492,9 +506,37 @@ int bn254_batch_g1_mul_device(bn254_ctx* c, const uint8_t* d_p, const uint8_t* d
 // The comb table of the generator for key derivation (k_g2_mul_fixed_pair, bn254_pair.hip): records j * 8 + (d - 1) = d 16^j G2::one() for
 // j = 0 .. 64, d = 1 .. 8, and record 520 = the blinding point.  Built once per context with the library's own ladder (k_g2_mul on the 521
 // scalars, reduced mod r on the host) and decoder; ~6 ms, on the context's own stream, waited for before the first use.
-static int g2_comb_build(bn254_ctx* c) {
-  if (c->g2_comb_ready) return 0;
-  const size_t N = BN_G2_COMB_RECORDS;
+// sk * G1::one() by the general ladder: the fallback of bn254_batch_g1_mul(points = NULL) when the comb table is switched off
+KERNEL void k_g1_gen_mul_reduce(const uint8_t* scalars, size_t n, int reduce, uint8_t* out, uint8_t* status) {
+  size_t i = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
+  if (i >= n) return;
+  G1Affine g, r;
+  g1_set_generator(g);
+  uint32_t k[8];
+  scalar_from_be(k, scalars + 32 * i, reduce != 0);
+  G1Jac jo;
+  jac_mul(jo, g, k);
+  jac_to_affine(r, jo);
+  encode_g1(out + 64 * i, r);
+  status[i] = ST_OK;
+}
+// ... and for the builder of the comb table
+KERNEL void k_g1_gen_mul(const uint8_t* scalars, size_t n, uint8_t* out) {
+  size_t i = (size_t)blockIdx.x * BN_WAVE + threadIdx.x;
+  if (i >= n) return;
+  G1Affine g, r;
+  g1_set_generator(g);
+  uint32_t k[8];
+  scalar_from_be(k, scalars + 32 * i, false);
+  G1Jac jo;
+  jac_mul(jo, g, k);
+  jac_to_affine(r, jo);
+  encode_g1(out + 64 * i, r);
+}
+static int comb_build(bn254_ctx* c, int g2) {
+  if (g2 ? c->g2_comb_ready : c->g1_comb_ready) return 0;
+  const size_t N = g2 ? BN_G2_COMB_RECORDS : BN_G1_COMB_RECORDS;
+  const size_t sz = g2 ? 128 : 64;
   uint8_t* h = (uint8_t*)malloc(N * 32);
   if (!h) return BN254_E_NO_MEMORY;
   // 256-bit arithmetic mod r on little-endian words: x -> 2x mod r, x + y mod r
@@ -516,20 +558,39 @@ static int g2_comb_build(bn254_ctx* c) {
   }
   // the blinding point: a fixed scalar nobody's key is related to (SHA-256("bn254-mi355x g2 comb blinding point"), reduced once)
   static const uint32_t blind[8] = {0x6b2f1c9du, 0x0f3a7e55u, 0x9c4d21a7u, 0x5be0cd19u, 0x1f83d9abu, 0x3c6ef372u, 0xa54ff53au, 0x2b67ae85u};
-  { uint32_t b[8]; memcpy(b, blind, sizeof b); if (geq(b)) sub_r(b); put(N - 1, b); }
+  {
+    uint32_t b0[8];
+    memcpy(b0, blind, sizeof b0);
+    if (geq(b0)) sub_r(b0);
+    put(65 * 8, b0);
+    if (!g2) {                                           // G1: one blinding point per lane of the pair, and minus their sum
+      uint32_t b1[8], sum[8], neg[8];
+      memcpy(b1, b0, sizeof b1); add(b1, b0); add(b1, b0);                 // B1 = 3 b0 (any fixed scalar unrelated to a key will do)
+      put(65 * 8 + 1, b1);
+      memcpy(sum, b0, sizeof sum); add(sum, b1);
+      uint64_t bw = 0;                                  // neg = r - sum
+      for (int i = 0; i < 8; ++i) { uint64_t d = (uint64_t)R[i] - sum[i] - bw; neg[i] = (uint32_t)d; bw = (d >> 63) & 1; }
+      put(65 * 8 + 2, neg);
+    }
+  }
   int rc;
-  if ((rc = pool_reserve_one(c, &c->g2_comb, 4, N))) { free(h); return rc; }
+  if ((rc = pool_reserve_one(c, g2 ? &c->g2_comb : &c->g1_comb, g2 ? 4 : 2, N))) { free(h); return rc; }
   // staging slots 5 .. 7: a host-pointer caller (mul_host) has ITS scalars in slots 0 .. 3 when this runs
   if ((rc = stage_in(c, 5, h, N * 32))) { free(h); return rc; }
-  if ((rc = stage_reserve(c, 6, N * 128))) { free(h); return rc; }
+  if ((rc = stage_reserve(c, 6, N * sz))) { free(h); return rc; }
   if ((rc = stage_reserve(c, 7, N))) { free(h); return rc; }
-  k_g2_mul<<<grid_for(N), BN_WAVE, 0, c->stream>>>(nullptr, c->stage[5], N, 0, c->stage[6], c->stage[7]);
-  k_pool_decode_g2<<<grid_for(N), BN_WAVE, 0, c->stream>>>(c->stage[6], N, 0, c->g2_comb);
+  if (g2) {
+    k_g2_mul<<<grid_for(N), BN_WAVE, 0, c->stream>>>(nullptr, c->stage[5], N, 0, c->stage[6], c->stage[7]);
+    k_pool_decode_g2<<<grid_for(N), BN_WAVE, 0, c->stream>>>(c->stage[6], N, 0, c->g2_comb);
+  } else {
+    k_g1_gen_mul<<<grid_for(N), BN_WAVE, 0, c->stream>>>(c->stage[5], N, c->stage[6]);
+    k_pool_decode_g1<<<grid_for(N), BN_WAVE, 0, c->stream>>>(c->stage[6], N, 0, c->g1_comb);
+  }
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);      // the staged scalars are read from `h`; the table is complete before any stream uses it
   free(h);
   if (e != hipSuccess) return -(int)e;
-  c->g2_comb_ready = 1;
+  if (g2) c->g2_comb_ready = 1; else c->g1_comb_ready = 1;
   return 0;
 }
 int bn254_batch_g2_mul_device(bn254_ctx* c, const uint8_t* d_p, const uint8_t* d_k, size_t n, int reduce, uint8_t* d_out, uint8_t* d_status, void* stream) {
@@ -540,7 +601,7 @@ int bn254_batch_g2_mul_device(bn254_ctx* c, const uint8_t* d_p, const uint8_t* d
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
   if (!d_p && c->pair_lanes && c->g2_fixed_base) {
     // key derivation multiplies the FIXED generator: 65 table additions on a lane pair instead of the 256-step ladder on one lane
-    int rc = g2_comb_build(c);
+    int rc = comb_build(c, 1);
     if (rc) return rc;
     CallDone call_done(c, s);
     return bn254_pair_g2_mul_fixed(d_k, n, reduce, c->g2_comb, d_out, d_status, s);
@@ -551,7 +612,7 @@ int bn254_batch_g2_mul_device(bn254_ctx* c, const uint8_t* d_p, const uint8_t* d
   return 0;
 }
 static int mul_host(bn254_ctx* c, int g2, const uint8_t* p, const uint8_t* k, size_t n, int reduce, uint8_t* out, uint8_t* status) {
-  if (!c || (n && (!k || !out || !status)) || (!g2 && n && !p)) return BN254_E_BAD_ARGUMENT;
+  if (!c || (n && (!k || !out || !status))) return BN254_E_BAD_ARGUMENT;             // p == NULL: the generator of the group
   if (n == 0) return 0;
   HIP_TRY(hipSetDevice(c->device));
   size_t sz = g2 ? 128 : 64;
@@ -561,7 +622,7 @@ static int mul_host(bn254_ctx* c, int g2, const uint8_t* p, const uint8_t* k, si
   if ((rc = stage_reserve(c, 2, n * sz))) return rc;
   if ((rc = stage_reserve(c, 3, n))) return rc;
   rc = g2 ? bn254_batch_g2_mul_device(c, p ? c->stage[0] : nullptr, c->stage[1], n, reduce, c->stage[2], c->stage[3], nullptr)
-          : bn254_batch_g1_mul_device(c, c->stage[0], c->stage[1], n, reduce, c->stage[2], c->stage[3], nullptr);
+          : bn254_batch_g1_mul_device(c, p ? c->stage[0] : nullptr, c->stage[1], n, reduce, c->stage[2], c->stage[3], nullptr);
   if (rc) return rc;
   if ((rc = stage_out(c, 2, out, n * sz))) return rc;
   if ((rc = stage_out(c, 3, status, n))) return rc;

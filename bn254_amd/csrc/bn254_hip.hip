@@ -635,6 +635,8 @@ void bn254_ctx_destroy(bn254_ctx* c) {
   for (int i = 0; i < 8; ++i) { if (c->pool[i].planes) (void)hipFree(c->pool[i].planes); if (c->pool[i].st) (void)hipFree(c->pool[i].st); }
   if (c->g2_comb.planes) (void)hipFree(c->g2_comb.planes);
   if (c->g2_comb.st) (void)hipFree(c->g2_comb.st);
+  if (c->g1_comb.planes) (void)hipFree(c->g1_comb.planes);
+  if (c->g1_comb.st) (void)hipFree(c->g1_comb.st);
   for (int i = 0; i < 8; ++i) if (c->stage[i]) (void)hipFree(c->stage[i]);
   if (c->key_lines) (void)hipFree(c->key_lines);
   if (c->key_xy) (void)hipFree(c->key_xy);

@@ -61,6 +61,8 @@ struct bn254_ctx {
   bool last_done_armed;      // waits for.  The context keeps no handle of a stream it does not own — the caller may destroy its stream any time.
   Pool g2_comb;              // fixed-base table of the G2 generator for key derivation (bn254_group.hip: g2_comb_build), built at the first keygen call
   int g2_comb_ready;
+  Pool g1_comb;              // ... and of the G1 generator (PublicKeyG1::from_private_key)
+  int g1_comb_ready;
   int g2_fixed_base;         // BN254_OPT_G2_FIXED_BASE (developer option, default 1): key derivation through the comb table; 0 = the 256-step ladder
   AggTables reg_pools;       // bn254_ctx_register_pools: the tables of the registered pools (valid until the next registration or raw-pool call)
   int max_chunk;             // BN254_OPT_MAX_CHUNK: verify-shaped batches above this size are processed in slices (0 = only when the workspace would not fit)

@@ -686,6 +686,87 @@ KERNEL_PAIR void k_g2_mul_fixed_pair(const uint8_t* scalars, size_t n, int reduc
   }
   if (role == 0) status[i] = ST_OK;
 }
+// The same for sk * G1::one() (PublicKeyG1::from_private_key, /root/reference/src/types.rs:155-157).  G1 lives over Fq, so the two lanes of a
+// pair are two independent adders: the real-part lane takes the even windows, the imaginary-part lane the odd ones, each into its own
+// blinded accumulator (records 520 / 521), the partner's sum is added at the end and record 522 = -(B0 + B1) removes the blinding.
+#define BN_G1_COMB_BLIND0 (BN_G2_COMB_WINDOWS * 8)
+KERNEL_PAIR void k_g1_mul_fixed_pair(const uint8_t* scalars, size_t n, int reduce, Pool comb, uint8_t* out, uint8_t* status) {
+  const unsigned role = threadIdx.x & 1u;
+  size_t i = ((size_t)blockIdx.x * BN_PAIR_WG + threadIdx.x) >> 1;
+  const bool live = i < n;
+  const size_t ii = live ? i : n - 1;
+  uint32_t k[8];
+  {
+    const uint32_t* w = (const uint32_t*)(scalars + 32 * ii);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) k[7 - j] = __builtin_bswap32(w[j]);
+    if (reduce) {
+      for (int it = 0; it < 6; ++it) {
+        const bool ge = u256_geq(k, C_ORDER_R);
+        uint32_t bw = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const uint64_t d = (uint64_t)k[j] - C_ORDER_R[j] - bw;
+          bw = (uint32_t)(d >> 63);
+          k[j] = ge ? (uint32_t)d : k[j];
+        }
+      }
+    }
+  }
+  __shared__ G1Jac lds_acc[BN_PAIR_WG];
+  G1Jac& acc = lds_acc[threadIdx.x];
+  {
+    G1Affine b;
+    PoolRec{comb.planes + pool_word(comb, 0, BN_G1_COMB_BLIND0 + role), false}(b);
+    jac_from_affine(acc, b);
+  }
+  int carry = 0;
+#pragma unroll 1
+  for (int j = 0; j < BN_G2_COMB_WINDOWS; ++j) {     // both lanes recode every digit (the carries run through all windows); a lane ADDS its own windows only
+    int v = (j < 64 ? (int)((k[j >> 3] >> (4 * (j & 7))) & 15u) : 0) + carry;
+    carry = v > 8;
+    const int d = v - 16 * carry, m = d < 0 ? -d : d;
+    if (((unsigned)j & 1u) != role) continue;        // a constant of the lane's position, not of the key
+    G1Affine q;
+    PoolRec{comb.planes + pool_word(comb, 0, (size_t)j * 8), false}(q);
+#pragma unroll 1
+    for (int e = 1; e < 8; ++e) {
+      G1Affine t;
+      PoolRec{comb.planes + pool_word(comb, 0, (size_t)j * 8 + e), false}(t);
+      q.x = fp_select(m == e + 1, t.x, q.x);
+      q.y = fp_select(m == e + 1, t.y, q.y);
+    }
+    q.y = fp_select(d < 0, fp_neg(q.y), q.y);
+    q.inf = m == 0;
+    jac_accumulate_from(acc, AffineValue<G1Affine>{q});
+  }
+  G1Jac other;
+#pragma unroll
+  for (int t = 0; t < BN_LIMBS; ++t) {
+    other.x.v[t] = bn_partner_word(acc.x.v[t]); other.y.v[t] = bn_partner_word(acc.y.v[t]); other.z.v[t] = bn_partner_word(acc.z.v[t]);
+  }
+  jac_add(acc, acc, other);
+  {
+    G1Affine b;
+    PoolRec{comb.planes + pool_word(comb, 0, BN_G1_COMB_BLIND0 + 2), false}(b);
+    jac_accumulate_from(acc, AffineValue<G1Affine>{b});
+  }
+  G1Affine r;
+  jac_to_affine(r, acc);
+  if (!live) return;
+  uint8_t* o = out + 64 * i;
+  if (role == 0) {                                   // both lanes hold the same point: the real-part lane writes x, the other y
+    if (r.inf) { uint32_t* w = (uint32_t*)o; for (int t = 0; t < 8; ++t) w[t] = 0; } else store_fp_be_pair(o, r.x);
+    status[i] = ST_OK;
+  } else {
+    if (r.inf) { uint32_t* w = (uint32_t*)(o + 32); for (int t = 0; t < 8; ++t) w[t] = 0; } else store_fp_be_pair(o + 32, r.y);
+  }
+}
+int bn254_pair_g1_mul_fixed(const uint8_t* d_scalars, size_t n, int reduce, Pool comb, uint8_t* d_out, uint8_t* d_status, hipStream_t s) {
+  k_g1_mul_fixed_pair<<<(unsigned)((2 * n + BN_PAIR_WG - 1) / BN_PAIR_WG), BN_PAIR_WG, 0, s>>>(d_scalars, n, reduce, comb, d_out, d_status);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
 int bn254_pair_g2_mul_fixed(const uint8_t* d_scalars, size_t n, int reduce, Pool comb, uint8_t* d_out, uint8_t* d_status, hipStream_t s) {
   k_g2_mul_fixed_pair<<<(unsigned)((2 * n + BN_PAIR_WG - 1) / BN_PAIR_WG), BN_PAIR_WG, 0, s>>>(d_scalars, n, reduce, comb, d_out, d_status);
   HIP_TRY(hipGetLastError());

@@ -183,6 +183,9 @@ __attribute__((visibility("hidden"))) int bn254_pair_aggregate(const uint32_t* t
 __attribute__((visibility("hidden"))) int bn254_pair_g2_mul_fixed(const uint8_t* d_scalars, size_t n, int reduce, Pool comb, uint8_t* d_out, uint8_t* d_status,
                                                                   hipStream_t s);      // sk * G2::one() from the comb table of the generator (520 + 1 records)
 #define BN_G2_COMB_RECORDS (65 * 8 + 1)
+__attribute__((visibility("hidden"))) int bn254_pair_g1_mul_fixed(const uint8_t* d_scalars, size_t n, int reduce, Pool comb, uint8_t* d_out, uint8_t* d_status,
+                                                                  hipStream_t s);      // sk * G1::one(): 520 records + the two blinding points + minus their sum
+#define BN_G1_COMB_RECORDS (65 * 8 + 3)
 __attribute__((visibility("hidden"))) int bn254_pair_decode_g2(const uint8_t* pts, size_t n, uint32_t flags, Ws ws, int accumulate, hipStream_t s);
 __attribute__((visibility("hidden"))) int bn254_pair_decompress_g2(const uint8_t* in, size_t n, Ws ws, hipStream_t s, int skip_subgroup_test = 0);
 

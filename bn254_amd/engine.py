@@ -214,9 +214,11 @@ class Engine:
         return self._binop("bn254_batch_g2_add", a, b, n, G2_BYTES)
 
     def batch_g1_mul(self, points, scalars, n, reduce_scalar=False):
+        """points=None multiplies the G1 generator (PublicKeyG1::from_private_key)."""
         out = ctypes.create_string_buffer(max(n, 1) * G1_BYTES)
         status = ctypes.create_string_buffer(max(n, 1))
-        _check("bn254_batch_g1_mul", self._lib.bn254_batch_g1_mul(self._h, bytes(points), bytes(scalars), n, int(reduce_scalar), out, status))
+        _check("bn254_batch_g1_mul", self._lib.bn254_batch_g1_mul(self._h, None if points is None else bytes(points), bytes(scalars), n,
+                                                               int(reduce_scalar), out, status))
         return out.raw[:n * G1_BYTES], status.raw[:n]
 
     def batch_g2_mul(self, points, scalars, n, reduce_scalar=False):

@@ -114,9 +114,8 @@ struct Signature : PointBytes<64> {
 };
 struct PublicKeyG1 : PointBytes<64> {
   static PublicKeyG1 from_private_key(const PrivateKey& k, Engine& e = Engine::default_engine()) {   // types.rs:155-157
-    uint8_t gen[64] = {0}; gen[31] = 1; gen[63] = 2;
-    PublicKeyG1 r; uint8_t st = 0;
-    check_rc("bn254_batch_g1_mul", bn254_batch_g1_mul(e.raw(), gen, k.bytes.data(), 1, 1, r.raw.data(), &st));
+    PublicKeyG1 r; uint8_t st = 0;       // points = nullptr: G1::one(), the fixed-base table of the generator
+    check_rc("bn254_batch_g1_mul", bn254_batch_g1_mul(e.raw(), nullptr, k.bytes.data(), 1, 1, r.raw.data(), &st));
     check_status(st);
     return r;
   }

@@ -748,6 +748,19 @@ def test_key_derivation_from_the_comb_table_vs_oracle_and_ladder(eng, c, kats):
         assert not bad, (reduce, [hex(vals[i]) for i in bad[:4]])
         assert ladder == want
         assert got[:128] == bytes(128)                       # 0 * G = the identity = all-zero bytes
+        # the same scalars on G1::one() (PublicKeyG1::from_private_key, src/types.rs:155-157): comb (points = None), the general ladder on
+        # the explicit generator, the comb switched off, and the oracle
+        g1 = c.g1_generator()
+        want1 = b"".join(c.g1_mul(g1, ((v % R) if reduce else v).to_bytes(32, "big")) for v in vals)
+        got1, st1 = eng.batch_g1_mul(None, scal, n, reduce_scalar=reduce)
+        lad1, st1l = eng.batch_g1_mul(g1 * n, scal, n, reduce_scalar=reduce)
+        eng.set_option(OPT_G2_FIXED_BASE, 0)
+        off1, st1o = eng.batch_g1_mul(None, scal, n, reduce_scalar=reduce)
+        eng.set_option(OPT_G2_FIXED_BASE, 1)
+        assert st1 == st1l == st1o == bytes(n)
+        bad = [i for i in range(n) if got1[64 * i:64 * i + 64] != want1[64 * i:64 * i + 64]]
+        assert not bad, ("G1", reduce, [hex(vals[i]) for i in bad[:4]])
+        assert lad1 == want1 and off1 == want1
     # one key, and the reference's own known answers, through the mirror of the reference API
     one, st = eng.batch_g2_mul(None, (5).to_bytes(32, "big"), 1)
     assert one == c.g2_mul(g2, (5).to_bytes(32, "big")) and st == b"\0"
