@@ -48,6 +48,7 @@ row("pairing", lambda: eng.batch_pairing(sig, pk, 1, 1), lambda: c.pairing(sig, 
 row("hash_to_g1", lambda: eng.batch_hash_to_g1([msg]), lambda: c.hash_to_g1(msg))
 row("sign", lambda: eng.batch_sign([msg], sk), lambda: c.sign(msg, sk))
 row("public key (G2 scalar multiplication)", lambda: eng.batch_g2_mul(None, sk, 1, reduce_scalar=True), lambda: c.public_key_g2(sk))
-row("G1 scalar multiplication", lambda: eng.batch_g1_mul(g1, sk, 1, reduce_scalar=True), lambda: c.g1_mul(g1, sk))
+row("public key in G1 (fixed base)", lambda: eng.batch_g1_mul(None, sk, 1, reduce_scalar=True), lambda: c.g1_mul(g1, sk))
+row("G1 scalar multiplication (variable base)", lambda: eng.batch_g1_mul(g1, sk, 1, reduce_scalar=True), lambda: c.g1_mul(g1, sk))
 sig33 = c.g1_compress(sig)
 row("G1 decompress", lambda: eng.batch_g1_decompress(sig33, 1), lambda: c.g1_decompress(sig33))
