@@ -51,4 +51,9 @@ row("public key (G2 scalar multiplication)", lambda: eng.batch_g2_mul(None, sk, 
 row("public key in G1 (fixed base)", lambda: eng.batch_g1_mul(None, sk, 1, reduce_scalar=True), lambda: c.g1_mul(g1, sk))
 row("G1 scalar multiplication (variable base)", lambda: eng.batch_g1_mul(g1, sk, 1, reduce_scalar=True), lambda: c.g1_mul(g1, sk))
 sig33 = c.g1_compress(sig)
+from bn254_amd.api import PublicKey  # noqa: E402  (byte logic only: the sign byte of the compressed form)
+pk65 = PublicKey(pk).to_compressed()
+assert eng.batch_verify_compressed([msg], sig33, pk65) == b"\0"
+row("verify from compressed encodings (one host core: decompress G1 + verify; no G2 decompression in the oracle's C API)",
+    lambda: eng.batch_verify_compressed([msg], sig33, pk65), lambda: (c.g1_decompress(sig33), c.verify(msg, sig, pk, 1)))
 row("G1 decompress", lambda: eng.batch_g1_decompress(sig33, 1), lambda: c.g1_decompress(sig33))
