@@ -150,6 +150,10 @@ def measured_valu_issue(kernel, lane_products, probe, kernel_seconds):
             "ns_per_wave_inst_per_simd": {"multiplier_class": 1e9 * t_mul, "other": 1e9 * t_other},
             "kernel_ms_this_run": 1e3 * kernel_seconds, "utilisation": priced / kernel_seconds,
             "utilisation_flat_4_cycles": 4.0 * k["SQ_INSTS_VALU"] / (probe["n_simd"] * k["GRBM_GUI_ACTIVE"] / 8.0) if "GRBM_GUI_ACTIVE" in k else None,
+            # rocprofv3's own derived metric VALUBusy = 100 * SQ_ACTIVE_INST_VALU / CU_NUM / max-over-XCDs(GRBM_GUI_ACTIVE) (counter_defs.yaml, gfx950);
+            # the committed pass sums GRBM_GUI_ACTIVE over the 8 XCDs, hence the / 8
+            "valu_busy_pct_rocprof_definition": (100.0 * k["SQ_ACTIVE_INST_VALU"] / 256.0 / (k["GRBM_GUI_ACTIVE"] / 8.0)
+                                                 if "GRBM_GUI_ACTIVE" in k and "SQ_ACTIVE_INST_VALU" in k else None),
             "sq_wait_any_over_wave_cycles": k["SQ_WAIT_ANY"] / k["SQ_WAVE_CYCLES"] if "SQ_WAIT_ANY" in k and k.get("SQ_WAVE_CYCLES") else None,
             "sq_wait_inst_any_over_wave_cycles": k["SQ_WAIT_INST_ANY"] / k["SQ_WAVE_CYCLES"] if "SQ_WAIT_INST_ANY" in k and k.get("SQ_WAVE_CYCLES") else None,
             "note": "a CONSISTENCY figure, not a measure of slack: the instruction mix priced with single-instruction probes (two waves per "

@@ -731,9 +731,44 @@ def test_key_derivation_from_the_comb_table_vs_oracle_and_ladder(eng, c, kats):
     rnd = random.Random(99)
     vals = [0, 1, 7, 8, 9, 15, 16, 17, 2 ** 64, 2 ** 64 - 1, 2 ** 128 + 1, 2 ** 252, 2 ** 253 - 1, int("8" * 64, 16), int("9" * 64, 16) % 2 ** 256, int("7" * 64, 16),
             R - 1, R, R + 1, 2 * R, 2 ** 256 - 1, 2 ** 256 - 2 ** 4]
+    # ADVERSARIAL scalars: the blinding scalar is a public constant of the library (comb_build, csrc/bn254_group.hip), so scalars exist that
+    # walk the blinded accumulator INTO the exceptional route of the in-place addition the blinding is there to avoid: accumulator == +entry
+    # (a doubling) or == -entry (the identity) at window 62 / 63, accumulator == -B at the final subtraction of the blinding point, and for
+    # G1 the two lanes' partial sums being each other's negative.  The derivation is restated here from the table's definition.
+    b0 = 0x2b67ae85a54ff53a3c6ef3721f83d9ab5be0cd199c4d21a70f3a7e556b2f1c9d
+
+    def comb_hits(k):
+        acc, hits, carry = b0, [], 0
+        for j in range(65):
+            v = ((k >> (4 * j)) & 15 if j < 64 else 0) + carry
+            carry = 1 if v > 8 else 0
+            d = v - 16 * carry
+            e = d * 16 ** j % R
+            if d and acc == e:
+                hits.append("doubling")
+            if d and (acc + e) % R == 0:
+                hits.append("identity")
+            acc = (acc + e) % R
+        return hits
+
+    adversarial = []
+    for j in (62, 63):
+        for nib in range(16):
+            for cin in (0, 1):
+                for sgn in (1, -1):
+                    v = nib + cin
+                    d = v - 16 * (v > 8)
+                    low = (sgn * d * 16 ** j + cin * 16 ** j - b0) % R
+                    k = low + nib * 16 ** j
+                    if d and low < 16 ** j and k < 2 ** 256 and comb_hits(k) and k not in adversarial:
+                        adversarial.append(k)
+    assert len(adversarial) >= 8 and {h for k in adversarial for h in comb_hits(k)} == {"doubling", "identity"}
+    vals += adversarial + [(-2 * b0) % R, (-4 * b0) % R, (-b0) % R, b0, (2 * b0) % R]
     vals += [rnd.randrange(2 ** 256) for _ in range(175)] + [rnd.randrange(R) for _ in range(70)]
     n = len(vals)
-    assert n % 128 != 0
+    if n % 128 == 0:
+        vals.append(3)
+        n += 1
     scal = b"".join(v.to_bytes(32, "big") for v in vals)
     g2 = c.g2_generator()
     for reduce in (False, True):
