@@ -89,8 +89,17 @@ template <class F> BN_DEVN void jac_dbl_lds(Jac<F>& acc) {
   acc = o;
 }
 
+#if defined(__HIPCC__)
+#define BN_WAVE_ANY(x) (__any((int)(x)) != 0)
+#else
+#define BN_WAVE_ANY(x) (x)
+#endif
 // add-2007-bl with every exceptional case resolved by selects (lanes never diverge):
-// P = O -> Q, Q = O -> P, P = Q -> 2P, P = -Q -> O
+// P = O -> Q, Q = O -> P, P = Q -> 2P, P = -Q -> O.
+// Round 6: the doubling that serves P = Q is computed only when some lane of the wave needs it (a wave vote; it was 7 of the 23 products of
+// EVERY addition).  In the windowed ladders below the accumulator is 16 x (prefix) x P and the entry d P with d <= 8: they coincide only
+// for a scalar built around the group order — nothing an honest caller holds, and nothing anyone can aim at without knowing the scalar —,
+// so a ladder's schedule still does not depend on its (secret) scalar.
 template <class F> BN_DEVN void jac_add(Jac<F>& r, const Jac<F>& p, const Jac<F>& q) {
   F z1z1 = f_sqr(p.z), z2z2 = f_sqr(q.z);
   F u1 = f_mul(p.x, z2z2), u2 = f_mul(q.x, z1z1);
@@ -103,12 +112,13 @@ template <class F> BN_DEVN void jac_add(Jac<F>& r, const Jac<F>& p, const Jac<F>
   o.z = f_mul(f_norm(f_sub(f_sub(f_sqr(f_norm(f_add(p.z, q.z))), z1z1), z2z2)), h);
   bool p_inf = f_is_zero(p.z), q_inf = f_is_zero(q.z);
   bool same_x = f_is_zero(h), same_y = f_is_zero(rr);
-  Jac<F> d;
-  jac_dbl(d, p);
+  const bool same_point = same_x && same_y && !p_inf && !q_inf;
+  Jac<F> d = p;
+  if (BN_WAVE_ANY(same_point)) jac_dbl(d, p);
   Jac<F> id;
   jac_set_identity(id);
   // generic result, then overrides in increasing priority
-  jac_select(o, same_x && same_y, d, o);
+  jac_select(o, same_point, d, o);
   jac_select(o, same_x && !same_y, id, o);
   jac_select(o, q_inf, p, o);
   jac_select(o, p_inf, q, o);
@@ -165,11 +175,6 @@ template <class F> BN_DEV void jac_madd_common_body(Jac<F>& r, bool& exceptional
   r = o;
 }
 template <class F> BN_DEVN void jac_madd_common(Jac<F>& r, bool& exceptional, const Jac<F>& p, const Affine<F>& q) { jac_madd_common_body(r, exceptional, p, q); }
-#if defined(__HIPCC__)
-#define BN_WAVE_ANY(x) (__any((int)(x)) != 0)
-#else
-#define BN_WAVE_ANY(x) (x)
-#endif
 // acc += q with identical control flow across the wave
 template <class F> BN_DEV void jac_accumulate(Jac<F>& acc, const Affine<F>& q) {
   Jac<F> t;
@@ -370,6 +375,107 @@ BN_DEVN void g1_mul_glv(G1Jac& r, const G1Affine& p, const uint32_t* k1, const u
     jac_window_entry<false>(t, tab, (int)d2[j]);
     t.x = fp_mul(t.x, beta);                                   // phi: x -> beta x (the identity keeps z = 0)
     jac_add_distinct(acc, acc, t);
+  }
+}
+
+// ---- k * P on G1 for a FULL scalar through the endomorphism (round 6): ECDSA::sign (/root/reference/src/ecdsa.rs:31, sk * H(m)) and the
+// variable-base bn254_batch_g1_mul.  G1 has prime order r (cofactor 1), so k * P = (k mod r) * P for every point of the curve, and
+// k mod r = k1 + k2 lambda with 0 <= k1 < 2^128, |k2| < 2^127 (constants and bounds: gen_constants.py): one joint ladder of 33 windows —
+// 128 doublings and 2 x 33 additions over the table j * P (the second addend is phi(j * P) = (beta X, Y, Z), its sign k2's) — where
+// jac_mul spends 256 doublings and 65 additions.  The scalar may be a private key: the decomposition is straight-line integer arithmetic
+// with selects, the window entries are found by scans (jac_window_entry<true>), the additions are the complete jac_add.
+// out = the low `no` words of a (na words) times b (nb words)
+BN_DEV void bn_mul_words(uint32_t* out, int no, const uint32_t* a, int na, const uint32_t* b, int nb) {
+  uint64_t carry = 0;
+  for (int k = 0; k < no; ++k) {
+    uint64_t lo = carry & 0xFFFFFFFFull, hi = carry >> 32;
+    for (int i = 0; i < na; ++i) {
+      const int j = k - i;
+      if (j < 0 || j >= nb) continue;
+      const uint64_t t = (uint64_t)a[i] * b[j];
+      lo += t & 0xFFFFFFFFull;
+      hi += t >> 32;
+    }
+    out[k] = (uint32_t)lo;
+    carry = hi + (lo >> 32);
+  }
+}
+// k in [0, r) -> k1 (four words), |k2| (four words), the sign of k2
+BN_DEV void glv_decompose(const uint32_t* k, uint32_t* k1, uint32_t* k2, bool& k2_neg) {
+  uint32_t t[13], c1[2], c2[4], u[5], v[5];
+  bn_mul_words(t, 11, k, 8, C_GLV_G1, 3);
+  c1[0] = t[8]; c1[1] = t[9];                                  // < 2^64 (k < 2^254, g1 < 2^66)
+  bn_mul_words(t, 13, k, 8, C_GLV_G2, 5);
+  for (int i = 0; i < 4; ++i) c2[i] = t[8 + i];                // < 2^128
+  // k1 = k - c1 a1 - c2 a2 (mod 2^160; the value is in [0, 2^128))
+  bn_mul_words(u, 5, c1, 2, C_GLV_A1, 2);
+  bn_mul_words(v, 5, c2, 4, C_GLV_A2, 4);
+  uint32_t w[5];
+  uint64_t bw = 0;
+  for (int i = 0; i < 5; ++i) {
+    const uint64_t d = (uint64_t)k[i] - u[i] - bw;
+    w[i] = (uint32_t)d; bw = (d >> 63) & 1;
+  }
+  bw = 0;
+  for (int i = 0; i < 5; ++i) {
+    const uint64_t d = (uint64_t)w[i] - v[i] - bw;
+    w[i] = (uint32_t)d; bw = (d >> 63) & 1;
+  }
+  for (int i = 0; i < 4; ++i) k1[i] = w[i];
+  // k2 = c1 b1n - c2 a1 (mod 2^160, two's complement; |k2| < 2^127)
+  bn_mul_words(u, 5, c1, 2, C_GLV_B1N, 4);
+  bn_mul_words(v, 5, c2, 4, C_GLV_A1, 2);
+  bw = 0;
+  for (int i = 0; i < 5; ++i) {
+    const uint64_t d = (uint64_t)u[i] - v[i] - bw;
+    w[i] = (uint32_t)d; bw = (d >> 63) & 1;
+  }
+  k2_neg = (w[4] >> 31) != 0;
+  const uint32_t m = k2_neg ? 0xFFFFFFFFu : 0u;
+  uint64_t cy = k2_neg ? 1 : 0;
+  for (int i = 0; i < 4; ++i) {                               // |k2| = (w ^ m) + (m & 1)
+    const uint64_t d = (uint64_t)(w[i] ^ m) + cy;
+    k2[i] = (uint32_t)d; cy = d >> 32;
+  }
+}
+BN_DEVN void g1_mul_glv_full(G1Jac& r, const G1Affine& p, const uint32_t* kin) {
+  uint32_t k[8], k1[4], k2[4];
+  for (int i = 0; i < 8; ++i) k[i] = kin[i];
+  for (int it = 0; it < 6; ++it) {                           // 2^256 / r < 6; the subtraction is applied by selects
+    const bool ge = u256_geq(k, C_ORDER_R);
+    uint32_t bw = 0;
+    for (int i = 0; i < 8; ++i) {
+      const uint64_t d = (uint64_t)k[i] - C_ORDER_R[i] - bw;
+      bw = (uint32_t)(d >> 63) & 1u;
+      k[i] = ge ? (uint32_t)d : k[i];
+    }
+  }
+  bool neg2;
+  glv_decompose(k, k1, k2, neg2);
+  G1Jac tab[8], t;
+  G1Jac& acc = r;
+  jac_from_affine(tab[0], p);
+  jac_dbl(tab[1], tab[0]);
+  for (int j = 2; j < 8; ++j) jac_add(tab[j], tab[j - 1], tab[0]);
+  const Fp beta = fp_load_const(C_GLV_BETA);
+  signed char d1[33], d2[33];
+  int c1 = 0, c2 = 0;
+  for (int j = 0; j < 32; ++j) {
+    int v = (int)((k1[j >> 3] >> (4 * (j & 7))) & 15u) + c1;
+    c1 = v > 8; d1[j] = (signed char)(v - 16 * c1);
+    v = (int)((k2[j >> 3] >> (4 * (j & 7))) & 15u) + c2;
+    c2 = v > 8; d2[j] = (signed char)(v - 16 * c2);
+  }
+  d1[32] = (signed char)c1; d2[32] = (signed char)c2;
+  jac_set_identity(acc);
+  for (int j = 32; j >= 0; --j) {
+    if (j != 32) { jac_dbl(acc, acc); jac_dbl(acc, acc); jac_dbl(acc, acc); jac_dbl(acc, acc); }
+    jac_window_entry<true>(t, tab, (int)d1[j]);
+    jac_add(acc, acc, t);
+    jac_window_entry<true>(t, tab, (int)d2[j]);
+    t.y = fp_select(neg2, fp_neg(t.y), t.y);
+    t.x = fp_mul(t.x, beta);                                   // phi: x -> beta x (the identity keeps z = 0)
+    jac_add(acc, acc, t);
   }
 }
 

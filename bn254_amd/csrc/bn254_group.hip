@@ -69,7 +69,7 @@ KERNEL void k_g1_mul(const uint8_t* p, const uint8_t* scalars, size_t n, int red
   uint32_t k[8];
   scalar_from_be(k, scalars + 32 * i, reduce != 0);
   G1Jac jo;
-  jac_mul(jo, pa, k);
+  g1_mul_glv_full(jo, pa, k);                       // round 6: the joint 128-step ladder over the endomorphism (bn254_curve.h); a raw scalar acts mod r
   jac_to_affine(r, jo);
   if (st != ST_OK) r.inf = true;
   encode_g1(out + 64 * i, r);
@@ -515,7 +515,7 @@ KERNEL void k_g1_gen_mul_reduce(const uint8_t* scalars, size_t n, int reduce, ui
   uint32_t k[8];
   scalar_from_be(k, scalars + 32 * i, reduce != 0);
   G1Jac jo;
-  jac_mul(jo, g, k);
+  g1_mul_glv_full(jo, g, k);
   jac_to_affine(r, jo);
   encode_g1(out + 64 * i, r);
   status[i] = ST_OK;

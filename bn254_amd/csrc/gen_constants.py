@@ -397,6 +397,22 @@ def main():
     assert acc == (glv_beta % Q, 2), "lambda * G1 != (beta * x, y)"
     o.append("BN_CONST int32_t C_GLV_BETA[BN_LIMBS] = %s;   /* phi(x, y) = (beta x, y) = lambda (x, y) on G1 */" % c_fp(glv_beta))
     o.append("BN_CONST uint32_t C_GLV_LAMBDA[8] = %s;       /* lambda (192 bits), plain U256 */" % c_u256(glv_lambda))
+    # decomposition of a FULL scalar k in [0, r) (round 6: g1_mul_glv_full — sign and variable-base G1 multiplication): the lattice
+    # {(x, y): x + y lambda = 0 mod r} has the reduced basis v1 = (a1, -b1n), v2 = (a2, a1) (extended Euclid on (r, lambda), det = r);
+    # (k, 0) = beta1 v1 + beta2 v2 with beta1 = k a1 / r, beta2 = k b1n / r; c_i = floor(k g_i / 2^256) <= floor(beta_i) with
+    # g1 = floor(2^256 a1 / r), g2 = floor(2^256 b1n / r); k1 = k - c1 a1 - c2 a2 in [0, a1 + a2) (< 2^128),
+    # k2 = c1 b1n - c2 a1 in (-b1n, a1] (|k2| < 2^127): k = k1 + k2 lambda mod r
+    glv_a1, glv_b1n, glv_a2 = 0x89d3256894d213e3, 0x6f4d8248eeb859fc8211bbeb7d4f1128, 0x6f4d8248eeb859fd0be4e1541221250b
+    assert (glv_a1 - glv_b1n * glv_lambda) % R_ORDER == 0 and (glv_a2 + glv_a1 * glv_lambda) % R_ORDER == 0
+    assert glv_a1 * glv_a1 + glv_a2 * glv_b1n == R_ORDER
+    glv_g1, glv_g2 = (glv_a1 << 256) // R_ORDER, (glv_b1n << 256) // R_ORDER
+    assert glv_g1 < 1 << 96 and glv_g2 < 1 << 160 and glv_a1 + glv_a2 < 1 << 128
+
+    def c_words(x, n):
+        return "{%s}" % ", ".join("0x%08xu" % ((x >> (32 * i)) & 0xFFFFFFFF) for i in range(n))
+    o.append("BN_CONST uint32_t C_GLV_A1[2] = %s, C_GLV_B1N[4] = %s, C_GLV_A2[4] = %s;   /* reduced basis (a1, -b1n), (a2, a1) of the GLV lattice */" %
+             (c_words(glv_a1, 2), c_words(glv_b1n, 4), c_words(glv_a2, 4)))
+    o.append("BN_CONST uint32_t C_GLV_G1[3] = %s, C_GLV_G2[5] = %s;   /* floor(2^256 a1 / r), floor(2^256 b1n / r) */" % (c_words(glv_g1, 3), c_words(glv_g2, 5)))
     o.append("/* width-4 sliding-window schedules for the fixed exponents: {squarings, odd multiplier} steps, MSB first;")
     o.append("   the first step only selects its multiplier, a multiplier of 0 means squarings only */")
     for name, e in (("QM2", Q - 2), ("QP1D4", (Q + 1) // 4), ("QM3D4", (Q - 3) // 4), ("QM1D2", (Q - 1) // 2)):

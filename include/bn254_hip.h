@@ -212,7 +212,10 @@ int bn254_batch_check_public_keys(bn254_ctx *ctx, const uint8_t *pk_g2 /* n*128 
  * reduce_scalar != 0: scalars are first reduced mod r like Fr::from_slice; 0: used as 256-bit integers.
  * p == NULL in the two _mul entry points multiplies the group's GENERATOR — key derivation, PublicKeyG1 / PublicKey::from_private_key
  * (src/types.rs:155-157, :85-87): a fixed base, served from a comb table of the generator's multiples built once per context (65 additions on a
- * lane pair instead of a 256-step ladder on one lane; window entries found by constant-time scans: the scalar is a private key). */
+ * lane pair instead of a 256-step ladder on one lane; window entries found by constant-time scans: the scalar is a private key).
+ * With explicit G1 points, and in bn254_batch_sign, the multiplication runs a joint 128-step ladder over the curve's endomorphism
+ * (k mod r = k1 + k2 lambda with 128-bit halves; every point of the G1 curve has order r, so a raw 256-bit scalar acts mod r — the same
+ * point as the 256-step ladder gives); window entries by scans, complete additions. */
 int bn254_batch_g1_add(bn254_ctx *ctx, const uint8_t *a /* n*64 */, const uint8_t *b /* n*64 */, size_t n, uint8_t *out, uint8_t *status);
 int bn254_batch_g2_add(bn254_ctx *ctx, const uint8_t *a /* n*128 */, const uint8_t *b /* n*128 */, size_t n, uint8_t *out, uint8_t *status);
 int bn254_batch_g1_mul(bn254_ctx *ctx, const uint8_t *p /* n*64 */, const uint8_t *scalars /* n*32 */, size_t n, int reduce_scalar,

@@ -285,13 +285,25 @@ int hs_g1_mul(const uint8_t* p, const uint8_t* scalar32, int reduce, uint8_t* ou
   uint32_t k[8];
   scalar_from_be(k, sc, reduce != 0);
   G1Jac jo;
-  jac_mul(jo, pa, k);
+  if (reduce & 2) jac_mul(jo, pa, k); else g1_mul_glv_full(jo, pa, k);    // reduce & 2: the plain 256-step ladder (what the kernels used before round 6)
   jac_to_affine(r, jo);
   if (st != ST_OK) r.inf = true;
   alignas(4) uint8_t tmp[64];
   encode_g1(tmp, r);
   memcpy(out, tmp, 64);
   return st;
+}
+// the GLV decomposition of a scalar in [0, r): k1 and |k2| as 16 little-endian bytes each, returns the sign of k2
+int hs_glv_decompose(const uint8_t* k32_be, uint8_t* k1_le16, uint8_t* k2_le16) {
+  alignas(4) uint8_t sc[32];
+  memcpy(sc, k32_be, 32);
+  uint32_t k[8], k1[4], k2[4];
+  scalar_from_be(k, sc, true);
+  bool neg;
+  glv_decompose(k, k1, k2, neg);
+  memcpy(k1_le16, k1, 16);
+  memcpy(k2_le16, k2, 16);
+  return neg ? 1 : 0;
 }
 int hs_g2_mul(const uint8_t* p, const uint8_t* scalar32, int reduce, uint8_t* out) {
   G2Affine pa, r;
@@ -318,7 +330,7 @@ int hs_sign(const uint8_t* msg, uint64_t len, const uint8_t* sk32, uint8_t* sig6
   uint32_t k[8];
   scalar_from_be(k, sc, true);
   G1Jac jo;
-  jac_mul(jo, h, k);
+  g1_mul_glv_full(jo, h, k);
   jac_to_affine(r, jo);
   if (st != ST_OK) r.inf = true;
   alignas(4) uint8_t tmp[64];

@@ -79,6 +79,20 @@ def g1_mul(p, k, reduce=False):
     o = _b(64); st = lib().hs_g1_mul(bytes(p), bytes(k), int(reduce), o); return st, o.raw
 
 
+def g1_mul_plain_ladder(p, k, reduce=False):
+    """the 256-step ladder the G1 kernels used before round 6 (hs_g1_mul: reduce | 2)"""
+    o = _b(64); st = lib().hs_g1_mul(bytes(p), bytes(k), int(reduce) | 2, o); return st, o.raw
+
+
+def glv_decompose(k):
+    """(k1, k2) of the device's GLV decomposition of k mod r"""
+    L = lib()
+    L.hs_glv_decompose.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p]
+    a, b = _b(16), _b(16)
+    neg = L.hs_glv_decompose(int(k).to_bytes(32, "big"), a, b)
+    return int.from_bytes(a.raw, "little"), int.from_bytes(b.raw, "little") * (-1 if neg else 1)
+
+
 def g2_mul(p, k, reduce=False):
     o = _b(128); st = lib().hs_g2_mul(None if p is None else bytes(p), bytes(k), int(reduce), o); return st, o.raw
 

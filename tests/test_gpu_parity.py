@@ -391,6 +391,45 @@ def test_bn256_vectors(eng, kats):
     assert st == bytes(len(muls)) and out.hex() == "".join(v["result"] for v in muls)
 
 
+def test_variable_base_g1_multiplication_and_sign_through_the_endomorphism_vs_oracle(eng, c, kats):
+    """round 6: bn254_batch_g1_mul with explicit points and bn254_batch_sign (sk * H(m), /root/reference/src/ecdsa.rs:26-35) run the joint
+    128-step ladder over phi(x, y) = (beta x, y) (csrc/bn254_curve.h: g1_mul_glv_full).  Against the oracle: scalars around 0, r, 2^128 and
+    2^256 raw and reduced (a raw scalar acts mod r: G1 has cofactor 1), scalars whose decomposition has the rare POSITIVE k2, window patterns
+    that carry through every digit, random ones; the generator, other points, the identity (all-zero bytes) and an invalid point (status,
+    no output); a ragged batch.  Signatures: the reference's known answer and random keys incl. keys above r."""
+    from tests.test_hostsim import GLV_R as R, GLV_LAMBDA, glv_positive_k2_scalars
+    rnd = random.Random(606)
+    pos = glv_positive_k2_scalars(5)
+    ks = [0, 1, 2, 15, 16, 17, R - 1, R, R + 1, 2 * R + 5, GLV_LAMBDA, GLV_LAMBDA + 1, R - GLV_LAMBDA, (R - 1) // 2, 2 ** 127 - 1, 2 ** 128, 2 ** 128 + 1, 2 ** 253,
+          2 ** 256 - 1, 2 ** 256 - 16, int("8" * 64, 16), int("9" * 63, 16), int("7" * 64, 16)] + pos
+    ks += [rnd.randrange(2 ** 256) for _ in range(120)] + [rnd.randrange(R) for _ in range(60)]
+    g1 = c.g1_generator()
+    bases = [g1, c.g1_mul(g1, (12345).to_bytes(32, "big")), c.g1_mul(g1, (R - 7).to_bytes(32, "big")), bytes(64)]
+    pts = b"".join(bases[i % len(bases)] for i in range(len(ks)))
+    n = len(ks)
+    assert n % 64 != 0
+    scal = b"".join(k.to_bytes(32, "big") for k in ks)
+    for reduce in (False, True):
+        got, st = eng.batch_g1_mul(pts, scal, n, reduce_scalar=reduce)
+        assert st == bytes(n)
+        for i, k in enumerate(ks):
+            want = c.g1_mul(bases[i % len(bases)], ((k % R) if reduce else k).to_bytes(32, "big"))
+            assert got[64 * i:64 * i + 64] == want, (hex(k), i % len(bases), reduce)
+    bad = (1).to_bytes(32, "big") + (1).to_bytes(32, "big")                       # (1, 1) is not on the curve
+    out, st = eng.batch_g1_mul(g1 + bad + g1, (5).to_bytes(32, "big") * 3, 3)
+    assert st[0] == 0 and st[2] == 0 and st[1] != 0 and out[:64] == out[128:] == c.g1_mul(g1, (5).to_bytes(32, "big"))
+    # signatures: known answer, keys above r (Fr::from_slice reduces), the positive-k2 keys
+    v = kats["sign"][0]
+    sig, st = eng.batch_sign([H(v["message_hex"])], H(v["private_key"]))
+    assert st == b"\0" and c.g1_compress(sig).hex() == v["signature_compressed"]
+    keys = [rnd.randrange(1, 2 ** 256) for _ in range(40)] + pos + [R - 1, R + 1, 1]
+    msgs = [b"glv sign %d" % i for i in range(len(keys))]
+    sigs, st = eng.batch_sign(msgs, b"".join(k.to_bytes(32, "big") for k in keys))
+    assert st == bytes(len(keys))
+    for i, k in enumerate(keys):
+        assert sigs[64 * i:64 * i + 64] == c.sign(msgs[i], k.to_bytes(32, "big")), hex(k)
+
+
 # ---- batches vs the oracle -----------------------------------------------------------------
 def test_batch_verify_vs_oracle_4k(eng, c):
     from tests.datagen import make_verify_batch

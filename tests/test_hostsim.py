@@ -120,6 +120,62 @@ def _codec_cases(kats, derived):
     return g1, g2, bad_g1, bad_g2
 
 
+# scalars whose GLV decomposition has a POSITIVE k2 (probability ~2^-63 for a random scalar): k a1 lands just above a multiple of r by more
+# than the rounding constants lose; restated from gen_constants.py's derivation
+GLV_R = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+GLV_LAMBDA = 0xB3C4D79D41A917585BFC41088D8DAAA78B17EA66B99C90DD
+GLV_A1, GLV_B1N, GLV_A2 = 0x89d3256894d213e3, 0x6f4d8248eeb859fc8211bbeb7d4f1128, 0x6f4d8248eeb859fd0be4e1541221250b
+
+
+def glv_model(k):
+    g1, g2 = (GLV_A1 << 256) // GLV_R, (GLV_B1N << 256) // GLV_R
+    c1, c2 = (k * g1) >> 256, (k * g2) >> 256
+    return k - c1 * GLV_A1 - c2 * GLV_A2, c1 * GLV_B1N - c2 * GLV_A1
+
+
+def glv_positive_k2_scalars(count, seed=3):
+    rnd, out = random.Random(seed), []
+    for trial in range(100000):                       # ~5 % of these land: only small multiples j leave room above the rounding loss
+        k = -(-(1 + trial % 40) * GLV_R // GLV_A1) + rnd.randrange(1 << 120, 1 << 127)
+        if glv_model(k)[1] > 0:
+            out.append(k)
+            if len(out) == count:
+                return out
+    raise AssertionError("no scalar with a positive k2 found")
+
+
+def test_glv_decomposition_and_full_scalar_ladder(kats):
+    """round 6: sk * H(m) (ECDSA::sign, src/ecdsa.rs:31) and the variable-base G1 multiplication run a joint 128-step ladder over the
+    endomorphism (bn254_curve.h: g1_mul_glv_full).  The device's integer decomposition against its big-integer restatement — k = k1 + k2 lambda
+    mod r, 0 <= k1 < 2^128, |k2| < 2^127, both signs of k2 — and the ladder against the oracle AND the plain 256-step ladder on scalars around
+    0, r, 2^128, 2^256 (raw scalars act mod r: G1 has cofactor 1), on the generator, other points and the identity."""
+    rnd = random.Random(11)
+    pos = glv_positive_k2_scalars(6)
+    ks = [0, 1, 2, 15, 16, GLV_R - 1, GLV_R - 2, GLV_LAMBDA, GLV_LAMBDA + 1, GLV_R - GLV_LAMBDA, (GLV_R - 1) // 2, 2 ** 253, 2 ** 128, 2 ** 127 - 1,
+          int("8" * 63, 16), int("9" * 63, 16) % GLV_R] + pos + [rnd.randrange(GLV_R) for _ in range(3000)]
+    signs = set()
+    for k in ks:
+        k1, k2 = hs.glv_decompose(k)
+        assert (k1, k2) == glv_model(k), hex(k)
+        assert (k1 + k2 * GLV_LAMBDA - k) % GLV_R == 0 and 0 <= k1 < 2 ** 128 and abs(k2) < 2 ** 127
+        signs.add(k2 > 0)
+    assert signs == {True, False}
+    g1 = c.g1_generator()
+    pts = [g1, c.g1_mul(g1, (12345).to_bytes(32, "big")), c.g1_mul(g1, (GLV_R - 7).to_bytes(32, "big")), bytes(64)]
+    raw = [0, 1, GLV_R - 1, GLV_R, GLV_R + 1, 2 * GLV_R + 5, 2 ** 256 - 1, 2 ** 256 - 2 ** 4, 2 ** 128, int("8" * 64, 16), int("7" * 64, 16)] + pos[:3] + \
+          [rnd.randrange(2 ** 256) for _ in range(12)]
+    for p in pts:
+        for k in raw:
+            kb = k.to_bytes(32, "big")
+            for reduce in (False, True):
+                want = c.g1_mul(p, ((k % GLV_R) if reduce else k).to_bytes(32, "big"))
+                st, got = hs.g1_mul(p, kb, reduce)
+                st2, ladder = hs.g1_mul_plain_ladder(p, kb, reduce)
+                assert st == st2 == 0 and got == want == ladder, (hex(k), reduce)
+    v = kats["sign"][0]
+    assert c.g1_compress(hs.sign(H(v["message_hex"]), H(v["private_key"]))[1]).hex() == v["signature_compressed"]    # src/ecdsa_test.rs:5-17
+
+
 def test_compressed_codecs(kats, derived):
     """bn::G1/G2::from_compressed semantics (types.rs:91-93, :233-237) vs the big-integer model"""
     from oracle import bn254_model as m
