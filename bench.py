@@ -177,7 +177,7 @@ def issue_probe(eng):
 # Algorithmic Fq products of the other workloads' kernels (tests/test_workcount.py keeps them in sync with the device source):
 FP_MUL_MILLER_KEYED = 8220         # keyed verify: two table lines per step, no twist-point arithmetic (2 508 dual + 348 single per lane)
 FP_MUL_G1_MADD, FP_MUL_G2_MADD = 11, 22            # mixed additions of k_aggregate_pair (per tuple: both lanes of the pair together)
-FP_MUL_AGG_TAIL = 6 + 16 + 23                      # G1 / G2 to affine, the final G1 addition of the two partial sums
+FP_MUL_AGG_TAIL = 6 + 16 + 16                      # G1 / G2 to affine, the final G1 addition of the two partial sums (its P = Q doubling runs only behind a wave vote: round 6)
 HASH_MEAN_TRIES = 2.116                            # counters tested per message on average (p = 0.4726 per try)
 
 
