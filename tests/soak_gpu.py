@@ -23,6 +23,9 @@ class SoakMismatch(AssertionError):
     pass
 
 
+R_ORDER = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120.0)
@@ -161,6 +164,25 @@ def soak(args):
             ps, st1 = eng.batch_g1_mul(g1 * m, b"".join(ks[:m]), m)
             qs, st2 = eng.batch_g2_mul(None, b"".join(ks[m:]), m)
             assert st1 == bytes(m) and st2 == bytes(m)
+            # the group operations behind them, themselves against the oracle (round 6: variable-base G1 multiplication and sign over the
+            # endomorphism, key derivation from the comb tables): generator and random bases, raw 256-bit and reduced scalars, signatures
+            g2gen = c.g2_generator()
+            for j in range(m):
+                if ps[64 * j:64 * j + 64] != c.g1_mul(g1, ks[j]) or qs[128 * j:128 * j + 128] != c.g2_mul(g2gen, ks[m + j]):
+                    raise SoakMismatch("MISMATCH g1_mul / g2 key derivation round %d item %d" % (rounds, j))
+            raw = [rnd.randrange(1 << 256).to_bytes(32, "big") for _ in range(m)]
+            for reduce in (False, True):
+                vb, stv = eng.batch_g1_mul(ps, b"".join(raw), m, reduce_scalar=reduce)
+                for j in range(m):
+                    kk = (int.from_bytes(raw[j], "big") % R_ORDER).to_bytes(32, "big") if reduce else raw[j]
+                    if stv[j] != 0 or vb[64 * j:64 * j + 64] != c.g1_mul(ps[64 * j:64 * j + 64], kk):
+                        raise SoakMismatch("MISMATCH variable-base g1_mul round %d item %d reduce %d" % (rounds, j, reduce))
+            smsgs = [rnd.randbytes(rnd.randrange(0, 90)) for _ in range(m)]
+            ssig, sst = eng.batch_sign(smsgs, b"".join(raw))
+            for j in range(m):
+                if sst[j] != 0 or ssig[64 * j:64 * j + 64] != c.sign(smsgs[j], raw[j]):
+                    raise SoakMismatch("MISMATCH sign round %d item %d" % (rounds, j))
+            extra["g1_mul_sign_keygen_items"] = extra.get("g1_mul_sign_keygen_items", 0) + 5 * m
             gt, stg = eng.batch_pairing(ps, qs, m, 1)          # a small batch: the small-batch kernels (lane machine, eighteen lane pairs) ...
             eng.set_option(OPT_LM_MAX_BATCH, 0)
             gt_lp, stg_lp = eng.batch_pairing(ps, qs, m, 1)    # ... and the lane-pair kernels
