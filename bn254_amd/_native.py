@@ -51,6 +51,11 @@ def build(force=False, verbose=False, jobs=None):
         subprocess.check_call(["python3", asm_gen, "selftest"], stdout=None if verbose else subprocess.DEVNULL)   # simulated before it is assembled
         with open(asm_h, "w") as f:
             subprocess.check_call(["python3", asm_gen, "header"], stdout=f)
+    mul_h = os.path.join(_CSRC, "bn254_mul_asm.h")
+    if not os.path.exists(mul_h) or os.path.getmtime(mul_h) < os.path.getmtime(asm_gen):
+        subprocess.check_call(["python3", asm_gen, "selftest_mul"], stdout=None if verbose else subprocess.DEVNULL)
+        with open(mul_h, "w") as f:
+            subprocess.check_call(["python3", asm_gen, "header_mul"], stdout=f)
     if force or _stale():
         import time
         from concurrent.futures import ThreadPoolExecutor

@@ -9,6 +9,9 @@
 #define BN_SPLIT_FP2 1
 #if !defined(BN_NO_ASM_CSQR)
 #define BN_ASM_CSQR_UNIT 1          // the accumulator machine of this unit runs on lane pairs with its accumulator in LDS (bn254_pairing.h: BN_FE_CSQR)
+#if !defined(BN_NO_ASM_MUL)
+#define BN_ASM_MUL 1                // ... and its MUL opcode is the generated block too (bn254_pairing.h: BN_FE_MUL)
+#endif
 #endif
 #ifndef BN_PAIR_NO_SQR_DPP_ASM
 #define BN_PAIR_SQR_DPP_ASM 1      // role prologue of the Fq2 squaring with folded DPP operands (bn254_fp2_pair.h)

@@ -1076,6 +1076,23 @@ BN_DEVN void final_exponentiation_check(Fp12& r, const Fp12& fin, Fp12& acc) {
 #else
 #define BN_FE_CSQR(acc) fp12_cyclotomic_sqr_body<170>(acc, acc)
 #endif
+// ... and the MUL opcode (51 steps) as the generated block of gen_step_asm.py header_mul (bn254_mul_asm.h; -DBN_NO_ASM_MUL restores the compiled
+// routine): same formulas and sites as fp12_mul_body, the eighteen dual products ONE subroutine inside the block (s_call_b64), operands built in
+// its input registers by the additions that form them, the slot read with scratch_load from an SGPR address, results at rest in input sets that
+// are dead by then (15 sets of nine registers + the leaf's).  Same box, alternating (profiles/r06_m_ab_asm_mul*.log): final exponentiation
+// 3.88-4.03 -> 3.82-3.94 ms per 65 536 (-1.6 ... -2.4 %); the chip is power-limited under this mix (1.25-1.28 kW of its 1.4 kW package limit,
+// tools/power_sample.sh), and a denser instruction stream pays part of its gain back in clock (Miller kernel +0.4 ... +0.9 % beside it).
+#if defined(BN_ASM_CSQR_UNIT) && defined(BN_ASM_MUL) && defined(__HIP_DEVICE_COMPILE__)
+#include "bn254_mul_asm.h"
+#define BN_FE_MUL(acc, b)                                                                                                                   \
+  do {                                                                                                                                      \
+    const uint32_t lds_addr_ = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&(acc);                                        \
+    const uint32_t prv_addr_ = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(5))) const void*)&(b));   \
+    asm volatile(BN_MUL_ASM_TEXT : : "v"(lds_addr_), "s"(prv_addr_) : BN_MUL_ASM_CLOBBERS);                                                 \
+  } while (0)
+#else
+#define BN_FE_MUL(acc, b) fp12_mul_body(acc, acc, b)
+#endif
 enum FeOpcode : int { FE_END = 0, FE_LOAD = 1, FE_STORE = 2, FE_CSQR = 3, FE_MUL = 4, FE_CONJ = 5, FE_FROB = 6, FE_INV = 7 };
 template <int NSLOTS>
 BN_DEV void fe_machine(Fp12& acc, Fp12 (&slot)[NSLOTS], const unsigned char (*prog)[2]) {
@@ -1090,7 +1107,7 @@ BN_DEV void fe_machine(Fp12& acc, Fp12 (&slot)[NSLOTS], const unsigned char (*pr
       case FE_LOAD: acc = slot[arg]; break;
       case FE_STORE: slot[arg] = acc; break;
       case FE_CSQR: BN_FE_CSQR(acc); break;
-      case FE_MUL: fp12_mul_body(acc, acc, slot[arg]); break;
+      case FE_MUL: BN_FE_MUL(acc, slot[arg]); break;
       case FE_CONJ: fp6_neg(acc.c1, acc.c1); break;        // balanced digits stay balanced: no carry
       case FE_FROB: fp12_frob_body(acc, acc, arg); break;
       default: fp12_inv(acc, acc); break;                   // FE_INV: once per program, a real call

@@ -5,6 +5,9 @@
 #define BN_SPLIT_FP2 1
 #if !defined(BN_NO_ASM_CSQR)
 #define BN_ASM_CSQR_UNIT 1          // the accumulator machine of this unit runs on lane pairs with its accumulator in LDS (bn254_pairing.h: BN_FE_CSQR)
+#if !defined(BN_NO_ASM_MUL)
+#define BN_ASM_MUL 1                // ... and its MUL opcode is the generated block too (bn254_pairing.h: BN_FE_MUL)
+#endif
 #endif
 #define BN_PAIR_SQR_DPP_ASM 1
 #define BN_PRIO_SHIFT 1

@@ -120,6 +120,19 @@ class Prog:
                     out.append("ds_read2_b32 %s, %s offset0:%d offset1:%d" % (dst, srcs[0], extra["o0"], extra["o1"]))
                 else:
                     out.append("ds_write2_b32 %s, %s, %s offset0:%d offset1:%d" % (srcs[0], srcs[1], srcs[2], extra["o0"], extra["o1"]))
+            elif op == "scratch_load":
+                out.append("scratch_load_dword%s %s, off, %s offset:%d" % ({1: "", 2: "x2", 3: "x3", 4: "x4"}[extra["n"]],
+                                                                           dst if extra["n"] == 1 else "v[%d:%d]" % (dst.n, dst.n + extra["n"] - 1), srcs[0], 4 * extra["o0"]))
+            elif op == "s_waitcnt_vm":
+                out.append("s_waitcnt vmcnt(0)")
+            elif op == "call":
+                out.append("s_call_b64 s[26:27], L%s_%%=" % extra["name"])
+            elif op == "ret":
+                out.append("s_setpc_b64 s[26:27]")
+            elif op == "label":
+                out.append("L%s_%%=:" % extra["name"])
+            elif op == "branch":
+                out.append("s_branch L%s_%%=" % extra["name"])
             elif op == "ds_read_b32":
                 out.append("ds_read_b32 %s, %s offset:%d" % (dst, srcs[0], 4 * extra["o0"]))
             elif op == "ds_write_b32":
@@ -132,7 +145,7 @@ class Prog:
         return out
 
     # ---- simulation: four lanes, 32-bit registers, LDS as word arrays per lane ---------------------------------------------
-    def simulate(self, lds, addr_reg, lanes=4):
+    def simulate(self, lds, addr_reg, lanes=4, priv=None, subs=None):
         """lds: [lane][word] (each lane's own slot, word-addressed from its base); addr_reg: the VGPR holding the slot's byte address
         (the simulator gives lane L the base 1000 * L words and checks every access against it)"""
         vg = [[0] * 256 for _ in range(lanes)]
@@ -161,11 +174,40 @@ class Prog:
             else:
                 vg[ln][d.n] = val & M32
 
-        for op, dst, srcs, dpp, extra in self.ins:
+        stream = []
+
+        def expand(ins, depth=0):
+            """flatten calls: a subroutine's instructions run in place (s_call_b64 / s_setpc_b64 are a jump there and back; the branch is
+            far longer than the two wait states of the DPP hazard window, which is therefore clear on entry and on return)"""
+            skipping = None
+            for it in ins:
+                op = it[0]
+                if skipping is not None:                      # the subroutine bodies sit behind an s_branch over them
+                    if op == "label" and it[4]["name"] == skipping:
+                        skipping = None
+                    continue
+                if op == "branch":
+                    skipping = it[4]["name"]
+                elif op == "call":
+                    assert depth == 0
+                    stream.append(("s_nop", None, (), None, {"n": 1}))
+                    expand(subs[it[4]["name"]], depth + 1)
+                    stream.append(("s_nop", None, (), None, {"n": 1}))
+                elif op in ("ret", "label"):
+                    pass
+                else:
+                    stream.append(it)
+        expand(self.ins)
+        for op, dst, srcs, dpp, extra in stream:
             if op == "s_nop":
                 last_writes = []                                 # s_nop 1 = two wait states: the window of two preceding VALU writes is clear
                 continue
-            if op == "s_waitcnt":
+            if op in ("s_waitcnt", "s_waitcnt_vm"):
+                continue
+            if op == "scratch_load":
+                for ln in range(lanes):
+                    for t in range(extra["n"]):
+                        vg[ln][dst.n + t] = priv[ln][extra["o0"] + t] & M32
                 continue
             if op == "s_mov_b32":
                 sg[dst.n] = srcs[0].v & M32
@@ -418,6 +460,190 @@ class Emitter(Prog):
         self.store(RT2, C01); self.store(RT3, C12); self.store(RX, C02); self.store(RS, C10)
 
 
+# ---- the MUL opcode: accumulator (LDS) x slot (private segment) -> accumulator -------------------------------------------------------------
+# bn254_field.h: fp12_mul_body (Karatsuba over Fq6: (a0 + a1)(b0 + b1), a0 b0, a1 b1; each Fq6 product six Fq2 products), site for site:
+#   sites 28 (off), 29, 30: carry on the sums of a; 31-33: carry on the sums of b; fp6_mul<34>: 34-37 carry; fp6_mul<20>: 20, 22 carry, 21, 23 off;
+#   fp6_mul<24>: 24-27 carry; outputs 41-43, 38, 39 weakly reduced, 40 carried.
+# The eighteen dual products are ONE subroutine inside the block (s_call_b64): operands in LA / LB — built there by the additions that form them,
+# or loaded there straight from LDS / the private segment —, result in LR, consumed by the next additions.  Everything else has a fixed home.
+Y_SET = vset(46)
+LA, LB, LR = vset(56), vset(66), vset(76)
+PSET = [vset(86 + 10 * i) for i in range(15)]
+N_VGPR_MUL = 86 + 10 * 15
+S_SLOT = "%1"                                          # the slot's private-segment address (SGPR operand of the asm statement)
+
+
+class MulEmitter(Emitter):
+    def __init__(self):
+        super().__init__()
+        self.subs = {}
+
+    def mov9(self, OUT, IN):
+        for i in range(LIMBS):
+            self.emit("v_mov_b32", OUT[i], IN[i])
+
+    def add9(self, OUT, A, B):
+        for i in range(LIMBS):
+            self.emit("v_add_u32", OUT[i], A[i], B[i])
+
+    def sub9(self, OUT, A, B):
+        for i in range(LIMBS):
+            self.emit("v_sub_u32", OUT[i], A[i], B[i])
+
+    def norm(self, OUT, A):
+        """OUT = carry(A): fp_norm"""
+        for i in range(LIMBS - 1):
+            if i == 0:
+                src = A[i]
+            else:
+                self.emit("v_add_u32", OUT[i], A[i], T1)
+                src = OUT[i]
+            self.emit("v_add_u32", T0, Imm(HALF), src)
+            self.emit("v_bfe_i32", OUT[i], src, Imm(0), Imm(W))
+            self.emit("v_ashrrev_i32", T1, Imm(W), T0)
+        self.emit("v_add_u32", OUT[8], A[8], T1)
+
+    def weak(self, OUT, X):
+        """OUT = fp_reduce_weak(X): k = mulhi(top + half, kmul), limb sums x_i + carry - k q_i in 64 bits"""
+        self.emit("v_add_u32", T0, Imm(WEAK_HALF), X[8])
+        self.emit("v_mul_hi_i32", KK, T0, S_KMUL)
+        self.emit("v_sub_u32", NK, Imm(0), KK)
+        for i in range(LIMBS):
+            self.mac(X[i], Imm(1), Imm(0) if i == 0 else CAR)
+            self.mac(NK, SQ[i])
+            if i < LIMBS - 1:
+                self.emit("v_bfe_i32", OUT[i], V(ACC.n), Imm(0), Imm(W))
+                self.emit("v_lshl_add_u64", CAR, ACC, Imm(0), S_HALF)
+                self.emit("v_ashrrev_i64", CAR, Imm(W), CAR)
+            else:
+                self.emit("v_mov_b32", OUT[i], V(ACC.n))
+
+    def load_priv(self, regs, word):
+        self.emit("scratch_load", regs[0], S_SLOT, n=4, o0=word)
+        self.emit("scratch_load", regs[4], S_SLOT, n=4, o0=word + 4)
+        self.emit("scratch_load", regs[8], S_SLOT, n=1, o0=word + 8)
+
+    def wait_all(self):
+        self.emit("s_waitcnt_vm", None)
+        self.emit("s_waitcnt", None)
+
+    def leaf_body(self):
+        """LR = the lane's half of LA * LB in Fq2 (fp_pair_mul_impl): own * bcast_re(b) + partner(a) * (+-bcast_im(b)), Montgomery-reduced"""
+        sub = MulEmitter()
+        sub.nsink = 0
+        AP, X, Yy, M = U, Vv, Y_SET, Mm
+        sub.nop()
+        for i in range(LIMBS):
+            sub.emit("v_mov_b32", AP[i], LA[i], dpp="partner")
+            sub.emit("v_mov_b32", X[i], LB[i], dpp="re")
+            sub.emit("v_xor_b32", Yy[i], LB[i], MASK, dpp="im")           # (b1 ^ mask) + one = -b1 in the real-part lanes, b1 in the others
+            sub.emit("v_add_u32", Yy[i], Yy[i], ONE)
+        first = True
+        for k in range(2 * LIMBS - 1):
+            for i in range(LIMBS):
+                j = k - i
+                if 0 <= j < LIMBS:
+                    sub.mac(LA[i], X[j], Imm(0) if first else None)
+                    first = False
+                    sub.mac(AP[i], Yy[j])
+            for i in range(LIMBS):
+                j = k - i
+                if j < 0 or j >= LIMBS or (k < LIMBS and i >= k):
+                    continue
+                sub.mac(M[i], SQ[j])
+            if k < LIMBS:
+                sub.emit("v_mul_lo_u32", M[k], V(ACC.n), S_N0)
+                sub.emit("v_ashrrev_i32", M[k], Imm(3), M[k])
+                sub.mac(M[k], SQ[0])
+                sub.emit("v_ashrrev_i64", ACC, Imm(W), ACC)
+            else:
+                sub.emit("v_bfe_i32", LR[k - LIMBS], V(ACC.n), Imm(0), Imm(W))
+                sub.emit("v_lshl_add_u64", ACC, ACC, Imm(0), S_HALF)
+                sub.emit("v_ashrrev_i64", ACC, Imm(W), ACC)
+        sub.emit("v_mov_b32", LR[LIMBS - 1], V(ACC.n))
+        return sub.ins
+
+    def product(self):
+        self.emit("call", None, name="leaf")
+
+    def fp6_mul(self, XS, YS, TMP, sites):
+        """XS * YS in Fq6 (fp6_mul<S>): XS, YS three register sets each (destroyed), TMP three sets for v0, v1, v2; sites = the modes of S .. S+3.
+        The results come to rest in input sets that are dead by then: returns [c0, c1, c2] = [XS[1], YS[1], XS[0]]."""
+        v0, v1, v2 = TMP
+        for k, vk in enumerate((v0, v1, v2)):
+            self.mov9(LA, XS[k]); self.mov9(LB, YS[k])
+            self.product()
+            self.mov9(vk, LR)
+        self.add9(LA, XS[1], XS[2]); self.add9(LB, YS[1], YS[2]); self.product()          # (x1 + x2)(y1 + y2)
+        result = LR
+        self.add9(LA, XS[0], XS[1]); self.add9(LB, YS[0], YS[1])                          # operands of the next product; x1, y1 are dead now
+        # c0 = xi * site_S(x12 - v1 - v2) + v0
+        c0 = XS[1]
+        self.sub2(result, result, v1, v2)
+        if sites[0]:
+            self.norm(result, result)
+        self.mul_xi(c0, result, PLUS=v0)
+        self.product()                                                                    # (x0 + x1)(y0 + y1)
+        self.add9(LA, XS[0], XS[2]); self.add9(LB, YS[0], YS[2])                          # x0, x2, y0, y2 are dead now
+        # c1 = x01 - v0 - v1 + xi v2
+        c1 = YS[1]
+        self.sub2(result, result, v0, v1)
+        self.mul_xi(c1, v2, PLUS=result)
+        self.product()                                                                    # (x0 + x2)(y0 + y2)
+        # c2 = x02 - v0 - v2 + v1
+        c2 = XS[0]
+        self.sub2(result, result, v0, v2)
+        self.add9(c2, result, v1)
+        for k, c in enumerate((c0, c1, c2)):
+            if sites[1 + k]:
+                self.norm(c, c)
+        return [c0, c1, c2]
+
+    def fp12_mul(self, addr_operand):
+        self.setup(addr_operand)
+        P = PSET
+        A0, A1, B0, B1, TMP = P[0:3], P[3:6], P[6:9], P[9:12], P[12:15]
+        aw, bw = (C00, C01, C02), (C10, C11, C12)
+        for k in range(3):
+            self.load(A0[k], aw[k]); self.load(A1[k], bw[k])
+            self.load_priv(B0[k], aw[k]); self.load_priv(B1[k], bw[k])
+        self.wait_all()
+        # s = a0 + a1 (sites 28 off, 29, 30), t = b0 + b1 (31, 32, 33) — over a1 / b1
+        self.add9(A1[0], A0[0], A1[0])
+        self.add_norm(A1[1], A0[1], A1[1]); self.add_norm(A1[2], A0[2], A1[2])
+        for k in range(3):
+            self.add_norm(B1[k], B0[k], B1[k])
+        UU = self.fp6_mul(A1, B1, TMP, (1, 1, 1, 1))              # u = s * t (fp6_mul<34>)
+        T0S = self.fp6_mul(A0, B0, TMP, (1, 0, 1, 0))             # t0 = a0 * b0 (fp6_mul<20>)
+        for k in range(3):
+            self.sub9(UU[k], UU[k], T0S[k])
+        # t1 = a1 * b1 (fp6_mul<24>): a1, b1 again from memory into sets that are free by now
+        live = {id(x) for x in UU + T0S + TMP}
+        free = [x for x in P if id(x) not in live]
+        assert len(free) >= 6
+        X1, Y1 = free[0:3], free[3:6]
+        for k in range(3):
+            self.load(X1[k], bw[k]); self.load_priv(Y1[k], bw[k])
+        self.wait_all()
+        T1S = self.fp6_mul(X1, Y1, TMP, (1, 1, 1, 1))
+        # r.c1 = weak(u - t0 - t1) (sites 41-43)
+        for k, word in enumerate(bw):
+            self.sub9(UU[k], UU[k], T1S[k])
+            self.weak(UU[k], UU[k])
+            self.store(UU[k], word)
+        # r.c0 = t0 + v t1: c0 = weak(t0_0 + xi t1_2) (38), c1 = weak(t0_1 + t1_0) (39), c2 = carry(t0_2 + t1_1) (40)
+        self.mul_xi(LR, T1S[2], PLUS=T0S[0]); self.weak(LR, LR); self.store(LR, C00)
+        self.add9(LR, T0S[1], T1S[0]); self.weak(LR, LR); self.store(LR, C01)
+        self.add_norm(LR, T0S[2], T1S[1]); self.store(LR, C02)
+        # the subroutine behind the block
+        self.emit("branch", None, name="end")
+        self.emit("label", None, name="leaf")
+        self.subs["leaf"] = self.leaf_body()
+        self.ins.extend(self.subs["leaf"])
+        self.emit("ret", None)
+        self.emit("label", None, name="end")
+
+
 # ---- big-integer model of the same squaring (Montgomery residues) ------------------------------------------------------------------
 def fq2_mul(a, b):
     return ((a[0] * b[0] - a[1] * b[1]) % Q, (a[0] * b[1] + a[1] * b[0]) % Q)
@@ -495,6 +721,67 @@ def selftest():
     print("selftest ok: %d instructions simulated x 40 trials x 2 lane pairs, outputs = the Granger-Scott formulas mod q, tight and weakly reduced" % len(e.ins))
 
 
+def fq6_mul(a, b):
+    """Fq6 = Fq2[v]/(v^3 - xi): schoolbook on plain residues"""
+    c = [(0, 0)] * 5
+    for i in range(3):
+        for j in range(3):
+            c[i + j] = fq2_add(c[i + j], fq2_mul(a[i], b[j]))
+    return [fq2_add(c[0], fq2_xi(c[3])), fq2_add(c[1], fq2_xi(c[4])), c[2]]
+
+
+def model_mul(a, b):
+    """a, b: dict name -> Fq2; Fq12 = Fq6[w]/(w^2 - v): (a0 + a1 w)(b0 + b1 w) = a0 b0 + v a1 b1 + (a0 b1 + a1 b0) w"""
+    a0, a1 = [a["c00"], a["c01"], a["c02"]], [a["c10"], a["c11"], a["c12"]]
+    b0, b1 = [b["c00"], b["c01"], b["c02"]], [b["c10"], b["c11"], b["c12"]]
+    t0, t1 = fq6_mul(a0, b0), fq6_mul(a1, b1)
+    vt1 = [fq2_xi(t1[2]), t1[0], t1[1]]
+    r0 = [fq2_add(x, y) for x, y in zip(t0, vt1)]
+    r1 = [fq2_add(x, y) for x, y in zip(fq6_mul(a0, b1), fq6_mul(a1, b0))]
+    return {"c00": r0[0], "c01": r0[1], "c02": r0[2], "c10": r1[0], "c11": r1[1], "c12": r1[2]}
+
+
+def selftest_mul(trials=12):
+    rnd = random.Random(12)
+    names = {"c00": C00, "c01": C01, "c02": C02, "c10": C10, "c11": C11, "c12": C12}
+    rinv = pow(R, -1, Q)
+    e = MulEmitter()
+    e.fp12_mul(V(250))
+    for trial in range(trials):
+        lds = [[0] * 55 for _ in range(4)]
+        priv = [[0] * 55 for _ in range(4)]
+        vals = [[{}, {}], [{}, {}]]                      # [operand][pair]: name -> (re, im) as integers (Montgomery residues)
+        for which, mem in ((0, lds), (1, priv)):
+            for pair in range(2):
+                for nm, off in names.items():
+                    comp = []
+                    for role in range(2):
+                        if trial < trials - 4:
+                            bound = 6 * Q if nm == "c02" and trial % 2 else Q // 2      # c02 of an accumulator may be a carried, not reduced, value
+                            limbs = balanced_limbs(rnd.randrange(-bound, bound))
+                        else:                            # extreme balanced digits, |value| <= 0.52 q: what an accumulator / a stored slot may hold
+                            limbs = [rnd.choice([-HALF, HALF - 1, rnd.randrange(-HALF, HALF)]) for _ in range(LIMBS - 1)] + [rnd.randrange(-1500000, 1500001)]
+                        for i in range(LIMBS):
+                            mem[2 * pair + role][off + i] = limbs[i] & M32
+                        comp.append(limbs_value(limbs))
+                    vals[which][pair][nm] = tuple(comp)
+        e.simulate(lds, V(250), priv=priv, subs=e.subs)
+        for pair in range(2):
+            plain = [{nm: tuple((x * rinv) % Q for x in v) for nm, v in vals[w][pair].items()} for w in range(2)]
+            want = model_mul(plain[0], plain[1])
+            for nm, off in names.items():
+                for role in range(2):
+                    got_limbs = lds[2 * pair + role][off:off + LIMBS]
+                    got = limbs_value(got_limbs)
+                    assert (got * rinv - want[nm][role]) % Q == 0, (trial, pair, nm, role)
+                    assert all(-HALF <= s32(x) < HALF for x in got_limbs[:8]), "output limbs not tight"
+                    # five outputs are weakly reduced; c02 (site 40) is only carried, as in the source: a short sum of products
+                    assert abs(got) < (0.7 if nm != "c02" else 12.0) * Q, "output %s not reduced: %f q" % (nm, got / Q)
+    n_leaf = len(e.subs["leaf"])
+    print("selftest mul ok: %d instructions in the block (%d of them the product subroutine, called 18 times), %d trials x 2 lane pairs, "
+          "outputs = the Fq12 product mod q" % (len(e.ins), n_leaf, trials))
+
+
 def stats():
     e = Emitter()
     e.csqr(V(200))
@@ -523,5 +810,20 @@ def header():
     print("#define BN_CSQR_ASM_CLOBBERS " + ", ".join('"v%d"' % r for r in range(N_VGPR)) + ", " + ", ".join('"s%d"' % r for r in range(4, 26)) + ', "memory"')
 
 
+def header_mul():
+    e = MulEmitter()
+    e.fp12_mul("%0")
+    print("// GENERATED by gen_step_asm.py header_mul — do not edit.  The MUL opcode of the final exponentiation's accumulator machine")
+    print("// (bn254_field.h: fp12_mul_body, accumulator in the lane's LDS slot times a slot of the private segment) as ONE gfx950 assembly block with a fixed")
+    print("// VGPR map; the eighteen dual products are a subroutine inside the block.  %0 = the accumulator's LDS byte address (VGPR), %1 = the slot's")
+    print("// private-segment address (SGPR).  Simulated against the big-integer model by `gen_step_asm.py selftest_mul` before it is assembled.")
+    print("#pragma once")
+    print("#define BN_MUL_ASM_TEXT \\")
+    for ln in e.text():
+        print('  "%s\\n" \\' % ln)
+    print('  ""')
+    print("#define BN_MUL_ASM_CLOBBERS " + ", ".join('"v%d"' % r for r in range(N_VGPR_MUL)) + ", " + ", ".join('"s%d"' % r for r in range(4, 28)) + ', "memory"')
+
+
 if __name__ == "__main__":
-    {"selftest": selftest, "stats": stats, "header": header}[sys.argv[1]]()
+    {"selftest": selftest, "stats": stats, "header": header, "selftest_mul": selftest_mul, "header_mul": header_mul}[sys.argv[1]]()

@@ -157,3 +157,8 @@ def test_generated_csqr_assembly_is_simulated_and_current():
     assert subprocess.check_output([sys.executable, gen, "header"], text=True) == open(os.path.join(ROOT, "bn254_amd", "csrc", "bn254_csqr_asm.h")).read()
     stats = subprocess.check_output([sys.executable, gen, "stats"], text=True)
     assert "v_mov 16" in stats                               # nine leaf outputs' top limbs + setup: no operand shuffling between operations
+    # ... and the MUL opcode's block (bn254_mul_asm.h): the Fq12 product of an LDS accumulator and a private-segment slot, its eighteen dual
+    # products a subroutine inside the block, against the schoolbook product over the tower (random and extreme limbs, a carried c02)
+    out = subprocess.check_output([sys.executable, gen, "selftest_mul"], text=True)
+    assert "selftest mul ok" in out and "called 18 times" in out
+    assert subprocess.check_output([sys.executable, gen, "header_mul"], text=True) == open(os.path.join(ROOT, "bn254_amd", "csrc", "bn254_mul_asm.h")).read()
