@@ -1076,6 +1076,9 @@ def run_verify(args, R):
             "hbm": {"algorithmic_bytes_per_step": io_bytes, "achieved_GBps": io_bytes / (1e-3 * 1e3 * elapsed / args.steps) / 1e9,
                     "peak_GBps": HBM_PEAK_GBPS, "note": "evidence that the path is not memory-bound"},
         }
+        # north_star's "VALU-busy counters against gfx950 peak": rocprofv3's VALUBusy of the two hot kernels, at the top level of the roofline object
+        vi = result["roofline"].get("valu_issue") or {}
+        result["roofline"]["valu_busy_pct"] = {kname: vi.get("valu_busy_pct_rocprof_definition"), "source": "profiles/pmc_latest.json (see pmc_as_of)"}
         # the OTHER hot kernel of the step priced the same way (the dominant one is `roofline` itself): its own algorithmic MAC32 per launch
         # over its own HIP-event duration in this run, its own PMC traffic against the algorithmic bytes
         try:
@@ -1091,7 +1094,9 @@ def run_verify(args, R):
                 "kernel_ms": k_avg[other], "traffic": (otr or {}).get("bytes_per_launch"),
                 "traffic_over_algorithmic": ((otr or {}).get("bytes_per_launch") / (432.0 * n)) if (otr or {}).get("bytes_per_launch") else None,
                 "algorithmic_bytes_per_launch": 432.0 * n,
+                "valu_busy_pct": (lambda k_: (100.0 * k_["SQ_ACTIVE_INST_VALU"] / 256.0 / (k_["GRBM_GUI_ACTIVE"] / 8.0)) if k_ and "GRBM_GUI_ACTIVE" in k_ and "SQ_ACTIVE_INST_VALU" in k_ else None)(_pmc(okname)),
                 "note": "algorithmic bytes of this kernel alone: one Fq12 Miller value per verify (12 x 9 words) between the two kernels"}
+            result["roofline"]["valu_busy_pct"][okname] = result["roofline"]["second_kernel"]["valu_busy_pct"]
         except Exception as exc:
             result["roofline"]["second_kernel"] = {"error": repr(exc)}
         if world == 1 and n >= 1024:
