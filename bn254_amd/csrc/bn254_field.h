@@ -579,6 +579,37 @@ struct bn_vec20 { int32_t e[2 * BN_LIMBS]; int32_t& operator[](int i) { return e
 BN_DEV void fp_dual_mul_reduce(int32_t* r, const int32_t* x0, const int32_t* y0, const int32_t* x1, const int32_t* y1) {
   BN_MONT_DUAL_BODY(x0, y0, x1, y1, r);
 }
+// r = Montgomery-reduce(sum_{t < N} x[t] * y[t]): N limb products share the 64-bit columns and ONE reduction (x, y: int32_t [N][BN_LIMBS]).
+// The Fq6-level lazy reduction (fp6_mul_lazy below): N = 6 is an output coefficient of a schoolbook Fq6 product in the pair layout — three
+// Fq2 products, two limb products each.  Column bound: 8 * sum A_t B_t + 9 * 2^56 + 2^37 < 2^63, i.e. sum A_t B_t <= 14 units of (2^28)^2:
+// six products of tight operands use 6 of them, so one operand of each may be a lazy sum of two.
+#define BN_MONT_MULTI_BODY(N, x, y, r)                                                   \
+  do {                                                                                   \
+    const int32_t q_[BN_LIMBS] = BN_QL_ARRAY;                                            \
+    int64_t acc_ = 0;                                                                    \
+    int32_t m_[BN_LIMBS];                                                                \
+    _Pragma("unroll") for (int k_ = 0; k_ < 2 * BN_LIMBS - 1; ++k_) {                    \
+      _Pragma("unroll") for (int i_ = 0; i_ < BN_LIMBS; ++i_) {                          \
+        int j_ = k_ - i_;                                                                \
+        if (j_ < 0 || j_ >= BN_LIMBS) continue;                                          \
+        _Pragma("unroll") for (int t_ = 0; t_ < (N); ++t_) BN_MAC(acc_, (x)[t_][i_], (y)[t_][j_]); \
+      }                                                                                  \
+      _Pragma("unroll") for (int i_ = 0; i_ < BN_LIMBS; ++i_) {                          \
+        int j_ = k_ - i_;                                                                \
+        if (j_ < 0 || j_ >= BN_LIMBS) continue;                                          \
+        if (k_ < BN_LIMBS && i_ >= k_) continue;                                         \
+        BN_MAC(acc_, m_[i_], q_[j_]);                                                    \
+      }                                                                                  \
+      if (k_ < BN_LIMBS) {                                                               \
+        m_[k_] = bn_digit((uint32_t)acc_ * BN_N0);                                       \
+        BN_MAC(acc_, m_[k_], q_[0]);                                                     \
+        BN_COLUMN_SHIFT(acc_);                                                           \
+      } else {                                                                           \
+        BN_COLUMN_OUT(acc_, (r)[k_ - BN_LIMBS]);                                         \
+      }                                                                                  \
+    }                                                                                    \
+    (r)[BN_LIMBS - 1] = (int32_t)acc_;                                                   \
+  } while (0)
 #if !defined(BN_SPLIT_FP2)
 BN_DEVN BN_VEC20 fp2_mul_impl(BN_VEC10 a0, BN_VEC10 a1, BN_VEC10 b0, BN_VEC10 b1) {
   BN_COUNT_MUL(); BN_COUNT_MUL(); BN_COUNT_MUL();   // algorithmic cost: a 3-product Karatsuba Fq2 multiplication
@@ -954,6 +985,38 @@ template <int S> BN_DEV void fp6_mul_01(Fp6& r, const Fp6& a, const Fp2& b0, con
   Fp2 c2 = fp2_add(fp2_mul(a.c2, b0), v1);
   r.c0 = NS(S, c0); r.c1 = NS(S + 1, c1); r.c2 = NS(S + 2, c2);
 }
+#if defined(BN_SPLIT_FP2) && defined(BN_FP6_LAZY)
+// ---- Fq6-level lazy reduction (pair layout) ----------------------------------------------------------------------------
+// a * b as the SCHOOLBOOK product with one reduction per output coefficient: xi is applied to the operands a1, a2 (carried, so they are
+// tight again), and every coefficient is a sum of three Fq2 products accumulated in the same 64-bit columns (fp2_mul_sum):
+//   c0 = a0 b0 + (xi a1) b2 + (xi a2) b1     c1 = a0 b1 + a1 b0 + (xi a2) b2     c2 = a0 b2 + a1 b1 + a2 b0
+// 18 limb products + 3 reductions per lane against the Karatsuba form's 12 + 6 — the same 486 + ... multiply-adds per three outputs, but
+// none of its 15 additions, four carry sites, two late xi and six calls (each with its own partner exchanges and argument moves).
+// Contract: b tight; a tight or a lazy sum of two tight values; outputs tight.
+BN_DEV void fp6_mul_lazy(Fp6& r, const Fp6& a, const Fp6& b) {
+  const Fp2 xa1 = fp2_norm(fp2_mul_xi(a.c1)), xa2 = fp2_norm(fp2_mul_xi(a.c2));
+  const Fp2* const x0[3] = {&a.c0, &xa1, &xa2};
+  const Fp2* const y0[3] = {&b.c0, &b.c2, &b.c1};
+  const Fp2* const x1[3] = {&a.c0, &a.c1, &xa2};
+  const Fp2* const y1[3] = {&b.c1, &b.c0, &b.c2};
+  const Fp2* const x2[3] = {&a.c0, &a.c1, &a.c2};
+  const Fp2* const y2[3] = {&b.c2, &b.c1, &b.c0};
+  const Fp2 c0 = fp2_mul_sum<3>(x0, y0), c1 = fp2_mul_sum<3>(x1, y1), c2 = fp2_mul_sum<3>(x2, y2);
+  r.c0 = c0; r.c1 = c1; r.c2 = c2;
+}
+// a * (b0 + b1 v): c0 = a0 b0 + (xi a2) b1, c1 = a0 b1 + a1 b0, c2 = a1 b1 + a2 b0
+BN_DEV void fp6_mul_01_lazy(Fp6& r, const Fp6& a, const Fp2& b0, const Fp2& b1) {
+  const Fp2 xa2 = fp2_norm(fp2_mul_xi(a.c2));
+  const Fp2* const x0[2] = {&a.c0, &xa2};
+  const Fp2* const y0[2] = {&b0, &b1};
+  const Fp2* const x1[2] = {&a.c0, &a.c1};
+  const Fp2* const y1[2] = {&b1, &b0};
+  const Fp2* const x2[2] = {&a.c1, &a.c2};
+  const Fp2* const y2[2] = {&b1, &b0};
+  const Fp2 c0 = fp2_mul_sum<2>(x0, y0), c1 = fp2_mul_sum<2>(x1, y1), c2 = fp2_mul_sum<2>(x2, y2);
+  r.c0 = c0; r.c1 = c1; r.c2 = c2;
+}
+#endif
 BN_DEVN void fp6_inv(Fp6& r, const Fp6& a) {      // sites 10 .. 15
   Fp2 t0 = NS(10, fp2_sub(fp2_sqr(a.c0), fp2_mul_xi(fp2_mul(a.c1, a.c2))));
   Fp2 t1 = NS(11, fp2_sub(fp2_mul_xi(fp2_sqr(a.c2)), fp2_mul(a.c0, a.c1)));
@@ -1211,6 +1274,22 @@ BN_DEV void fp12_mul_body(Fp12& r, const Fp12& a, const Fp12& b) { fp12_kmul4<26
 BN_DEVN void fp12_mul(Fp12& r, const Fp12& a, const Fp12& b) { fp12_mul_body(r, a, b); }
 BN_DEVF void fp12_mul_hot(Fp12& r, const Fp12& a, const Fp12& b) { fp12_mul_body(r, a, b); }
 #endif
+#if defined(BN_SPLIT_FP2) && defined(BN_FP6_LAZY) && !defined(BN_FP6_LAZY_ONLY_LINE2)
+BN_DEVH void fp12_sqr(Fp12& r, const Fp12& a) {                       // sites 300 .. 305
+  Fp6 ab, s, t, u;
+  fp6_mul_lazy(ab, a.c0, a.c1);
+  fp6_add(s, a.c0, a.c1);                                             // lazy: the other operand is carried
+  fp6_mul_v(t, a.c1);
+  fp6_add(t, t, a.c0); fp6_norm(t, t);
+  fp6_mul_lazy(u, s, t);
+  fp6_sub(u, u, ab);
+  fp6_mul_v(s, ab);
+  fp6_sub(u, u, s);
+  fp6_site_r<300>(r.c0, u);
+  fp6_add(s, ab, ab);
+  fp6_site_r<303>(r.c1, s);
+}
+#else
 BN_DEVH void fp12_sqr(Fp12& r, const Fp12& a) {                       // sites 50 .. 79
   Fp6 ab, s, t, u;
   fp6_mul<50>(ab, a.c0, a.c1);
@@ -1225,6 +1304,7 @@ BN_DEVH void fp12_sqr(Fp12& r, const Fp12& a) {                       // sites 5
   fp6_add(s, ab, ab);
   fp6_site_r<67>(r.c1, s);
 }
+#endif
 // the negated half keeps balanced digits balanced: no carry needed
 BN_DEV void fp12_conj(Fp12& r, const Fp12& a) { r.c0 = a.c0; fp6_neg(r.c1, a.c1); }
 BN_DEVN void fp12_inv(Fp12& r, const Fp12& a) {                       // sites 80 .. 109
@@ -1257,6 +1337,22 @@ BN_DEVN void fp12_mul_line(Fp12& r, const Fp12& f, const Fp2& l0, const Fp2& l1,
   fp6_site_r<123>(r.c1, u);
 }
 // f * (b0 + b1 w): b0 a full Fq6, b1 = b10 + b11 v — the shape of a product of two lines; the b's tight
+#if defined(BN_SPLIT_FP2) && defined(BN_FP6_LAZY) && !defined(BN_FP6_LAZY_ONLY_SQR)
+BN_DEVH void fp12_mul_line2(Fp12& r, const Fp12& f, const Fp6& b0, const Fp2& b10, const Fp2& b11) {   // sites 306 .. 313
+  Fp6 t0, t1, s, u, bs;
+  fp6_mul_lazy(t0, f.c0, b0);
+  fp6_mul_01_lazy(t1, f.c1, b10, b11);
+  fp6_add(s, f.c0, f.c1);                                             // lazy: bs is carried
+  bs.c0 = NS(306, fp2_add(b0.c0, b10)); bs.c1 = NS(307, fp2_add(b0.c1, b11)); bs.c2 = b0.c2;
+  fp6_mul_lazy(u, s, bs);
+  fp6_sub(u, u, t0);
+  fp6_sub(u, u, t1);
+  fp6_mul_v(s, t1);
+  fp6_add(s, t0, s);
+  fp6_site_r<308>(r.c0, s);
+  fp6_site_r<311>(r.c1, u);
+}
+#else
 BN_DEVH void fp12_mul_line2(Fp12& r, const Fp12& f, const Fp6& b0, const Fp2& b10, const Fp2& b11) {   // sites 140 .. 169
   Fp6 t0, t1, s, u, bs;
   fp6_mul<140>(t0, f.c0, b0);
@@ -1271,6 +1367,7 @@ BN_DEVH void fp12_mul_line2(Fp12& r, const Fp12& f, const Fp6& b0, const Fp2& b1
   fp6_site_r<156>(r.c0, s);
   fp6_site_r<159>(r.c1, u);
 }
+#endif
 // coefficient k of w^k in the polynomial basis: c[2i] = c0.c_i, c[2i+1] = c1.c_i
 BN_DEV Fp2& fp12_coef(Fp12& a, int k) {
   Fp6& h = (k & 1) ? a.c1 : a.c0;

@@ -155,6 +155,62 @@ BN_DEV Fp2 fp2_mul(const Fp2& a, const Fp2& b) {   // outputs are tight
   }
   return r;
 }
+// ---- sum of N Fq2 products with ONE reduction per coefficient (the Fq6-level lazy reduction, bn254_field.h: fp6_mul_lazy) --------------
+// r = a[0] b[0] + ... + a[N-1] b[N-1]: per lane 2N limb products share the columns (BN_MONT_MULTI_BODY).  Operand contract (checked by the
+// bound tracker): sum over the 2N limb products of A_t B_t <= 14 units — tight operands, one side of each product may be a lazy sum of two.
+#if defined(BN_TRACK_BOUNDS) && !defined(__HIPCC__)
+static inline void bn_trk_multi(Fp& r, int n, const Fp* x, const Fp* y) {
+  double col = BN_COL_EXTRA, lo = 0, hi = 0;
+  for (int t = 0; t < n; ++t) {
+    col += bn_col_ab(x[t], y[t]);
+    double c[4] = {x[t].bd.vlo * y[t].bd.vlo, x[t].bd.vlo * y[t].bd.vhi, x[t].bd.vhi * y[t].bd.vlo, x[t].bd.vhi * y[t].bd.vhi};
+    lo += std::fmin(std::fmin(c[0], c[1]), std::fmin(c[2], c[3])) / BN_R_OVER_Q;
+    hi += std::fmax(std::fmax(c[0], c[1]), std::fmax(c[2], c[3])) / BN_R_OVER_Q;
+  }
+  if (col >= 9223372036854775808.0) bn_bound_fail("multi product column overflow", col);
+  if (std::fmax(std::fabs(lo), std::fabs(hi)) > BN_VALUE_CAP) bn_bound_fail("multi product value bound", hi);
+  bn_set_tight(r, lo - 0.501, hi + 0.501);
+}
+#endif
+template <int N> BN_DEV Fp2 fp2_mul_sum(const Fp2* const (&a)[N], const Fp2* const (&b)[N]) {
+  Fp2 r;
+#if defined(__HIPCC__)
+  // own * bcast_re(b) + partner * (+-bcast_im(b)) for every product: the exchanges of fp_pair_mul_impl, once per operand
+  const int32_t one = 1 - (int32_t)(threadIdx.x & 1u), mask = -one;
+  int32_t x[2 * N][BN_LIMBS], y[2 * N][BN_LIMBS], z[BN_LIMBS];
+#pragma unroll
+  for (int t = 0; t < N; ++t)
+#pragma unroll
+    for (int i = 0; i < BN_LIMBS; ++i) {
+      x[2 * t][i] = a[t]->c[0].v[i];
+      x[2 * t + 1][i] = bn_partner_word(a[t]->c[0].v[i]);
+      y[2 * t][i] = bn_pair_re_word(b[t]->c[0].v[i]);
+      y[2 * t + 1][i] = (bn_pair_im_word(b[t]->c[0].v[i]) ^ mask) + one;
+    }
+  BN_MONT_MULTI_BODY(2 * N, x, y, z);
+#pragma unroll
+  for (int i = 0; i < BN_LIMBS; ++i) r.c[0].v[i] = z[i];
+#else
+  BN_FOR_ROLES(k) {
+    const bool im = bn_role_im(k);
+    Fp xs[2 * N], ys[2 * N];
+    int32_t x[2 * N][BN_LIMBS], y[2 * N][BN_LIMBS], z[BN_LIMBS];
+    for (int t = 0; t < N; ++t) {
+      const Fp ap = bn_partner(*a[t], k), bp = bn_partner(*b[t], k);
+      xs[2 * t] = a[t]->c[k]; ys[2 * t] = fp_select(im, bp, b[t]->c[k]);
+      xs[2 * t + 1] = ap; ys[2 * t + 1] = fp_select(im, b[t]->c[k], fp_neg(bp));
+      BN_COUNT_MUL(); BN_COUNT_DUAL();
+    }
+    for (int t = 0; t < 2 * N; ++t)
+      for (int i = 0; i < BN_LIMBS; ++i) { x[t][i] = xs[t].v[i]; y[t][i] = ys[t].v[i]; }
+    BN_MONT_MULTI_BODY(2 * N, x, y, z);
+    for (int i = 0; i < BN_LIMBS; ++i) r.c[k].v[i] = z[i];
+    BN_TRK(bn_trk_multi(r.c[k], 2 * N, xs, ys));
+  }
+#endif
+  return r;
+}
+
 #if defined(__HIPCC__)
 // Device form of fp2_sqr, same idea: re (a0 + a1)(a0 - a1), im 2 * (a1 * a0) — one product per lane
 // A leaf: the product body is inlined (no call frame, no saved return address in scratch).

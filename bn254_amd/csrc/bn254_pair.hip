@@ -7,6 +7,9 @@
 #include <hip/hip_runtime.h>
 
 #define BN_SPLIT_FP2 1
+#if defined(BN_PAIR_FP6_LAZY) && !defined(BN_FP6_LAZY)
+#define BN_FP6_LAZY 1              // Fq6-level lazy reduction in fp12_sqr / fp12_mul_line2 of this translation unit (bn254_field.h: fp6_mul_lazy)
+#endif
 #ifndef BN_PAIR_NO_SQR_DPP_ASM
 #define BN_PAIR_SQR_DPP_ASM 1      // role prologue of the Fq2 squaring with folded DPP operands (bn254_fp2_pair.h)
 #endif

@@ -311,6 +311,49 @@ def test_pair_layout_bounds_hold(pair_lib):
     assert p.returncode == 0 and p.stdout.strip() == "ok", (p.stdout[-500:], p.stderr[-2000:])
 
 
+def test_fp6_lazy_reduction_variant_parity_and_bounds(pair_lib, derived):
+    """the A/B build with the Fq6-level lazy reduction (bn254_field.h: fp6_mul_lazy — schoolbook Fq6 products, one reduction per output
+    coefficient over six limb products, in fp12_sqr and fp12_mul_line2; -DBN_PAIR_FP6_LAZY for bn254_pair.hip, measured neutral on the
+    GPU: profiles/r06_z_ab_fp6_lazy.log): every verify case gives the oracle's status through the generic AND the keyed loop, the keyed
+    tables are the default build's words, and the same flows pass the interval tracker build (columns of SIX limb products, int32 limbs,
+    value bounds; it aborts on a violation)."""
+    lazy = ctypes.CDLL(os.path.join(ROOT, "tests", "hostsim", "libhostsim_pair_lazy.so"))
+    W = 87 * 2 * 2 * 9
+    n = 0
+    for v in derived["verify_cases"]:
+        if v["status"] not in (0, 9):
+            continue
+        st, h, _ = c.hash_to_g1(H(v["message_hex"]))
+        assert lazy.hp_verify_decoded(h, H(v["sig"]), H(v["pk"])) == v["status"], v["name"]
+        tab_lazy, tab_dflt = (ctypes.c_int32 * W)(), (ctypes.c_int32 * W)()
+        assert lazy.hp_verify_keyed_decoded(h, H(v["sig"]), H(v["pk"]), tab_lazy) == v["status"], v["name"]
+        assert pair_lib.hp_verify_keyed_decoded(h, H(v["sig"]), H(v["pk"]), tab_dflt) == v["status"]
+        assert list(tab_lazy) == list(tab_dflt)
+        n += 1
+    assert n >= 10
+    drv = r'''
+import ctypes, json, sys
+sys.path.insert(0, sys.argv[1])
+from oracle import c_oracle as c
+root = sys.argv[1]
+L = ctypes.CDLL(root + "/tests/hostsim/libhostsim_pair_lazy_bounds.so")
+d = json.load(open(root + "/tests/golden/derived_vectors.json"))
+H = bytes.fromhex
+W = 87 * 2 * 2 * 9
+n = 0
+for v in d["verify_cases"]:
+    if v["status"] in (0, 9):
+        st, h, _ = c.hash_to_g1(H(v["message_hex"]))
+        assert L.hp_verify_decoded(h, H(v["sig"]), H(v["pk"])) == v["status"]
+        assert L.hp_verify_keyed_decoded(h, H(v["sig"]), H(v["pk"]), (ctypes.c_int32 * W)()) == v["status"]
+        n += 1
+assert n >= 10
+print("ok")
+'''
+    p = subprocess.run([sys.executable, "-c", drv, ROOT], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and p.stdout.strip() == "ok", (p.stdout[-500:], p.stderr[-2000:])
+
+
 def test_nonet_schedule_bounds_hold(pair_lib):
     """the nonet schedule under the interval tracker, on its own (the DRIVER above runs it too): no 64-bit column, int32 limb or value
     bound can be exceeded in the nine-pair arrangement — identity operands included (data-independent control flow: one pass per
