@@ -130,6 +130,35 @@ BN_DEVN BN_VEC10 fp_pair_mul_impl(BN_VEC10 a, BN_VEC10 b) {
     y[i] = (bn_pair_im_word(b[i]) ^ mask) + one;
   }
   BN_MONT_DUAL_BODY(ao, x, ap, y, r);
+#if defined(BN_PROBE_EXTRA_ADDS) || defined(BN_PROBE_EXTRA_MACS)
+  // Measurement builds only (tools/build_variant.sh … -DBN_PROBE_EXTRA_ADDS=k / -DBN_PROBE_EXTRA_MACS=k): 4 k extra 32-bit additions, or 4 k extra
+  // multiply-adds, per dual product on registers of their own (four independent chains each) — what ONE more instruction of either class costs
+  // the kernels in time at the clock the part grants the mix (profiles/r06_z_marginal_instruction_cost.log).
+#define BN_REP1(s) s
+#define BN_REP2(s) s s
+#define BN_REP3(s) s s s
+#define BN_REP4(s) s s s s
+#define BN_REP6(s) s s s s s s
+#define BN_REP8(s) s s s s s s s s
+#define BN_REP12(s) BN_REP6(s) BN_REP6(s)
+#define BN_REPX(k, s) BN_REP##k(s)
+#define BN_REP(k, s) BN_REPX(k, s)
+  {
+#if defined(BN_PROBE_EXTRA_ADDS)
+    int32_t d0 = ao[0], d1 = ao[1], d2 = ao[2], d3 = ao[3];
+    asm volatile(BN_REP(BN_PROBE_EXTRA_ADDS, "v_add_u32 %0, %0, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n")
+                 : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(x[0]));
+    asm volatile("" ::"v"(d0), "v"(d1), "v"(d2), "v"(d3));
+#endif
+#if defined(BN_PROBE_EXTRA_MACS)
+    int64_t e0 = ao[0], e1 = ao[1], e2 = ao[2], e3 = ao[3];
+    uint64_t k0, k1, k2, k3;
+    asm volatile(BN_REP(BN_PROBE_EXTRA_MACS, "v_mad_i64_i32 %0, %4, %8, %9, %0\n v_mad_i64_i32 %1, %5, %8, %9, %1\n v_mad_i64_i32 %2, %6, %8, %9, %2\n v_mad_i64_i32 %3, %7, %8, %9, %3\n")
+                 : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "=&s"(k0), "=&s"(k1), "=&s"(k2), "=&s"(k3) : "v"(x[0]), "v"(y[0]));
+    asm volatile("" ::"v"(e0), "v"(e1), "v"(e2), "v"(e3));
+#endif
+  }
+#endif
   BN_VEC10 z;
 #pragma unroll
   for (int i = 0; i < BN_LIMBS; ++i) z[i] = r[i];
